@@ -1,0 +1,358 @@
+"""Procedural ("synthetic") checkpoints for the three networks on the RVC inference path.
+
+No real checkpoint (content-vec-best.safetensors, rmvpe.pt, RVC *.pth) is reachable offline, so parity
+tests and bench.py run on deterministic pseudo-random weights w = f(seed, tensor_name, shape).
+The state-dict *names and shapes* follow the reference so the very same dict loads into the
+reference modules with `load_state_dict(strict=True)`:
+  * HuBERT   : transformers HubertModel + final_proj   (reference lib/infer_pack/loaders.py:10-17)
+  * RMVPE    : E2E(4, 1, (2, 2))                       (reference lib/rmvpe.py:431-470, :579)
+  * synthesizer `cpt` dict {weight, config, f0, version, sr, info}
+                                                        (reference training_cli.py:38-74,
+                                                         vc_infer_pipeline.py:198-221)
+Values depend only on (seed, name, shape) through numpy's PCG64, so the build container and the
+GPU box regenerate identical tensors; nothing is stored on disk.
+"""
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+
+CONFIG_40K_V2 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [10, 10, 2, 2], 512, [16, 16, 4, 4], 109, 256, 40000]
+CONFIG_48K_V2 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [12, 10, 2, 2], 512, [24, 20, 4, 4], 109, 256, 48000]
+CONFIG_40K_V1 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [10, 10, 2, 2], 512, [16, 16, 4, 4], 109, 256, 40000]
+
+
+def _rng(seed, name):
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return np.random.Generator(np.random.PCG64(int.from_bytes(h[:16], "little")))
+
+
+def _normal(seed, name, shape, std):
+    return (_rng(seed, name).standard_normal(shape) * std).astype(np.float32)
+
+
+def _uniform(seed, name, shape, lo, hi):
+    return _rng(seed, name).uniform(lo, hi, shape).astype(np.float32)
+
+
+def _fan_in(shape):
+    return int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+
+
+# ----------------------------------------------------------------------------------- HuBERT
+def hubert_spec(num_layers=12):
+    """name -> shape for HubertModelWithFinalProj(HubertConfig()) (transformers 5.x parametrized names)."""
+    s = OrderedDict()
+    s["masked_spec_embed"] = (768,)
+    kern = (10, 3, 3, 3, 3, 2, 2)
+    for i, k in enumerate(kern):
+        s[f"feature_extractor.conv_layers.{i}.conv.weight"] = (512, 1 if i == 0 else 512, k)
+        if i == 0:
+            s["feature_extractor.conv_layers.0.layer_norm.weight"] = (512,)
+            s["feature_extractor.conv_layers.0.layer_norm.bias"] = (512,)
+    s["feature_projection.layer_norm.weight"] = (512,)
+    s["feature_projection.layer_norm.bias"] = (512,)
+    s["feature_projection.projection.weight"] = (768, 512)
+    s["feature_projection.projection.bias"] = (768,)
+    s["encoder.pos_conv_embed.conv.bias"] = (768,)
+    s["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (1, 1, 128)
+    s["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = (768, 48, 128)
+    s["encoder.layer_norm.weight"] = (768,)
+    s["encoder.layer_norm.bias"] = (768,)
+    for l in range(num_layers):
+        p = f"encoder.layers.{l}."
+        for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[p + f"attention.{proj}.weight"] = (768, 768)
+            s[p + f"attention.{proj}.bias"] = (768,)
+        s[p + "layer_norm.weight"] = (768,)
+        s[p + "layer_norm.bias"] = (768,)
+        s[p + "feed_forward.intermediate_dense.weight"] = (3072, 768)
+        s[p + "feed_forward.intermediate_dense.bias"] = (3072,)
+        s[p + "feed_forward.output_dense.weight"] = (768, 3072)
+        s[p + "feed_forward.output_dense.bias"] = (768,)
+        s[p + "final_layer_norm.weight"] = (768,)
+        s[p + "final_layer_norm.bias"] = (768,)
+    s["final_proj.weight"] = (256, 768)
+    s["final_proj.bias"] = (256,)
+    return s
+
+
+def hubert_state_dict(seed=0):
+    sd = OrderedDict()
+    for name, shape in hubert_spec().items():
+        if name.endswith("layer_norm.weight"):
+            v = _uniform(seed, name, shape, 0.8, 1.2)
+        elif name.endswith("layer_norm.bias"):
+            v = _normal(seed, name, shape, 0.05)
+        elif name.endswith("original0"):          # weight-norm g, dim=2 -> one gain per kernel tap
+            v = _uniform(seed, name, shape, 0.8, 1.2) * np.float32(np.sqrt(768 * 48) * 0.5 / np.sqrt(48 * 128))
+        elif name.endswith("original1"):
+            v = _normal(seed, name, shape, 1.0)
+        elif name.endswith(".bias"):
+            v = _normal(seed, name, shape, 0.02)
+        elif name == "masked_spec_embed":
+            v = _uniform(seed, name, shape, 0.0, 1.0)
+        elif "feature_extractor" in name:         # conv + GELU stack: keep the variance roughly constant
+            v = _normal(seed, name, shape, 1.4 / np.sqrt(_fan_in(shape)))
+        else:
+            v = _normal(seed, name, shape, 1.0 / np.sqrt(_fan_in(shape)))
+        sd[name] = v
+    return sd
+
+
+HUBERT_CONFIG = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                     conv_dim=[512] * 7, conv_stride=[5, 2, 2, 2, 2, 2, 2], conv_kernel=[10, 3, 3, 3, 3, 2, 2],
+                     num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16, layer_norm_eps=1e-5,
+                     classifier_proj_size=256, feat_extract_norm="group", conv_bias=False,
+                     do_stable_layer_norm=False, feat_proj_layer_norm=True)
+
+
+# ----------------------------------------------------------------------------------- RMVPE
+def _convblockres_spec(s, p, cin, cout):
+    for conv, bn, ci in (("conv.0", "conv.1", cin), ("conv.3", "conv.4", cout)):
+        s[p + f"{conv}.weight"] = (cout, ci, 3, 3)
+        for q, shp in (("weight", (cout,)), ("bias", (cout,)), ("running_mean", (cout,)),
+                       ("running_var", (cout,)), ("num_batches_tracked", ())):
+            s[p + f"{bn}.{q}"] = shp
+    if cin != cout:
+        s[p + "shortcut.weight"] = (cout, cin, 1, 1)
+        s[p + "shortcut.bias"] = (cout,)
+
+
+def rmvpe_spec():
+    """name -> shape for E2E(n_blocks=4, n_gru=1, kernel_size=(2,2)) in state_dict order."""
+    s = OrderedDict()
+    for q, shp in (("weight", (1,)), ("bias", (1,)), ("running_mean", (1,)), ("running_var", (1,)),
+                   ("num_batches_tracked", ())):
+        s[f"unet.encoder.bn.{q}"] = shp
+    cin, cout = 1, 16
+    for i in range(5):
+        for b in range(4):
+            _convblockres_spec(s, f"unet.encoder.layers.{i}.conv.{b}.", cin if b == 0 else cout, cout)
+        cin, cout = cout, cout * 2
+    cin, cout = 256, 512
+    for i in range(4):
+        for b in range(4):
+            _convblockres_spec(s, f"unet.intermediate.layers.{i}.conv.{b}.", cin if b == 0 else cout, cout)
+        cin = cout
+    cin = 512
+    for i in range(5):
+        cout = cin // 2
+        p = f"unet.decoder.layers.{i}."
+        s[p + "conv1.0.weight"] = (cin, cout, 3, 3)
+        for q, shp in (("weight", (cout,)), ("bias", (cout,)), ("running_mean", (cout,)),
+                       ("running_var", (cout,)), ("num_batches_tracked", ())):
+            s[p + f"conv1.1.{q}"] = shp
+        for b in range(4):
+            _convblockres_spec(s, p + f"conv2.{b}.", cout * 2 if b == 0 else cout, cout)
+        cin = cout
+    s["cnn.weight"] = (3, 16, 3, 3)
+    s["cnn.bias"] = (3,)
+    for sfx in ("", "_reverse"):
+        s[f"fc.0.gru.weight_ih_l0{sfx}"] = (768, 384)
+        s[f"fc.0.gru.weight_hh_l0{sfx}"] = (768, 256)
+        s[f"fc.0.gru.bias_ih_l0{sfx}"] = (768,)
+        s[f"fc.0.gru.bias_hh_l0{sfx}"] = (768,)
+    s["fc.1.weight"] = (360, 512)
+    s["fc.1.bias"] = (360,)
+    return s
+
+
+def rmvpe_state_dict(seed=0):
+    sd = OrderedDict()
+    for name, shape in rmvpe_spec().items():
+        if name.endswith("num_batches_tracked"):
+            v = np.array(1000, dtype=np.int64)
+        elif name.endswith("running_mean"):
+            v = _normal(seed, name, shape, 0.1)
+        elif name.endswith("running_var"):
+            v = _uniform(seed, name, shape, 0.5, 1.5)
+        elif name == "unet.encoder.bn.weight":
+            v = np.full(shape, 0.25, dtype=np.float32)   # log-mel spans roughly [-11.5, 3] -> O(1)
+        elif name == "unet.encoder.bn.running_mean":
+            v = np.full(shape, -4.0, dtype=np.float32)
+        elif len(shape) == 1 and (".conv.1." in name or ".conv.4." in name or ".conv1.1." in name) \
+                and name.endswith("weight"):
+            v = _uniform(seed, name, shape, 0.8, 1.2)
+        elif "gru" in name:
+            v = _uniform(seed, name, shape, -1.0 / 16.0, 1.0 / 16.0)
+        elif name == "fc.1.bias":
+            v = _normal(seed, name, shape, 0.5) - np.float32(3.0)
+        elif name == "fc.1.weight":
+            v = _normal(seed, name, shape, 4.0 / np.sqrt(512))
+        elif name.endswith(".bias"):
+            v = _normal(seed, name, shape, 0.05)
+        elif "conv1.0.weight" in name:                  # ConvTranspose2d [Cin, Cout, 3, 3]; ~9/4 taps hit
+            v = _normal(seed, name, shape, 1.4 / np.sqrt(shape[0] * 9 / 4))
+        else:
+            v = _normal(seed, name, shape, 1.0 / np.sqrt(_fan_in(shape)))
+        sd[name] = v
+    return sd
+
+
+# ----------------------------------------------------------------------------------- synthesizer
+def synth_spec(config, version="v2"):
+    """name -> shape for SynthesizerTrnMs{256,768}NSFsid(*config) after `del net_g.enc_q`."""
+    (_spec, _seg, inter, hidden, filt, n_heads, n_layers, ksz, _pd, _rb, rb_k, rb_d, up_rates, up_init, up_k,
+     n_spk, gin, _sr) = config
+    s = OrderedDict()
+    s["enc_p.emb_phone.weight"] = (hidden, 768 if version == "v2" else 256)
+    s["enc_p.emb_phone.bias"] = (hidden,)
+    s["enc_p.emb_pitch.weight"] = (256, hidden)
+    kc = hidden // n_heads
+    for l in range(n_layers):
+        p = f"enc_p.encoder.attn_layers.{l}."
+        s[p + "emb_rel_k"] = (1, 21, kc)
+        s[p + "emb_rel_v"] = (1, 21, kc)
+        for c in ("conv_q", "conv_k", "conv_v", "conv_o"):
+            s[p + c + ".weight"] = (hidden, hidden, 1)
+            s[p + c + ".bias"] = (hidden,)
+    for l in range(n_layers):
+        s[f"enc_p.encoder.norm_layers_1.{l}.gamma"] = (hidden,)
+        s[f"enc_p.encoder.norm_layers_1.{l}.beta"] = (hidden,)
+    for l in range(n_layers):
+        p = f"enc_p.encoder.ffn_layers.{l}."
+        s[p + "conv_1.weight"] = (filt, hidden, ksz)
+        s[p + "conv_1.bias"] = (filt,)
+        s[p + "conv_2.weight"] = (hidden, filt, ksz)
+        s[p + "conv_2.bias"] = (hidden,)
+    for l in range(n_layers):
+        s[f"enc_p.encoder.norm_layers_2.{l}.gamma"] = (hidden,)
+        s[f"enc_p.encoder.norm_layers_2.{l}.beta"] = (hidden,)
+    s["enc_p.proj.weight"] = (inter * 2, hidden, 1)
+    s["enc_p.proj.bias"] = (inter * 2,)
+    s["dec.m_source.l_linear.weight"] = (1, 1)
+    s["dec.m_source.l_linear.bias"] = (1,)
+    nu = len(up_rates)
+    for i in range(nu):
+        c_cur = up_init // (2 ** (i + 1))
+        if i + 1 < nu:
+            sf0 = int(np.prod(up_rates[i + 1:]))
+            s[f"dec.noise_convs.{i}.weight"] = (c_cur, 1, sf0 * 2)
+        else:
+            s[f"dec.noise_convs.{i}.weight"] = (c_cur, 1, 1)
+        s[f"dec.noise_convs.{i}.bias"] = (c_cur,)
+    s["dec.conv_pre.weight"] = (up_init, inter, 7)
+    s["dec.conv_pre.bias"] = (up_init,)
+    for i in range(nu):
+        cin, cout = up_init // (2 ** i), up_init // (2 ** (i + 1))
+        s[f"dec.ups.{i}.bias"] = (cout,)
+        s[f"dec.ups.{i}.weight_g"] = (cin, 1, 1)
+        s[f"dec.ups.{i}.weight_v"] = (cin, cout, up_k[i])
+    for i in range(nu):
+        ch = up_init // (2 ** (i + 1))
+        for j, k in enumerate(rb_k):
+            p = f"dec.resblocks.{i * len(rb_k) + j}."
+            for cs in ("convs1", "convs2"):
+                for m in range(3):
+                    s[p + f"{cs}.{m}.bias"] = (ch,)
+                    s[p + f"{cs}.{m}.weight_g"] = (ch, 1, 1)
+                    s[p + f"{cs}.{m}.weight_v"] = (ch, ch, k)
+    s["dec.conv_post.weight"] = (1, up_init // (2 ** nu), 7)
+    s["dec.cond.weight"] = (up_init, gin, 1)
+    s["dec.cond.bias"] = (up_init,)
+    for f in range(4):
+        p = f"flow.flows.{2 * f}."
+        s[p + "pre.weight"] = (hidden, inter // 2, 1)
+        s[p + "pre.bias"] = (hidden,)
+        for l in range(3):
+            s[p + f"enc.in_layers.{l}.bias"] = (2 * hidden,)
+            s[p + f"enc.in_layers.{l}.weight_g"] = (2 * hidden, 1, 1)
+            s[p + f"enc.in_layers.{l}.weight_v"] = (2 * hidden, hidden, 5)
+        for l in range(3):
+            rs = 2 * hidden if l < 2 else hidden
+            s[p + f"enc.res_skip_layers.{l}.bias"] = (rs,)
+            s[p + f"enc.res_skip_layers.{l}.weight_g"] = (rs, 1, 1)
+            s[p + f"enc.res_skip_layers.{l}.weight_v"] = (rs, hidden, 1)
+        s[p + "enc.cond_layer.bias"] = (2 * hidden * 3,)
+        s[p + "enc.cond_layer.weight_g"] = (2 * hidden * 3, 1, 1)
+        s[p + "enc.cond_layer.weight_v"] = (2 * hidden * 3, gin, 1)
+        s[p + "post.weight"] = (inter // 2, hidden, 1)
+        s[p + "post.bias"] = (inter // 2,)
+    s["emb_g.weight"] = (n_spk, gin)
+    return s
+
+
+def synth_state_dict(config, version="v2", seed=0, fp16_round=True):
+    spec = synth_spec(config, version)
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if name.endswith("weight_g"):
+            vshape = spec[name[:-1] + "v"]
+            fan = int(np.prod(vshape[1:]))
+            gain = 1.0
+            if ".ups." in name:                    # ConvTranspose1d: only k/stride taps hit per output
+                gain = 1.2
+            # |v| per dim-0 slice is ~ sqrt(fan) for unit-normal v; g sets the effective row norm
+            v = _uniform(seed, name, shape, 0.8, 1.2) * np.float32(gain)
+            if ".ups." in name:
+                k = vshape[2]
+                v = v * np.float32(np.sqrt(vshape[1] * k) / np.sqrt(vshape[0] * 2.0))
+            elif "res_skip" in name or "cond_layer" in name:
+                v = v * np.float32(0.5)
+        elif name.endswith("weight_v"):
+            v = _normal(seed, name, shape, 1.0)
+        elif name.endswith("gamma"):
+            v = _uniform(seed, name, shape, 0.8, 1.2)
+        elif name.endswith("beta"):
+            v = _normal(seed, name, shape, 0.05)
+        elif "emb_rel" in name:
+            v = _normal(seed, name, shape, shape[-1] ** -0.5)
+        elif name == "enc_p.emb_pitch.weight":
+            v = _normal(seed, name, shape, 0.05)
+        elif name == "emb_g.weight":
+            v = _normal(seed, name, shape, 0.5)
+        elif name == "dec.m_source.l_linear.weight":
+            v = np.full(shape, 0.9, dtype=np.float32)
+        elif name == "dec.m_source.l_linear.bias":
+            v = np.full(shape, 0.01, dtype=np.float32)
+        elif name == "dec.conv_post.weight":
+            v = _normal(seed, name, shape, 0.4 / np.sqrt(_fan_in(shape)))
+        elif "noise_convs" in name and name.endswith("weight"):
+            v = _normal(seed, name, shape, 2.0 / np.sqrt(_fan_in(shape)))
+        elif "flow" in name and "post.weight" in name:
+            v = _normal(seed, name, shape, 0.3 / np.sqrt(_fan_in(shape)))
+        elif name == "enc_p.proj.weight":
+            v = _normal(seed, name, shape, 0.5 / np.sqrt(_fan_in(shape)))
+        elif name.endswith(".bias"):
+            v = _normal(seed, name, shape, 0.02)
+        else:
+            v = _normal(seed, name, shape, 1.0 / np.sqrt(_fan_in(shape)))
+        if fp16_round:                             # real RVC checkpoints store fp16 (training_cli.py:38-74)
+            v = v.astype(np.float16).astype(np.float32)
+        sd[name] = v
+    return sd
+
+
+def synth_checkpoint(config=None, version="v2", seed=0):
+    """The `cpt` dict layout `get_vc` reads (reference vc_infer_pipeline.py:199-221), as numpy arrays."""
+    config = list(CONFIG_40K_V2 if config is None else config)
+    return {"weight": synth_state_dict(config, version, seed), "config": config, "f0": 1, "version": version,
+            "sr": {32000: "32k", 40000: "40k", 48000: "48k"}[config[-1]], "info": "synthetic"}
+
+
+# ----------------------------------------------------------------------------------- inputs
+def synth_audio(seconds, seed=0, sr=16000):
+    """SURVEY 8(d) synthetic clip: AM'd glide 110-440 Hz with 20 % silent gaps plus a little noise."""
+    n = int(round(seconds * sr))
+    t = np.arange(n, dtype=np.float64) / sr
+    rng = _rng(seed, "audio")
+    f = 110.0 * 2.0 ** (2.0 * (0.5 - 0.5 * np.cos(2 * np.pi * t / 7.0)))
+    phase = 2 * np.pi * np.cumsum(f) / sr
+    x = 0.3 * np.sin(phase) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t))
+    gap = ((t % 2.5) > 2.0)
+    x = np.where(gap, 0.0, x)
+    x = x + 0.01 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def designed_f0(n_frames, seed=0):
+    """A voiced/unvoiced contour at 100 fps (Hz, 0 = unvoiced) for driving the synthesizer directly."""
+    t = np.arange(n_frames, dtype=np.float64) / 100.0
+    f0 = 220.0 * 2.0 ** (0.5 * np.sin(2 * np.pi * t / 1.7) + 0.3 * np.sin(2 * np.pi * t / 0.31))
+    uv = ((t % 0.9) > 0.7)
+    f0 = np.where(uv, 0.0, f0)
+    return f0.astype(np.float32)

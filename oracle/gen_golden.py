@@ -1,0 +1,266 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported via oracle/ref_shim.py).
+
+Container-only (needs /root/reference); the GPU box only sees the committed .npz files.
+Weights: comfy-rvc_amd/synthetic.py procedural checkpoints (regenerated, never stored).
+Noise:   torch.randn_like is patched to draw from torch.Generator(cpu).manual_seed(seed) in the
+         reference's call order, so oracle / HIP runs can replay the identical draws.
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz (a few MB)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim                                  # noqa: E402
+from comfy_rvc_amd import synthetic as S                      # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+class NoiseTape:
+    """Replays randn draws from a seeded CPU generator; patched over torch.randn_like."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.shapes = []
+
+    def __call__(self, shape):
+        self.shapes.append(tuple(shape))
+        return torch.randn(tuple(shape), generator=self.g)
+
+    def randn_like(self, x, **kw):
+        return self(tuple(x.shape)).to(x.dtype)
+
+
+class patched_randn_like:
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.old = torch.randn_like
+        torch.randn_like = self.tape.randn_like
+
+    def __exit__(self, *a):
+        torch.randn_like = self.old
+
+
+def np_(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def build_models(ns, config, version, seed=0):
+    from transformers import HubertConfig
+    hub = ns.loaders.HubertModelWithFinalProj(HubertConfig())
+    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(seed)))
+    hub.eval()
+    mdir = os.path.join(ns.ws, "models")
+    torch.save(to_torch_sd(S.rmvpe_state_dict(seed)), os.path.join(mdir, "rmvpe.pt"))
+    cpt = S.synth_checkpoint(config, version, seed)
+    cpt["weight"] = {k: v.half() for k, v in to_torch_sd(cpt["weight"]).items()}
+    name = f"synth_{version}_{config[-1]}.pth"
+    torch.save(cpt, os.path.join(mdir, name))
+    with ref_shim.chdir_ws():
+        vcd = ns.vc_infer_pipeline.get_vc(os.path.join(mdir, name), file_index="")
+    return hub, vcd
+
+
+def gen_hubert(ns):
+    from transformers import HubertConfig
+    hub = ns.loaders.HubertModelWithFinalProj(HubertConfig())
+    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(0)))
+    hub.eval()
+    audio = torch.from_numpy(S.synth_audio(1.0, seed=3)).view(1, -1)
+    with torch.no_grad():
+        conv = hub.feature_extractor(audio)
+        out = hub(audio, output_hidden_states=True)
+        hs = out["hidden_states"]
+        h_in = hub.feature_projection(conv.transpose(1, 2))
+        pos = hub.encoder.pos_conv_embed(h_in)
+    v2 = hub.extract_features(audio, version="v2")
+    v1 = hub.extract_features(audio, version="v1")
+    assert len(hs) == 13 and torch.equal(v2, hs[11])
+    np.savez_compressed(os.path.join(OUT, "hubert_1s.npz"), audio=np_(audio), conv_stack=np_(conv), pos_conv=np_(pos),
+                        hidden_0=np_(hs[0]), hidden_8=np_(hs[8]), out_v2=np_(v2), out_v1=np_(v1))
+    print("hubert_1s", v2.shape, v1.shape, float(v2.abs().mean()), float(v2.std()))
+
+
+def gen_rmvpe(ns):
+    mdir = os.path.join(ns.ws, "models")
+    torch.save(to_torch_sd(S.rmvpe_state_dict(0)), os.path.join(mdir, "rmvpe.pt"))
+    m = ns.rmvpe.RMVPE(os.path.join(mdir, "rmvpe.pt"), is_half=False, device="cpu")
+    audio = S.synth_audio(1.3, seed=5)
+    a = torch.from_numpy(audio).float().unsqueeze(0)
+    mel = m.mel_extractor(a, center=True)
+    hidden = m.mel2hidden(mel).squeeze(0).numpy()
+    f0 = m.infer_from_audio(audio, thred=0.03)
+    f0p = m.infer_from_audio_with_pitch(audio, thred=0.03, f0_min=50, f0_max=1600)
+    # synthetic salience for the decoder: peaks, ties, sub-threshold rows, edge bins
+    rng = np.random.default_rng(11)
+    sal = rng.uniform(0, 0.02, (64, 360)).astype(np.float32)
+    for i in range(48):
+        cbin = [0, 1, 3, 4, 356, 358, 359][i % 7] if i < 14 else int(rng.integers(0, 360))
+        w = np.exp(-0.5 * ((np.arange(360) - cbin) / 1.5) ** 2).astype(np.float32)
+        sal[i] += (0.025 if i % 11 == 10 else rng.uniform(0.1, 0.9)) * w
+    f0_syn = m.decode(sal.copy(), thred=0.03)
+    np.savez_compressed(os.path.join(OUT, "rmvpe_1s.npz"), audio=audio, mel=np_(mel), salience=hidden, f0=f0, f0_plus=f0p,
+                        syn_salience=sal, syn_f0=f0_syn)
+    print("rmvpe_1s mel", mel.shape, "sal", hidden.shape, "f0 range", f0.min(), f0.max(), "voiced", (f0 > 0).mean())
+
+
+def gen_synth(ns, config, version, tag, T=16, full_taps=False):
+    cls = ns.models.SynthesizerTrnMs768NSFsid if version == "v2" else ns.models.SynthesizerTrnMs256NSFsid
+    net = cls(*config, is_half=False)
+    del net.enc_q
+    sd = to_torch_sd(S.synth_state_dict(config, version, 0))
+    missing = net.load_state_dict(sd, strict=True)
+    net.eval()
+    rng = np.random.default_rng(21)
+    D = 768 if version == "v2" else 256
+    phone = torch.from_numpy(rng.standard_normal((1, T, D)).astype(np.float32) * 0.5)
+    f0 = S.designed_f0(T + 40, seed=0)[20:20 + T].copy()
+    f0[T // 2: T // 2 + 3] = 0.0
+    from oracle.pipeline import f0_postprocess
+    coarse, f0f = f0_postprocess(f0.astype(np.float64))
+    pitch = torch.from_numpy(coarse.astype(np.int64)).view(1, -1)
+    pitchf = torch.from_numpy(f0f.astype(np.float32)).view(1, -1)
+    tape = NoiseTape(1234)
+    taps = {}
+    hooks = []
+    if full_taps:
+        hooks.append(net.dec.m_source.register_forward_hook(lambda m, i, o: taps.__setitem__("har_source", o[0].transpose(1, 2))))
+        hooks.append(net.dec.ups[0].register_forward_hook(lambda m, i, o: taps.__setitem__("ups0_raw", o)))
+        hooks.append(net.dec.conv_pre.register_forward_hook(lambda m, i, o: taps.__setitem__("conv_pre_raw", o)))
+        hooks.append(net.enc_p.encoder.norm_layers_2[0].register_forward_hook(lambda m, i, o: taps.__setitem__("enc_p_layer0", o)))
+    with torch.no_grad(), patched_randn_like(tape):
+        o, x_mask, (z, z_p, m_p, logs_p) = net.infer(phone, torch.LongTensor([T]), pitch, pitchf, torch.LongTensor([3]))
+    for h in hooks:
+        h.remove()
+    upp = int(np.prod(config[12]))
+    assert tape.shapes == [(1, config[2], T), (1, T * upp, 1)], tape.shapes
+    tape2 = NoiseTape(1234)
+    d = dict(phone=np_(phone), pitch=np_(pitch), pitchf=np_(pitchf), sid=np.int64(3), noise_seed=np.int64(1234),
+             noise_z=np_(tape2((1, config[2], T))), noise_src=np_(tape2((1, T * upp, 1))),
+             m_p=np_(m_p), logs_p=np_(logs_p), z_p=np_(z_p), z=np_(z), wav=np_(o))
+    d.update({k: np_(v) for k, v in taps.items()})
+    np.savez_compressed(os.path.join(OUT, f"synth_{tag}.npz"), **d)
+    print(f"synth_{tag}", o.shape, "wav rms", float(o.pow(2).mean().sqrt()), "max", float(o.abs().max()))
+
+
+class Cfg:
+    """Stand-in for the reference's global `config` singleton with chosen segmentation constants."""
+
+    def __init__(self, x_pad=1, x_query=6, x_center=38, x_max=41):
+        self.x_pad, self.x_query, self.x_center, self.x_max = x_pad, x_query, x_center, x_max
+        self.is_half = False
+        self.device = "cpu"
+
+
+def run_ref_pipeline(ns, hub, vcd, audio, seed, cfg=None, designed_f0=None, **kw):
+    vc = vcd["vc"] if cfg is None else ns.vc_infer_pipeline.VC(vcd["cpt"]["config"][-1], cfg)
+    captured = {}
+    orig_get_f0 = vc.get_f0
+
+    def get_f0(*a, **k):
+        r = orig_get_f0(*a, **k)
+        captured["pitch"], captured["pitchf"] = np.array(r[0]), np.array(r[1])
+        return r
+
+    vc.get_f0 = get_f0
+    if designed_f0 is not None:
+        vc.f0_method_dict["pm"] = lambda x, **k: designed_f0(x)
+    tape = NoiseTape(seed)
+    args = dict(sid=0, f0_up_key=0, f0_method="rmvpe", merge_type="median", file_index="", index_rate=0.0,
+                filter_radius=3, resample_sr=0, rms_mix_rate=0.25, protect=0.33, crepe_hop_length=160,
+                f0_autotune=False)
+    args.update(kw)
+    with ref_shim.chdir_ws(), patched_randn_like(tape), torch.no_grad():
+        out = ns.vc_infer_pipeline.vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub,
+                                             input_audio=(audio, 16000), config=cfg, **args)
+    assert out is not None, "reference vc_single swallowed an exception"
+    return out[0], out[1], captured, tape.shapes
+
+
+def gen_pipeline(ns):
+    hub, vcd = build_models(ns, S.CONFIG_40K_V2, "v2")
+    # warm the lazy RMVPE constructor (it consumes global RNG; irrelevant with the patched randn_like)
+    audio = S.synth_audio(2.0, seed=7)
+    i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=99)
+    np.savez_compressed(os.path.join(OUT, "pipeline_2s_rmvpe.npz"), audio=audio, out_i16=i16, sr=np.int64(sr),
+                        pitch=cap["pitch"], pitchf=cap["pitchf"], noise_seed=np.int64(99))
+    print("pipeline_2s_rmvpe", i16.shape, sr, shapes, "voiced", (cap["pitchf"] > 0).mean())
+
+    # designed f0 + autotune + transposition + protect<0.5 + rms mix (all host-side branches)
+    def dz(x):
+        n = x.shape[0] // 160 + 1
+        return S.designed_f0(n, seed=0).astype(np.float64)
+
+    i16b, srb, capb, _ = run_ref_pipeline(ns, hub, vcd, audio, seed=100, designed_f0=dz, f0_method="pm",
+                                          f0_up_key=3, f0_autotune=True, protect=0.2, rms_mix_rate=0.5)
+    np.savez_compressed(os.path.join(OUT, "pipeline_2s_designed.npz"), audio=audio, out_i16=i16b, sr=np.int64(srb),
+                        pitch=capb["pitch"], pitchf=capb["pitchf"], noise_seed=np.int64(100))
+    print("pipeline_2s_designed", i16b.shape)
+
+    # segmentation: short constants so a 7 s clip is cut into 3 segments (x_pad 1, x_query 1, x_center 2, x_max 3)
+    cfg = Cfg(1, 1, 2, 3)
+    audio7 = S.synth_audio(7.0, seed=8)
+    i16c, src, capc, shapes = run_ref_pipeline(ns, hub, vcd, audio7, seed=101, cfg=cfg, designed_f0=dz, f0_method="pm",
+                                               rms_mix_rate=1.0, protect=0.5)
+    np.savez_compressed(os.path.join(OUT, "pipeline_7s_segmented.npz"), audio=audio7, out_i16=i16c, sr=np.int64(src),
+                        pitchf=capc["pitchf"], noise_seed=np.int64(101), n_segments=np.int64(len(shapes) // 2),
+                        seg_T=np.array([s[2] for s in shapes[0::2]], dtype=np.int64))
+    print("pipeline_7s_segmented", i16c.shape, "segments", len(shapes) // 2, shapes)
+
+
+def gen_hostdsp(ns):
+    from scipy import signal
+    audio = S.synth_audio(3.0, seed=9).astype(np.float32)
+    filt = signal.filtfilt(ns.vc_infer_pipeline.bh, ns.vc_infer_pipeline.ah, audio)
+    rng = np.random.default_rng(5)
+    f0 = np.concatenate([np.zeros(5), rng.uniform(40, 1700, 200), [50.0, 1600.0, 49.9, 1601.0, 0.0]])
+    fe = ns.pitch_extraction.FeatureExtractor(40000, Cfg())
+    fe.f0_method_dict["pm"] = lambda **k: f0.copy()
+    res = {}
+    for key, tune in ((0, False), (-5, False), (7, True)):
+        c, f = fe.get_f0(np.zeros(16000), key, "pm", f0_autotune=tune, f0_min=50, f0_max=1600)
+        res[f"coarse_k{key}_a{int(tune)}"] = np.array(c)
+        res[f"f0_k{key}_a{int(tune)}"] = np.array(f)
+    d1 = S.synth_audio(2.0, seed=1).astype(np.float64)
+    d2 = (rng.standard_normal(80000) * 0.1).astype(np.float32)
+    mixed = ns.model_utils.change_rms(d1, 16000, d2.copy(), 40000, 0.25)
+    st = np.stack([audio[:16000], audio[16000:32000] * 4.0])
+    rem, _ = ns.audio.remix_audio((st, 16000), target_sr=16000)
+    np.savez_compressed(os.path.join(OUT, "hostdsp.npz"), audio=audio, filtfilt=filt, f0_in=f0, rms_d1=d1, rms_d2=d2,
+                        rms_out=mixed, remix_in=st, remix_out=rem, **res)
+    print("hostdsp ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_shim.load_reference()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["hostdsp", "hubert", "rmvpe", "synth", "pipeline"]
+    if "hostdsp" in which:
+        gen_hostdsp(ns)
+    if "hubert" in which:
+        gen_hubert(ns)
+    if "rmvpe" in which:
+        gen_rmvpe(ns)
+    if "synth" in which:
+        gen_synth(ns, S.CONFIG_40K_V2, "v2", "40k_v2", T=16, full_taps=True)
+        gen_synth(ns, S.CONFIG_48K_V2, "v2", "48k_v2", T=12)
+        gen_synth(ns, S.CONFIG_40K_V1, "v1", "40k_v1", T=12)
+    if "pipeline" in which:
+        gen_pipeline(ns)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""CPU: pins the oracle (oracle/nets.py, oracle/pipeline.py) against golden vectors captured from the real
+reference (oracle/gen_golden.py).  These are the 'oracle vs reference' half of the parity chain; the
+'-m gpu' tests then compare the HIP path with the oracle."""
+import numpy as np
+import torch
+
+from conftest import golden, rel_err
+from comfy_rvc_amd import synthetic as S
+from oracle import nets, pipeline as opl
+
+
+def test_hostdsp_filtfilt_coarse_rms_remix():
+    from scipy import signal
+    g = golden("hostdsp.npz")
+    assert np.array_equal(signal.filtfilt(opl.BH, opl.AH, g["audio"]), g["filtfilt"])
+    for key, tune in ((0, False), (-5, False), (7, True)):
+        c, f = opl.f0_postprocess(g["f0_in"], key, tune)
+        assert np.array_equal(c, g[f"coarse_k{key}_a{int(tune)}"])
+        assert np.allclose(f, g[f"f0_k{key}_a{int(tune)}"], rtol=1e-12, atol=0)
+    out = opl.change_rms(g["rms_d1"], 16000, g["rms_d2"].copy(), 40000, 0.25)
+    assert rel_err(out, g["rms_out"]) < 1e-6
+    rem, _ = opl.remix_audio(g["remix_in"], 16000)
+    assert np.array_equal(rem, g["remix_out"])
+
+
+def test_hubert_oracle_matches_reference():
+    g = golden("hubert_1s.npz")
+    sd = S.hubert_state_dict(0)
+    taps = {}
+    v2 = nets.hubert_extract_features(sd, g["audio"], "v2", taps)
+    v1 = nets.hubert_extract_features(sd, g["audio"], "v1")
+    assert rel_err(taps["conv_stack"], g["conv_stack"]) < 1e-6
+    assert rel_err(taps["pos_conv"], g["pos_conv"]) < 1e-5
+    assert rel_err(taps["hidden_0"], g["hidden_0"]) < 1e-5
+    assert rel_err(taps["hidden_8"], g["hidden_8"]) < 1e-5
+    assert rel_err(v2, g["out_v2"]) < 1e-5
+    assert rel_err(v1, g["out_v1"]) < 1e-5
+
+
+def test_rmvpe_oracle_matches_reference():
+    g = golden("rmvpe_1s.npz")
+    sd = S.rmvpe_state_dict(0)
+    taps = {}
+    f0 = nets.rmvpe_infer_from_audio(sd, g["audio"], taps=taps)
+    assert rel_err(taps["mel"], g["mel"]) < 1e-6
+    assert np.max(np.abs(taps["salience"] - g["salience"])) < 2e-5
+    assert np.allclose(f0, g["f0"], rtol=1e-4)
+    assert np.allclose(np.clip(f0, 50, 1600), g["f0_plus"], rtol=1e-4)
+    assert np.array_equal(nets.rmvpe_decode(g["syn_salience"]), g["syn_f0"])
+
+
+def _synth_case(name, config, version):
+    g = golden(name)
+    sd = S.synth_state_dict(config, version, 0)
+    taps = {}
+    wav = nets.synth_infer(sd, config, g["phone"], g["pitch"], g["pitchf"], int(g["sid"]), g["noise_z"], g["noise_src"], taps)
+    return g, taps, wav
+
+
+def test_synth_40k_v2_oracle_matches_reference(noise_tape):
+    g, taps, wav = _synth_case("synth_40k_v2.npz", S.CONFIG_40K_V2, "v2")
+    tape = noise_tape(g["noise_seed"])
+    assert np.array_equal(tape(g["noise_z"].shape).numpy(), g["noise_z"])
+    assert np.array_equal(tape(g["noise_src"].shape).numpy(), g["noise_src"])
+    for k in ("m_p", "logs_p", "z_p", "z", "har_source", "enc_p_layer0"):
+        assert rel_err(taps[k], g[k]) < 2e-5, k
+    assert rel_err(wav, g["wav"]) < 1e-4
+
+
+def test_synth_48k_v2_and_v1_oracle_match_reference():
+    for name, cfg, ver in (("synth_48k_v2.npz", S.CONFIG_48K_V2, "v2"), ("synth_40k_v1.npz", S.CONFIG_40K_V1, "v1")):
+        g, taps, wav = _synth_case(name, cfg, ver)
+        assert rel_err(taps["z"], g["z"]) < 2e-5
+        assert rel_err(wav, g["wav"]) < 1e-4, name
+
+
+def _run_pipeline(gname, noise_tape, **kw):
+    g = golden(gname)
+    tape = noise_tape(g["noise_seed"])
+    out = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0),
+                       S.CONFIG_40K_V2, "v2", g["audio"], noise_fn=tape, **kw)
+    return g, out
+
+
+def test_pipeline_rmvpe_2s_oracle_matches_reference(noise_tape):
+    g, out = _run_pipeline("pipeline_2s_rmvpe.npz", noise_tape)
+    assert out.shape == g["out_i16"].shape and out.dtype == np.int16
+    assert np.max(np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))) <= 33   # 1e-3 * 32768
+
+
+def test_pipeline_designed_f0_branches_oracle_matches_reference(noise_tape):
+    dz = lambda x: S.designed_f0(x.shape[0] // 160 + 1, seed=0).astype(np.float64)
+    g, out = _run_pipeline("pipeline_2s_designed.npz", noise_tape, f0_override=dz, f0_up_key=3, f0_autotune=True,
+                           protect=0.2, rms_mix_rate=0.5)
+    assert np.max(np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))) <= 33
+
+
+def test_pipeline_segmentation_oracle_matches_reference(noise_tape):
+    dz = lambda x: S.designed_f0(x.shape[0] // 160 + 1, seed=0).astype(np.float64)
+    g, out = _run_pipeline("pipeline_7s_segmented.npz", noise_tape, f0_override=dz, rms_mix_rate=1.0, protect=0.5,
+                           x_pad=1, x_query=1, x_center=2, x_max=3)
+    assert int(g["n_segments"]) == 4
+    assert out.shape == g["out_i16"].shape
+    assert np.max(np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))) <= 33
