@@ -1,0 +1,515 @@
+// fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// One kernel family serves every dense contraction on the RVC inference path:
+//   * Conv1d (dilated / strided / grouped), ConvTranspose1d (polyphase rows), Linear (k = 1)
+//   * batched A^T.B products for attention (activation tensor as the "weight" operand)
+//   * Conv2d 3x3 pad 1 and ConvTranspose2d k3 s2 (2x2 phases) for the RMVPE U-Net
+// Layout: activations are channel-major [C][T] (time contiguous) == the reference's NCL / NCHW.
+//
+// GEMM view:  Y[m][n] = sum_kk Wp[kk][m] * Xtile[kk][n],  m = output row, n = output position,
+//             kk = (chunk, tap, virtual channel).  Virtual channel = (ci, phase) where phase is the
+//             input position modulo the stride, so that the MFMA loop only ever sees unit-stride
+//             rows in LDS (im2col-free: the input tile with its halo is staged once per chunk).
+// MFMA 32x32x2 f32: A = Wp[kk][m] (lane i = m, lane half = kk parity), B = Xs[kk][n] (lane i = n);
+// both are single conflict-free ds_read_b32 per operand; fp32 accumulate, bitwise an fmaf chain.
+// Workgroup = 4 waves (WM x WN), each wave owns AM x AN accumulators of 32x32.
+#include "rvc_internal.h"
+
+namespace rvc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgsX : ConvArgs {
+  long long ldW;   // pitch (floats) of one packed-weight row
+  int Wcols;       // valid columns in a weight row
+  int Wrows;       // valid rows of the weight matrix
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_LOGCLAMP: return logf(fmaxf(v, slope));
+    default: return v;
+  }
+}
+
+template <int WM, int WN, int AM, int AN, int MODE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CK = p.CK, WROW = p.WROW;
+  float* Xs = smem;
+  float* Ws = smem + ((CK * WROW + 3) & ~3);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int z = blockIdx.z;
+  const int co0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+
+  const float* __restrict__ X = p.X + (long long)z * p.xBatch;
+  const float* __restrict__ W = p.W + (long long)z * p.wBatch;
+
+  // tile origin
+  int h0 = 0, w0 = 0;
+  if (MODE == 2) { h0 = n0 / p.Wd; w0 = n0 % p.Wd; }
+
+  int bb[AN];
+#pragma unroll
+  for (int an = 0; an < AN; ++an) {
+    const int nl = (wn * AN + an) * 32 + li;
+    bb[an] = (MODE == 2) ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl;
+  }
+
+  f32x16 acc[AM][AN];
+#pragma unroll
+  for (int am = 0; am < AM; ++am)
+#pragma unroll
+    for (int an = 0; an < AN; ++an)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+
+  const int ntb = (p.ktaps + p.KT - 1) / p.KT;
+  const bool wvec = ((p.ldW & 3) == 0) && ((p.Wcols & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+
+  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    for (int tb = 0; tb < ntb; ++tb) {
+      __syncthreads();
+      if (tb == 0) {
+        // ---------------------------------------------------------------- stage the input tile (+halo)
+        if (MODE == 1) {
+          if (p.stride == 1) {
+            const int used = BN + (p.ktaps - 1) * p.dil;
+            const int bx = n0 - p.pad;
+            for (int vcc = wave; vcc < CK; vcc += 4) {
+              const int ci = chunk * CK + vcc;
+              const float* src = X + (long long)ci * p.ldX;
+              float* dst = Xs + vcc * WROW;
+              const bool cok = ci < p.Ci;
+              for (int q = lane; q < used; q += 64) {
+                const int x = bx + q;
+                float v = 0.f;
+                if (cok && x >= 0 && x < p.Tin) v = src[x];
+                if (p.pre_act) v = apply_act(v, p.pre_act, p.pre_slope);
+                dst[q] = v;
+              }
+            }
+          } else {
+            const int s = p.stride;
+            const int used = BN + (p.ktaps - 1);
+            const int span = used * s;
+            const int bx = n0 * s - p.pad;
+            const int cpc = CK / s;   // whole input channels per chunk
+            for (int cl = wave; cl < cpc; cl += 4) {
+              const int ci = chunk * cpc + cl;
+              const float* src = X + (long long)ci * p.ldX;
+              const bool cok = ci < p.Ci;
+              for (int e = lane; e < span; e += 64) {
+                const int x = bx + e;
+                const int q = e / s, r = e - q * s;
+                float v = 0.f;
+                if (cok && x >= 0 && x < p.Tin) v = src[x];
+                if (p.pre_act) v = apply_act(v, p.pre_act, p.pre_slope);
+                Xs[(cl * s + r) * WROW + q] = v;
+              }
+            }
+          }
+        } else {
+          const int RH = p.BH + 2, PW = p.PW;
+          for (int vcc = wave; vcc < CK; vcc += 4) {
+            const int ci = chunk * CK + vcc;
+            const float* src = X + (long long)ci * p.ldX;
+            float* dst = Xs + vcc * WROW;
+            const bool cok = ci < p.Ci;
+            if (PW >= 34) {
+              for (int rr = 0; rr < RH; ++rr) {
+                const int hh = h0 - 1 + rr;
+                const bool hok = cok && hh >= 0 && hh < p.Tin;
+                for (int cc = lane; cc < PW; cc += 64) {
+                  const int ww = w0 - 1 + cc;
+                  float v = 0.f;
+                  if (hok && ww >= 0 && ww < p.Wd) v = src[(long long)hh * p.Wd + ww];
+                  dst[rr * PW + cc] = v;
+                }
+              }
+            } else {
+              for (int e = lane; e < RH * PW; e += 64) {
+                const int rr = e / PW, cc = e - rr * PW;
+                const int hh = h0 - 1 + rr, ww = w0 - 1 + cc;
+                float v = 0.f;
+                if (cok && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd) v = src[(long long)hh * p.Wd + ww];
+                dst[e] = v;
+              }
+            }
+          }
+        }
+      }
+      // ------------------------------------------------------------------ stage the weight slab
+      const int ut = min(p.KT, p.ktaps - tb * p.KT);
+      {
+        const int rows = ut * CK;
+        const long long row0 = ((long long)chunk * p.ktaps + (long long)tb * p.KT) * CK;
+        if (wvec) {
+          constexpr int V4 = BM / 4;
+          for (int e = tid; e < rows * V4; e += 256) {
+            const int rr = e / V4, c4 = (e - rr * V4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + rr < p.Wrows && co0 + c4 < p.Wcols)
+              v = *reinterpret_cast<const float4*>(W + (row0 + rr) * p.ldW + co0 + c4);
+            *reinterpret_cast<float4*>(Ws + rr * BM + c4) = v;
+          }
+        } else {
+          for (int e = tid; e < rows * BM; e += 256) {
+            const int rr = e / BM, c = e - rr * BM;
+            float v = 0.f;
+            if (row0 + rr < p.Wrows && co0 + c < p.Wcols) v = W[(row0 + rr) * p.ldW + co0 + c];
+            Ws[rr * BM + c] = v;
+          }
+        }
+      }
+      __syncthreads();
+      // ------------------------------------------------------------------ MFMA
+      for (int uu = 0; uu < ut; ++uu) {
+        const int u = tb * p.KT + uu;
+        int toff;
+        if (MODE == 2) toff = (u / 3) * p.PW + (u % 3);
+        else toff = u * p.dil;
+        const float* wrow = Ws + (uu * CK + lh) * BM + wm * AM * 32 + li;
+        const float* xrow = Xs + lh * WROW + toff;
+#pragma unroll 2
+        for (int m = 0; m < CK / 2; ++m) {
+          float a[AM], b[AN];
+#pragma unroll
+          for (int am = 0; am < AM; ++am) a[am] = wrow[2 * m * BM + am * 32];
+#pragma unroll
+          for (int an = 0; an < AN; ++an) b[an] = xrow[2 * m * WROW + bb[an]];
+#pragma unroll
+          for (int am = 0; am < AM; ++am)
+#pragma unroll
+            for (int an = 0; an < AN; ++an)
+              acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[am], b[an], acc[am][an], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // -------------------------------------------------------------------------- epilogue
+  const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
+  const float* __restrict__ R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
+  float* __restrict__ Y = p.Y + (long long)z * p.yBatch;
+#pragma unroll
+  for (int am = 0; am < AM; ++am) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.Co) continue;
+      const int co = m % p.orows, ph = m / p.orows;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        if (n >= p.Tout) continue;
+        float v = acc[am][an][r] + bv;
+        long long oidx;
+        if (MODE == 2) {
+          if (p.up2) {
+            const int hh = n / p.Wd, ww = n - hh * p.Wd;
+            oidx = (long long)co * p.ldY + (long long)(2 * hh + (ph >> 1)) * (2 * p.Wd) + 2 * ww + (ph & 1);
+          } else {
+            oidx = (long long)co * p.ldY + n;
+          }
+        } else {
+          if (p.ostride == 1) oidx = (long long)co * p.ldY + n;
+          else {
+            const long long to = (long long)n * p.ostride + ph;
+            if (to >= p.ldY) continue;   // ldY doubles as the true output length for interleaved stores
+            oidx = (long long)co * p.ldY + to;
+          }
+        }
+        if (p.act_before_res) {
+          v = apply_act(v, p.act, p.act_slope);
+          if (R) v += R[(long long)co * p.ldR + n];
+        } else {
+          if (R) v += R[(long long)co * p.ldR + n];
+          v = apply_act(v, p.act, p.act_slope);
+        }
+        v *= p.out_scale;
+        if (p.accumulate) v += Y[oidx];
+        Y[oidx] = v;
+      }
+    }
+  }
+}
+
+// ============================================================================ host side
+float* dev_upload(const float* host, size_t n) {
+  float* d = nullptr;
+  RVC_HIP_CHECK(hipMalloc(&d, (n ? n : 1) * sizeof(float)));
+  if (n) RVC_HIP_CHECK(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+
+void Arena::ensure(size_t bytes) {
+  if (bytes <= cap) return;
+  if (base) { RVC_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(base); base = nullptr; cap = 0; }
+  size_t want = bytes + bytes / 8 + (1 << 20);
+  RVC_HIP_CHECK(hipMalloc(&base, want));
+  cap = want;
+}
+void Arena::release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+
+static int pick_ck(int V, int ktaps, int stride) {
+  int ck = ktaps >= 4 ? 8 : (ktaps >= 2 ? 16 : 32);
+  if (stride > 1) { ck = ((ck + stride - 1) / stride) * stride; if (ck & 1) ck *= 2; }
+  if (V < ck) { ck = stride > 1 ? ((V + stride - 1) / stride) * stride : V; if (ck & 1) ck += (stride > 1 ? stride : 1); if (ck < 2) ck = 2; }
+  return ck;
+}
+
+static void upload_layer(ConvLayer& L, const std::vector<float>& packed, const float* bias, int nbias) {
+  L.Wd_ = dev_upload(packed.data(), packed.size());
+  L.bd_ = bias ? dev_upload(bias, nbias) : nullptr;
+}
+
+void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); L.Wd_ = L.bd_ = nullptr; }
+
+void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci, int k, int stride, int pad,
+                       int dil, int groups) {
+  RVC_REQUIRE(Co % groups == 0 && Ci % groups == 0, "groups must divide channels");
+  RVC_REQUIRE(stride == 1 || dil == 1, "strided convs must have dilation 1");
+  const int Cog = Co / groups, Cig = Ci / groups;
+  L.mode = 1; L.groups = groups; L.Ci = Cig; L.Co = Cog; L.co_real = Cog; L.CoP = (Cog + 31) & ~31;
+  L.k = k; L.stride = stride; L.dil = dil; L.pad = pad; L.tconv_u = 0; L.up2 = 0;
+  L.ktaps = (k + stride - 1) / stride;
+  const int V = Cig * stride;
+  L.CK = pick_ck(V, L.ktaps, stride);
+  L.nchunk = (V + L.CK - 1) / L.CK;
+  L.wBatch = (long long)L.nchunk * L.ktaps * L.CK * L.CoP;
+  std::vector<float> P((size_t)groups * L.wBatch, 0.f);
+  for (int g = 0; g < groups; ++g)
+    for (int co = 0; co < Cog; ++co)
+      for (int ci = 0; ci < Cig; ++ci)
+        for (int tap = 0; tap < k; ++tap) {
+          const int u = tap / stride, r = tap % stride;
+          const int vc = ci * stride + r;
+          const int chunk = vc / L.CK, vcc = vc % L.CK;
+          P[(size_t)g * L.wBatch + (((size_t)chunk * L.ktaps + u) * L.CK + vcc) * L.CoP + co] =
+              w[((size_t)(g * Cog + co) * Cig + ci) * k + tap];
+        }
+  upload_layer(L, P, bias, Co);
+}
+
+void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci, int Co, int k, int u, int pad) {
+  const int E2 = (k - 1 - pad) / u, E1 = (u - 1 + pad) / u;
+  L.mode = 1; L.groups = 1; L.Ci = Ci; L.co_real = Co; L.Co = u * Co; L.CoP = (L.Co + 31) & ~31;
+  L.k = E1 + E2 + 1; L.stride = 1; L.dil = 1; L.pad = E2; L.tconv_u = u; L.up2 = 0;
+  L.ktaps = L.k;
+  L.CK = pick_ck(Ci, L.ktaps, 1);
+  L.nchunk = (Ci + L.CK - 1) / L.CK;
+  L.wBatch = (long long)L.nchunk * L.ktaps * L.CK * L.CoP;
+  std::vector<float> P((size_t)L.wBatch, 0.f);
+  for (int r = 0; r < u; ++r)
+    for (int co = 0; co < Co; ++co)
+      for (int ci = 0; ci < Ci; ++ci)
+        for (int j = 0; j < L.ktaps; ++j) {
+          const int e = E2 - j;
+          const int kk = e * u + r + pad;
+          if (kk < 0 || kk >= k) continue;
+          const int chunk = ci / L.CK, vcc = ci % L.CK;
+          P[(((size_t)chunk * L.ktaps + j) * L.CK + vcc) * L.CoP + (size_t)r * Co + co] = w[((size_t)ci * Co + co) * k + kk];
+        }
+  // remember the true transposed-conv geometry for the output length
+  L.k = k; L.pad = pad;
+  L.dil = 1;
+  L.conv_pad = E2;
+  upload_layer(L, P, bias, Co);
+}
+
+void conv2d3x3_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci) {
+  L.mode = 2; L.groups = 1; L.Ci = Ci; L.Co = Co; L.co_real = Co; L.CoP = (Co + 31) & ~31;
+  L.k = 3; L.stride = 1; L.dil = 1; L.pad = 1; L.tconv_u = 0; L.up2 = 0; L.ktaps = 9;
+  L.CK = pick_ck(Ci, 9, 1);
+  L.nchunk = (Ci + L.CK - 1) / L.CK;
+  L.wBatch = (long long)L.nchunk * 9 * L.CK * L.CoP;
+  std::vector<float> P((size_t)L.wBatch, 0.f);
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int u = 0; u < 9; ++u) {
+        const int chunk = ci / L.CK, vcc = ci % L.CK;
+        P[(((size_t)chunk * 9 + u) * L.CK + vcc) * L.CoP + co] = w[((size_t)co * Ci + ci) * 9 + u];
+      }
+  upload_layer(L, P, bias, Co);
+}
+
+void conv2d1x1_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci) {
+  conv1d_layer_init(L, w, bias, Co, Ci, 1, 1, 0, 1, 1);
+}
+
+void tconv2d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci, int Co) {
+  // ConvTranspose2d(k=3, stride=2, padding=1, output_padding=1): out[2h+a][2w+b] uses x[h+dh][w+dw], dh,dw in {0,1},
+  // with kernel index kh = a + 1 - 2*dh (valid iff 0 <= kh <= 2).  Stated as a 3x3 conv whose taps (dh+1, dw+1) carry
+  // the weights and all other taps are zero, with 4*Co phase-major output rows.
+  L.mode = 2; L.groups = 1; L.Ci = Ci; L.co_real = Co; L.Co = 4 * Co; L.CoP = (L.Co + 31) & ~31;
+  L.k = 3; L.stride = 1; L.dil = 1; L.pad = 1; L.tconv_u = 0; L.up2 = 1; L.ktaps = 9;
+  L.CK = pick_ck(Ci, 9, 1);
+  L.nchunk = (Ci + L.CK - 1) / L.CK;
+  L.wBatch = (long long)L.nchunk * 9 * L.CK * L.CoP;
+  std::vector<float> P((size_t)L.wBatch, 0.f);
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci)
+          for (int dh = 0; dh < 2; ++dh)
+            for (int dw = 0; dw < 2; ++dw) {
+              const int kh = a + 1 - 2 * dh, kw = b + 1 - 2 * dw;
+              if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+              const int u = (dh + 1) * 3 + (dw + 1);
+              const int chunk = ci / L.CK, vcc = ci % L.CK;
+              P[(((size_t)chunk * 9 + u) * L.CK + vcc) * L.CoP + (size_t)(a * 2 + b) * Co + co] =
+                  w[(((size_t)ci * Co + co) * 3 + kh) * 3 + kw];
+            }
+  upload_layer(L, P, bias, Co);
+}
+
+// ---------------------------------------------------------------------------- launch
+struct TileCfg { int WM, WN, AM, AN; };
+
+template <int WM, int WN, int AM, int AN, int MODE>
+static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_mfma_kernel<WM, WN, AM, AN, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
+
+static TileCfg choose_tile(int M, long long N, int batch, int mode, int Wd) {
+  // candidates ordered by preference for large problems; pick the first that yields enough workgroups
+  const int Mp = (M + 31) / 32 * 32;
+  TileCfg best{2, 2, 1, 1};
+  if (Mp <= 32) {
+    if (N * batch >= 512LL * 512) return TileCfg{1, 4, 1, 4};
+    if (N * batch >= 256LL * 384) return TileCfg{1, 4, 1, 2};
+    return TileCfg{1, 4, 1, 1};
+  }
+  auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+  if (Mp >= 128 && blocks(128, 128) >= 384) return TileCfg{2, 2, 2, 2};
+  if (Mp <= 64 && blocks(64, 256) >= 384) return TileCfg{2, 2, 1, 4};
+  if (blocks(64, 128) >= 384) return TileCfg{2, 2, 1, 2};
+  (void)mode; (void)Wd;
+  return best;   // 64 x 64
+}
+
+static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s) {
+  TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
+  int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
+  if (mode == 2) {
+    // tile must be whole rows or a power-of-two fraction of a row
+    a.BWd = BN < a.Wd ? BN : a.Wd;
+    a.BH = BN < a.Wd ? 1 : BN / a.Wd;
+    a.PW = a.BWd + 2;
+    a.WROW = (a.BH + 2) * a.PW;
+    if ((a.WROW & 1) == 0) a.WROW += 1;
+  } else {
+    const int used = BN + (a.ktaps - 1) * (a.stride == 1 ? a.dil : 1);
+    a.WROW = used | 1;
+  }
+  // taps per weight stage: keep the slab <= 48 KB
+  int kt = a.ktaps;
+  const int maxrows = (48 * 1024 / 4) / BM;
+  if (kt * a.CK > maxrows) kt = maxrows / a.CK > 0 ? maxrows / a.CK : 1;
+  a.KT = kt;
+  const size_t lds = ((size_t)((a.CK * a.WROW + 3) & ~3) + (size_t)a.KT * a.CK * BM) * sizeof(float);
+  RVC_REQUIRE(lds <= 160 * 1024, "conv tile does not fit LDS");
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)batch);
+#define RVC_LAUNCH(WM_, WN_, AM_, AN_)                                                          \
+  if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \
+    if (mode == 2) launch_cfg<WM_, WN_, AM_, AN_, 2>(a, grid, lds, s);                          \
+    else launch_cfg<WM_, WN_, AM_, AN_, 1>(a, grid, lds, s);                                    \
+    return;                                                                                     \
+  }
+  RVC_LAUNCH(1, 4, 1, 4)
+  RVC_LAUNCH(1, 4, 1, 2)
+  RVC_LAUNCH(1, 4, 1, 1)
+  RVC_LAUNCH(2, 2, 2, 2)
+  RVC_LAUNCH(2, 2, 1, 4)
+  RVC_LAUNCH(2, 2, 1, 2)
+  RVC_LAUNCH(2, 2, 1, 1)
+#undef RVC_LAUNCH
+  throw Error("no tile configuration matched");
+}
+
+static void fill_epilogue(ConvArgsX& a, const ConvEpilogue& e) {
+  a.R = e.R; a.ldR = e.ldR; a.pre_act = e.pre_act; a.pre_slope = e.pre_slope; a.act = e.act; a.act_slope = e.act_slope;
+  a.act_before_res = e.act_before_res; a.out_scale = e.out_scale; a.accumulate = e.accumulate;
+}
+
+int conv1d_out_len(const ConvLayer& L, int Tin) {
+  if (L.tconv_u > 0) return (Tin - 1) * L.tconv_u - 2 * L.pad + L.k;
+  return (Tin + 2 * L.pad - L.dil * (L.k - 1) - 1) / L.stride + 1;
+}
+
+void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int Tin, float* Y, long long ldY,
+                const ConvEpilogue& e) {
+  RVC_REQUIRE(L.mode == 1 && L.Wd_, "conv1d_run on an uninitialised / non-1D layer");
+  ConvArgsX a{};
+  a.X = X; a.W = L.Wd_; a.bias = L.bd_; a.Y = Y;
+  fill_epilogue(a, e);
+  a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = Tin; a.Wd = 0; a.ktaps = L.ktaps; a.dil = L.dil; a.stride = L.stride;
+  a.CK = L.CK; a.nchunk = L.nchunk;
+  a.ldX = ldX; a.ldY = ldY; a.up2 = 0;
+  a.ldW = L.CoP; a.Wcols = L.CoP; a.Wrows = L.nchunk * L.ktaps * L.CK;
+  if (e.bias_override) a.bias = e.bias_override;
+  int Tout = conv1d_out_len(L, Tin);
+  if (e.tout_limit > 0 && e.tout_limit < Tout) { RVC_REQUIRE(L.tconv_u == 0, "tout_limit on a transposed conv"); Tout = e.tout_limit; }
+  if (L.tconv_u > 0) {
+    a.pad = L.conv_pad;                             // left pad of the equivalent stride-1 conv
+    a.Tout = (Tout + L.tconv_u - 1) / L.tconv_u;    // GEMM positions q
+    a.ostride = L.tconv_u; a.orows = L.co_real;
+    RVC_REQUIRE(ldY == Tout, "interleaved ConvTranspose1d store needs a dense output (ldY == Tout)");
+    RVC_REQUIRE(e.R == nullptr, "residual not supported on the interleaved store");
+  } else {
+    a.pad = L.pad; a.Tout = Tout; a.ostride = 1; a.orows = L.Co;
+  }
+  a.xBatch = (long long)L.Ci * ldX; a.wBatch = L.wBatch; a.yBatch = (long long)L.Co * ldY; a.rBatch = (long long)L.Co * e.ldR;
+  a.bBatch = L.Co;
+  run_conv(a, 1, L.groups, s);
+}
+
+void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch, const float* B, long long ldB, long long bBatch,
+                 float* Y, long long ldY, long long yBatch, int M, int N, int K, int batch, const float* bias, int biasBatch,
+                 const ConvEpilogue& e) {
+  ConvArgsX a{};
+  a.X = B; a.W = A; a.bias = bias; a.Y = Y;
+  fill_epilogue(a, e);
+  a.Ci = K; a.Co = M; a.CoP = M; a.Tin = N; a.Tout = N; a.Wd = 0; a.ktaps = 1; a.dil = 1; a.stride = 1; a.pad = 0;
+  a.CK = K >= 32 ? 32 : ((K + 1) & ~1); a.nchunk = (K + a.CK - 1) / a.CK;
+  a.ldX = ldB; a.ldY = ldY; a.up2 = 0; a.ostride = 1; a.orows = M;
+  a.ldW = ldA; a.Wcols = M; a.Wrows = K;
+  a.xBatch = bBatch; a.wBatch = aBatch; a.yBatch = yBatch; a.rBatch = 0; a.bBatch = biasBatch;
+  run_conv(a, 1, batch, s);
+}
+
+void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
+                const ConvEpilogue& e) {
+  RVC_REQUIRE(L.mode == 2 && L.Wd_, "conv2d_run on an uninitialised / non-2D layer");
+  RVC_REQUIRE((Wd & (Wd - 1)) == 0 && Wd >= 2, "width must be a power of two");
+  ConvArgsX a{};
+  a.X = X; a.W = L.Wd_; a.bias = L.bd_; a.Y = Y;
+  fill_epilogue(a, e);
+  a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = H; a.Tout = H * Wd; a.Wd = Wd; a.ktaps = 9; a.dil = 1; a.stride = 1; a.pad = 1;
+  a.CK = L.CK; a.nchunk = L.nchunk;
+  a.ldX = ldX; a.ldY = ldY; a.up2 = L.up2; a.ostride = 1; a.orows = L.up2 ? L.co_real : L.Co;
+  a.ldW = L.CoP; a.Wcols = L.CoP; a.Wrows = L.nchunk * 9 * L.CK;
+  a.xBatch = 0; a.wBatch = 0; a.yBatch = 0; a.rBatch = 0; a.bBatch = 0;
+  run_conv(a, 2, 1, s);
+}
+
+}  // namespace rvc

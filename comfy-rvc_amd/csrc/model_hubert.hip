@@ -1,0 +1,207 @@
+// HubertModelWithFinalProj.extract_features as a HIP kernel graph (reference lib/infer_pack/loaders.py:55-61 over
+// transformers/models/hubert/modeling_hubert.py:45-477,878-955): 7-layer conv feature encoder (GroupNorm on layer 0),
+// LayerNorm + projection, grouped k=128 positional conv, post-LN transformer layers.  Channel-major [C][T] throughout.
+#include "model_common.h"
+#include "models.h"
+
+namespace rvc {
+
+struct HubLayer {
+  ConvLayer qk;        // fused q (pre-scaled by head_dim^-0.5) and k projections: 768 -> 1536
+  DevVec wvT, bv;      // v projection as [in][out]; bias added after P.V (softmax rows sum to 1)
+  ConvLayer o, ff1, ff2;
+  DevVec g1, b1, g2, b2;
+};
+
+struct Hubert {
+  Ctx* ctx = nullptr;
+  Arena arena;
+  TensorStore ts;
+  bool ready = false;
+  ConvLayer conv[7];
+  DevVec gn_g, gn_b, fp_g, fp_b, enc_g, enc_b;
+  ConvLayer proj, pos, final_proj;
+  std::vector<HubLayer> layers;
+};
+
+static const int kKern[7] = {10, 3, 3, 3, 3, 2, 2};
+static const int kStride[7] = {5, 2, 2, 2, 2, 2, 2};
+
+long long hubert_num_frames(long long L) {
+  long long t = L;
+  for (int i = 0; i < 7; ++i) { if (t < kKern[i]) return 0; t = (t - kKern[i]) / kStride[i] + 1; }
+  return t;
+}
+
+Hubert* hubert_create(Ctx* ctx) { Hubert* H = new Hubert(); H->ctx = ctx; return H; }
+void hubert_set_tensor(Hubert* H, const char* name, const float* d, const long long* shape, int ndim) { H->ts.set(name, d, shape, ndim); }
+
+static void hubert_free(Hubert& H) {
+  for (auto& c : H.conv) conv_layer_free(c);
+  H.gn_g.free_(); H.gn_b.free_(); H.fp_g.free_(); H.fp_b.free_(); H.enc_g.free_(); H.enc_b.free_();
+  conv_layer_free(H.proj); conv_layer_free(H.pos); conv_layer_free(H.final_proj);
+  for (auto& l : H.layers) { conv_layer_free(l.qk); l.wvT.free_(); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
+  H.layers.clear();
+}
+void hubert_destroy(Hubert* H) { if (H) { hubert_free(*H); H->arena.release(); delete H; } }
+
+static void linear_layer(ConvLayer& L, const TensorStore& ts, const std::string& p, int out, int in) {
+  conv1d_layer_init(L, ts.get(p + ".weight", {out, in}).data.data(), ts.get(p + ".bias", {out}).data.data(), out, in, 1, 1, 0, 1, 1);
+}
+
+void hubert_finalize(Hubert* H) {
+  const TensorStore& ts = H->ts;
+  hubert_free(*H);
+  // conv0: Conv1d(1, 512, 10, stride 5) == Linear(10 -> 512) over im2col frames
+  conv1d_layer_init(H->conv[0], ts.get("feature_extractor.conv_layers.0.conv.weight", {512, 1, 10}).data.data(), nullptr, 512, 10, 1, 1, 0, 1, 1);
+  for (int i = 1; i < 7; ++i)
+    conv1d_layer_init(H->conv[i], ts.get("feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight", {512, 512, kKern[i]}).data.data(),
+                      nullptr, 512, 512, kKern[i], kStride[i], 0, 1, 1);
+  H->gn_g.upload(ts.get("feature_extractor.conv_layers.0.layer_norm.weight", {512}).data);
+  H->gn_b.upload(ts.get("feature_extractor.conv_layers.0.layer_norm.bias", {512}).data);
+  H->fp_g.upload(ts.get("feature_projection.layer_norm.weight", {512}).data);
+  H->fp_b.upload(ts.get("feature_projection.layer_norm.bias", {512}).data);
+  linear_layer(H->proj, ts, "feature_projection.projection", 768, 512);
+  {
+    // weight_norm(dim=2): w[:, :, k] = v[:, :, k] * g[k] / ||v[:, :, k]||   (modeling_hubert.py:61-77); both key spellings accepted
+    const bool par = ts.has("encoder.pos_conv_embed.conv.parametrizations.weight.original1");
+    const HostTensor& v = ts.get(par ? "encoder.pos_conv_embed.conv.parametrizations.weight.original1" : "encoder.pos_conv_embed.conv.weight_v", {768, 48, 128});
+    const HostTensor& g = ts.get(par ? "encoder.pos_conv_embed.conv.parametrizations.weight.original0" : "encoder.pos_conv_embed.conv.weight_g", {1, 1, 128});
+    std::vector<float> w(v.numel());
+    for (int k = 0; k < 128; ++k) {
+      double s = 0.0;
+      for (size_t r = 0; r < (size_t)768 * 48; ++r) { const double x = v.data[r * 128 + k]; s += x * x; }
+      const float sc = (float)((double)g.data[k] / std::sqrt(s));
+      for (size_t r = 0; r < (size_t)768 * 48; ++r) w[r * 128 + k] = v.data[r * 128 + k] * sc;
+    }
+    conv1d_layer_init(H->pos, w.data(), ts.get("encoder.pos_conv_embed.conv.bias", {768}).data.data(), 768, 768, 128, 1, 64, 1, 16);
+  }
+  H->enc_g.upload(ts.get("encoder.layer_norm.weight", {768}).data);
+  H->enc_b.upload(ts.get("encoder.layer_norm.bias", {768}).data);
+  int nl = 0;
+  while (ts.has("encoder.layers." + std::to_string(nl) + ".attention.q_proj.weight")) ++nl;
+  RVC_REQUIRE(nl >= 11, "expected at least 11 encoder layers");
+  H->layers.resize(nl);
+  const float qs = 0.125f;   // head_dim^-0.5 = 64^-0.5, exact in fp32
+  for (int l = 0; l < nl; ++l) {
+    HubLayer& Y = H->layers[l];
+    const std::string p = "encoder.layers." + std::to_string(l) + ".";
+    const HostTensor& wq = ts.get(p + "attention.q_proj.weight", {768, 768});
+    const HostTensor& wk = ts.get(p + "attention.k_proj.weight", {768, 768});
+    const HostTensor& bq = ts.get(p + "attention.q_proj.bias", {768});
+    const HostTensor& bk = ts.get(p + "attention.k_proj.bias", {768});
+    std::vector<float> w(2 * (size_t)768 * 768), b(2 * 768);
+    for (size_t i = 0; i < (size_t)768 * 768; ++i) { w[i] = wq.data[i] * qs; w[(size_t)768 * 768 + i] = wk.data[i]; }
+    for (int i = 0; i < 768; ++i) { b[i] = bq.data[i] * qs; b[768 + i] = bk.data[i]; }
+    conv1d_layer_init(Y.qk, w.data(), b.data(), 1536, 768, 1, 1, 0, 1, 1);
+    Y.wvT.upload(transpose2d(ts.get(p + "attention.v_proj.weight", {768, 768}).data.data(), 768, 768));
+    Y.bv.upload(ts.get(p + "attention.v_proj.bias", {768}).data);
+    linear_layer(Y.o, ts, p + "attention.out_proj", 768, 768);
+    linear_layer(Y.ff1, ts, p + "feed_forward.intermediate_dense", 3072, 768);
+    linear_layer(Y.ff2, ts, p + "feed_forward.output_dense", 768, 3072);
+    Y.g1.upload(ts.get(p + "layer_norm.weight", {768}).data); Y.b1.upload(ts.get(p + "layer_norm.bias", {768}).data);
+    Y.g2.upload(ts.get(p + "final_layer_norm.weight", {768}).data); Y.b2.upload(ts.get(p + "final_layer_norm.bias", {768}).data);
+  }
+  linear_layer(H->final_proj, ts, "final_proj", 256, 768);
+  H->ts.clear();
+  H->ready = true;
+}
+
+static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio, long long L, int version, int n_layers, float* out_rm,
+                         float* out_cm, const HubertTaps* taps) {
+  const bool dry = A.dry;
+  auto tap = [&](float* dst, const float* src, size_t n) {
+    if (!dry && dst) RVC_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  };
+  ConvEpilogue E0;
+  int Tc[8]; Tc[0] = (int)L;
+  for (int i = 0; i < 7; ++i) Tc[i + 1] = (Tc[i] - kKern[i]) / kStride[i] + 1;
+  const int T = Tc[7];
+  // ---- feature encoder
+  float* fr = A.alloc<float>((size_t)10 * Tc[1]);
+  float* c0 = A.alloc<float>((size_t)512 * Tc[1]);
+  float* c1 = A.alloc<float>((size_t)512 * Tc[2]);
+  if (!dry) {
+    frames(s, audio, fr, (int)L, 10, 5, 0, Tc[1], 0);
+    conv1d_run(H->conv[0], s, fr, Tc[1], Tc[1], c0, Tc[1], E0);
+    groupnorm_t_gelu(s, c0, H->gn_g.p, H->gn_b.p, 512, Tc[1], Tc[1], 1e-5f);
+  }
+  float* in = c0; float* outb = c1;
+  for (int i = 1; i < 7; ++i) {
+    if (!dry) { ConvEpilogue Eg; Eg.act = ACT_GELU; conv1d_run(H->conv[i], s, in, Tc[i], Tc[i], outb, Tc[i + 1], Eg); }
+    std::swap(in, outb);      // ping-pong inside the two largest buffers (each layer's output is smaller than its input)
+  }
+  float* feat = in;           // [512][T]
+  if (taps) tap(taps->conv_stack, feat, (size_t)512 * T);
+  float* ln = A.alloc<float>((size_t)512 * T);
+  float* h = A.alloc<float>((size_t)768 * T);
+  float* hb = A.alloc<float>((size_t)768 * T);
+  if (!dry) {
+    layernorm_c(s, feat, nullptr, H->fp_g.p, H->fp_b.p, ln, 512, T, T, 1e-5f);
+    conv1d_run(H->proj, s, ln, T, T, h, T, E0);
+    if (taps && taps->pos_conv) { ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.tout_limit = T; conv1d_run(H->pos, s, h, T, T, taps->pos_conv, T, Ep); }
+    ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.act_before_res = 1; Ep.R = h; Ep.ldR = T; Ep.tout_limit = T;
+    conv1d_run(H->pos, s, h, T, T, hb, T, Ep);
+    layernorm_c(s, hb, nullptr, H->enc_g.p, H->enc_b.p, h, 768, T, T, 1e-5f);
+  }
+  int need = version == 1 ? 8 : 11;
+  if (n_layers > 0) need = n_layers;
+  RVC_REQUIRE(need <= (int)H->layers.size(), "not enough encoder layers loaded");
+  {
+    const size_t mark = A.off;
+    float* qk = A.alloc<float>((size_t)1536 * T);
+    float* vr = A.alloc<float>((size_t)T * 768);
+    float* Sc = A.alloc<float>((size_t)12 * T * T);
+    float* attn = A.alloc<float>((size_t)768 * T);
+    float* ff = A.alloc<float>((size_t)3072 * T);
+    if (!dry) {
+      for (int l = 0; l < need; ++l) {
+        HubLayer& Y = H->layers[l];
+        if (taps && l == 0) tap(taps->hidden_0, h, (size_t)768 * T);
+        if (taps && l == 8) tap(taps->hidden_8, h, (size_t)768 * T);
+        conv1d_run(Y.qk, s, h, T, T, qk, T, E0);
+        gemm_tn_run(s, h, T, 0, Y.wvT.p, 768, 0, vr, 768, 0, T, 768, 768, 1, nullptr, 0, E0);
+        gemm_tn_run(s, qk + (size_t)768 * T, T, 64LL * T, qk, T, 64LL * T, Sc, T, (long long)T * T, T, T, 64, 12, nullptr, 0, E0);
+        softmax_cols(s, Sc, T, T, T, (long long)T * T, 12, nullptr, 0, 0, nullptr, 0);
+        gemm_tn_run(s, vr, 768, 64, Sc, T, (long long)T * T, attn, T, 64LL * T, 64, T, T, 12, Y.bv.p, 64, E0);
+        ConvEpilogue Er; Er.R = h; Er.ldR = T;
+        conv1d_run(Y.o, s, attn, T, T, hb, T, Er);
+        layernorm_c(s, hb, nullptr, Y.g1.p, Y.b1.p, h, 768, T, T, 1e-5f);
+        ConvEpilogue Eg; Eg.act = ACT_GELU;
+        conv1d_run(Y.ff1, s, h, T, T, ff, T, Eg);
+        conv1d_run(Y.ff2, s, ff, T, T, hb, T, Er);
+        layernorm_c(s, hb, nullptr, Y.g2.p, Y.b2.p, h, 768, T, T, 1e-5f);
+      }
+      if (taps && need == 8) tap(taps->hidden_8, h, (size_t)768 * T);
+    }
+    A.off = mark;
+  }
+  const float* res = h; int D = 768;
+  if (version == 1) {
+    float* fp = A.alloc<float>((size_t)256 * T);
+    if (!dry) conv1d_run(H->final_proj, s, h, T, T, fp, T, E0);
+    res = fp; D = 256;
+  }
+  if (!dry) {
+    if (out_cm) RVC_HIP_CHECK(hipMemcpyAsync(out_cm, res, (size_t)D * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_rm) transpose(s, res, out_rm, D, T, T, D, 1, 0, 0);
+  }
+}
+
+void hubert_forward(Hubert* H, hipStream_t s, const float* audio, long long L, int version, int n_layers, float* out_rm, float* out_cm,
+                    const HubertTaps* taps) {
+  RVC_REQUIRE(H->ready, "hubert_finalize has not been called");
+  RVC_REQUIRE(version == 1 || version == 2, "version must be 1 or 2");
+  RVC_REQUIRE(hubert_num_frames(L) >= 2, "audio too short");
+  Arena& A = H->arena;
+  for (int pass = 0; pass < 2; ++pass) {
+    A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
+    hubert_graph(H, s, A, audio, L, version, n_layers, out_rm, out_cm, taps);
+    if (pass == 0) A.ensure(A.peak);
+  }
+  A.dry = false;
+}
+
+size_t hubert_workspace(const Hubert* M) { return M->arena.cap; }
+
+}  // namespace rvc

@@ -1,0 +1,243 @@
+// RMVPE.infer_from_audio as a HIP kernel graph (reference lib/rmvpe.py:614-659): conv-STFT log-mel (:114-150,:510-556),
+// Deep U-Net of 3x3 Conv2d blocks with folded BatchNorm (:233-428), Conv2d 16->3, BiGRU(384 -> 2x256), Linear(512 -> 360),
+// sigmoid (:464-470) and the local-average-cents decoder (:607-612,:661-685).  NCHW with H = time, W = 128 mel bins.
+#include "model_common.h"
+#include "models.h"
+
+namespace rvc {
+
+struct CBR {           // ConvBlockRes with BatchNorm folded into both convs
+  ConvLayer c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
+};
+struct Rmvpe {
+  Ctx* ctx = nullptr;
+  Arena arena;
+  TensorStore ts;
+  bool ready = false;
+  ConvLayer stft, melproj;
+  float bn_a = 1.f, bn_b = 0.f;
+  CBR enc[5][4], inter[4][4], dec[5][4];
+  ConvLayer dect[5];
+  ConvLayer cnn;
+  DevVec wihT, b_ih, w_hh, b_hh;
+  ConvLayer fc;
+  unsigned long long* xbuf = nullptr; int* gru_err = nullptr;
+};
+
+Rmvpe* rmvpe_create(Ctx* ctx) { Rmvpe* R = new Rmvpe(); R->ctx = ctx; return R; }
+void rmvpe_set_tensor(Rmvpe* R, const char* name, const float* d, const long long* shape, int ndim) { R->ts.set(name, d, shape, ndim); }
+
+static void cbr_free(CBR& b) { conv_layer_free(b.c1); conv_layer_free(b.c2); conv_layer_free(b.sc); }
+static void rmvpe_free(Rmvpe& R) {
+  conv_layer_free(R.stft); conv_layer_free(R.melproj);
+  for (auto& l : R.enc) for (auto& b : l) cbr_free(b);
+  for (auto& l : R.inter) for (auto& b : l) cbr_free(b);
+  for (auto& l : R.dec) for (auto& b : l) cbr_free(b);
+  for (auto& c : R.dect) conv_layer_free(c);
+  conv_layer_free(R.cnn); conv_layer_free(R.fc);
+  R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.b_hh.free_();
+  dev_free(R.xbuf); dev_free(R.gru_err); R.xbuf = nullptr; R.gru_err = nullptr;
+}
+void rmvpe_destroy(Rmvpe* R) { if (R) { rmvpe_free(*R); R->arena.release(); delete R; } }
+
+// BatchNorm2d (eval) folded into the preceding bias-free conv: w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)
+static void bn_fold(const TensorStore& ts, const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& shift) {
+  const HostTensor& g = ts.get(bn + ".weight", {C}); const HostTensor& b = ts.get(bn + ".bias", {C});
+  const HostTensor& m = ts.get(bn + ".running_mean", {C}); const HostTensor& v = ts.get(bn + ".running_var", {C});
+  scale.resize(C); shift.resize(C);
+  for (int c = 0; c < C; ++c) {
+    const float inv = 1.f / std::sqrt(v.data[c] + 1e-5f);
+    scale[c] = g.data[c] * inv; shift[c] = b.data[c] - m.data[c] * g.data[c] * inv;
+  }
+}
+
+static void make_cbr(CBR& B, const TensorStore& ts, const std::string& p, int cin, int cout) {
+  B.cin = cin; B.cout = cout;
+  std::vector<float> sc, sh;
+  {
+    std::vector<float> w = ts.get(p + "conv.0.weight", {cout, cin, 3, 3}).data;
+    bn_fold(ts, p + "conv.1", cout, sc, sh);
+    for (int co = 0; co < cout; ++co) for (size_t i = 0; i < (size_t)cin * 9; ++i) w[(size_t)co * cin * 9 + i] *= sc[co];
+    conv2d3x3_layer_init(B.c1, w.data(), sh.data(), cout, cin);
+  }
+  {
+    std::vector<float> w = ts.get(p + "conv.3.weight", {cout, cout, 3, 3}).data;
+    bn_fold(ts, p + "conv.4", cout, sc, sh);
+    for (int co = 0; co < cout; ++co) for (size_t i = 0; i < (size_t)cout * 9; ++i) w[(size_t)co * cout * 9 + i] *= sc[co];
+    conv2d3x3_layer_init(B.c2, w.data(), sh.data(), cout, cout);
+  }
+  B.has_sc = cin != cout;
+  if (B.has_sc) conv2d1x1_layer_init(B.sc, ts.get(p + "shortcut.weight", {cout, cin, 1, 1}).data.data(), ts.get(p + "shortcut.bias", {cout}).data.data(), cout, cin);
+}
+
+void rmvpe_finalize(Rmvpe* R) {
+  const TensorStore& ts = R->ts;
+  rmvpe_free(*R);
+  conv1d_layer_init(R->stft, ts.get("stft.forward_basis", {1026, 1024}).data.data(), nullptr, 1026, 1024, 1, 1, 0, 1, 1);
+  conv1d_layer_init(R->melproj, ts.get("mel_basis", {128, 513}).data.data(), nullptr, 128, 513, 1, 1, 0, 1, 1);
+  {
+    const float g = ts.get("unet.encoder.bn.weight", {1}).data[0], b = ts.get("unet.encoder.bn.bias", {1}).data[0];
+    const float m = ts.get("unet.encoder.bn.running_mean", {1}).data[0], v = ts.get("unet.encoder.bn.running_var", {1}).data[0];
+    const float inv = 1.f / std::sqrt(v + 1e-5f);
+    R->bn_a = g * inv; R->bn_b = b - m * g * inv;
+  }
+  int cin = 1, cout = 16;
+  for (int i = 0; i < 5; ++i) {
+    for (int b = 0; b < 4; ++b) make_cbr(R->enc[i][b], ts, "unet.encoder.layers." + std::to_string(i) + ".conv." + std::to_string(b) + ".", b == 0 ? cin : cout, cout);
+    cin = cout; cout *= 2;
+  }
+  cin = 256; cout = 512;
+  for (int i = 0; i < 4; ++i) {
+    for (int b = 0; b < 4; ++b) make_cbr(R->inter[i][b], ts, "unet.intermediate.layers." + std::to_string(i) + ".conv." + std::to_string(b) + ".", b == 0 ? cin : cout, cout);
+    cin = cout;
+  }
+  cin = 512;
+  for (int i = 0; i < 5; ++i) {
+    cout = cin / 2;
+    const std::string p = "unet.decoder.layers." + std::to_string(i) + ".";
+    std::vector<float> w = ts.get(p + "conv1.0.weight", {cin, cout, 3, 3}).data;
+    std::vector<float> sc, sh;
+    bn_fold(ts, p + "conv1.1", cout, sc, sh);
+    for (int ci = 0; ci < cin; ++ci) for (int co = 0; co < cout; ++co) for (int k = 0; k < 9; ++k) w[((size_t)ci * cout + co) * 9 + k] *= sc[co];
+    tconv2d_layer_init(R->dect[i], w.data(), sh.data(), cin, cout);
+    for (int b = 0; b < 4; ++b) make_cbr(R->dec[i][b], ts, p + "conv2." + std::to_string(b) + ".", b == 0 ? 2 * cout : cout, cout);
+    cin = cout;
+  }
+  conv2d3x3_layer_init(R->cnn, ts.get("cnn.weight", {3, 16, 3, 3}).data.data(), ts.get("cnn.bias", {3}).data.data(), 3, 16);
+  {
+    std::vector<float> wT((size_t)384 * 1536), bi(1536), wh((size_t)2 * 768 * 256), bh(1536);
+    for (int d = 0; d < 2; ++d) {
+      const std::string sfx = d ? "_reverse" : "";
+      const HostTensor& wi = ts.get("fc.0.gru.weight_ih_l0" + sfx, {768, 384});
+      for (int r = 0; r < 768; ++r) for (int k = 0; k < 384; ++k) wT[(size_t)k * 1536 + d * 768 + r] = wi.data[(size_t)r * 384 + k];
+      const HostTensor& whh = ts.get("fc.0.gru.weight_hh_l0" + sfx, {768, 256});
+      std::copy(whh.data.begin(), whh.data.end(), wh.begin() + (size_t)d * 768 * 256);
+      const HostTensor& b1 = ts.get("fc.0.gru.bias_ih_l0" + sfx, {768}); const HostTensor& b2 = ts.get("fc.0.gru.bias_hh_l0" + sfx, {768});
+      std::copy(b1.data.begin(), b1.data.end(), bi.begin() + d * 768);
+      std::copy(b2.data.begin(), b2.data.end(), bh.begin() + d * 768);
+    }
+    R->wihT.upload(wT); R->b_ih.upload(bi); R->w_hh.upload(wh); R->b_hh.upload(bh);
+  }
+  conv1d_layer_init(R->fc, ts.get("fc.1.weight", {360, 512}).data.data(), ts.get("fc.1.bias", {360}).data.data(), 360, 512, 1, 1, 0, 1, 1);
+  RVC_HIP_CHECK(hipMalloc(&R->xbuf, sizeof(unsigned long long) * 2 * 2 * 256));
+  RVC_HIP_CHECK(hipMalloc(&R->gru_err, sizeof(int)));
+  R->ts.clear();
+  R->ready = true;
+}
+
+// one ConvBlockRes: out = relu(bn(conv(relu(bn(conv(x)))))) + (shortcut(x) | x)       (reference lib/rmvpe.py:264-268)
+static void run_cbr(const CBR& B, hipStream_t s, Arena& A, const float* x, int H, int W, float* out) {
+  const long long plane = (long long)H * W;
+  const size_t mark = A.off;
+  float* y1 = A.alloc<float>((size_t)B.cout * plane);
+  float* scb = B.has_sc ? A.alloc<float>((size_t)B.cout * plane) : nullptr;
+  if (!A.dry) {
+    ConvEpilogue E1; E1.act = ACT_RELU;
+    conv2d_run(B.c1, s, x, plane, H, W, y1, plane, E1);
+    const float* res = x;
+    if (B.has_sc) { ConvEpilogue E0; conv1d_run(B.sc, s, x, plane, (int)plane, scb, plane, E0); res = scb; }
+    ConvEpilogue E2; E2.act = ACT_RELU; E2.act_before_res = 1; E2.R = res; E2.ldR = plane;
+    conv2d_run(B.c2, s, y1, plane, H, W, out, plane, E2);
+  }
+  A.off = mark;
+}
+
+static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, long long L, float thred, float* mel_out, float* sal_out,
+                        double* f0_out, const RmvpeTaps* taps) {
+  const bool dry = A.dry;
+  ConvEpilogue E0;
+  const int n = (int)(L / 160) + 1;
+  const int Tr = 32 * ((n - 1) / 32 + 1);
+  // ---- log-mel
+  float* mel = A.alloc<float>((size_t)128 * n);
+  {
+    const size_t mark = A.off;
+    float* fr = A.alloc<float>((size_t)1024 * n);
+    float* ft = A.alloc<float>((size_t)1026 * n);
+    float* mag = A.alloc<float>((size_t)513 * n);
+    if (!dry) {
+      frames(s, audio, fr, (int)L, 1024, 160, 512, n, 1);
+      conv1d_run(R->stft, s, fr, n, n, ft, n, E0);
+      magnitude(s, ft, mag, 513, n);
+      ConvEpilogue El; El.act = ACT_LOGCLAMP; El.act_slope = 1e-5f;
+      conv1d_run(R->melproj, s, mag, n, n, mel, n, El);
+      if (mel_out) RVC_HIP_CHECK(hipMemcpyAsync(mel_out, mel, (size_t)128 * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    A.off = mark;
+  }
+  // ---- U-Net
+  int Hs[6], Ws[6];
+  for (int i = 0; i < 6; ++i) { Hs[i] = Tr >> i; Ws[i] = 128 >> i; }
+  float* x0 = A.alloc<float>((size_t)Tr * 128);
+  if (!dry) mel_to_unet(s, mel, x0, n, Tr, R->bn_a, R->bn_b);
+  float* cat[5];
+  for (int i = 0; i < 5; ++i) cat[i] = A.alloc<float>((size_t)2 * (16 << i) * Hs[i] * Ws[i]);   // [deconv out | encoder skip]
+  const float* cur = x0;
+  for (int i = 0; i < 5; ++i) {
+    const int C = 16 << i; const long long plane = (long long)Hs[i] * Ws[i];
+    float* a = A.alloc<float>((size_t)C * plane); float* b = A.alloc<float>((size_t)C * plane);
+    float* skip = cat[i] + (size_t)C * plane;
+    const float* in = cur;
+    for (int k = 0; k < 4; ++k) { float* o = (k == 3) ? skip : ((k & 1) ? b : a); run_cbr(R->enc[i][k], s, A, in, Hs[i], Ws[i], o); in = o; }
+    float* pooled = A.alloc<float>((size_t)C * Hs[i + 1] * Ws[i + 1]);
+    if (!dry) avgpool2(s, skip, pooled, C, Hs[i], Ws[i], plane);
+    cur = pooled;
+  }
+  {
+    const long long plane = (long long)Hs[5] * Ws[5];
+    float* a = A.alloc<float>((size_t)512 * plane); float* b = A.alloc<float>((size_t)512 * plane);
+    for (int i = 0; i < 4; ++i)
+      for (int k = 0; k < 4; ++k) { float* o = (cur == a) ? b : a; run_cbr(R->inter[i][k], s, A, cur, Hs[5], Ws[5], o); cur = o; }
+  }
+  for (int i = 0; i < 5; ++i) {
+    const int lvl = 4 - i; const int C = 16 << lvl; const long long plane = (long long)Hs[lvl] * Ws[lvl];
+    if (!dry) { ConvEpilogue Er; Er.act = ACT_RELU; conv2d_run(R->dect[i], s, cur, (long long)Hs[lvl + 1] * Ws[lvl + 1], Hs[lvl + 1], Ws[lvl + 1], cat[lvl], plane, Er); }
+    float* a = A.alloc<float>((size_t)C * plane); float* b = A.alloc<float>((size_t)C * plane);
+    const float* in = cat[lvl];
+    for (int k = 0; k < 4; ++k) { float* o = (k & 1) ? b : a; run_cbr(R->dec[i][k], s, A, in, Hs[lvl], Ws[lvl], o); in = o; }
+    cur = in;
+  }
+  if (!dry && taps && taps->unet_out) RVC_HIP_CHECK(hipMemcpyAsync(taps->unet_out, cur, (size_t)16 * Tr * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // ---- cnn -> BiGRU -> Linear -> sigmoid
+  float* c3 = A.alloc<float>((size_t)3 * Tr * 128);
+  float* feat = A.alloc<float>((size_t)384 * Tr);
+  float* gi = A.alloc<float>((size_t)Tr * 1536);
+  float* hid = A.alloc<float>((size_t)512 * Tr);
+  float* sal = A.alloc<float>((size_t)360 * Tr);
+  if (!dry) {
+    conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
+    transpose(s, c3, feat, Tr, 128, 128, Tr, 3, (long long)Tr * 128, 128LL * Tr);           // [c][t][m] -> [c*128+m][t]
+    gemm_tn_run(s, feat, Tr, 0, R->wihT.p, 1536, 0, gi, 1536, 0, Tr, 1536, 384, 1, nullptr, 0, E0);
+    gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr);
+    if (taps && taps->gru) RVC_HIP_CHECK(hipMemcpyAsync(taps->gru, hid, (size_t)512 * Tr * sizeof(float), hipMemcpyDeviceToDevice, s));
+    ConvEpilogue Es; Es.act = ACT_SIGMOID;
+    conv1d_run(R->fc, s, hid, Tr, Tr, sal, Tr, Es);
+    if (sal_out) transpose(s, sal, sal_out, 360, n, Tr, 360, 1, 0, 0);
+    if (f0_out) rmvpe_decode(s, sal, f0_out, n, Tr, thred);
+  }
+}
+
+void rmvpe_forward(Rmvpe* R, hipStream_t s, const float* audio, long long L, float thred, float* mel_out, float* salience_out, double* f0_out,
+                   const RmvpeTaps* taps) {
+  RVC_REQUIRE(R->ready, "rmvpe_finalize has not been called");
+  RVC_REQUIRE(L >= 1024 && L / 160 + 1 >= 32, "audio too short for RMVPE (need >= 0.32 s)");
+  Arena& A = R->arena;
+  for (int pass = 0; pass < 2; ++pass) {
+    A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
+    rmvpe_graph(R, s, A, audio, L, thred, mel_out, salience_out, f0_out, taps);
+    if (pass == 0) A.ensure(A.peak);
+  }
+  A.dry = false;
+}
+
+void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, float thred, double* f0) {
+  Arena& A = R->arena;
+  A.dry = false; A.reset(); A.ensure((size_t)360 * n * sizeof(float) + 4096);
+  float* cm = A.alloc<float>((size_t)360 * n);
+  transpose(s, sal_rm, cm, (int)n, 360, 360, n, 1, 0, 0);
+  rmvpe_decode(s, cm, f0, (int)n, n, thred);
+}
+
+size_t rmvpe_workspace(const Rmvpe* M) { return M->arena.cap; }
+
+}  // namespace rvc

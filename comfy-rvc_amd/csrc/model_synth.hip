@@ -1,0 +1,368 @@
+// SynthesizerTrnMs{256,768}NSFsid.infer as a HIP kernel graph (reference lib/infer_pack/models.py:682-693,:798-809):
+// enc_p (TextEncoder + 6 relative-position attention layers) -> z_p sampling -> 4 reversed coupling layers (WN)
+// -> GeneratorNSF (SineGen source, ConvTranspose1d stages, 3x ResBlock1 per stage, conv_post, tanh).
+// Activations are channel-major [C][T]; weights arrive with the reference's state-dict names and are folded here.
+#include "model_common.h"
+#include "models.h"
+
+namespace rvc {
+
+static ConvLayer make_conv1d(const TensorStore& ts, const std::string& p, int stride, int pad, int dil, bool wn, bool bias = true,
+                             float wscale = 1.f, int row0 = 0, int rows = -1) {
+  std::vector<float> w; std::vector<long long> shape;
+  if (wn) { const HostTensor& v = ts.get(p + ".weight_v"); w = weight_norm0(v, ts.get(p + ".weight_g")); shape = v.shape; }
+  else { const HostTensor& v = ts.get(p + ".weight"); w = v.data; shape = v.shape; }
+  RVC_REQUIRE(shape.size() == 3, p + ": expected a [Co][Ci][k] weight");
+  int Co = (int)shape[0], Ci = (int)shape[1], k = (int)shape[2];
+  std::vector<float> b;
+  if (bias) b = ts.get(p + ".bias").data;
+  if (rows < 0) rows = Co;
+  const size_t per = (size_t)Ci * k;
+  std::vector<float> ws(w.begin() + row0 * per, w.begin() + (size_t)(row0 + rows) * per);
+  if (wscale != 1.f) for (auto& x : ws) x *= wscale;
+  std::vector<float> bs;
+  if (bias) { bs.assign(b.begin() + row0, b.begin() + row0 + rows); if (wscale != 1.f) for (auto& x : bs) x *= wscale; }
+  ConvLayer L;
+  conv1d_layer_init(L, ws.data(), bias ? bs.data() : nullptr, rows, Ci, k, stride, pad, dil, 1);
+  return L;
+}
+
+struct EncLayer {
+  ConvLayer qk;            // fused conv_q (pre-scaled by 1/sqrt(kc)) and conv_k: C -> 2C
+  DevVec wvT, bv;          // conv_v as [Ci][Co] for the row-major V product; its bias is added after P.V
+  ConvLayer relk, relv;    // emb_rel_k as a 21-row projection of Q; emb_rel_v as a 21 -> kc projection of banded P
+  ConvLayer o, ffn1, ffn2;
+  DevVec g1, b1, g2, b2;
+};
+struct FlowLayer {
+  ConvLayer pre, post, in[3], res[2], skip[3];
+  DevVec cond_w, cond_b;   // weight-normed cond_layer [2*H*3][gin]
+};
+struct ResBlock { ConvLayer c1[3], c2[3]; };
+struct GenStage { ConvLayer up, noise; int u = 1, k = 1, noise_k = 1, noise_s = 1; ResBlock rb[3]; };
+
+struct Synth {
+  Ctx* ctx = nullptr;
+  Arena arena;           // activation workspace (grown on demand between launches)
+  TensorStore ts;
+  bool ready = false;
+  // config
+  int inter = 192, hidden = 192, filt = 768, n_heads = 2, n_layers = 6, ksz = 3, gin = 256, n_spk = 1, sr = 40000, feat_dim = 768;
+  int up_init = 512; std::vector<int> rb_k, up_rates, up_k; std::vector<std::vector<int>> rb_d;
+  int upp = 1;
+  // weights
+  DevVec emb_phone_wT, emb_phone_b, emb_pitch, emb_g;
+  std::vector<EncLayer> enc;
+  ConvLayer proj;
+  FlowLayer flow[4];
+  ConvLayer conv_pre, conv_post;
+  DevVec dec_cond_w, dec_cond_b;
+  std::vector<GenStage> stages;
+  float lin_w = 1.f, lin_b = 0.f;
+};
+
+static void synth_free(Synth& S) {
+  auto fl = [](ConvLayer& L) { conv_layer_free(L); };
+  S.emb_phone_wT.free_(); S.emb_phone_b.free_(); S.emb_pitch.free_(); S.emb_g.free_();
+  for (auto& e : S.enc) { fl(e.qk); e.wvT.free_(); e.bv.free_(); fl(e.relk); fl(e.relv); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
+  S.enc.clear();
+  fl(S.proj);
+  for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); f.cond_w.free_(); f.cond_b.free_(); }
+  fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_();
+  for (auto& st : S.stages) { fl(st.up); fl(st.noise); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
+  S.stages.clear();
+}
+
+Synth* synth_create(Ctx* ctx, const SynthConfig& c) {
+  std::unique_ptr<Synth> S(new Synth());
+  S->ctx = ctx;
+  S->inter = c.inter_channels; S->hidden = c.hidden_channels; S->filt = c.filter_channels; S->n_heads = c.n_heads;
+  S->n_layers = c.n_layers; S->ksz = c.kernel_size; S->gin = c.gin_channels; S->n_spk = c.spk_embed_dim; S->sr = c.sr;
+  S->feat_dim = c.feat_dim; S->up_init = c.upsample_initial_channel;
+  RVC_REQUIRE(c.n_resblock_kernels == 3, "ResBlock1 x3 expected");
+  for (int i = 0; i < 3; ++i) { S->rb_k.push_back(c.resblock_kernel_sizes[i]); S->rb_d.push_back({c.resblock_dilations[i][0], c.resblock_dilations[i][1], c.resblock_dilations[i][2]}); }
+  S->upp = 1;
+  for (int i = 0; i < c.n_upsamples; ++i) { S->up_rates.push_back(c.upsample_rates[i]); S->up_k.push_back(c.upsample_kernel_sizes[i]); S->upp *= c.upsample_rates[i]; }
+  RVC_REQUIRE(S->hidden % S->n_heads == 0, "heads must divide hidden");
+  return S.release();
+}
+void synth_destroy(Synth* S) { if (S) { synth_free(*S); S->arena.release(); delete S; } }
+void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim) { S->ts.set(name, d, shape, ndim); }
+int synth_upp(const Synth* S) { return S->upp; }
+
+void synth_finalize(Synth* S) {
+  const TensorStore& ts = S->ts;
+  synth_free(*S);
+  const int C = S->hidden, kc = C / S->n_heads;
+  {
+    const HostTensor& w = ts.get("enc_p.emb_phone.weight", {C, S->feat_dim});
+    S->emb_phone_wT.upload(transpose2d(w.data.data(), C, S->feat_dim));
+    S->emb_phone_b.upload(ts.get("enc_p.emb_phone.bias", {C}).data);
+    S->emb_pitch.upload(ts.get("enc_p.emb_pitch.weight", {256, C}).data);
+    S->emb_g.upload(ts.get("emb_g.weight").data);
+    S->n_spk = (int)ts.get("emb_g.weight").shape[0];
+  }
+  S->enc.resize(S->n_layers);
+  const float qscale = 1.f / std::sqrt((float)kc);
+  for (int l = 0; l < S->n_layers; ++l) {
+    EncLayer& e = S->enc[l];
+    const std::string p = "enc_p.encoder.attn_layers." + std::to_string(l) + ".";
+    const HostTensor& wq = ts.get(p + "conv_q.weight", {C, C, 1});
+    const HostTensor& wk = ts.get(p + "conv_k.weight", {C, C, 1});
+    std::vector<float> w(2 * (size_t)C * C), b(2 * (size_t)C);
+    for (size_t i = 0; i < (size_t)C * C; ++i) { w[i] = wq.data[i] * qscale; w[(size_t)C * C + i] = wk.data[i]; }
+    const HostTensor& bq = ts.get(p + "conv_q.bias", {C}); const HostTensor& bk = ts.get(p + "conv_k.bias", {C});
+    for (int i = 0; i < C; ++i) { b[i] = bq.data[i] * qscale; b[C + i] = bk.data[i]; }
+    conv1d_layer_init(e.qk, w.data(), b.data(), 2 * C, C, 1, 1, 0, 1, 1);
+    e.wvT.upload(transpose2d(ts.get(p + "conv_v.weight", {C, C, 1}).data.data(), C, C));
+    e.bv.upload(ts.get(p + "conv_v.bias", {C}).data);
+    const HostTensor& rk = ts.get(p + "emb_rel_k", {1, 21, kc});
+    conv1d_layer_init(e.relk, rk.data.data(), nullptr, 21, kc, 1, 1, 0, 1, 1);            // [r][d]: out[r][q] = sum_d E_k[r][d] Q[d][q]
+    const HostTensor& rv = ts.get(p + "emb_rel_v", {1, 21, kc});
+    std::vector<float> rvT = transpose2d(rv.data.data(), 21, kc);                           // [d][r]: out[d][q] = sum_r E_v[r][d] Pb[r][q]
+    conv1d_layer_init(e.relv, rvT.data(), nullptr, kc, 21, 1, 1, 0, 1, 1);
+    e.o = make_conv1d(ts, p + "conv_o", 1, 0, 1, false);
+    const std::string f = "enc_p.encoder.ffn_layers." + std::to_string(l) + ".";
+    e.ffn1 = make_conv1d(ts, f + "conv_1", 1, (S->ksz - 1) / 2, 1, false);
+    e.ffn2 = make_conv1d(ts, f + "conv_2", 1, (S->ksz - 1) / 2, 1, false);
+    RVC_REQUIRE(S->ksz % 2 == 1, "enc_p FFN kernel must be odd (symmetric same-padding)");
+    e.g1.upload(ts.get("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".gamma", {C}).data);
+    e.b1.upload(ts.get("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".beta", {C}).data);
+    e.g2.upload(ts.get("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".gamma", {C}).data);
+    e.b2.upload(ts.get("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".beta", {C}).data);
+  }
+  S->proj = make_conv1d(ts, "enc_p.proj", 1, 0, 1, false);
+  for (int f = 0; f < 4; ++f) {
+    FlowLayer& F = S->flow[f];
+    const std::string p = "flow.flows." + std::to_string(2 * f) + ".";
+    F.pre = make_conv1d(ts, p + "pre", 1, 0, 1, false);
+    F.post = make_conv1d(ts, p + "post", 1, 0, 1, false);
+    for (int i = 0; i < 3; ++i) {
+      F.in[i] = make_conv1d(ts, p + "enc.in_layers." + std::to_string(i), 1, 2, 1, true);
+      const std::string rs = p + "enc.res_skip_layers." + std::to_string(i);
+      if (i < 2) {
+        F.res[i] = make_conv1d(ts, rs, 1, 0, 1, true, true, 1.f, 0, C);
+        F.skip[i] = make_conv1d(ts, rs, 1, 0, 1, true, true, 1.f, C, C);
+      } else {
+        F.skip[i] = make_conv1d(ts, rs, 1, 0, 1, true);
+      }
+    }
+    F.cond_w.upload(weight_norm0(ts.get(p + "enc.cond_layer.weight_v"), ts.get(p + "enc.cond_layer.weight_g")));
+    F.cond_b.upload(ts.get(p + "enc.cond_layer.bias").data);
+  }
+  S->conv_pre = make_conv1d(ts, "dec.conv_pre", 1, 3, 1, false);
+  S->conv_post = make_conv1d(ts, "dec.conv_post", 1, 3, 1, false, false);
+  S->dec_cond_w.upload(ts.get("dec.cond.weight").data);
+  S->dec_cond_b.upload(ts.get("dec.cond.bias").data);
+  S->lin_w = ts.get("dec.m_source.l_linear.weight").data[0];
+  S->lin_b = ts.get("dec.m_source.l_linear.bias").data[0];
+  const int nu = (int)S->up_rates.size();
+  S->stages.resize(nu);
+  for (int i = 0; i < nu; ++i) {
+    GenStage& st = S->stages[i];
+    const int cin = S->up_init >> i, cout = S->up_init >> (i + 1);
+    st.u = S->up_rates[i]; st.k = S->up_k[i];
+    const std::string up = "dec.ups." + std::to_string(i);
+    const HostTensor& v = ts.get(up + ".weight_v", {cin, cout, st.k});
+    std::vector<float> w = weight_norm0(v, ts.get(up + ".weight_g"));
+    tconv1d_layer_init(st.up, w.data(), ts.get(up + ".bias", {cout}).data.data(), cin, cout, st.k, st.u, (st.k - st.u) / 2);
+    int sf0 = 1;
+    for (int j = i + 1; j < nu; ++j) sf0 *= S->up_rates[j];
+    const std::string nc = "dec.noise_convs." + std::to_string(i);
+    if (i + 1 < nu) { st.noise_k = 2 * sf0; st.noise_s = sf0; } else { st.noise_k = 1; st.noise_s = 1; }
+    const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
+    // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
+    conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
+    for (int j = 0; j < 3; ++j) {
+      const std::string rb = "dec.resblocks." + std::to_string(i * 3 + j) + ".";
+      const int k = S->rb_k[j];
+      for (int m = 0; m < 3; ++m) {
+        const int d = S->rb_d[j][m];
+        st.rb[j].c1[m] = make_conv1d(ts, rb + "convs1." + std::to_string(m), 1, (k * d - d) / 2, d, true);
+        st.rb[j].c2[m] = make_conv1d(ts, rb + "convs2." + std::to_string(m), 1, (k - 1) / 2, 1, true);
+      }
+    }
+  }
+  S->ts.clear();
+  S->ready = true;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm, const long long* pitch, const float* pitchf, int sid,
+                        const float* noise_z, const float* noise_src, int T, float* out, const SynthTaps* taps) {
+  const int C = S->hidden, H = S->n_heads, kc = C / H, IC = S->inter;
+  const bool dry = A.dry;
+  auto tap = [&](float* dst, const float* src, size_t n) {
+    if (!dry && dst) RVC_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  };
+  ConvEpilogue E0;
+  // ---- speaker conditioning vectors
+  const float* g = S->emb_g.p + (size_t)sid * S->gin;
+  float* pre_bias = A.alloc<float>(S->up_init);
+  float* gcond[4];
+  for (int f = 0; f < 4; ++f) gcond[f] = A.alloc<float>(6 * C);
+  if (!dry) {
+    gemv(s, S->dec_cond_w.p, g, S->dec_cond_b.p, pre_bias, S->up_init, S->gin, S->conv_pre.bd_);
+    for (int f = 0; f < 4; ++f) gemv(s, S->flow[f].cond_w.p, g, S->flow[f].cond_b.p, gcond[f], 6 * C, S->gin, nullptr);
+  }
+  // ---- enc_p
+  float* x = A.alloc<float>((size_t)C * T);
+  float* xb = A.alloc<float>((size_t)C * T);
+  if (!dry) {
+    gemm_tn_run(s, S->emb_phone_wT.p, C, 0, feat_cm, T, 0, x, T, 0, C, T, S->feat_dim, 1, S->emb_phone_b.p, 0, E0);
+    encp_embed(s, x, S->emb_pitch.p, pitch, C, T);
+  }
+  {
+    const size_t mark = A.off;
+    float* qk = A.alloc<float>((size_t)2 * C * T);
+    float* vr = A.alloc<float>((size_t)T * C);
+    float* Sc = A.alloc<float>((size_t)H * T * T);
+    float* relk = A.alloc<float>((size_t)H * 21 * T);
+    float* pb = A.alloc<float>((size_t)H * 21 * T);
+    float* attn = A.alloc<float>((size_t)C * T);
+    float* ff = A.alloc<float>((size_t)S->filt * T);
+    if (!dry) {
+      for (int l = 0; l < S->n_layers; ++l) {
+        EncLayer& e = S->enc[l];
+        conv1d_run(e.qk, s, x, T, T, qk, T, E0);
+        gemm_tn_run(s, x, T, 0, e.wvT.p, C, 0, vr, C, 0, T, C, C, 1, nullptr, 0, E0);                       // V row-major [T][C] (bias later)
+        gemm_tn_run(s, qk + (size_t)C * T, T, (long long)kc * T, qk, T, (long long)kc * T, Sc, T, (long long)T * T, T, T, kc, H, nullptr, 0, E0);
+        for (int h = 0; h < H; ++h) conv1d_run(e.relk, s, qk + (size_t)h * kc * T, T, T, relk + (size_t)h * 21 * T, T, E0);
+        fill(s, pb, 0.f, (long long)H * 21 * T);
+        softmax_cols(s, Sc, T, T, T, (long long)T * T, H, relk, 21LL * T, 10, pb, 21LL * T);
+        gemm_tn_run(s, vr, C, kc, Sc, T, (long long)T * T, attn, T, (long long)kc * T, kc, T, T, H, e.bv.p, kc, E0);
+        ConvEpilogue Ea; Ea.accumulate = 1;
+        for (int h = 0; h < H; ++h) conv1d_run(e.relv, s, pb + (size_t)h * 21 * T, T, T, attn + (size_t)h * kc * T, T, Ea);
+        ConvEpilogue Er; Er.R = x; Er.ldR = T;
+        conv1d_run(e.o, s, attn, T, T, xb, T, Er);
+        layernorm_c(s, xb, nullptr, e.g1.p, e.b1.p, x, C, T, T, 1e-5f);
+        ConvEpilogue Ef; Ef.act = ACT_RELU;
+        conv1d_run(e.ffn1, s, x, T, T, ff, T, Ef);
+        conv1d_run(e.ffn2, s, ff, T, T, xb, T, Er);
+        layernorm_c(s, xb, nullptr, e.g2.p, e.b2.p, x, C, T, T, 1e-5f);
+        if (l == 0 && taps) tap(taps->enc_p_layer0, x, (size_t)C * T);
+      }
+    }
+    A.off = mark;
+  }
+  float* stats = A.alloc<float>((size_t)2 * IC * T);
+  float* z = A.alloc<float>((size_t)IC * T);
+  float* zf = A.alloc<float>((size_t)IC * T);
+  if (!dry) {
+    conv1d_run(S->proj, s, x, T, T, stats, T, E0);
+    if (taps) { tap(taps->m_p, stats, (size_t)IC * T); tap(taps->logs_p, stats + (size_t)IC * T, (size_t)IC * T); }
+    zp_sample(s, stats, noise_z, z, IC, T);
+    if (taps) tap(taps->z_p, z, (size_t)IC * T);
+  }
+  // ---- flow (reverse)
+  {
+    const size_t mark = A.off;
+    float* h = A.alloc<float>((size_t)C * T);
+    float* xin = A.alloc<float>((size_t)2 * C * T);
+    float* acts = A.alloc<float>((size_t)C * T);
+    float* wo = A.alloc<float>((size_t)C * T);
+    const int half = IC / 2;
+    if (!dry) {
+      float* cur = z; float* oth = zf;
+      for (int f = 3; f >= 0; --f) {
+        FlowLayer& F = S->flow[f];
+        flip_c(s, cur, oth, IC, T);
+        std::swap(cur, oth);
+        conv1d_run(F.pre, s, cur, T, T, h, T, E0);
+        for (int i = 0; i < 3; ++i) {
+          conv1d_run(F.in[i], s, h, T, T, xin, T, E0);
+          wn_gate(s, xin, gcond[f] + (size_t)i * 2 * C, acts, C, T);
+          ConvEpilogue Es; Es.accumulate = (i > 0);
+          conv1d_run(F.skip[i], s, acts, T, T, wo, T, Es);
+          if (i < 2) { ConvEpilogue Er; Er.R = h; Er.ldR = T; conv1d_run(F.res[i], s, acts, T, T, h, T, Er); }
+        }
+        ConvEpilogue Ep; Ep.out_scale = -1.f; Ep.accumulate = 1;
+        conv1d_run(F.post, s, wo, T, T, cur + (size_t)half * T, T, Ep);     // x1 = x1 - m
+      }
+      if (cur != z) RVC_HIP_CHECK(hipMemcpyAsync(z, cur, (size_t)IC * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (taps) tap(taps->z, z, (size_t)IC * T);
+    }
+    A.off = mark;
+  }
+  // ---- generator
+  const long long N = (long long)T * S->upp;
+  float* har = A.alloc<float>((size_t)N);
+  {
+    float* rad = A.alloc<float>((size_t)T);
+    float* tmp = A.alloc<float>((size_t)T);
+    double* bsum = A.alloc<double>((size_t)((N + 1023) / 1024));
+    if (!dry) {
+      sine_source(s, pitchf, noise_src, har, taps ? taps->sine_waves : nullptr, rad, tmp, bsum, T, S->upp, (float)S->sr, S->lin_w, S->lin_b);
+      if (taps) tap(taps->har_source, har, (size_t)N);
+    }
+  }
+  float* cur = A.alloc<float>((size_t)S->up_init * T);
+  if (!dry) { ConvEpilogue Eb; Eb.bias_override = pre_bias; conv1d_run(S->conv_pre, s, z, T, T, cur, T, Eb); }
+  int Tc = T;
+  const int nu = (int)S->stages.size();
+  for (int i = 0; i < nu; ++i) {
+    GenStage& st = S->stages[i];
+    const int Cc = S->up_init >> (i + 1);
+    const int Tn = Tc * st.u;
+    float* up = A.alloc<float>((size_t)Cc * Tn);
+    float* t1 = A.alloc<float>((size_t)Cc * Tn);
+    float* ya = A.alloc<float>((size_t)Cc * Tn);
+    float* yb = A.alloc<float>((size_t)Cc * Tn);
+    float* xs = A.alloc<float>((size_t)Cc * Tn);
+    float* fr = st.noise_k > 1 ? A.alloc<float>((size_t)st.noise_k * Tn) : nullptr;
+    if (!dry) {
+      RVC_REQUIRE(conv1d_out_len(st.up, Tc) == Tn, "ConvTranspose1d geometry must give T_out = u * T_in");
+      if (st.noise_k > 1) {
+        frames(s, har, fr, (int)N, st.noise_k, st.noise_s, st.noise_s / 2, Tn, 0);
+        conv1d_run(st.noise, s, fr, Tn, Tn, up, Tn, E0);
+      } else {
+        conv1d_run(st.noise, s, har, Tn, Tn, up, Tn, E0);
+      }
+      ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f; Eu.accumulate = 1;
+      conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
+      if (taps && i == 0) tap(taps->gen_ups0, up, (size_t)Cc * Tn);
+      for (int j = 0; j < 3; ++j) {
+        const float* in = up;
+        for (int m = 0; m < 3; ++m) {
+          ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f;
+          conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
+          ConvEpilogue E2; E2.pre_act = ACT_LRELU; E2.pre_slope = 0.1f; E2.R = in; E2.ldR = Tn;
+          float* dst = (m == 0) ? ya : (m == 1 ? yb : xs);
+          if (m == 2) { E2.out_scale = 1.f / 3.f; E2.accumulate = (j > 0); }
+          conv1d_run(st.rb[j].c2[m], s, t1, Tn, Tn, dst, Tn, E2);
+          in = dst;
+        }
+      }
+      if (taps && i == nu - 1) tap(taps->gen_last, xs, (size_t)Cc * Tn);
+    }
+    cur = xs; Tc = Tn;
+  }
+  if (!dry) {
+    ConvEpilogue Ep; Ep.pre_act = ACT_LRELU; Ep.pre_slope = 0.01f; Ep.act = ACT_TANH;
+    conv1d_run(S->conv_post, s, cur, Tc, Tc, out, Tc, Ep);
+  }
+}
+
+void synth_infer(Synth* S, hipStream_t s, const float* feat, int feat_channel_major, const long long* pitch, const float* pitchf, int sid,
+                 const float* noise_z, const float* noise_src, int T, float* out, const SynthTaps* taps) {
+  RVC_REQUIRE(S->ready, "synth_finalize has not been called");
+  RVC_REQUIRE(T >= 11, "need at least 11 frames (relative-position window)");
+  RVC_REQUIRE(sid >= 0 && sid < S->n_spk, "speaker id out of range");
+  Arena& A = S->arena;
+  for (int pass = 0; pass < 2; ++pass) {
+    A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
+    const float* fcm = feat;
+    if (!feat_channel_major) {
+      float* t = A.alloc<float>((size_t)S->feat_dim * T);
+      if (!A.dry) transpose(s, feat, t, T, S->feat_dim, S->feat_dim, T, 1, 0, 0);
+      fcm = t;
+    }
+    synth_graph(S, s, A, fcm, pitch, pitchf, sid, noise_z, noise_src, T, out, taps);
+    if (pass == 0) A.ensure(A.peak);
+  }
+  A.dry = false;
+}
+
+size_t synth_workspace(const Synth* M) { return M->arena.cap; }
+
+}  // namespace rvc

@@ -1,0 +1,46 @@
+// Internal C++ interface of the three network graphs; the extern "C" layer (rvc_api.hip) wraps these.
+#pragma once
+#include "model_common.h"
+#include "../../include/rvc_hip.h"
+
+namespace rvc {
+
+typedef rvc_synth_config SynthConfig;
+typedef rvc_synth_taps SynthTaps;
+typedef rvc_hubert_taps HubertTaps;
+typedef rvc_rmvpe_taps RmvpeTaps;
+
+struct Synth;
+Synth* synth_create(Ctx* ctx, const SynthConfig& c);
+void synth_destroy(Synth* S);
+void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim);
+void synth_finalize(Synth* S);
+int synth_upp(const Synth* S);
+void synth_infer(Synth* S, hipStream_t s, const float* feat, int feat_channel_major, const long long* pitch, const float* pitchf, int sid,
+                 const float* noise_z, const float* noise_src, int T, float* out, const SynthTaps* taps);
+
+struct Hubert;
+Hubert* hubert_create(Ctx* ctx);
+void hubert_destroy(Hubert* H);
+void hubert_set_tensor(Hubert* H, const char* name, const float* d, const long long* shape, int ndim);
+void hubert_finalize(Hubert* H);
+long long hubert_num_frames(long long L);
+// out_rm: [T_h][D] row-major (the reference's [1,T_h,D]) or null; out_cm: channel-major [D][T_h] or null
+void hubert_forward(Hubert* H, hipStream_t s, const float* audio, long long L, int version, int n_layers, float* out_rm, float* out_cm,
+                    const HubertTaps* taps);
+
+struct Rmvpe;
+Rmvpe* rmvpe_create(Ctx* ctx);
+void rmvpe_destroy(Rmvpe* R);
+void rmvpe_set_tensor(Rmvpe* R, const char* name, const float* d, const long long* shape, int ndim);
+void rmvpe_finalize(Rmvpe* R);
+// mel_out [128][n], salience_out [n][360], f0_out [n] (float64); any may be null.  Returns through *gru_err a sticky flag.
+void rmvpe_forward(Rmvpe* R, hipStream_t s, const float* audio, long long L, float thred, float* mel_out, float* salience_out, double* f0_out,
+                   const RmvpeTaps* taps);
+
+void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, float thred, double* f0);
+size_t synth_workspace(const Synth* S);
+size_t hubert_workspace(const Hubert* H);
+size_t rmvpe_workspace(const Rmvpe* R);
+
+}  // namespace rvc

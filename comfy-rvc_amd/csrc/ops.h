@@ -1,0 +1,31 @@
+// Launch wrappers of the non-GEMM device ops (ops.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rvc {
+
+void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gamma, const float* beta, float* y, int C, int T,
+                 long long ld, float eps);
+void groupnorm_t_gelu(hipStream_t s, float* x, const float* gamma, const float* beta, int C, int T, long long ld, float eps);
+void softmax_cols(hipStream_t s, float* S, int Tk, int Tq, long long ld, long long batchS, int batch, const float* rel,
+                  long long batchRel, int win, float* pb, long long batchPb);
+void fill(hipStream_t s, float* p, float v, long long n);
+void wn_gate(hipStream_t s, const float* a, const float* g, float* out, int H, int T);
+void gemv(hipStream_t s, const float* W, const float* x, const float* b, float* y, int N, int K, const float* add);
+void zp_sample(hipStream_t s, const float* stats, const float* noise, float* zp, int C, int T);
+void flip_c(hipStream_t s, const float* x, float* y, int C, int T);
+void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitch, int C, int T);
+void transpose(hipStream_t s, const float* in, float* out, int R, int C, long long ldin, long long ldout, int batch, long long bin,
+               long long bout);
+void feats_prepare(hipStream_t s, const float* f, const float* pitchf, float* out, int D, int Th, int T, float protect, int do_protect);
+void frames(hipStream_t s, const float* src, float* out, int L, int k, int stride, int pad, int Tout, int reflect);
+void magnitude(hipStream_t s, const float* ft, float* mag, int F, int T);
+void mel_to_unet(hipStream_t s, const float* mel, float* x, int n, int Tr, float a, float b);
+void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long long ldx);
+void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* b_hh, float* out,
+              unsigned long long* xbuf, int* err, int T);
+void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred);
+void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
+                 int T, int upp, float sr, float lw, float lb);
+
+}  // namespace rvc

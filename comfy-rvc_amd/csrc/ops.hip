@@ -1,0 +1,548 @@
+// Non-GEMM device ops of the RVC inference path (gfx950): normalisations, softmax, gates, scans, layout
+// changes, SineGen source, GRU recurrence, RMVPE decode.  All tensors are channel-major [C][T] unless noted.
+#include "rvc_internal.h"
+#include "ops.h"
+
+namespace rvc {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// ---------------------------------------------------------------------------------------------- LayerNorm over channels
+// y[c][t] = (x[c][t] (+ r[c][t]) - mean_t) * rstd_t * gamma[c] + beta[c];  block = 64 columns x 4 channel slices.
+__global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ y, int C, int T, long long ld, float eps) {
+  __shared__ float s_sum[4][64], s_sq[4][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + col;
+  const bool ok = t < T;
+  float sum = 0.f;
+  for (int c = sl; c < C; c += 4) {
+    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; sum += v; }
+  }
+  s_sum[sl][col] = sum;
+  __syncthreads();
+  const float mean = (s_sum[0][col] + s_sum[1][col] + s_sum[2][col] + s_sum[3][col]) / (float)C;
+  float sq = 0.f;
+  for (int c = sl; c < C; c += 4) {
+    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; v -= mean; sq += v * v; }
+  }
+  s_sq[sl][col] = sq;
+  __syncthreads();
+  const float var = (s_sq[0][col] + s_sq[1][col] + s_sq[2][col] + s_sq[3][col]) / (float)C;
+  const float rstd = rsqrtf(var + eps);
+  for (int c = sl; c < C; c += 4) {
+    if (ok) {
+      float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t];
+      y[(long long)c * ld + t] = (v - mean) * rstd * gamma[c] + beta[c];
+    }
+  }
+}
+void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gamma, const float* beta, float* y, int C, int T,
+                 long long ld, float eps) {
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 63) / 64), dim3(256), 0, s, x, r, gamma, beta, y, C, T, ld, eps);
+}
+
+// ---------------------------------------------------------------------------------------------- GroupNorm(C, C) over time + GELU
+__global__ __launch_bounds__(256) void groupnorm_t_gelu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int T, long long ld, float eps) {
+  __shared__ double red[4];
+  float* row = x + (long long)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  for (int t = tid; t < T; t += 256) s += (double)row[t];
+  s = wave_sum_d(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)T;
+  __syncthreads();
+  double q = 0.0;
+  for (int t = tid; t < T; t += 256) { const double d = (double)row[t] - mean; q += d * d; }
+  q = wave_sum_d(q);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  const double var = (red[0] + red[1] + red[2] + red[3]) / (double)T;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma[blockIdx.x], b = beta[blockIdx.x], mf = (float)mean;
+  for (int t = tid; t < T; t += 256) row[t] = gelu_f((row[t] - mf) * rstd * g + b);
+}
+void groupnorm_t_gelu(hipStream_t s, float* x, const float* gamma, const float* beta, int C, int T, long long ld, float eps) {
+  hipLaunchKernelGGL(groupnorm_t_gelu_kernel, dim3(C), dim3(256), 0, s, x, gamma, beta, T, ld, eps);
+}
+
+// ---------------------------------------------------------------------------------------------- column softmax of S^T [Tk][Tq]
+// Softmax over the key axis (rows) for every query column; optional relative-position bias
+// rel[(k - q + win)][q] for |k - q| <= win (enc_p, reference attentions.py:230-239) and optional gather of the banded
+// probabilities pb[r][q] = P[q][q + r - win] (reference attentions.py:260-267).  Block = 32 columns x 8 row slices.
+__global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ S, int Tk, int Tq, long long ld, long long batchS,
+                                                           const float* __restrict__ rel, long long batchRel, int win,
+                                                           float* __restrict__ pb, long long batchPb) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int q = blockIdx.x * 32 + col;
+  const bool ok = q < Tq;
+  float* Sb = S + (long long)blockIdx.y * batchS;
+  const float* relb = rel ? rel + (long long)blockIdx.y * batchRel : nullptr;
+  float mx = -3.0e38f;
+  for (int k = sl; k < Tk; k += 8) {
+    if (ok) {
+      float v = Sb[(long long)k * ld + q];
+      if (relb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) { v += relb[(long long)d * Tq + q]; Sb[(long long)k * ld + q] = v; } }
+      mx = fmaxf(mx, v);
+    }
+  }
+  red[sl][col] = mx;
+  __syncthreads();
+  mx = red[0][col];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) mx = fmaxf(mx, red[i][col]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = sl; k < Tk; k += 8) {
+    if (ok) { const float e = expf(Sb[(long long)k * ld + q] - mx); Sb[(long long)k * ld + q] = e; sum += e; }
+  }
+  red[sl][col] = sum;
+  __syncthreads();
+  sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += red[i][col];
+  const float inv = 1.f / sum;
+  for (int k = sl; k < Tk; k += 8) {
+    if (ok) {
+      const float pv = Sb[(long long)k * ld + q] * inv;
+      Sb[(long long)k * ld + q] = pv;
+      if (pb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) pb[(long long)blockIdx.y * batchPb + (long long)d * Tq + q] = pv; }
+    }
+  }
+}
+void softmax_cols(hipStream_t s, float* S, int Tk, int Tq, long long ld, long long batchS, int batch, const float* rel,
+                  long long batchRel, int win, float* pb, long long batchPb) {
+  hipLaunchKernelGGL(softmax_cols_kernel, dim3((Tq + 31) / 32, batch), dim3(256), 0, s, S, Tk, Tq, ld, batchS, rel, batchRel,
+                     win, pb, batchPb);
+}
+
+// ---------------------------------------------------------------------------------------------- small elementwise ops
+__global__ void fill_kernel(float* p, float v, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) p[i] = v;
+}
+void fill(hipStream_t s, float* p, float v, long long n) {
+  if (n <= 0) return;
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, v, n);
+}
+
+// WN gate: out[c][t] = tanh(a[c][t] + g[c]) * sigmoid(a[c+H][t] + g[c+H])     (reference commons.py:211-218)
+__global__ void wn_gate_kernel(const float* __restrict__ a, const float* __restrict__ g, float* __restrict__ out, int H, int T) {
+  const long long n = (long long)H * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int c = (int)(i / T);
+    const float ta = a[i] + g[c], sa = a[i + n] + g[c + H];
+    out[i] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+  }
+}
+void wn_gate(hipStream_t s, const float* a, const float* g, float* out, int H, int T) {
+  long long n = (long long)H * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wn_gate_kernel, dim3(blocks), dim3(256), 0, s, a, g, out, H, T);
+}
+
+// y = W x + b for a single vector (speaker conditioning: cond layers applied to g = emb_g[sid]).
+__global__ __launch_bounds__(64) void gemv_kernel(const float* __restrict__ W, const float* __restrict__ x, const float* __restrict__ b,
+                                                   float* __restrict__ y, int K, const float* __restrict__ add) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += W[(long long)row * K + k] * x[k];
+  s = wave_sum(s);
+  if (lane == 0) y[row] = s + (b ? b[row] : 0.f) + (add ? add[row] : 0.f);
+}
+void gemv(hipStream_t s, const float* W, const float* x, const float* b, float* y, int N, int K, const float* add) {
+  hipLaunchKernelGGL(gemv_kernel, dim3(N), dim3(64), 0, s, W, x, b, y, K, add);
+}
+
+// z_p = m + exp(logs) * noise * 0.66666      (reference models.py:801)
+__global__ void zp_kernel(const float* __restrict__ stats, const float* __restrict__ noise, float* __restrict__ zp, int C, int T) {
+  const long long n = (long long)C * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) zp[i] = stats[i] + expf(stats[i + n]) * noise[i] * 0.66666f;
+}
+void zp_sample(hipStream_t s, const float* stats, const float* noise, float* zp, int C, int T) {
+  long long n = (long long)C * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zp_kernel, dim3(blocks), dim3(256), 0, s, stats, noise, zp, C, T);
+}
+
+// channel flip (reference modules.py:373-380): y[c] = x[C-1-c]
+__global__ void flip_c_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int T) {
+  const long long n = (long long)C * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) { const int c = (int)(i / T); const int t = (int)(i - (long long)c * T); y[i] = x[(long long)(C - 1 - c) * T + t]; }
+}
+void flip_c(hipStream_t s, const float* x, float* y, int C, int T) {
+  long long n = (long long)C * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(flip_c_kernel, dim3(blocks), dim3(256), 0, s, x, y, C, T);
+}
+
+// enc_p embedding: x[c][t] = lrelu((lin[c][t] + emb_pitch[pitch[t]][c]) * sqrt(C), 0.1)   (reference models.py:90-97)
+__global__ void encp_embed_kernel(float* __restrict__ x, const float* __restrict__ emb, const long long* __restrict__ pitch, int C,
+                                  int T, float scale) {
+  const long long n = (long long)C * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int c = (int)(i / T); const int t = (int)(i - (long long)c * T);
+    float v = (x[i] + emb[pitch[t] * C + c]) * scale;
+    x[i] = v > 0.f ? v : v * 0.1f;
+  }
+}
+void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitch, int C, int T) {
+  long long n = (long long)C * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(encp_embed_kernel, dim3(blocks), dim3(256), 0, s, x, emb, pitch, C, T, sqrtf((float)C));
+}
+
+// ---------------------------------------------------------------------------------------------- transpose [R][C] -> [C][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
+                                                        long long ldin, long long ldout, long long bin, long long bout) {
+  __shared__ float tile[32][33];
+  in += (long long)blockIdx.z * bin; out += (long long)blockIdx.z * bout;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) { const int r = r0 + j, c = c0 + tx; tile[j][tx] = (r < R && c < C) ? in[(long long)r * ldin + c] : 0.f; }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) { const int c = c0 + j, r = r0 + tx; if (c < C && r < R) out[(long long)c * ldout + r] = tile[tx][j]; }
+}
+void transpose(hipStream_t s, const float* in, float* out, int R, int C, long long ldin, long long ldout, int batch, long long bin,
+               long long bout) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, s, in, out, R, C, ldin, ldout, bin, bout);
+}
+
+// features for the synthesizer: nearest x2 upsample of [D][Th] and the protect blend (reference vc_infer_pipeline.py:77-95)
+__global__ void feats_prepare_kernel(const float* __restrict__ f, const float* __restrict__ pitchf, float* __restrict__ out, int D,
+                                     int Th, int T, float protect, int do_protect) {
+  const long long n = (long long)D * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int c = (int)(i / T); const int t = (int)(i - (long long)c * T);
+    const float v = f[(long long)c * Th + (t >> 1)];
+    float o = v;
+    if (do_protect) {
+      const float pf = pitchf[t];
+      float w = pf;
+      if (pf > 0.f) w = 1.f;
+      if (pf < 1.f) w = protect;
+      o = v * w + v * (1.f - w);
+    }
+    out[i] = o;
+  }
+}
+void feats_prepare(hipStream_t s, const float* f, const float* pitchf, float* out, int D, int Th, int T, float protect, int do_protect) {
+  long long n = (long long)D * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(feats_prepare_kernel, dim3(blocks), dim3(256), 0, s, f, pitchf, out, D, Th, T, protect, do_protect);
+}
+
+// ---------------------------------------------------------------------------------------------- im2col for single-channel convs
+// out[j][t] = src[t*stride + j - pad]  (pad_mode 0: zeros, 1: reflect);  j < k, t < Tout
+__global__ void frames_kernel(const float* __restrict__ src, float* __restrict__ out, int L, int k, int stride, int pad, int Tout,
+                              int reflect) {
+  const long long n = (long long)k * Tout;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int j = (int)(i / Tout); const int t = (int)(i - (long long)j * Tout);
+    long long x = (long long)t * stride + j - pad;
+    float v = 0.f;
+    if (reflect) { if (x < 0) x = -x; if (x >= L) x = 2LL * (L - 1) - x; v = src[x]; }
+    else if (x >= 0 && x < L) v = src[x];
+    out[i] = v;
+  }
+}
+void frames(hipStream_t s, const float* src, float* out, int L, int k, int stride, int pad, int Tout, int reflect) {
+  long long n = (long long)k * Tout; int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(frames_kernel, dim3(blocks), dim3(256), 0, s, src, out, L, k, stride, pad, Tout, reflect);
+}
+
+// |STFT|: mag[f][t] = sqrt(re^2 + im^2) with re = ft[f][t], im = ft[f + F][t]   (reference lib/rmvpe.py:143-147)
+__global__ void magnitude_kernel(const float* __restrict__ ft, float* __restrict__ mag, int F, int T) {
+  const long long n = (long long)F * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) { const float re = ft[i], im = ft[i + n]; mag[i] = sqrtf(re * re + im * im); }
+}
+void magnitude(hipStream_t s, const float* ft, float* mag, int F, int T) {
+  long long n = (long long)F * T; int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(magnitude_kernel, dim3(blocks), dim3(256), 0, s, ft, mag, F, T);
+}
+
+// RMVPE U-Net input: x[t][m] = bn(logmel[m][reflect_right(t)])  for t < Tr  (reference lib/rmvpe.py:590-594,:302,:466)
+__global__ __launch_bounds__(256) void mel_to_unet_kernel(const float* __restrict__ mel, float* __restrict__ x, int n, int Tr, float a, float b) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int t = t0 + tx; float v = 0.f;
+    if (t < Tr) { if (t >= n) t = 2 * (n - 1) - t; v = mel[(long long)(m0 + j) * n + t]; }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) { const int t = t0 + j; if (t < Tr) x[(long long)t * 128 + m0 + tx] = tile[tx][j] * a + b; }
+}
+void mel_to_unet(hipStream_t s, const float* mel, float* x, int n, int Tr, float a, float b) {
+  hipLaunchKernelGGL(mel_to_unet_kernel, dim3((Tr + 31) / 32, 4), dim3(256), 0, s, mel, x, n, Tr, a, b);
+}
+
+// AvgPool2d(2,2) on [C][H][W] -> [C][H/2][W/2]
+__global__ void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W, long long ldx) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long long n = (long long)C * Ho * Wo;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int w = (int)(i % Wo); const long long r = i / Wo; const int h = (int)(r % Ho); const int c = (int)(r / Ho);
+    const float* p = x + (long long)c * ldx + (long long)(2 * h) * W + 2 * w;
+    y[i] = (p[0] + p[1] + p[W] + p[W + 1]) * 0.25f;
+  }
+}
+void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long long ldx) {
+  long long n = (long long)C * (H / 2) * (W / 2); int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks), dim3(256), 0, s, x, y, C, H, W, ldx);
+}
+
+// ---------------------------------------------------------------------------------------------- GRU recurrence (bidirectional)
+// 16 workgroups: (direction, slice of 32 hidden units).  Each keeps its 96 x 256 block of W_hh in registers
+// (2 threads per row, 128 weights each).  h_t is exchanged through 8-byte {step tag, value} granules written with
+// agent-scope relaxed atomics (write-through) into a 2-deep ring and gathered by polling (bounded spin).
+// gi: [T][1536] = W_ih x + (bias added here); out: channel-major [512][T].   nn.GRU gate order r, z, n.
+__global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
+                                                       const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                       float* __restrict__ out, unsigned long long* xbuf, int* err, int T) {
+  constexpr int H = 256, NS = 8, HS = 32;
+  __shared__ __attribute__((aligned(16))) float hs[H];
+  __shared__ float ghs[96];
+  const int dir = blockIdx.x / NS, sl = blockIdx.x % NS;
+  const int tid = threadIdx.x;
+  const float* W = w_hh + (long long)dir * 3 * H * H;
+  const float* BH = b_hh + dir * 3 * H;
+  const float* BI = b_ih + dir * 3 * H;
+  unsigned long long* xb = xbuf + dir * 2 * H;
+
+  // weights of this thread: local row lr = tid >> 1 (gate g = lr / 32, unit jj = lr % 32), column half = tid & 1
+  float w[128];
+  const int lr = tid >> 1, half = tid & 1;
+  const bool worker = tid < 192;
+  if (worker) {
+    const int grow = (lr / HS) * H + sl * HS + (lr % HS);
+#pragma unroll
+    for (int c = 0; c < 128; ++c) w[c] = W[(long long)grow * H + half * 128 + c];
+  }
+  float bi_r = 0.f, bi_z = 0.f, bi_n = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f;
+  const int unit = sl * HS + tid;   // valid for tid < 32
+  if (tid < HS) {
+    bi_r = BI[unit]; bi_z = BI[H + unit]; bi_n = BI[2 * H + unit];
+    bh_r = BH[unit]; bh_z = BH[H + unit]; bh_n = BH[2 * H + unit];
+  }
+  hs[tid] = 0.f;
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (tid < HS) {
+      const float* g = gi + (long long)t * (6 * H) + dir * 3 * H + unit;
+      gr = g[0]; gz = g[H]; gn = g[2 * H];
+    }
+    if (step > 0) {
+      // gather h_{step-1}: one granule per thread
+      const unsigned long long* gp = xb + ((step - 1) & 1) * H + tid;
+      unsigned long long v;
+      unsigned spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == (unsigned)step) break;
+        if (++spins > (1u << 24)) { if (err) atomicExch(err, 1); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      hs[tid] = __uint_as_float((unsigned)v);
+      __syncthreads();
+    }
+    if (worker) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float4* hv = reinterpret_cast<const float4*>(hs + half * 128);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const float4 h4 = hv[c];
+        a0 = fmaf(w[4 * c + 0], h4.x, a0); a1 = fmaf(w[4 * c + 1], h4.y, a1);
+        a2 = fmaf(w[4 * c + 2], h4.z, a2); a3 = fmaf(w[4 * c + 3], h4.w, a3);
+      }
+      float a = (a0 + a1) + (a2 + a3);
+      a += __shfl_xor(a, 1);
+      if (half == 0) ghs[lr] = a;
+    }
+    __syncthreads();
+    if (tid < HS) {
+      const float r = 1.f / (1.f + expf(-((gr + bi_r) + (ghs[tid] + bh_r))));
+      const float zg = 1.f / (1.f + expf(-((gz + bi_z) + (ghs[HS + tid] + bh_z))));
+      const float nn = tanhf((gn + bi_n) + r * (ghs[2 * HS + tid] + bh_n));
+      const float hprev = hs[unit];
+      const float hnew = (1.f - zg) * nn + zg * hprev;
+      out[(long long)(dir * H + unit) * T + t] = hnew;
+      const unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hnew);
+      __hip_atomic_store(xb + (step & 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+}
+void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* b_hh, float* out,
+              unsigned long long* xbuf, int* err, int T) {
+  (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
+  (void)hipMemsetAsync(err, 0, sizeof(int), s);
+  hipLaunchKernelGGL(gru_scan_kernel, dim3(16), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T);
+}
+
+// ---------------------------------------------------------------------------------------------- RMVPE decode
+// salience channel-major [360][ld]; f0[t] = 10 * 2^(cents/1200) with the 9-bin local weighted average around the argmax
+// (reference lib/rmvpe.py:607-612,:661-685); 0 where max <= thred.  Output float64 like the numpy reference.
+__global__ void rmvpe_decode_kernel(const float* __restrict__ sal, double* __restrict__ f0, int n, long long ld, float thred) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float mx = -1.f; int am = 0;
+  for (int c = 0; c < 360; ++c) { const float v = sal[(long long)c * ld + t]; if (v > mx) { mx = v; am = c; } }
+  double ps = 0.0, ws = 0.0;
+  for (int d = -4; d <= 4; ++d) {
+    const int c = am + d;
+    if (c < 0 || c >= 360) continue;   // zero padding contributes nothing
+    const float v = sal[(long long)c * ld + t];
+    ps += (double)v * (20.0 * (double)c + 1997.3794084376191);
+    ws += (double)v;
+  }
+  double cents = ps / ws;
+  if (mx <= thred) cents = 0.0;
+  double f = 10.0 * exp2(cents / 1200.0);
+  if (f == 10.0) f = 0.0;
+  f0[t] = f;
+}
+void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred) {
+  hipLaunchKernelGGL(rmvpe_decode_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sal, f0, n, ld, thred);
+}
+
+// ---------------------------------------------------------------------------------------------- SineGen / SourceModuleHnNSF
+// (reference lib/infer_pack/models.py:361-411,:455-467, harmonic_num = 0).  fp64 running sums restate torch.cumsum on CPU.
+// Stage 1 (one block): rad[t] = (f0/sr) % 1; tmp[t] = float(cumsum_fp64(rad)) * upp
+__global__ __launch_bounds__(1024) void sine_frame_kernel(const float* __restrict__ f0, float* __restrict__ rad, float* __restrict__ tmp,
+                                                          int T, float sr, float upp) {
+  __shared__ double part[1024];
+  const int tid = threadIdx.x;
+  const int per = (T + 1023) / 1024;
+  const int b = tid * per, e = min(T, b + per);
+  double s = 0.0;
+  for (int t = b; t < e; ++t) { const float r = fmodf(f0[t] / sr, 1.f); rad[t] = r; s += (double)r; }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { double run = 0.0; for (int i = 0; i < 1024; ++i) { const double v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  double run = part[tid];
+  for (int t = b; t < e; ++t) { run += (double)rad[t]; tmp[t] = (float)run * upp; }
+}
+
+__device__ __forceinline__ float sine_interp(const float* __restrict__ tmp, int T, float scale, long long i) {
+  const float src = scale * (float)i;
+  int i0 = (int)src;
+  const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
+  float l1 = src - (float)i0; l1 = fminf(fmaxf(l1, 0.f), 1.f);
+  const float l0 = 1.f - l1;
+  const float v = l0 * tmp[i0] + l1 * tmp[i1];
+  return fmodf(v, 1.f);
+}
+__device__ __forceinline__ float sine_incr(const float* __restrict__ rad, const float* __restrict__ tmp, int T, int upp, float scale, long long i) {
+  float v = rad[i / upp];
+  if (i > 0) { if (sine_interp(tmp, T, scale, i) - sine_interp(tmp, T, scale, i - 1) < 0.f) v += -1.f; }
+  return v;
+}
+// Stage 2: per-block (1024 samples) sums of the phase increments
+__global__ __launch_bounds__(256) void sine_blocksum_kernel(const float* __restrict__ rad, const float* __restrict__ tmp, double* __restrict__ bsum,
+                                                            int T, int upp, float scale, long long N) {
+  __shared__ double red[4];
+  const long long base = (long long)blockIdx.x * 1024;
+  double s = 0.0;
+  for (int j = 0; j < 4; ++j) { const long long i = base + threadIdx.x * 4 + j; if (i < N) s += (double)sine_incr(rad, tmp, T, upp, scale, i); }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// Stage 3 (one block): exclusive scan of the block sums
+__global__ __launch_bounds__(1024) void sine_scan_kernel(double* __restrict__ bsum, int nb) {
+  __shared__ double part[1024];
+  const int tid = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int b = tid * per, e = min(nb, b + per);
+  double s = 0.0;
+  for (int i = b; i < e; ++i) s += bsum[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { double run = 0.0; for (int i = 0; i < 1024; ++i) { const double v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  double run = part[tid];
+  for (int i = b; i < e; ++i) { const double v = bsum[i]; bsum[i] = run; run += v; }
+}
+// Stage 4: in-block scan + sin + uv gating + noise + Linear(1,1) + tanh -> har[i]
+__global__ __launch_bounds__(256) void sine_final_kernel(const float* __restrict__ f0, const float* __restrict__ rad, const float* __restrict__ tmp,
+                                                         const double* __restrict__ bsum, const float* __restrict__ noise, float* __restrict__ har,
+                                                         float* __restrict__ sine_out, int T, int upp, float scale, long long N, float lw, float lb) {
+  __shared__ double wsum[4];
+  const long long base = (long long)blockIdx.x * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double v[4]; double loc = 0.0;
+  for (int j = 0; j < 4; ++j) { const long long i = base + tid * 4 + j; v[j] = (i < N) ? (double)sine_incr(rad, tmp, T, upp, scale, i) : 0.0; loc += v[j]; }
+  // inclusive scan of `loc` across the wave
+  double inc = loc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const double nbr = __shfl_up(inc, o); if (lane >= o) inc += nbr; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  double off = bsum[blockIdx.x];
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+  double run = off + (inc - loc);
+  for (int j = 0; j < 4; ++j) {
+    const long long i = base + tid * 4 + j;
+    run += v[j];
+    if (i < N) {
+      const float ph = (float)run;
+      float sw = sinf(ph * 2.f * 3.14159265358979323846f) * 0.1f;
+      const float uv = f0[i / upp] > 0.f ? 1.f : 0.f;
+      const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
+      sw = sw * uv + namp * noise[i];
+      if (sine_out) sine_out[i] = sw;
+      har[i] = tanhf(sw * lw + lb);
+    }
+  }
+}
+void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
+                 int T, int upp, float sr, float lw, float lb) {
+  const long long N = (long long)T * upp;
+  const int nb = (int)((N + 1023) / 1024);
+  const float scale = N > 1 ? (float)(T - 1) / (float)(N - 1) : 0.f;
+  hipLaunchKernelGGL(sine_frame_kernel, dim3(1), dim3(1024), 0, s, f0, rad, tmp, T, sr, (float)upp);
+  hipLaunchKernelGGL(sine_blocksum_kernel, dim3(nb), dim3(256), 0, s, rad, tmp, bsum, T, upp, scale, N);
+  hipLaunchKernelGGL(sine_scan_kernel, dim3(1), dim3(1024), 0, s, bsum, nb);
+  hipLaunchKernelGGL(sine_final_kernel, dim3(nb), dim3(256), 0, s, f0, rad, tmp, bsum, noise, har, sine_out, T, upp, scale, N, lw, lb);
+}
+
+}  // namespace rvc

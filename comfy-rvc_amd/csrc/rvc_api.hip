@@ -1,0 +1,260 @@
+// extern "C" layer of librvc_hip.so (see include/rvc_hip.h).  Every entry point converts C++ exceptions into a status code
+// plus a thread-local message; nothing here has a CPU fallback.
+#include "models.h"
+
+namespace rvc {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace rvc
+
+using namespace rvc;
+
+struct rvc_ctx { Ctx c; };
+struct rvc_hubert { Hubert* m; rvc_ctx* ctx; };
+struct rvc_rmvpe { Rmvpe* m; rvc_ctx* ctx; };
+struct rvc_synth { Synth* m; rvc_ctx* ctx; };
+struct rvc_conv1d_plan { ConvLayer L; };
+
+#define RVC_TRY try {
+#define RVC_CATCH                                                            \
+  return 0;                                                                  \
+  }                                                                          \
+  catch (const std::exception& e) { rvc::set_error(e.what()); return 1; }    \
+  catch (...) { rvc::set_error("unknown error"); return 2; }
+
+static void check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw Error(std::string("kernel launch failed: ") + hipGetErrorString(e));
+}
+
+extern "C" {
+
+const char* rvc_last_error(void) { return g_err.c_str(); }
+const char* rvc_version(void) { return "rvc_hip 0.1.0 (gfx950, fp32 MFMA)"; }
+
+int rvc_ctx_create(int device_id, rvc_ctx** out) {
+  RVC_TRY
+  int n = 0;
+  RVC_HIP_CHECK(hipGetDeviceCount(&n));
+  RVC_REQUIRE(n > 0 && device_id >= 0 && device_id < n, "no such HIP device (this library has no CPU path)");
+  RVC_HIP_CHECK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  RVC_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  RVC_REQUIRE(std::string(prop.gcnArchName).find("gfx950") != std::string::npos,
+              std::string("kernels are built for gfx950 only, found ") + prop.gcnArchName);
+  rvc_ctx* c = new rvc_ctx();
+  c->c.device = device_id;
+  *out = c;
+  RVC_CATCH
+}
+int rvc_ctx_destroy(rvc_ctx* ctx) { delete ctx; return 0; }
+int64_t rvc_ctx_workspace_bytes(rvc_ctx* ctx) { return ctx ? (int64_t)ctx->c.workspace_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------ hubert
+int rvc_hubert_create(rvc_ctx* ctx, rvc_hubert** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && out, "null argument");
+  rvc_hubert* h = new rvc_hubert(); h->ctx = ctx; h->m = hubert_create(&ctx->c); *out = h;
+  RVC_CATCH
+}
+int rvc_hubert_set_tensor(rvc_hubert* h, const char* name, const float* d, const int64_t* shape, int ndim) {
+  RVC_TRY
+  RVC_REQUIRE(h && name && d && ndim <= 8, "bad argument");
+  long long sh[8]; for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+  hubert_set_tensor(h->m, name, d, sh, ndim);
+  RVC_CATCH
+}
+int rvc_hubert_finalize(rvc_hubert* h) { RVC_TRY RVC_HIP_CHECK(hipSetDevice(h->ctx->c.device)); hubert_finalize(h->m); RVC_CATCH }
+int rvc_hubert_destroy(rvc_hubert* h) { if (h) { hubert_destroy(h->m); delete h; } return 0; }
+int64_t rvc_hubert_num_frames(int64_t L) { return hubert_num_frames(L); }
+int rvc_hubert_forward(rvc_hubert* h, void* stream, const float* audio, int64_t L, int version, int n_layers, float* out_rm, float* out_cm,
+                       const rvc_hubert_taps* taps) {
+  RVC_TRY
+  RVC_REQUIRE(h && audio, "null argument");
+  hubert_forward(h->m, (hipStream_t)stream, audio, L, version, n_layers, out_rm, out_cm, taps);
+  check_launch();
+  h->ctx->c.workspace_bytes = hubert_workspace(h->m);
+  RVC_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ rmvpe
+int rvc_rmvpe_create(rvc_ctx* ctx, rvc_rmvpe** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && out, "null argument");
+  rvc_rmvpe* r = new rvc_rmvpe(); r->ctx = ctx; r->m = rmvpe_create(&ctx->c); *out = r;
+  RVC_CATCH
+}
+int rvc_rmvpe_set_tensor(rvc_rmvpe* r, const char* name, const float* d, const int64_t* shape, int ndim) {
+  RVC_TRY
+  RVC_REQUIRE(r && name && d && ndim <= 8, "bad argument");
+  long long sh[8]; for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+  rmvpe_set_tensor(r->m, name, d, sh, ndim);
+  RVC_CATCH
+}
+int rvc_rmvpe_finalize(rvc_rmvpe* r) { RVC_TRY RVC_HIP_CHECK(hipSetDevice(r->ctx->c.device)); rmvpe_finalize(r->m); RVC_CATCH }
+int rvc_rmvpe_destroy(rvc_rmvpe* r) { if (r) { rmvpe_destroy(r->m); delete r; } return 0; }
+int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio, int64_t L, float thred, float* mel, float* sal, double* f0,
+                      const rvc_rmvpe_taps* taps) {
+  RVC_TRY
+  RVC_REQUIRE(r && audio, "null argument");
+  rmvpe_forward(r->m, (hipStream_t)stream, audio, L, thred, mel, sal, f0, taps);
+  check_launch();
+  RVC_CATCH
+}
+int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* sal, int64_t n, float thred, double* f0) {
+  RVC_TRY
+  RVC_REQUIRE(r && sal && f0 && n > 0, "bad argument");
+  rmvpe_decode_rm(r->m, (hipStream_t)stream, sal, n, thred, f0);
+  check_launch();
+  RVC_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ synth
+int rvc_synth_create(rvc_ctx* ctx, const rvc_synth_config* cfg, rvc_synth** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && cfg && out, "null argument");
+  rvc_synth* s = new rvc_synth(); s->ctx = ctx; s->m = nullptr;
+  try { s->m = synth_create(&ctx->c, *cfg); } catch (...) { delete s; throw; }
+  *out = s;
+  RVC_CATCH
+}
+int rvc_synth_set_tensor(rvc_synth* s, const char* name, const float* d, const int64_t* shape, int ndim) {
+  RVC_TRY
+  RVC_REQUIRE(s && name && d && ndim <= 8, "bad argument");
+  long long sh[8]; for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+  synth_set_tensor(s->m, name, d, sh, ndim);
+  RVC_CATCH
+}
+int rvc_synth_finalize(rvc_synth* s) { RVC_TRY RVC_HIP_CHECK(hipSetDevice(s->ctx->c.device)); synth_finalize(s->m); RVC_CATCH }
+int rvc_synth_destroy(rvc_synth* s) { if (s) { synth_destroy(s->m); delete s; } return 0; }
+int rvc_synth_upp(rvc_synth* s) { return s ? synth_upp(s->m) : 0; }
+int rvc_synth_infer(rvc_synth* s, void* stream, const float* phone, int phone_cm, const int64_t* pitch, const float* pitchf, int sid,
+                    const float* noise_z, const float* noise_src, int64_t T, float* out, const rvc_synth_taps* taps) {
+  RVC_TRY
+  RVC_REQUIRE(s && phone && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  synth_infer(s->m, (hipStream_t)stream, phone, phone_cm, (const long long*)pitch, pitchf, sid, noise_z, noise_src, (int)T, out, taps);
+  check_launch();
+  RVC_CATCH
+}
+
+int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio, int64_t L, int version, const int64_t* pitch,
+                   const float* pitchf, int sid, float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
+  RVC_TRY
+  RVC_REQUIRE(h && s && audio && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const long long Th = hubert_num_frames(L);
+  const int D = version == 1 ? 256 : 768;
+  const int T = (int)(2 * Th);
+  // scratch for the channel-major features lives in two small allocations owned by this call's stream order
+  float* fcm = nullptr; float* fup = nullptr;
+  RVC_HIP_CHECK(hipMallocAsync((void**)&fcm, (size_t)D * Th * sizeof(float), st));
+  RVC_HIP_CHECK(hipMallocAsync((void**)&fup, (size_t)D * T * sizeof(float), st));
+  try {
+    hubert_forward(h->m, st, audio, L, version, 0, nullptr, fcm, nullptr);
+    feats_prepare(st, fcm, pitchf, fup, D, (int)Th, T, protect, do_protect);
+    synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
+    check_launch();
+  } catch (...) { (void)hipFreeAsync(fcm, st); (void)hipFreeAsync(fup, st); throw; }
+  RVC_HIP_CHECK(hipFreeAsync(fcm, st));
+  RVC_HIP_CHECK(hipFreeAsync(fup, st));
+  RVC_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ single ops
+int rvc_op_conv1d(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int Tin, int k,
+                  int stride, int pad, int dil, int groups, int pre_act, float pre_slope, int act, float act_slope, int act_before_res,
+                  float out_scale, int accumulate) {
+  RVC_TRY
+  ConvLayer L;
+  conv1d_layer_init(L, w, bias, Co, Ci, k, stride, pad, dil, groups);
+  ConvEpilogue e; e.pre_act = pre_act; e.pre_slope = pre_slope; e.act = act; e.act_slope = act_slope; e.act_before_res = act_before_res;
+  e.out_scale = out_scale; e.accumulate = accumulate;
+  const int Tout = conv1d_out_len(L, Tin);
+  e.R = res; e.ldR = Tout;
+  try { conv1d_run(L, (hipStream_t)stream, x, Tin, Tin, y, Tout, e); check_launch(); RVC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+  catch (...) { conv_layer_free(L); throw; }
+  conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_conv_transpose1d(void* stream, const float* x, const float* w, const float* bias, float* y, int Ci, int Co, int Tin, int k, int u,
+                            int pad, int pre_act, float pre_slope, int accumulate) {
+  RVC_TRY
+  ConvLayer L;
+  tconv1d_layer_init(L, w, bias, Ci, Co, k, u, pad);
+  ConvEpilogue e; e.pre_act = pre_act; e.pre_slope = pre_slope; e.accumulate = accumulate;
+  const int Tout = conv1d_out_len(L, Tin);
+  try { conv1d_run(L, (hipStream_t)stream, x, Tin, Tin, y, Tout, e); check_launch(); RVC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+  catch (...) { conv_layer_free(L); throw; }
+  conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_conv2d3x3(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int H, int W,
+                     int relu) {
+  RVC_TRY
+  ConvLayer L;
+  conv2d3x3_layer_init(L, w, bias, Co, Ci);
+  ConvEpilogue e; e.act = relu ? ACT_RELU : ACT_NONE; e.act_before_res = 1; e.R = res; e.ldR = (long long)H * W;
+  try { conv2d_run(L, (hipStream_t)stream, x, (long long)H * W, H, W, y, (long long)H * W, e); check_launch(); RVC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+  catch (...) { conv_layer_free(L); throw; }
+  conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_conv_transpose2d(void* stream, const float* x, const float* w, const float* bias, float* y, int Ci, int Co, int H, int W, int relu) {
+  RVC_TRY
+  ConvLayer L;
+  tconv2d_layer_init(L, w, bias, Ci, Co);
+  ConvEpilogue e; e.act = relu ? ACT_RELU : ACT_NONE;
+  try { conv2d_run(L, (hipStream_t)stream, x, (long long)H * W, H, W, y, 4LL * H * W, e); check_launch(); RVC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+  catch (...) { conv_layer_free(L); throw; }
+  conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_gemm_tn(void* stream, const float* a, const float* b, float* y, int M, int N, int K, int batch) {
+  RVC_TRY
+  ConvEpilogue e;
+  gemm_tn_run((hipStream_t)stream, a, M, (long long)K * M, b, N, (long long)K * N, y, N, (long long)M * N, M, N, K, batch, nullptr, 0, e);
+  check_launch();
+  RVC_CATCH
+}
+int rvc_conv1d_plan_create(const float* w, const float* bias, int Ci, int Co, int k, int stride, int pad, int dil, int groups,
+                           rvc_conv1d_plan** out) {
+  RVC_TRY
+  rvc_conv1d_plan* p = new rvc_conv1d_plan();
+  try { conv1d_layer_init(p->L, w, bias, Co, Ci, k, stride, pad, dil, groups); } catch (...) { delete p; throw; }
+  *out = p;
+  RVC_CATCH
+}
+int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x, int Tin, const float* res, float* y, int pre_act, float pre_slope,
+                        int act, float act_slope) {
+  RVC_TRY
+  ConvEpilogue e; e.pre_act = pre_act; e.pre_slope = pre_slope; e.act = act; e.act_slope = act_slope;
+  const int Tout = conv1d_out_len(p->L, Tin);
+  e.R = res; e.ldR = Tout;
+  conv1d_run(p->L, (hipStream_t)stream, x, Tin, Tin, y, Tout, e);
+  check_launch();
+  RVC_CATCH
+}
+int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
+int rvc_op_layernorm_c(void* stream, const float* x, const float* res, const float* gamma, const float* beta, float* y, int C, int T) {
+  RVC_TRY
+  layernorm_c((hipStream_t)stream, x, res, gamma, beta, y, C, T, T, 1e-5f);
+  check_launch();
+  RVC_CATCH
+}
+int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float* har, float* sine, int T, int upp, float sr, float lw, float lb) {
+  RVC_TRY
+  hipStream_t st = (hipStream_t)stream;
+  const long long N = (long long)T * upp;
+  float* rad = nullptr; float* tmp = nullptr; double* bsum = nullptr;
+  RVC_HIP_CHECK(hipMalloc(&rad, T * sizeof(float)));
+  RVC_HIP_CHECK(hipMalloc(&tmp, T * sizeof(float)));
+  RVC_HIP_CHECK(hipMalloc(&bsum, ((N + 1023) / 1024) * sizeof(double)));
+  sine_source(st, f0, noise, har, sine, rad, tmp, bsum, T, upp, sr, lw, lb);
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(rad); (void)hipFree(tmp); (void)hipFree(bsum);
+  RVC_HIP_CHECK(e);
+  check_launch();
+  RVC_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal declarations shared by the HIP translation units of librvc_hip.so (gfx950 only).
+// Public C ABI: include/rvc_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+namespace rvc {
+
+// ----------------------------------------------------------------------------- errors
+void set_error(const std::string& msg);
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define RVC_HIP_CHECK(expr)                                                                       \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      throw rvc::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                       ":" + std::to_string(__LINE__) + ")");                                     \
+  } while (0)
+
+#define RVC_REQUIRE(cond, msg)                                                                    \
+  do {                                                                                            \
+    if (!(cond)) throw rvc::Error(std::string("requirement failed: ") + #cond + " : " + (msg));   \
+  } while (0)
+
+// ----------------------------------------------------------------------------- activations
+enum Act : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5, ACT_LOGCLAMP = 6 };
+
+// ----------------------------------------------------------------------------- conv (conv_mfma.hip)
+// One implicit-GEMM convolution: Y[m, n] = epilogue( sum_k Wp[k, m] * Xtile[k, n] ).
+// 1-D: X [Ci][Tin] (time contiguous), 2-D: X [Ci][H][Wd].  Weights are pre-packed on the host.
+struct ConvArgs {
+  const float* X; const float* W; const float* bias; const float* R; float* Y;
+  int Ci;        // input channels (per group)
+  int Co;        // GEMM rows that are stored (per group)
+  int CoP;       // padded rows in the packed weights (multiple of 32)
+  int Tin;       // 1-D: input length.  2-D: H
+  int Tout;      // 1-D: output length. 2-D: H*Wd (output positions of the GEMM)
+  int Wd;        // 2-D: width (power of two); 0 for 1-D
+  int ktaps;     // taps per virtual channel (1-D: ceil(k/stride); 2-D: 9)
+  int dil, stride, pad;
+  int CK;        // virtual channels per chunk (even)
+  int KT;        // taps per weight stage
+  int nchunk;    // number of chunks
+  int WROW;      // LDS row pitch in floats
+  int PW, BWd, BH;  // 2-D: LDS row pitch of one image row, tile width, tile rows
+  long long xBatch, wBatch, yBatch, rBatch; int bBatch;   // blockIdx.z strides (elements)
+  long long ldX, ldY, ldR;                               // channel strides (elements)
+  int pre_act; float pre_slope;                          // activation applied to X while staging
+  int act; float act_slope;                              // epilogue activation
+  int act_before_res;                                    // 1: act(v)+R   0: act(v+R)
+  float out_scale; int accumulate;                       // y = [y +] out_scale * v
+  int ostride, orows;                                    // 1-D interleaved store: m -> (co = m % orows, r = m / orows); addr = co*ldY + n*ostride + r
+  int up2;                                               // 2-D: ConvTranspose 2x2 phase interleave
+};
+
+// A convolution layer with its weights packed for the kernel and resident on the device.
+struct ConvLayer {
+  float* Wd_ = nullptr;    // packed weights (device)
+  float* bd_ = nullptr;    // bias (device) or null
+  int mode = 1;            // 1: 1-D, 2: 2-D 3x3
+  int Ci = 0, Co = 0, CoP = 0, groups = 1;
+  int k = 1, stride = 1, dil = 1, pad = 0;
+  int ktaps = 1, CK = 8, KT = 1, nchunk = 1;
+  int tconv_u = 0;         // >0: ConvTranspose1d with stride u (polyphase rows), `Co` = u * co_real
+  int co_real = 0;
+  int up2 = 0;             // 2-D ConvTranspose (k3 s2 p1 op1) as 4 phase convs
+  int conv_pad = 0;        // ConvTranspose1d: left pad of the equivalent stride-1 conv
+  long long wBatch = 0;    // packed elements per group
+};
+
+struct ConvEpilogue {
+  const float* R = nullptr; long long ldR = 0;
+  int pre_act = ACT_NONE; float pre_slope = 0.f;
+  int act = ACT_NONE; float act_slope = 0.f;
+  int act_before_res = 0;
+  float out_scale = 1.f; int accumulate = 0;
+  const float* bias_override = nullptr;   // per-call bias vector replacing the layer's own (speaker conditioning)
+  int tout_limit = 0;                     // >0: compute only the first tout_limit output positions
+};
+
+// host-side packing + upload (weights in PyTorch layouts)
+void conv1d_layer_init(ConvLayer& L, const float* w /*[Co][Ci/groups][k]*/, const float* bias, int Co, int Ci, int k,
+                       int stride, int pad, int dil, int groups);
+void tconv1d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][k]*/, const float* bias, int Ci, int Co, int k, int u, int pad);
+void conv2d3x3_layer_init(ConvLayer& L, const float* w /*[Co][Ci][3][3]*/, const float* bias, int Co, int Ci);
+void conv2d1x1_layer_init(ConvLayer& L, const float* w /*[Co][Ci]*/, const float* bias, int Co, int Ci);
+void tconv2d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][3][3]*/, const float* bias, int Ci, int Co);
+void conv_layer_free(ConvLayer& L);
+
+// launches.  1-D: X [Ci][Tin] with channel stride ldX, Y [Co][Tout] with channel stride ldY.
+int conv1d_out_len(const ConvLayer& L, int Tin);
+void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int Tin, float* Y, long long ldY,
+                const ConvEpilogue& e);
+// GEMM with an activation tensor as the "weight" operand: Y[z][m][n] = sum_k A[z][k][m] * B[z][k][n]  (k = channel)
+void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch, const float* B, long long ldB, long long bBatch,
+                 float* Y, long long ldY, long long yBatch, int M, int N, int K, int batch, const float* bias, int biasBatch,
+                 const ConvEpilogue& e);
+// 2-D: X [Ci][H][Wd], Y [Co][H][Wd] (or [Co][2H][2Wd] for up2).
+void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
+                const ConvEpilogue& e);
+
+// ----------------------------------------------------------------------------- device memory
+float* dev_upload(const float* host, size_t n);
+void dev_free(void* p);
+
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false;
+  void reset() { off = 0; }
+  template <typename T> T* alloc(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+    size_t o = off; off += bytes; if (off > peak) peak = off;
+    if (dry) return reinterpret_cast<T*>(uintptr_t(0x1000) + o);   // never dereferenced
+    RVC_REQUIRE(off <= cap, "arena overflow");
+    return reinterpret_cast<T*>(base + o);
+  }
+  void ensure(size_t bytes);
+  void release();
+};
+
+}  // namespace rvc

@@ -1,0 +1,150 @@
+/* librvc_hip.so - C ABI of the MI355X-native RVC voice-conversion inference path.
+ *
+ * The reference (SayanoAI/Comfy-RVC) is pure Python with no FFI; its "operator API" for this path is a set of
+ * duck-typed Python callables.  Each entry point below is what a ctypes binding of that callable binds
+ * (comfy-rvc_amd/_lib.py is that binding; INTEGRATION.md shows the reference-side stubs):
+ *
+ *   rvc_hubert_forward   <- HubertModelWithFinalProj.extract_features   lib/infer_pack/loaders.py:55-61
+ *   rvc_rmvpe_forward    <- RMVPE.infer_from_audio / _with_pitch         lib/rmvpe.py:614-659 (mel :510-556, E2E :464-470,
+ *                                                                        decode :607-612,:661-685)
+ *   rvc_synth_infer      <- SynthesizerTrnMs{256,768}NSFsid.infer        lib/infer_pack/models.py:682-693,:798-809
+ *   rvc_vc_segment       <- VC.vc (features -> x2 upsample -> protect -> infer)   vc_infer_pipeline.py:25-114
+ *   rvc_*_set_tensor     <- load_state_dict of the checkpoint tensors    vc_infer_pipeline.py:199-221,
+ *                                                                        lib/infer_pack/loaders.py:19-31, lib/rmvpe.py:579-586
+ *
+ * Conventions: every function returns 0 on success and a non-zero status otherwise; rvc_last_error() gives the
+ * thread-local message.  `stream` is a hipStream_t (NULL = default stream); all `*_dev` pointers are device pointers
+ * owned by the caller (e.g. torch allocations); kernels are enqueued on `stream` and NOT synchronised.
+ * Host pointers are only used for weights at load time.  Handles are not thread-safe; use one context per GPU/stream.
+ * All tensors are float32 unless stated.  No CPU fallback exists: without a gfx950 device every call fails.
+ */
+#ifndef RVC_HIP_H
+#define RVC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvc_ctx rvc_ctx;
+typedef struct rvc_hubert rvc_hubert;
+typedef struct rvc_rmvpe rvc_rmvpe;
+typedef struct rvc_synth rvc_synth;
+
+const char* rvc_last_error(void);
+const char* rvc_version(void);
+
+int rvc_ctx_create(int device_id, rvc_ctx** out);
+int rvc_ctx_destroy(rvc_ctx* ctx);
+/* bytes of activation workspace currently held by the context */
+int64_t rvc_ctx_workspace_bytes(rvc_ctx* ctx);
+
+/* ------------------------------------------------------------------ HuBERT / ContentVec (HF HubertModel + final_proj) */
+typedef struct rvc_hubert_taps {   /* optional device buffers for intermediate tensors (NULL = skip) */
+  float* conv_stack;   /* [512][T_h]   output of the 7-layer feature encoder (channel-major == HF [1,512,T_h]) */
+  float* pos_conv;     /* [768][T_h]   gelu(pos_conv(x)) before the residual add                                */
+  float* hidden_0;     /* [768][T_h]   hidden_states[0]                                                         */
+  float* hidden_8;     /* [768][T_h]   hidden_states[8]                                                         */
+} rvc_hubert_taps;
+
+int rvc_hubert_create(rvc_ctx* ctx, rvc_hubert** out);
+int rvc_hubert_set_tensor(rvc_hubert* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int rvc_hubert_finalize(rvc_hubert* h);
+int rvc_hubert_destroy(rvc_hubert* h);
+/* T_h = floor((L - 400) / 320) + 1 */
+int64_t rvc_hubert_num_frames(int64_t L);
+/* version 1: final_proj(hidden_states[8]) -> D = 256; version 2: hidden_states[11] -> D = 768.
+ * n_layers = 0 runs only the layers the output needs (8 / 11); 12 reproduces the reference's full stack (timing only).
+ * out_rm_dev: [T_h][D] row-major (reference layout [1,T_h,D]) or NULL; out_cm_dev: [D][T_h] channel-major or NULL. */
+int rvc_hubert_forward(rvc_hubert* h, void* stream, const float* audio_dev, int64_t L, int version, int n_layers,
+                       float* out_rm_dev, float* out_cm_dev, const rvc_hubert_taps* taps);
+
+/* ------------------------------------------------------------------ RMVPE */
+typedef struct rvc_rmvpe_taps {
+  float* unet_out;     /* [16][T_r][128] */
+  float* gru;          /* [512][T_r] channel-major (fwd | bwd) */
+} rvc_rmvpe_taps;
+
+int rvc_rmvpe_create(rvc_ctx* ctx, rvc_rmvpe** out);
+int rvc_rmvpe_set_tensor(rvc_rmvpe* r, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* mel_basis [128][513] and the STFT forward basis [1026][1024] are tensors "mel_basis" / "stft.forward_basis" */
+int rvc_rmvpe_finalize(rvc_rmvpe* r);
+int rvc_rmvpe_destroy(rvc_rmvpe* r);
+/* n = L / 160 + 1 frames.  mel_dev [128][n], salience_dev [n][360], f0_dev float64 [n]; any may be NULL. */
+int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio_dev, int64_t L, float thred, float* mel_dev,
+                      float* salience_dev, double* f0_dev, const rvc_rmvpe_taps* taps);
+/* decode alone: salience_dev [n][360] row-major -> f0 float64 [n] */
+int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* salience_dev, int64_t n, float thred, double* f0_dev);
+
+/* ------------------------------------------------------------------ synthesizer */
+typedef struct rvc_synth_config {   /* the fields of cpt["config"] that the inference graph needs */
+  int inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;
+  int n_resblock_kernels; int resblock_kernel_sizes[3]; int resblock_dilations[3][3];
+  int n_upsamples; int upsample_rates[8]; int upsample_kernel_sizes[8];
+  int upsample_initial_channel, spk_embed_dim, gin_channels, sr;
+  int feat_dim;                    /* 768 (v2) or 256 (v1) */
+} rvc_synth_config;
+
+typedef struct rvc_synth_taps {
+  float* enc_p_layer0;  /* [192][T] */
+  float* m_p;           /* [192][T] */
+  float* logs_p;        /* [192][T] */
+  float* z_p;           /* [192][T] */
+  float* z;             /* [192][T] */
+  float* sine_waves;    /* [T*upp]  SineGen output before Linear+tanh */
+  float* har_source;    /* [T*upp] */
+  float* gen_ups0;      /* [C0][T*u0] first upsample + noise conv */
+  float* gen_last;      /* [C_last][T*upp] output of the last ResBlock stage */
+} rvc_synth_taps;
+
+int rvc_synth_create(rvc_ctx* ctx, const rvc_synth_config* cfg, rvc_synth** out);
+int rvc_synth_set_tensor(rvc_synth* s, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int rvc_synth_finalize(rvc_synth* s);
+int rvc_synth_destroy(rvc_synth* s);
+int rvc_synth_upp(rvc_synth* s);
+/* phone_dev: [T][D] row-major (reference [1,T,D]) if phone_channel_major == 0, else [D][T].
+ * pitch_dev int64 [T] (coarse 1..255), pitchf_dev [T] (Hz), noise_z_dev [inter][T], noise_src_dev [T*upp]
+ * (the two torch.randn_like draws of the reference, models.py:801 and :409).  out_dev [T*upp]. */
+int rvc_synth_infer(rvc_synth* s, void* stream, const float* phone_dev, int phone_channel_major, const int64_t* pitch_dev,
+                    const float* pitchf_dev, int sid, const float* noise_z_dev, const float* noise_src_dev, int64_t T,
+                    float* out_dev, const rvc_synth_taps* taps);
+
+/* ------------------------------------------------------------------ fused segment: VC.vc without index retrieval */
+/* audio_dev [L] 16 kHz segment; pitch/pitchf as above with at least p_len = 2*T_h entries; out_dev [2*T_h*upp].
+ * do_protect != 0 applies the protect blend (protect < 0.5 in the reference). */
+int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio_dev, int64_t L, int version,
+                   const int64_t* pitch_dev, const float* pitchf_dev, int sid, float protect, int do_protect,
+                   const float* noise_z_dev, const float* noise_src_dev, float* out_dev);
+
+/* ------------------------------------------------------------------ single ops (parity tests / kernel benchmarks) */
+/* Conv1d: x_dev [Ci][Tin], w_host [Co][Ci/groups][k], y_dev [Co][Tout]; act codes: 0 none 1 lrelu 2 relu 3 gelu 4 tanh 5 sigmoid */
+int rvc_op_conv1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
+                  int Ci, int Co, int Tin, int k, int stride, int pad, int dil, int groups, int pre_act, float pre_slope, int act,
+                  float act_slope, int act_before_res, float out_scale, int accumulate);
+/* ConvTranspose1d: w_host [Ci][Co][k]; y_dev [Co][(Tin-1)*u - 2*pad + k] */
+int rvc_op_conv_transpose1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int Ci, int Co,
+                            int Tin, int k, int u, int pad, int pre_act, float pre_slope, int accumulate);
+/* Conv2d 3x3 pad 1: x_dev [Ci][H][W], w_host [Co][Ci][3][3]; ReLU-then-residual epilogue if relu != 0 */
+int rvc_op_conv2d3x3(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
+                     int Ci, int Co, int H, int W, int relu);
+/* ConvTranspose2d k3 s2 p1 op1: w_host [Ci][Co][3][3]; y_dev [Co][2H][2W] */
+int rvc_op_conv_transpose2d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int Ci, int Co,
+                            int H, int W, int relu);
+/* y[z][m][n] = sum_k a[z][k][m] * b[z][k][n] */
+int rvc_op_gemm_tn(void* stream, const float* a_dev, const float* b_dev, float* y_dev, int M, int N, int K, int batch);
+/* plan API for benchmarking the dominant kernel without host-side packing in the loop */
+typedef struct rvc_conv1d_plan rvc_conv1d_plan;
+int rvc_conv1d_plan_create(const float* w_host, const float* bias_host, int Ci, int Co, int k, int stride, int pad, int dil, int groups,
+                           rvc_conv1d_plan** out);
+int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x_dev, int Tin, const float* res_dev, float* y_dev, int pre_act,
+                        float pre_slope, int act, float act_slope);
+int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
+int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                       int C, int T);
+int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev, float* har_dev, float* sine_dev, int T, int upp, float sr,
+                       float lin_w, float lin_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVC_HIP_H */

@@ -1,0 +1,164 @@
+"""GPU parity of the single HIP ops (through the C ABI) against the same torch-CPU fp32 ops the oracle is built from."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+ACT = {"none": 0, "lrelu": 1, "relu": 2, "gelu": 3, "tanh": 4, "sigmoid": 5}
+
+
+def _act(x, name, slope):
+    return {"none": lambda v: v, "lrelu": lambda v: F.leaky_relu(v, slope), "relu": F.relu, "gelu": F.gelu,
+            "tanh": torch.tanh, "sigmoid": torch.sigmoid}[name](x)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from comfy_rvc_amd import _lib
+    _lib.get_ctx(0)
+    return _lib
+
+
+def dev(x):
+    return torch.as_tensor(x, dtype=torch.float32).contiguous().cuda()
+
+
+CONV1D = [
+    # Ci, Co, T, k, s, pad, dil, groups, pre, act, res, out_scale, accumulate
+    (32, 32, 1000, 3, 1, 1, 1, 1, "lrelu", "none", True, 1.0, False),
+    (32, 32, 777, 11, 1, 25, 5, 1, "lrelu", "none", False, 1.0, False),
+    (64, 64, 600, 7, 1, 9, 3, 1, "lrelu", "none", True, 1.0 / 3, True),
+    (128, 128, 300, 3, 1, 1, 1, 1, "none", "none", False, 1.0, False),
+    (256, 256, 130, 11, 1, 5, 1, 1, "none", "lrelu", False, 1.0, False),
+    (192, 384, 100, 5, 1, 2, 1, 1, "none", "none", False, -1.0, True),
+    (512, 512, 401, 3, 2, 0, 1, 1, "none", "gelu", False, 1.0, False),
+    (512, 512, 200, 2, 2, 0, 1, 1, "none", "gelu", False, 1.0, False),
+    (768, 768, 50, 128, 1, 64, 1, 16, "none", "gelu", False, 1.0, False),
+    (10, 512, 3000, 1, 1, 0, 1, 1, "none", "none", False, 1.0, False),
+    (32, 1, 2000, 7, 1, 3, 1, 1, "lrelu", "tanh", False, 1.0, False),
+    (21, 96, 50, 1, 1, 0, 1, 1, "none", "none", False, 1.0, True),
+    (1, 32, 500, 1, 1, 0, 1, 1, "none", "none", False, 1.0, False),
+    (513, 128, 131, 1, 1, 0, 1, 1, "none", "sigmoid", False, 1.0, False),
+    (768, 3072, 49, 1, 1, 0, 1, 1, "none", "gelu", False, 1.0, False),
+    (32, 32, 70000, 7, 1, 3, 1, 1, "lrelu", "none", True, 1.0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV1D, ids=[f"c{i}" for i in range(len(CONV1D))])
+def test_conv1d(L, case):
+    Ci, Co, T, k, s, pad, dil, groups, pre, act, res, scale, accum = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci // groups, k, generator=g) / np.sqrt(Ci // groups * k)
+    b = torch.randn(Co, generator=g) * 0.1
+    xin = _act(x, pre, 0.1)
+    ref = F.conv1d(xin[None], w, b, stride=s, padding=pad, dilation=dil, groups=groups)[0]
+    Tout = ref.shape[1]
+    r = torch.randn(Co, Tout, generator=g) if res else None
+    if r is not None:
+        ref = ref + r
+    ref = _act(ref, act, 0.1) * scale
+    y0 = torch.randn(Co, Tout, generator=g)
+    if accum:
+        ref = ref + y0
+    y = dev(y0)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    L.check(L.lib.rvc_op_conv1d(None, L.ptr(dev(x)), L.ptr(wc), L.ptr(bc), L.ptr(dev(r)) if res else None, L.ptr(y), Ci, Co, T, k, s,
+                                pad, dil, groups, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
+    assert rel_err(y.cpu(), ref) < 2e-5
+
+
+TCONV1D = [(512, 256, 30, 16, 10, 3), (64, 32, 100, 4, 2, 1), (128, 64, 33, 24, 12, 6), (256, 128, 40, 20, 10, 5)]
+
+
+@pytest.mark.parametrize("case", TCONV1D)
+def test_conv_transpose1d(L, case):
+    Ci, Co, T, k, u, pad = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Ci, Co, k, generator=g) / np.sqrt(Ci * k / u)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1)[None], w, b, stride=u, padding=pad)[0]
+    y0 = torch.randn(ref.shape, generator=g)
+    y = dev(y0)
+    L.check(L.lib.rvc_op_conv_transpose1d(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(y), Ci, Co, T, k, u,
+                                          pad, 1, 0.1, 1))
+    assert y.shape[1] == T * u
+    assert rel_err(y.cpu(), ref + y0) < 2e-5
+
+
+CONV2D = [(1, 16, 64, 128), (16, 16, 96, 128), (32, 64, 48, 32), (128, 128, 12, 16), (256, 512, 6, 4), (16, 3, 64, 128), (512, 512, 3, 4)]
+
+
+@pytest.mark.parametrize("case", CONV2D)
+def test_conv2d3x3_relu_residual(L, case):
+    Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / np.sqrt(Ci * 9)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, H, W, generator=g)
+    ref = F.relu(F.conv2d(x[None], w, b, padding=1)[0]) + r
+    y = torch.empty(Co, H, W, device="cuda")
+    L.check(L.lib.rvc_op_conv2d3x3(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(dev(r)), L.ptr(y), Ci, Co, H, W, 1))
+    assert rel_err(y.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(512, 256, 3, 4), (32, 16, 32, 64), (64, 32, 16, 32)])
+def test_conv_transpose2d(L, case):
+    Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, 3, 3, generator=g) / np.sqrt(Ci * 9 / 4)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x[None], w, b, stride=2, padding=1, output_padding=1)[0])
+    y = torch.empty(Co, 2 * H, 2 * W, device="cuda")
+    L.check(L.lib.rvc_op_conv_transpose2d(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(y), Ci, Co, H, W, 1))
+    assert rel_err(y.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", [(49, 49, 64, 12), (64, 49, 49, 12), (100, 192, 192, 1), (1536, 70, 384, 1), (96, 333, 333, 2), (333, 333, 96, 2)])
+def test_gemm_tn(L, case):
+    M, N, K, B = case
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn(B, K, M, generator=g)
+    b = torch.randn(B, K, N, generator=g)
+    ref = torch.einsum("zkm,zkn->zmn", a, b)
+    y = torch.empty(B, M, N, device="cuda")
+    L.check(L.lib.rvc_op_gemm_tn(None, L.ptr(dev(a)), L.ptr(dev(b)), L.ptr(y), M, N, K, B))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref) < 2e-5
+
+
+def test_layernorm_channels(L):
+    g = torch.Generator().manual_seed(19)
+    x, r = torch.randn(192, 333, generator=g), torch.randn(192, 333, generator=g)
+    ga, be = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g)
+    ref = F.layer_norm((x + r).t(), (192,), ga, be, 1e-5).t()
+    y = torch.empty(192, 333, device="cuda")
+    L.check(L.lib.rvc_op_layernorm_c(None, L.ptr(dev(x)), L.ptr(dev(r)), L.ptr(dev(ga)), L.ptr(dev(be)), L.ptr(y), 192, 333))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("upp,sr,T", [(400, 40000, 320), (480, 48000, 200)])
+def test_sine_source_matches_oracle(L, upp, sr, T):
+    from oracle import nets
+    from comfy_rvc_amd import synthetic as S
+    f0 = torch.from_numpy(S.designed_f0(T, seed=0)).view(1, T)
+    noise = torch.randn(1, T * upp, 1, generator=torch.Generator().manual_seed(3))
+    sd = {"dec.m_source.l_linear.weight": torch.tensor([[0.9]]), "dec.m_source.l_linear.bias": torch.tensor([0.01])}
+    taps = {}
+    ref = nets.sine_source(sd, f0, upp, sr, noise, taps)[0, :, 0]
+    har = torch.empty(T * upp, device="cuda")
+    sine = torch.empty(T * upp, device="cuda")
+    L.check(L.lib.rvc_op_sine_source(None, L.ptr(dev(f0.view(-1))), L.ptr(dev(noise.view(-1))), L.ptr(har), L.ptr(sine), T, upp, float(sr), 0.9, 0.01))
+    # 1e-3 of the sine amplitude (0.1); the phase itself is an fp64 running sum on both sides
+    assert float((sine.cpu() - taps["sine_waves"][0, :, 0]).abs().max()) < 1e-4
+    assert float((har.cpu() - ref).abs().max()) < 1e-4
