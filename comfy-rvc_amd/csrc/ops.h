@@ -26,6 +26,6 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
               unsigned long long* xbuf, int* err, int T);
 void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred);
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
-                 int T, int upp, float sr, float lw, float lb);
+                 int T, int upp, float sr, float lw, float lb, float* phase_out = nullptr);
 
 }  // namespace rvc

@@ -467,7 +467,9 @@ __device__ __forceinline__ float sine_interp(const float* __restrict__ tmp, int 
   const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
   float l1 = src - (float)i0; l1 = fminf(fmaxf(l1, 0.f), 1.f);
   const float l0 = 1.f - l1;
-  const float v = l0 * tmp[i0] + l1 * tmp[i1];
+  // torch's CPU upsample evaluates fma(w0, in0, fl(w1 * in1)); on flat (unvoiced) stretches the last-bit jitter of this
+  // expression is what trips the reference's wrap detector, so the exact rounding sequence is part of the algorithm.
+  const float v = __fmaf_rn(l0, tmp[i0], __fmul_rn(l1, tmp[i1]));
   return fmodf(v, 1.f);
 }
 __device__ __forceinline__ float sine_incr(const float* __restrict__ rad, const float* __restrict__ tmp, int T, int upp, float scale, long long i) {
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(1024) void sine_scan_kernel(double* __restrict__ bs
 // Stage 4: in-block scan + sin + uv gating + noise + Linear(1,1) + tanh -> har[i]
 __global__ __launch_bounds__(256) void sine_final_kernel(const float* __restrict__ f0, const float* __restrict__ rad, const float* __restrict__ tmp,
                                                          const double* __restrict__ bsum, const float* __restrict__ noise, float* __restrict__ har,
-                                                         float* __restrict__ sine_out, int T, int upp, float scale, long long N, float lw, float lb) {
+                                                         float* __restrict__ sine_out, float* __restrict__ phase_out, int T, int upp, float scale, long long N, float lw, float lb) {
   __shared__ double wsum[4];
   const long long base = (long long)blockIdx.x * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -524,8 +526,12 @@ __global__ __launch_bounds__(256) void sine_final_kernel(const float* __restrict
     const long long i = base + tid * 4 + j;
     run += v[j];
     if (i < N) {
+      // The reference evaluates sin(fl32(fl32(c) * 2 * pi)) with |c| reaching several hundred cycles, so the fp32 rounding
+      // of the argument is part of its result; reproduce that rounding exactly and take the sine itself in fp64.
       const float ph = (float)run;
-      float sw = sinf(ph * 2.f * 3.14159265358979323846f) * 0.1f;
+      if (phase_out) phase_out[i] = ph;
+      const float arg = ph * 2.f * 3.14159265358979323846f;
+      float sw = (float)sin((double)arg) * 0.1f;
       const float uv = f0[i / upp] > 0.f ? 1.f : 0.f;
       const float namp = uv * 0.003f + (1.f - uv) * 0.1f / 3.f;
       sw = sw * uv + namp * noise[i];
@@ -535,14 +541,14 @@ __global__ __launch_bounds__(256) void sine_final_kernel(const float* __restrict
   }
 }
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
-                 int T, int upp, float sr, float lw, float lb) {
+                 int T, int upp, float sr, float lw, float lb, float* phase_out) {
   const long long N = (long long)T * upp;
   const int nb = (int)((N + 1023) / 1024);
   const float scale = N > 1 ? (float)(T - 1) / (float)(N - 1) : 0.f;
   hipLaunchKernelGGL(sine_frame_kernel, dim3(1), dim3(1024), 0, s, f0, rad, tmp, T, sr, (float)upp);
   hipLaunchKernelGGL(sine_blocksum_kernel, dim3(nb), dim3(256), 0, s, rad, tmp, bsum, T, upp, scale, N);
   hipLaunchKernelGGL(sine_scan_kernel, dim3(1), dim3(1024), 0, s, bsum, nb);
-  hipLaunchKernelGGL(sine_final_kernel, dim3(nb), dim3(256), 0, s, f0, rad, tmp, bsum, noise, har, sine_out, T, upp, scale, N, lw, lb);
+  hipLaunchKernelGGL(sine_final_kernel, dim3(nb), dim3(256), 0, s, f0, rad, tmp, bsum, noise, har, sine_out, phase_out, T, upp, scale, N, lw, lb);
 }
 
 }  // namespace rvc

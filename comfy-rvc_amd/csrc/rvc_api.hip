@@ -241,7 +241,8 @@ int rvc_op_layernorm_c(void* stream, const float* x, const float* res, const flo
   check_launch();
   RVC_CATCH
 }
-int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float* har, float* sine, int T, int upp, float sr, float lw, float lb) {
+int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float* har, float* sine, int T, int upp, float sr, float lw, float lb,
+                       float* rad_out, float* tmp_out, float* phase_out) {
   RVC_TRY
   hipStream_t st = (hipStream_t)stream;
   const long long N = (long long)T * upp;
@@ -249,7 +250,9 @@ int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float*
   RVC_HIP_CHECK(hipMalloc(&rad, T * sizeof(float)));
   RVC_HIP_CHECK(hipMalloc(&tmp, T * sizeof(float)));
   RVC_HIP_CHECK(hipMalloc(&bsum, ((N + 1023) / 1024) * sizeof(double)));
-  sine_source(st, f0, noise, har, sine, rad, tmp, bsum, T, upp, sr, lw, lb);
+  sine_source(st, f0, noise, har, sine, rad, tmp, bsum, T, upp, sr, lw, lb, phase_out);
+  if (rad_out) (void)hipMemcpyAsync(rad_out, rad, T * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (tmp_out) (void)hipMemcpyAsync(tmp_out, tmp, T * sizeof(float), hipMemcpyDeviceToDevice, st);
   hipError_t e = hipStreamSynchronize(st);
   (void)hipFree(rad); (void)hipFree(tmp); (void)hipFree(bsum);
   RVC_HIP_CHECK(e);

@@ -52,7 +52,7 @@ class _SynthesizerNSFsid:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and _lib is not None and getattr(_lib, 'lib', None) is not None:   # (module may be torn down at exit)
             _lib.lib.rvc_synth_destroy(h)
             self._h = None
 

@@ -174,19 +174,24 @@ def rmvpe_state_dict(seed=0):
             v = np.full(shape, 0.25, dtype=np.float32)   # log-mel spans roughly [-11.5, 3] -> O(1)
         elif name == "unet.encoder.bn.running_mean":
             v = np.full(shape, -4.0, dtype=np.float32)
-        elif len(shape) == 1 and (".conv.1." in name or ".conv.4." in name or ".conv1.1." in name) \
-                and name.endswith("weight"):
+        elif name.endswith(".conv.4.weight"):           # BN gain of the residual branch: keeps the 52-block U-Net O(1)
+            v = _uniform(seed, name, shape, 0.15, 0.3)
+        elif len(shape) == 1 and (".conv.1." in name or ".conv1.1." in name) and name.endswith("weight"):
             v = _uniform(seed, name, shape, 0.8, 1.2)
         elif "gru" in name:
             v = _uniform(seed, name, shape, -1.0 / 16.0, 1.0 / 16.0)
         elif name == "fc.1.bias":
-            v = _normal(seed, name, shape, 0.5) - np.float32(3.0)
-        elif name == "fc.1.weight":
-            v = _normal(seed, name, shape, 4.0 / np.sqrt(512))
+            v = _normal(seed, name, shape, 0.3) - np.float32(6.0)
+        elif name == "fc.1.weight":                     # per-bin part + a part shared by all bins (gives unvoiced frames)
+            v = _normal(seed, name, shape, 2.5 / np.sqrt(512)) + _normal(seed, name + ".shared", (1, 512), 8.0 / np.sqrt(512))
+        elif name == "cnn.weight":
+            v = _normal(seed, name, shape, 0.15 / np.sqrt(_fan_in(shape)))
         elif name.endswith(".bias"):
             v = _normal(seed, name, shape, 0.05)
-        elif "conv1.0.weight" in name:                  # ConvTranspose2d [Cin, Cout, 3, 3]; ~9/4 taps hit
-            v = _normal(seed, name, shape, 1.4 / np.sqrt(shape[0] * 9 / 4))
+        elif "conv1.0.weight" in name:                  # ConvTranspose2d [Cin, Cout, 3, 3]; ~9/4 taps hit per output
+            v = _normal(seed, name, shape, np.sqrt(2.0 / (shape[0] * 9 / 4)))
+        elif name.endswith("conv.0.weight") or name.endswith("conv.3.weight"):   # He scaling in front of the ReLUs
+            v = _normal(seed, name, shape, np.sqrt(2.0 / _fan_in(shape)))
         else:
             v = _normal(seed, name, shape, 1.0 / np.sqrt(_fan_in(shape)))
         sd[name] = v

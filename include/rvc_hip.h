@@ -141,8 +141,9 @@ int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x_dev, in
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                        int C, int T);
+/* optional debug outputs: rad_dev [T] per-frame phase increment, tmp_dev [T] scaled frame cumsum, phase_dev [T*upp] running phase (cycles) */
 int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev, float* har_dev, float* sine_dev, int T, int upp, float sr,
-                       float lin_w, float lin_b);
+                       float lin_w, float lin_b, float* rad_dev, float* tmp_dev, float* phase_dev);
 
 #ifdef __cplusplus
 }

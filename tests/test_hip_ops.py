@@ -69,7 +69,8 @@ def test_conv1d(L, case):
         ref = ref + y0
     y = dev(y0)
     wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
-    L.check(L.lib.rvc_op_conv1d(None, L.ptr(dev(x)), L.ptr(wc), L.ptr(bc), L.ptr(dev(r)) if res else None, L.ptr(y), Ci, Co, T, k, s,
+    xd, rd = dev(x), (dev(r) if res else None)      # keep device tensors alive across the call
+    L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, T, k, s,
                                 pad, dil, groups, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
     assert rel_err(y.cpu(), ref) < 2e-5
 
@@ -86,8 +87,8 @@ def test_conv_transpose1d(L, case):
     b = torch.randn(Co, generator=g) * 0.1
     ref = F.conv_transpose1d(F.leaky_relu(x, 0.1)[None], w, b, stride=u, padding=pad)[0]
     y0 = torch.randn(ref.shape, generator=g)
-    y = dev(y0)
-    L.check(L.lib.rvc_op_conv_transpose1d(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(y), Ci, Co, T, k, u,
+    y, xd, wc, bc = dev(y0), dev(x), w.contiguous().numpy(), b.numpy()
+    L.check(L.lib.rvc_op_conv_transpose1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(y), Ci, Co, T, k, u,
                                           pad, 1, 0.1, 1))
     assert y.shape[1] == T * u
     assert rel_err(y.cpu(), ref + y0) < 2e-5
@@ -105,8 +106,8 @@ def test_conv2d3x3_relu_residual(L, case):
     b = torch.randn(Co, generator=g) * 0.1
     r = torch.randn(Co, H, W, generator=g)
     ref = F.relu(F.conv2d(x[None], w, b, padding=1)[0]) + r
-    y = torch.empty(Co, H, W, device="cuda")
-    L.check(L.lib.rvc_op_conv2d3x3(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(dev(r)), L.ptr(y), Ci, Co, H, W, 1))
+    y, xd, rd, wc, bc = torch.empty(Co, H, W, device="cuda"), dev(x), dev(r), w.contiguous().numpy(), b.numpy()
+    L.check(L.lib.rvc_op_conv2d3x3(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, H, W, 1))
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
@@ -118,8 +119,8 @@ def test_conv_transpose2d(L, case):
     w = torch.randn(Ci, Co, 3, 3, generator=g) / np.sqrt(Ci * 9 / 4)
     b = torch.randn(Co, generator=g) * 0.1
     ref = F.relu(F.conv_transpose2d(x[None], w, b, stride=2, padding=1, output_padding=1)[0])
-    y = torch.empty(Co, 2 * H, 2 * W, device="cuda")
-    L.check(L.lib.rvc_op_conv_transpose2d(None, L.ptr(dev(x)), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(y), Ci, Co, H, W, 1))
+    y, xd, wc, bc = torch.empty(Co, 2 * H, 2 * W, device="cuda"), dev(x), w.contiguous().numpy(), b.numpy()
+    L.check(L.lib.rvc_op_conv_transpose2d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(y), Ci, Co, H, W, 1))
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
@@ -130,8 +131,8 @@ def test_gemm_tn(L, case):
     a = torch.randn(B, K, M, generator=g)
     b = torch.randn(B, K, N, generator=g)
     ref = torch.einsum("zkm,zkn->zmn", a, b)
-    y = torch.empty(B, M, N, device="cuda")
-    L.check(L.lib.rvc_op_gemm_tn(None, L.ptr(dev(a)), L.ptr(dev(b)), L.ptr(y), M, N, K, B))
+    y, ad, bd = torch.empty(B, M, N, device="cuda"), dev(a), dev(b)
+    L.check(L.lib.rvc_op_gemm_tn(None, L.ptr(ad), L.ptr(bd), L.ptr(y), M, N, K, B))
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), ref) < 2e-5
 
@@ -141,8 +142,8 @@ def test_layernorm_channels(L):
     x, r = torch.randn(192, 333, generator=g), torch.randn(192, 333, generator=g)
     ga, be = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g)
     ref = F.layer_norm((x + r).t(), (192,), ga, be, 1e-5).t()
-    y = torch.empty(192, 333, device="cuda")
-    L.check(L.lib.rvc_op_layernorm_c(None, L.ptr(dev(x)), L.ptr(dev(r)), L.ptr(dev(ga)), L.ptr(dev(be)), L.ptr(y), 192, 333))
+    y, xd, rd, gd, bd = torch.empty(192, 333, device="cuda"), dev(x), dev(r), dev(ga), dev(be)
+    L.check(L.lib.rvc_op_layernorm_c(None, L.ptr(xd), L.ptr(rd), L.ptr(gd), L.ptr(bd), L.ptr(y), 192, 333))
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), ref) < 1e-5
 
@@ -158,7 +159,8 @@ def test_sine_source_matches_oracle(L, upp, sr, T):
     ref = nets.sine_source(sd, f0, upp, sr, noise, taps)[0, :, 0]
     har = torch.empty(T * upp, device="cuda")
     sine = torch.empty(T * upp, device="cuda")
-    L.check(L.lib.rvc_op_sine_source(None, L.ptr(dev(f0.view(-1))), L.ptr(dev(noise.view(-1))), L.ptr(har), L.ptr(sine), T, upp, float(sr), 0.9, 0.01))
+    fd, nd = dev(f0.view(-1)), dev(noise.view(-1))
+    L.check(L.lib.rvc_op_sine_source(None, L.ptr(fd), L.ptr(nd), L.ptr(har), L.ptr(sine), T, upp, float(sr), 0.9, 0.01, None, None, None))
     # 1e-3 of the sine amplitude (0.1); the phase itself is an fp64 running sum on both sides
     assert float((sine.cpu() - taps["sine_waves"][0, :, 0]).abs().max()) < 1e-4
     assert float((har.cpu() - ref).abs().max()) < 1e-4
