@@ -1,0 +1,72 @@
+"""Host-side audio helpers on the inference path (mirror of reference lib/audio.py:14,:115-124,:144-163,:274-304)."""
+from collections.abc import Mapping
+
+import numpy as np
+
+MAX_INT16 = 32768
+
+# Note table C2..B7 in Hz.  These are the exact constants of reference lib/audio.py:17-30 (hand-rounded equal temperament,
+# e.g. E5 = 659.25 rather than 659.26), kept verbatim because autotune parity depends on every digit.
+AUTOTUNE_NOTES = np.array([
+    65.41, 69.30, 73.42, 77.78, 82.41, 87.31, 92.50, 98.00, 103.83, 110.00, 116.54, 123.47,
+    130.81, 138.59, 146.83, 155.56, 164.81, 174.61, 185.00, 196.00, 207.65, 220.00, 233.08, 246.94,
+    261.63, 277.18, 293.66, 311.13, 329.63, 349.23, 369.99, 392.00, 415.30, 440.00, 466.16, 493.88,
+    523.25, 554.37, 587.33, 622.25, 659.25, 698.46, 739.99, 783.99, 830.61, 880.00, 932.33, 987.77,
+    1046.50, 1108.73, 1174.66, 1244.51, 1318.51, 1396.91, 1479.98, 1567.98, 1661.22, 1760.00, 1864.66, 1975.53,
+    2093.00, 2217.46, 2349.32, 2489.02, 2637.02, 2793.83, 2959.96, 3135.96, 3322.44, 3520.00, 3729.31, 3951.07])
+
+
+def get_merge_func(merge_type):
+    """reference lib/utils.py:104-108"""
+    return {"min": np.nanmin, "max": np.nanmax, "median": np.nanmedian}.get(merge_type, np.nanmean)
+
+
+def hz_to_mel(hz):
+    return 2595 * np.log10(1 + hz / 700)
+
+
+def get_audio(audio):
+    """ComfyUI AUDIO dict ({'waveform': [1, N, C], 'sample_rate'}) or a VHS_AUDIO thunk -> (ndarray [C, N], sr)."""
+    if callable(audio):
+        audio = audio()
+    if isinstance(audio, Mapping):
+        return audio["waveform"].squeeze(0).transpose(0, 1).numpy(), audio["sample_rate"]
+    if isinstance(audio, bytes):
+        raise NotImplementedError("encoded byte streams need soundfile/ffmpeg (file IO is out of scope of this build)")
+    return audio
+
+
+def remix_audio(input_audio, target_sr=None, norm=False, to_int16=False, resample=False, axis=0, merge_type=None, max_volume=.95, **kwargs):
+    """float32 mono at target_sr, peak-limited to max_volume (reference lib/audio.py:144-163)."""
+    audio = np.array(input_audio[0], dtype="float32")
+    if target_sr is None:
+        target_sr = input_audio[1]
+    if resample or input_audio[1] != target_sr:
+        raise NotImplementedError("resampling needs librosa/soxr, absent here (parity-unpinned branch, SURVEY 8c); feed 16 kHz audio")
+    if audio.ndim > 1:
+        audio = get_merge_func(merge_type)(audio, axis=axis)
+    if norm:
+        peak = np.abs(audio).max(axis=axis, keepdims=True)
+        audio = audio / np.where(peak < np.finfo(np.float32).tiny, 1.0, peak)
+    audio_max = np.abs(audio).max() / max_volume
+    if audio_max > 1:
+        audio = audio / audio_max
+    if to_int16:
+        audio = np.clip(audio * MAX_INT16, a_min=1 - MAX_INT16, a_max=MAX_INT16 - 1).astype("int16")
+    return audio, target_sr
+
+
+def autotune_f0(f0, threshold=0.):
+    """Snap each frame to the nearest note unless it is closer than `threshold` (reference lib/audio.py:274-300)."""
+    f0 = np.asarray(f0)
+    diff = np.abs(AUTOTUNE_NOTES[None, :] - f0[:, None])
+    idx = np.argmin(diff, axis=1)
+    near = diff[np.arange(f0.shape[0]), idx] < threshold
+    return np.where(near, f0, AUTOTUNE_NOTES[idx]).astype("float32")
+
+
+def pad_audio(*audios, axis=0):
+    """Right-pad to the longest and stack (reference lib/audio.py:257-262)."""
+    arrs = [a for a in audios if a is not None]
+    maxlen = max((len(a) for a in arrs), default=0)
+    return np.stack([np.pad(a, (0, maxlen - len(a))) for a in arrs], axis=axis)

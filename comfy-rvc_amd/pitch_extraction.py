@@ -1,0 +1,111 @@
+"""FeatureExtractor: f0 front-end dispatch and coarse-pitch quantisation (mirror of reference pitch_extraction.py:13-303).
+
+Only the RMVPE front-ends ("rmvpe", "rmvpe+") run on this build's HIP path; pm / harvest / dio / crepe are third-party
+CPU libraries in the reference (parselmouth, pyworld, torchcrepe) and stay out of scope - their dictionary slots exist
+so that a caller can plug a replacement in, exactly as with the reference's `f0_method_dict`.
+"""
+import os
+
+import numpy as np
+
+from .lib import BASE_MODELS_DIR
+from .lib.audio import autotune_f0, hz_to_mel, pad_audio, get_merge_func
+from .lib.rmvpe import RMVPE
+from .lib.utils import gc_collect
+
+
+def _unsupported(name):
+    def fn(*args, **kwargs):
+        raise NotImplementedError(f"f0 method '{name}' relies on a third-party CPU library that is out of scope here; "
+                                  "use 'rmvpe' / 'rmvpe+' or assign a callable to f0_method_dict['%s']" % name)
+    return fn
+
+
+class FeatureExtractor:
+    def __init__(self, tgt_sr, config, onnx=False):
+        self.x_pad, self.x_query, self.x_center, self.x_max, self.is_half = (
+            config.x_pad, config.x_query, config.x_center, config.x_max, config.is_half)
+        self.sr = 16000          # hubert / rmvpe input rate
+        self.window = 160        # 10 ms hop
+        self.f0_bins = 256
+        self.t_pad = self.sr * self.x_pad
+        self.t_pad_tgt = tgt_sr * self.x_pad
+        self.t_pad2 = self.t_pad * 2
+        self.t_query = self.sr * self.x_query
+        self.t_center = self.sr * self.x_center
+        self.t_max = self.sr * self.x_max
+        self.device = config.device
+        self.onnx = onnx
+        self.f0_method_dict = {
+            "pm": _unsupported("pm"), "harvest": _unsupported("harvest"), "dio": _unsupported("dio"),
+            "rmvpe": self.get_rmvpe, "rmvpe_onnx": self.get_rmvpe, "rmvpe+": self.get_pitch_dependant_rmvpe,
+            "crepe": _unsupported("crepe"), "crepe-tiny": _unsupported("crepe-tiny"),
+            "mangio-crepe": _unsupported("mangio-crepe"), "mangio-crepe-tiny": _unsupported("mangio-crepe-tiny"),
+        }
+
+    def __del__(self):
+        if hasattr(self, "model_rmvpe"):
+            del self.model_rmvpe
+            try:
+                gc_collect()
+            except Exception:   # noqa: BLE001 - interpreter teardown
+                pass
+
+    def load_index(self, file_index):
+        """Index retrieval (faiss) is the first 'next' row of the scope table; without it the reference runs index-free too."""
+        if isinstance(file_index, tuple):
+            return file_index
+        return None, None
+
+    def _rmvpe(self):
+        if not hasattr(self, "model_rmvpe"):
+            self.model_rmvpe = RMVPE(os.path.join(BASE_MODELS_DIR, "rmvpe.pt"), is_half=self.is_half, device=self.device, onnx=False)
+        return self.model_rmvpe
+
+    def get_rmvpe(self, x, *args, **kwargs):
+        return self._rmvpe().infer_from_audio(x, thred=0.03)
+
+    def get_pitch_dependant_rmvpe(self, x, f0_min=0, f0_max=40000, *args, **kwargs):
+        return self._rmvpe().infer_from_audio_with_pitch(x, thred=0.03, f0_min=f0_min, f0_max=f0_max)
+
+    def get_f0_hybrid_computation(self, methods_list, merge_type, x, f0_min, f0_max, filter_radius, crepe_hop_length, time_step, **kwargs):
+        """Median/mean/... merge of several f0 tracks (reference pitch_extraction.py:205-248), run sequentially."""
+        params = {"x": x, "f0_min": f0_min, "f0_max": f0_max, "time_step": time_step, "filter_radius": filter_radius,
+                  "crepe_hop_length": crepe_hop_length, "model": "full"}
+        x = x.astype(np.float32)
+        x /= np.quantile(np.abs(x), 0.999)
+        stack = []
+        for method in methods_list:
+            if method not in self.f0_method_dict:
+                raise Exception(f"Method {method} not found.")
+            stack.append(self.f0_method_dict[method](**params))
+        stack = pad_audio(*stack)
+        return get_merge_func(merge_type)(stack, axis=0)
+
+    def get_f0(self, x, f0_up_key, f0_method, merge_type="median", filter_radius=3, crepe_hop_length=160, f0_autotune=False,
+               rmvpe_onnx=False, inp_f0=None, f0_min=50, f0_max=1100, **kwargs):
+        time_step = self.window / self.sr * 1000
+        f0_mel_min = hz_to_mel(f0_min)
+        f0_mel_max = hz_to_mel(f0_max)
+        params = {"x": x, "f0_up_key": f0_up_key, "f0_min": f0_min, "f0_max": f0_max, "time_step": time_step,
+                  "filter_radius": filter_radius, "crepe_hop_length": crepe_hop_length, "model": "full", "onnx": rmvpe_onnx}
+        if hasattr(f0_method, "pop") and len(f0_method) == 1:
+            f0_method = f0_method.pop()
+        if isinstance(f0_method, list):
+            f0 = self.get_f0_hybrid_computation(f0_method, merge_type, **params)
+        else:
+            f0 = self.f0_method_dict[f0_method](**params)
+        if f0_autotune:
+            f0 = autotune_f0(f0)
+        f0 *= pow(2, f0_up_key / 12)
+        tf0 = self.sr // self.window
+        if inp_f0 is not None:   # f0 curve supplied by the user: splice it in after the left pad
+            delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+            replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+            shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
+            f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
+        f0_mel = hz_to_mel(f0)
+        f0_mel = (f0_mel - f0_mel_min) * (self.f0_bins - 2) / (f0_mel_max - f0_mel_min) + 1
+        f0_mel = np.clip(f0_mel, a_min=1, a_max=self.f0_bins - 1)
+        f0_coarse = np.rint(f0_mel).astype(np.int16)
+        return f0_coarse, f0

@@ -1,0 +1,217 @@
+"""VC / get_vc / vc_single on the HIP path (mirror of reference vc_infer_pipeline.py:23-327).
+
+Same call surface as the reference: `get_vc(model_path, file_index=None, config=config, device=None)`,
+`vc_single(cpt, net_g, vc, hubert_model, sid, input_audio, ..., f0_method, ...)`, `VC(tgt_sr, config).pipeline(...)`
+and `VC.vc(...)`.  Host work is what the reference also does on the host (zero-phase high-pass, reflect padding,
+segmentation, f0 post-processing, RMS mixing, int16 normalisation); the three networks run through librvc_hip.so.
+When both callees are this package's HIP-backed objects, `VC.vc` uses the fused `rvc_vc_segment` entry point (features
+stay channel-major on the device); any other object that honours the callee protocol takes the generic tensor path.
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy import signal
+
+from . import _lib
+from .config import config
+from .lib.audio import MAX_INT16, remix_audio
+from .lib.infer_pack.loaders import HubertModelWithFinalProj
+from .lib.infer_pack.models import SynthesizerTrnMs256NSFsid, SynthesizerTrnMs768NSFsid, _SynthesizerNSFsid
+from .lib.model_utils import change_rms, load_hubert
+from .lib.utils import gc_collect
+from .pitch_extraction import FeatureExtractor
+
+bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)   # 48 Hz zero-phase high-pass (reference :21)
+
+
+class VC(FeatureExtractor):
+    noise_fn = None        # optional callable(shape) -> CPU float tensor replacing the global-RNG draws (tests / replay)
+    noise_on_device = False  # True: draw the synthesizer noise with the GPU generator (faster, not CPU-replayable)
+
+    def _draw(self, shape):
+        if self.noise_fn is not None:
+            return self.noise_fn(shape)
+        if self.noise_on_device:
+            return torch.randn(shape, device=self.device)
+        return torch.randn(shape)
+
+    def _noise(self, inter, T, upp):
+        nz = self._draw((1, inter, T))
+        if self.noise_fn is None and not self.noise_on_device:
+            torch.rand(1, 1)       # SineGen's rand_ini draw keeps the global stream aligned with the reference
+        ns = self._draw((1, T * upp, 1))
+        return nz, ns
+
+    def vc(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect):
+        feats = torch.from_numpy(audio0).float()
+        if feats.dim() == 2:
+            feats = feats.mean(-1)
+        assert feats.dim() == 1, feats.dim()
+        feats = feats.view(1, -1)
+        if index is not None and big_npy is not None and index_rate > 0:
+            raise NotImplementedError("index retrieval (faiss) is a 'next' row of the scope table")
+        fused = isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) \
+            and pitch is not None and pitchf is not None
+        if fused:
+            L = feats.shape[1]
+            Th = model.num_frames(L)
+            T = 2 * Th
+            p_len = min(audio0.shape[0] // self.window, T)
+            assert p_len == T and pitch.shape[1] >= T, "p_len = 2*T_h always holds (SURVEY 9)"
+            dev = net_g.device
+            a = feats.view(-1).to(dev)
+            pc = pitch[0, :T].to(dev, torch.int64).contiguous()
+            pf = pitchf[0, :T].to(dev, torch.float32).contiguous()
+            nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
+            nz = nz.to(dev, torch.float32).contiguous()
+            ns = ns.to(dev, torch.float32).contiguous()
+            out = torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)
+            sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.rvc_vc_segment(model._h, net_g._h, _lib.current_stream(), _lib.ptr(a), L, 1 if version == "v1" else 2,
+                                                   _lib.ptr(pc), _lib.ptr(pf), sid_i, float(protect), 1 if protect < 0.5 else 0,
+                                                   _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
+            return out.cpu().numpy()
+        # ---- generic callee-protocol path (any extract_features / infer implementation)
+        dev = self.device
+        feats = model.extract_features(version=version, source=feats.to(dev), padding_mask=None, output_layer=9 if version == "v1" else 12)
+        feats0 = feats.clone() if (protect < 0.5 and pitch is not None and pitchf is not None) else None
+        feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+        if feats0 is not None:
+            feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+        p_len = min(audio0.shape[0] // self.window, feats.shape[1])
+        if pitch is not None and pitchf is not None:
+            pitch, pitchf = pitch[:, :p_len].to(feats.device), pitchf[:, :p_len].to(feats.device)
+            if protect < 0.5:
+                pitchff = pitchf.clone()
+                pitchff[pitchf > 0] = 1
+                pitchff[pitchf < 1] = protect
+                pitchff = pitchff.unsqueeze(-1)
+                feats = (feats * pitchff + feats0 * (1 - pitchff)).to(feats0.dtype)
+        p_len_t = torch.tensor([p_len], device=feats.device).long()
+        with torch.no_grad():
+            if pitch is not None and pitchf is not None:
+                kw = {}
+                if isinstance(net_g, _SynthesizerNSFsid):
+                    kw["noise"] = self._noise(net_g.inter_channels, p_len, net_g.upp)
+                audio1 = net_g.infer(feats, p_len_t, pitch, pitchf, sid, **kw)[0][0, 0].data.cpu().float().numpy()
+            else:
+                audio1 = net_g.infer(feats, p_len_t, sid)[0][0, 0].data.cpu().float().numpy()
+        return audio1
+
+    def pipeline(self, model, net_g, sid, audio, times, f0_up_key, f0_method, merge_type, file_index, index_rate, if_f0,
+                 filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx,
+                 f0_file=None, f0_min=50, f0_max=1600):
+        index, big_npy = self.load_index(file_index)
+        audio = signal.filtfilt(bh, ah, audio)
+        opt_ts = []
+        if audio.shape[0] + self.window > self.t_max:
+            # cut points: the quietest sample (|160-tap moving sum|) within +-t_query of every t_center (reference :127-135)
+            # (160 sequential adds on purpose: a cumulative-sum shortcut would change the rounding and could move a cut)
+            audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
+            audio_sum = np.zeros_like(audio)
+            for i in range(self.window):
+                audio_sum += audio_pad[i: i - self.window]
+            for t in range(self.t_center, audio.shape[0], self.t_center):
+                seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
+                opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+        s = 0
+        audio_opt = []
+        t = None
+        audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        inp_f0 = None
+        if f0_file is not None:
+            try:
+                with open(f0_file.name, "r") as f:
+                    inp_f0 = np.array([list(map(float, line.split(","))) for line in f.read().strip("\n").split("\n")], dtype="float32")
+            except Exception:   # noqa: BLE001
+                traceback.print_exc()
+        sid = torch.tensor(sid).unsqueeze(0).long()
+        pitch, pitchf = None, None
+        if if_f0:
+            pitch, pitchf = self.get_f0(audio_pad, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune,
+                                        rmvpe_onnx, inp_f0, f0_min, f0_max)
+            p_len = min(pitch.shape[0], pitchf.shape[0])
+            pitch = torch.from_numpy(pitch[:p_len].astype(np.int64)).unsqueeze(0)
+            pitchf = torch.from_numpy(pitchf[:p_len].astype(np.float32)).unsqueeze(0)
+        for t in opt_ts:
+            t = t // self.window * self.window
+            start, end = s, t + self.t_pad2 + self.window
+            ps = pitch[:, start // self.window: end // self.window] if if_f0 else None
+            pfs = pitchf[:, start // self.window: end // self.window] if if_f0 else None
+            audio_opt.append(self.vc(model, net_g, sid, audio_pad[start:end], ps, pfs, times, index, big_npy, index_rate, version,
+                                     protect)[self.t_pad_tgt: -self.t_pad_tgt])
+            s = t
+        ps = pitch[:, t // self.window:] if if_f0 and t is not None else pitch
+        pfs = pitchf[:, t // self.window:] if if_f0 and t is not None else pitchf
+        audio_opt.append(self.vc(model, net_g, sid, audio_pad[t:], ps, pfs, times, index, big_npy, index_rate, version,
+                                 protect)[self.t_pad_tgt: -self.t_pad_tgt])
+        audio_opt = np.concatenate(audio_opt)
+        if rms_mix_rate < 1:
+            audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)
+        if resample_sr >= 16000 and tgt_sr != resample_sr:
+            raise NotImplementedError("output resampling needs librosa/soxr (parity-unpinned branch, SURVEY 8c); use resample_sr=0")
+        self.last_float = audio_opt          # float waveform before the int16 normalisation (parity tests compare this too)
+        audio_max = np.abs(audio_opt).max() / 0.99
+        audio_opt = (audio_opt * MAX_INT16 / audio_max).astype(np.int16)
+        return audio_opt
+
+
+def _synth_class(version, if_f0):
+    if if_f0 != 1:
+        raise NotImplementedError("the *_nono (no-f0) synthesizers are out of scope of this build")
+    return SynthesizerTrnMs256NSFsid if version == "v1" else SynthesizerTrnMs768NSFsid
+
+
+def get_vc(model_path, file_index=None, config=config, device=None):
+    """`.pth` (or an already loaded cpt dict) -> {vc, cpt, net_g, model_name, file_index, sr} (reference :198-249)."""
+    if isinstance(model_path, dict):
+        cpt, model_name = model_path, model_path.get("info", "cpt")
+    else:
+        cpt = torch.load(model_path, map_location="cpu")
+        model_name = os.path.basename(model_path).split(".")[0]
+    tgt_sr = cpt["config"][-1]
+    cpt["config"][-3] = cpt["weight"]["emb_g.weight"].shape[0]   # n_spk
+    if_f0 = cpt.get("f0", 1)
+    version = cpt.get("version", "v1")
+    net_g = _synth_class(version, if_f0)(*cpt["config"], is_half=config.is_half, device=device if device else config.device)
+    net_g.load_state_dict(cpt["weight"], strict=False)
+    net_g.eval()
+    vc = VC(tgt_sr, config)
+    if file_index and os.path.exists(str(file_index)):
+        sys.stdout.write(f"{file_index}: index retrieval is not built yet, continuing without it\n")
+    return {"vc": vc, "cpt": cpt, "net_g": net_g, "model_name": model_name, "file_index": "", "sr": cpt["config"][-1]}
+
+
+def vc_single(cpt=None, net_g=None, vc=None, hubert_model=None, sid=0, input_audio=None, input_audio_path=None, f0_up_key=0,
+              f0_file=None, f0_method="crepe", merge_type="median", file_index="", index_rate=.75, filter_radius=3, resample_sr=0,
+              rms_mix_rate=.25, protect=0.33, crepe_hop_length=160, f0_autotune=False, is_onnx=False, config=config,
+              hubert_path=None, **kwargs):
+    """(int16 ndarray, sr) or None on any failure, like the reference (:251-327)."""
+    if hubert_model is None:
+        hubert_model = load_hubert(hubert_path, config)
+    if not (cpt and net_g and vc and hubert_model):
+        return None
+    tgt_sr = cpt["config"][-1]
+    version = cpt.get("version", "v1")
+    if input_audio is None and input_audio_path is None:
+        return None
+    f0_up_key = int(f0_up_key)
+    try:
+        if input_audio is None:
+            raise NotImplementedError("file decoding needs ffmpeg/soundfile; pass input_audio=(ndarray, sr)")
+        audio, _ = remix_audio((input_audio[0], input_audio[1]), target_sr=16000)
+        times = [0, 0, 0]
+        if_f0 = cpt.get("f0", 1)
+        audio_opt = vc.pipeline(hubert_model, net_g, sid, audio, times, f0_up_key,
+                                f0_method if len(f0_method) > 1 else f0_method[0], merge_type, file_index, index_rate, if_f0,
+                                filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune,
+                                is_onnx, f0_file=f0_file)
+        return audio_opt, resample_sr if resample_sr >= 16000 and tgt_sr != resample_sr else tgt_sr
+    except Exception as error:   # noqa: BLE001 - reference behaviour: print and return None
+        print(error)
+        return None

@@ -1,0 +1,68 @@
+"""CPU: the product's host-side logic (no GPU compute) against the golden vectors captured from the reference."""
+import numpy as np
+
+from conftest import golden, rel_err
+
+
+def _fe():
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.pitch_extraction import FeatureExtractor
+    return FeatureExtractor(40000, Config())
+
+
+def test_constants_match_reference_cpu_set():
+    fe = _fe()
+    assert (fe.t_pad, fe.t_pad_tgt, fe.t_pad2, fe.t_query, fe.t_center, fe.t_max) == (16000, 40000, 32000, 96000, 608000, 656000)
+    assert (fe.sr, fe.window, fe.f0_bins) == (16000, 160, 256)
+
+
+def test_get_f0_postprocessing_matches_reference():
+    g = golden("hostdsp.npz")
+    fe = _fe()
+    fe.f0_method_dict["pm"] = lambda **k: g["f0_in"].copy()
+    for key, tune in ((0, False), (-5, False), (7, True)):
+        coarse, f0 = fe.get_f0(np.zeros(16000), key, "pm", f0_autotune=tune, f0_min=50, f0_max=1600)
+        assert coarse.dtype == np.int16 and np.array_equal(coarse, g[f"coarse_k{key}_a{int(tune)}"])
+        assert np.allclose(f0, g[f"f0_k{key}_a{int(tune)}"], rtol=1e-12, atol=0)
+    coarse, _ = fe.get_f0(np.zeros(16000), 0, ["pm"], f0_min=50, f0_max=1600)       # single-element method list
+    assert np.array_equal(coarse, g["coarse_k0_a0"])
+
+
+def test_unsupported_f0_methods_fail_loudly():
+    import pytest
+    fe = _fe()
+    with pytest.raises(NotImplementedError):
+        fe.get_f0(np.zeros(16000), 0, "harvest")
+
+
+def test_filter_coefficients_rms_and_remix():
+    from scipy import signal
+    from comfy_rvc_amd import vc_infer_pipeline as P
+    from comfy_rvc_amd.lib.audio import remix_audio
+    from comfy_rvc_amd.lib.model_utils import change_rms
+    g = golden("hostdsp.npz")
+    assert np.array_equal(signal.filtfilt(P.bh, P.ah, g["audio"]), g["filtfilt"])
+    out = change_rms(g["rms_d1"], 16000, g["rms_d2"].copy(), 40000, 0.25)
+    assert rel_err(out, g["rms_out"]) < 1e-6
+    rem, sr = remix_audio((g["remix_in"], 16000), target_sr=16000)
+    assert sr == 16000 and np.array_equal(rem, g["remix_out"])
+
+
+def test_vc_single_returns_none_like_the_reference_on_bad_input():
+    from comfy_rvc_amd.vc_infer_pipeline import vc_single
+    assert vc_single(cpt=None, net_g=None, vc=None, hubert_model=object()) is None
+    assert vc_single(cpt={"config": [40000]}, net_g=object(), vc=object(), hubert_model=object(), input_audio=None) is None
+
+
+def test_node_surface_matches_reference():
+    from comfy_rvc_amd.custom_nodes import rvc_nodes as N
+    assert set(N.NODE_CLASS_MAPPINGS) >= {"LoadRVCModelNode", "RVCNode", "LoadHubertModel", "LoadPitchExtractionParams"}
+    it = N.LoadPitchExtractionParams.INPUT_TYPES()["required"]
+    assert it["f0_method"][0] == ["crepe", "mangio-crepe", "rmvpe", "rmvpe+"] and it["f0_method"][1]["default"] == "rmvpe"
+    assert N.LoadPitchExtractionParams.RETURN_TYPES == ("PITCH_EXTRACTION",)
+    assert N.RVCNode.RETURN_TYPES == ("VHS_AUDIO", "AUDIO") and N.RVCNode.OUTPUT_NODE is True and N.RVCNode.FUNCTION == "convert"
+    params = N.LoadPitchExtractionParams().load_params(f0_method="rmvpe", f0_autotune=False, index_rate=.75, resample_sr=0,
+                                                       rms_mix_rate=.25, protect=.25, crepe_hop_length=160)[0]
+    assert params["f0_method"] == "rmvpe" and params["protect"] == .25
+    a = N.to_audio_dict(np.zeros(100, dtype=np.float32), 40000)
+    assert tuple(a["waveform"].shape) == (1, 100, 1) and a["sample_rate"] == 40000
