@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: end-to-end 40k_v2 voice conversion throughput in audio-seconds per wall-second (xRT).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = every rank converts ONE synthetic 30 s / 16 kHz clip end to end through `vc_single` (host float32 array in,
+int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz) and the
+int16 waveforms are gathered on rank 0 over RCCL (the path's only exchange step).  Clips are independent, so the work
+shards one-clip-per-GPU with no data-path collective besides that gather: weak scaling.  Weights are procedural
+(comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32 on the MFMA units.
+Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+CLIP_SECONDS = 30.0
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def cpu_baseline(seconds=3.0):
+    """The CPU oracle (validated restatement of the reference) timed on this box's host cores on a bounded sample."""
+    from comfy_rvc_amd import synthetic as S
+    from oracle import pipeline as opl
+    threads = torch.get_num_threads()
+    audio = S.synth_audio(seconds, seed=1)
+    sds = (S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0))
+    g = torch.Generator().manual_seed(0)
+    t0 = time.perf_counter()
+    out = opl.pipeline(sds[0], sds[1], sds[2], S.CONFIG_40K_V2, "v2", audio, noise_fn=lambda shp: torch.randn(shp, generator=g),
+                       n_hubert_layers=12)   # the reference runs all 12 HuBERT layers (and discards the last)
+    dt = time.perf_counter() - t0
+    return {"value": round(out.shape[0] / 40000.0 / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(threads), "kind": "port",
+            "sample": f"1 x {seconds:g} s clip, same procedural weights, oracle.pipeline (torch-CPU fp32 restatement of the "
+                      f"reference, validated against reference goldens), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    from comfy_rvc_amd import _lib, synthetic as S
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.rmvpe import RMVPE
+    from comfy_rvc_amd.parallel import gather_waveforms
+    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+
+    cfg = Config(device=dev)
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
+    vcd = get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0), config=cfg, device=dev)
+    vc = VC(40000, cfg)
+    vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
+    vc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
+    audio = S.synth_audio(args.seconds, seed=100 + rank)
+    params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
+
+    def step():
+        out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), config=cfg, **params)
+        assert out is not None, "vc_single failed"
+        wav = out[0]
+        if world > 1:
+            gather_waveforms(wav, dev)
+        return wav
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wav = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    delivered = wav.shape[0] / 40000.0                       # audio seconds one rank delivers per step
+    value = delivered * world * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # one extra, untimed-for-the-headline pass with every conv-kernel launch bracketed by HIP events on its own stream
+        _lib.check(_lib.lib.rvc_prof_enable(1))
+        step()
+        torch.cuda.synchronize()
+        ms = (C.c_double * 14)(); fl = (C.c_double * 14)(); ln = (C.c_int64 * 14)()
+        _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
+        _lib.check(_lib.lib.rvc_prof_enable(0))
+        tot_ms, tot_fl, tot_l = sum(ms), sum(fl), sum(ln)
+        per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
+                                                            "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
+                   for i in range(14) if ln[i]}
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (all instantiations; fp32 v_mfma_f32_32x32x2_f32)",
+                    "launches_per_clip": int(tot_l), "avg_launch_us": round(tot_ms * 1e3 / max(tot_l, 1), 2),
+                    "algorithmic_gflop_per_launch": round(tot_fl / max(tot_l, 1) / 1e9, 3),
+                    "kernel_ms_per_clip": round(tot_ms, 2), "algorithmic_tflop_per_clip": round(tot_fl / 1e12, 3), "per_tile_config": per_cfg}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "audio-sec/wall-sec (xRT), 40k_v2 end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Full VC 40k_v2 (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clip per GPU "
+                                   "per step, vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
+                       "clips_per_step": world, "audio_seconds_delivered_per_clip": round(delivered, 3),
+                       "weights": "procedural (comfy-rvc_amd/synthetic.py)", "noise": "device generator",
+                       "parallelism": f"clip-per-GPU x{world}, RCCL gather of int16 waveforms"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -407,7 +407,31 @@ static TileCfg choose_tile(int M, long long N, int batch, int mode, int Wd) {
   return best;   // 64 x 64
 }
 
-static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s) {
+// ---------------------------------------------------------------------------- optional per-launch profiling (HIP events)
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static const char* kCfgNames[14] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
+                                    "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d"};
+void conv_prof_enable(bool on) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = on;
+}
+// Sums the event-timed conv launches recorded since conv_prof_enable(true).  Per tile configuration: ms, flops, launches.
+int conv_prof_collect(double* ms, double* flops, long long* launches) {
+  for (int i = 0; i < 14; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (auto& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms[r.cfg] += t; flops[r.cfg] += r.flops; launches[r.cfg] += 1;
+  }
+  return (int)g_prof.size();
+}
+const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < 14) ? kCfgNames[i] : ""; }
+
+static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flops) {
   TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
   int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   if (mode == 2) {
@@ -429,19 +453,23 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s) {
   const size_t lds = ((size_t)((a.CK * a.WROW + 3) & ~3) + (size_t)a.KT * a.CK * BM) * sizeof(float);
   RVC_REQUIRE(lds <= 160 * 1024, "conv tile does not fit LDS");
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)batch);
-#define RVC_LAUNCH(WM_, WN_, AM_, AN_)                                                          \
+  ProfRec rec{}; int cfg_id = 0;
+#define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
   if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \
+    cfg_id = ID_ + (mode == 2 ? 7 : 0);                                                         \
+    if (g_prof_on) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); (void)hipEventRecord(rec.a, s); } \
     if (mode == 2) launch_cfg<WM_, WN_, AM_, AN_, 2>(a, grid, lds, s);                          \
     else launch_cfg<WM_, WN_, AM_, AN_, 1>(a, grid, lds, s);                                    \
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); } \
     return;                                                                                     \
   }
-  RVC_LAUNCH(1, 4, 1, 4)
-  RVC_LAUNCH(1, 4, 1, 2)
-  RVC_LAUNCH(1, 4, 1, 1)
-  RVC_LAUNCH(2, 2, 2, 2)
-  RVC_LAUNCH(2, 2, 1, 4)
-  RVC_LAUNCH(2, 2, 1, 2)
-  RVC_LAUNCH(2, 2, 1, 1)
+  RVC_LAUNCH(0, 1, 4, 1, 4)
+  RVC_LAUNCH(1, 1, 4, 1, 2)
+  RVC_LAUNCH(2, 1, 4, 1, 1)
+  RVC_LAUNCH(3, 2, 2, 2, 2)
+  RVC_LAUNCH(4, 2, 2, 1, 4)
+  RVC_LAUNCH(5, 2, 2, 1, 2)
+  RVC_LAUNCH(6, 2, 2, 1, 1)
 #undef RVC_LAUNCH
   throw Error("no tile configuration matched");
 }
@@ -480,7 +508,9 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   }
   a.xBatch = (long long)L.Ci * ldX; a.wBatch = L.wBatch; a.yBatch = (long long)L.Co * ldY; a.rBatch = (long long)L.Co * e.ldR;
   a.bBatch = L.Co;
-  run_conv(a, 1, L.groups, s);
+  const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
+                                     : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
+  run_conv(a, 1, L.groups, s, flops);
 }
 
 void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch, const float* B, long long ldB, long long bBatch,
@@ -494,7 +524,7 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
   a.ldX = ldB; a.ldY = ldY; a.up2 = 0; a.ostride = 1; a.orows = M;
   a.ldW = ldA; a.Wcols = M; a.Wrows = K;
   a.xBatch = bBatch; a.wBatch = aBatch; a.yBatch = yBatch; a.rBatch = 0; a.bBatch = biasBatch;
-  run_conv(a, 1, batch, s);
+  run_conv(a, 1, batch, s, 2.0 * M * (double)N * K * batch);
 }
 
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
@@ -509,7 +539,7 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.ldX = ldX; a.ldY = ldY; a.up2 = L.up2; a.ostride = 1; a.orows = L.up2 ? L.co_real : L.Co;
   a.ldW = L.CoP; a.Wcols = L.CoP; a.Wrows = L.nchunk * 9 * L.CK;
   a.xBatch = 0; a.wBatch = 0; a.yBatch = 0; a.rBatch = 0; a.bBatch = 0;
-  run_conv(a, 2, 1, s);
+  run_conv(a, 2, 1, s, 2.0 * H * (double)Wd * 9 * L.Ci * (L.up2 ? L.co_real : L.Co));
 }
 
 }  // namespace rvc

@@ -260,4 +260,14 @@ int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float*
   RVC_CATCH
 }
 
+int rvc_prof_enable(int on) { RVC_TRY conv_prof_enable(on != 0); RVC_CATCH }
+int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14) {
+  RVC_TRY
+  long long l[14];
+  conv_prof_collect(ms14, flops14, l);
+  for (int i = 0; i < 14; ++i) launches14[i] = l[i];
+  RVC_CATCH
+}
+const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
+
 }  // extern "C"

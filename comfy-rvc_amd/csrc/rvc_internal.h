@@ -106,6 +106,11 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
                 const ConvEpilogue& e);
 
+// per-launch HIP-event profiling of the conv kernels (bench.py's roofline leg)
+void conv_prof_enable(bool on);
+int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of 14 (tile configuration x {1d, 2d})
+const char* conv_prof_cfg_name(int i);
+
 // ----------------------------------------------------------------------------- device memory
 float* dev_upload(const float* host, size_t n);
 void dev_free(void* p);

@@ -145,6 +145,13 @@ int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, c
 int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev, float* har_dev, float* sine_dev, int T, int upp, float sr,
                        float lin_w, float lin_b, float* rad_dev, float* tmp_dev, float* phase_dev);
 
+/* ------------------------------------------------------------------ kernel profiling (bench.py roofline leg) */
+/* While enabled, every launch of the MFMA convolution kernel is bracketed by HIP events on its own stream and tagged with its
+ * algorithmic FLOPs.  rvc_prof_collect sums them per tile configuration (14 = 7 tilings x {1-D, 2-D}); names via rvc_prof_cfg_name. */
+int rvc_prof_enable(int on);
+int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14);
+const char* rvc_prof_cfg_name(int i);
+
 #ifdef __cplusplus
 }
 #endif
