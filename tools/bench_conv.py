@@ -1,0 +1,35 @@
+"""Micro-benchmark of the MFMA conv kernel on the generator / HuBERT shapes (HIP events around plan launches)."""
+import sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np, torch
+from comfy_rvc_amd import _lib as L
+L.get_ctx(0)
+T = 3198
+CASES = [  # name, Ci, Co, Tin, k, stride, dil
+    ("gen s1 C256 k3", 256, 256, 10 * T, 3, 1, 1), ("gen s1 C256 k11 d5", 256, 256, 10 * T, 11, 1, 5),
+    ("gen s2 C128 k3", 128, 128, 100 * T, 3, 1, 1), ("gen s2 C128 k7 d3", 128, 128, 100 * T, 7, 1, 3), ("gen s2 C128 k11", 128, 128, 100 * T, 11, 1, 1),
+    ("gen s3 C64 k7", 64, 64, 200 * T, 7, 1, 1), ("gen s4 C32 k3", 32, 32, 400 * T, 3, 1, 1), ("gen s4 C32 k7", 32, 32, 400 * T, 7, 1, 1), ("gen s4 C32 k11 d5", 32, 32, 400 * T, 11, 1, 5),
+    ("hubert ffn1 768->3072", 768, 3072, 1599, 1, 1, 1), ("hubert ffn2 3072->768", 3072, 768, 1599, 1, 1, 1), ("hubert qk 768->1536", 768, 1536, 1599, 1, 1, 1),
+    ("hubert conv1 s2", 512, 512, 102399, 3, 2, 1), ("hubert conv2 s2", 512, 512, 51199, 3, 2, 1),
+]
+sel = sys.argv[1:] 
+reps = 5
+for name, Ci, Co, Tin, k, s, d in CASES:
+    if sel and not any(x in name for x in sel): continue
+    w = (np.random.randn(Co, Ci, k) / np.sqrt(Ci * k)).astype(np.float32); b = np.zeros(Co, np.float32)
+    pad = (k * d - d) // 2 if s == 1 else 0
+    plan = C.c_void_p()
+    L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w), L.ptr(b), Ci, Co, k, s, pad, d, 1, C.byref(plan)))
+    x = torch.randn(Ci, Tin, device="cuda")
+    Tout = (Tin + 2 * pad - d * (k - 1) - 1) // s + 1
+    y = torch.empty(Co, Tout, device="cuda"); r = torch.randn(Co, Tout, device="cuda")
+    run = lambda: L.check(L.lib.rvc_conv1d_plan_run(plan, None, L.ptr(x), Tin, L.ptr(r), L.ptr(y), 1, 0.1, 0, 0.0))
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * Co * Tout * Ci * k
+    print(f"{name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)")
+    L.lib.rvc_conv1d_plan_destroy(plan)
