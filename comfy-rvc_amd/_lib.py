@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librvc_hip.so")
+LIB_PATH = os.environ.get("RVC_HIP_LIB") or os.path.join(_HERE, "csrc", "librvc_hip.so")   # env override: A/B kernel builds
 
 
 class RvcHipError(RuntimeError):

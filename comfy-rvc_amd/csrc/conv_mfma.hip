@@ -15,6 +15,10 @@
 // Workgroup = 4 waves (WM x WN), each wave owns AM x AN accumulators of 32x32.
 #include "rvc_internal.h"
 
+#ifndef RVC_EPI_TWOPHASE
+#define RVC_EPI_TWOPHASE 0
+#endif
+
 namespace rvc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,6 +27,7 @@ struct ConvArgsX : ConvArgs {
   long long ldW;   // pitch (floats) of one packed-weight row
   int Wcols;       // valid columns in a weight row
   int Wrows;       // valid rows of the weight matrix
+  unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -37,15 +42,32 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+constexpr int kXSlots = 36;   // register slots (floats per thread) for the prefetched input tile
+constexpr int kWSlots = 32;   // register slots (floats per thread) for the prefetched weight slab (<= 32 KB / 256 threads)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {   // out-of-range -> 0 (hardware bounds check)
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+// Software pipeline: the global loads of stage s+1 (input tile with halo + weight slab) are issued into registers before the
+// MFMA loop of stage s and written to LDS after it, so HBM/L2 latency is covered by matrix work instead of a barrier wait.
+// Loads go through buffer descriptors: zero padding, channel tails and ragged edges come from the hardware range check.
+// MODE 1: 1-D stride 1, MODE 2: 2-D 3x3, MODE 3: 1-D strided (phase-decomposed rows).
 template <int WM, int WN, int AM, int AN, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32;
+  constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CK = p.CK, WROW = p.WROW;
   float* Xs = smem;
   float* Ws = smem + ((CK * WROW + 3) & ~3);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int z = blockIdx.z;
@@ -55,7 +77,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   const float* __restrict__ X = p.X + (long long)z * p.xBatch;
   const float* __restrict__ W = p.W + (long long)z * p.wBatch;
 
-  // tile origin
   int h0 = 0, w0 = 0;
   if (MODE == 2) { h0 = n0 / p.Wd; w0 = n0 % p.Wd; }
 
@@ -75,133 +96,248 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
 
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
-  const bool wvec = ((p.ldW & 3) == 0) && ((p.Wcols & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+  const int nstages = p.nchunk * ntb;
+  const bool wvec = (p.ldW & 3) == 0 && (p.Wcols & 3) == 0 && ((((uintptr_t)W) & 15) == 0);
+  const int used1 = BN + (p.ktaps - 1) * (MODE == 1 ? p.dil : 1);   // 1-D: LDS columns in use per row
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(W, (unsigned)p.Wrows * (unsigned)p.ldW * 4u);
 
-  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    for (int tb = 0; tb < ntb; ++tb) {
-      __syncthreads();
-      if (tb == 0) {
-        // ---------------------------------------------------------------- stage the input tile (+halo)
-        if (MODE == 1) {
-          if (p.stride == 1) {
-            const int used = BN + (p.ktaps - 1) * p.dil;
-            const int bx = n0 - p.pad;
-            for (int vcc = wave; vcc < CK; vcc += 4) {
-              const int ci = chunk * CK + vcc;
-              const float* src = X + (long long)ci * p.ldX;
-              float* dst = Xs + vcc * WROW;
-              const bool cok = ci < p.Ci;
-              for (int q = lane; q < used; q += 64) {
-                const int x = bx + q;
-                float v = 0.f;
-                if (cok && x >= 0 && x < p.Tin) v = src[x];
-                if (p.pre_act) v = apply_act(v, p.pre_act, p.pre_slope);
-                dst[q] = v;
-              }
-            }
-          } else {
-            const int s = p.stride;
-            const int used = BN + (p.ktaps - 1);
-            const int span = used * s;
-            const int bx = n0 * s - p.pad;
-            const int cpc = CK / s;   // whole input channels per chunk
-            for (int cl = wave; cl < cpc; cl += 4) {
-              const int ci = chunk * cpc + cl;
-              const float* src = X + (long long)ci * p.ldX;
-              const bool cok = ci < p.Ci;
-              for (int e = lane; e < span; e += 64) {
-                const int x = bx + e;
-                const int q = e / s, r = e - q * s;
-                float v = 0.f;
-                if (cok && x >= 0 && x < p.Tin) v = src[x];
-                if (p.pre_act) v = apply_act(v, p.pre_act, p.pre_slope);
-                Xs[(cl * s + r) * WROW + q] = v;
-              }
-            }
-          }
-        } else {
-          const int RH = p.BH + 2, PW = p.PW;
-          for (int vcc = wave; vcc < CK; vcc += 4) {
-            const int ci = chunk * CK + vcc;
-            const float* src = X + (long long)ci * p.ldX;
-            float* dst = Xs + vcc * WROW;
-            const bool cok = ci < p.Ci;
-            if (PW >= 34) {
-              for (int rr = 0; rr < RH; ++rr) {
-                const int hh = h0 - 1 + rr;
-                const bool hok = cok && hh >= 0 && hh < p.Tin;
-                for (int cc = lane; cc < PW; cc += 64) {
-                  const int ww = w0 - 1 + cc;
-                  float v = 0.f;
-                  if (hok && ww >= 0 && ww < p.Wd) v = src[(long long)hh * p.Wd + ww];
-                  dst[rr * PW + cc] = v;
-                }
-              }
-            } else {
-              for (int e = lane; e < RH * PW; e += 64) {
-                const int rr = e / PW, cc = e - rr * PW;
-                const int hh = h0 - 1 + rr, ww = w0 - 1 + cc;
-                float v = 0.f;
-                if (cok && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd) v = src[(long long)hh * p.Wd + ww];
-                dst[e] = v;
-              }
-            }
-          }
+  const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;   // input activation: leaky ReLU (slope 1 = identity)
+  float xr[kXSlots];
+  float wr[kWSlots];
+  const int lane0 = lane, tid0 = tid;   // re-materialised inside the staging lambdas (keeps their address math out of loop-invariant registers)
+
+  // ---- input tile: global -> registers
+  auto load_x = [&](int chunk) {
+    int lane = lane0, tid = tid0;
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    if (MODE == 1) {
+      int row = wave, qb = 0;
+      const int ci0 = chunk * CK;
+      __amdgpu_buffer_rsrc_t rs = make_rsrc(X + (long long)(ci0 + row) * p.ldX, (ci0 + row < p.Ci && row < CK) ? (unsigned)p.Tin * 4u : 0u);
+#pragma unroll
+      for (int s = 0; s < kXSlots; ++s) {
+        const int x = n0 - p.pad + qb + lane;
+        float v = buf_load(rs, x >= 0 ? (unsigned)x * 4u : OOB);
+        v = fmaxf(v, v * pre_slope);
+        xr[s] = v;
+        qb += 64;
+        if (qb >= used1) {
+          qb = 0; row += 4;
+          rs = make_rsrc(X + (long long)(ci0 + row) * p.ldX, (ci0 + row < p.Ci && row < CK) ? (unsigned)p.Tin * 4u : 0u);
         }
       }
-      // ------------------------------------------------------------------ stage the weight slab
-      const int ut = min(p.KT, p.ktaps - tb * p.KT);
-      {
-        const int rows = ut * CK;
-        const long long row0 = ((long long)chunk * p.ktaps + (long long)tb * p.KT) * CK;
-        if (wvec) {
-          constexpr int V4 = BM / 4;
-          for (int e = tid; e < rows * V4; e += 256) {
-            const int rr = e / V4, c4 = (e - rr * V4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + rr < p.Wrows && co0 + c4 < p.Wcols)
-              v = *reinterpret_cast<const float4*>(W + (row0 + rr) * p.ldW + co0 + c4);
-            *reinterpret_cast<float4*>(Ws + rr * BM + c4) = v;
-          }
-        } else {
-          for (int e = tid; e < rows * BM; e += 256) {
-            const int rr = e / BM, c = e - rr * BM;
-            float v = 0.f;
-            if (row0 + rr < p.Wrows && co0 + c < p.Wcols) v = W[(row0 + rr) * p.ldW + co0 + c];
-            Ws[rr * BM + c] = v;
-          }
+    } else if (MODE == 3) {
+      const int st = p.stride, span = used1 * st, cpc = CK / st, c0 = chunk * cpc;
+      int cl = wave, eb = 0;
+      __amdgpu_buffer_rsrc_t rs = make_rsrc(X + (long long)(c0 + cl) * p.ldX, (c0 + cl < p.Ci && cl < cpc) ? (unsigned)p.Tin * 4u : 0u);
+#pragma unroll
+      for (int s = 0; s < kXSlots; ++s) {
+        const int x = n0 * st - p.pad + eb + lane;
+        float v = buf_load(rs, x >= 0 ? (unsigned)x * 4u : OOB);
+        v = fmaxf(v, v * pre_slope);
+        xr[s] = v;
+        eb += 64;
+        if (eb >= span) {
+          eb = 0; cl += 4;
+          rs = make_rsrc(X + (long long)(c0 + cl) * p.ldX, (c0 + cl < p.Ci && cl < cpc) ? (unsigned)p.Tin * 4u : 0u);
         }
       }
-      __syncthreads();
-      // ------------------------------------------------------------------ MFMA
-      for (int uu = 0; uu < ut; ++uu) {
-        const int u = tb * p.KT + uu;
-        int toff;
-        if (MODE == 2) toff = (u / 3) * p.PW + (u % 3);
-        else toff = u * p.dil;
-        const float* wrow = Ws + (uu * CK + lh) * BM + wm * AM * 32 + li;
-        const float* xrow = Xs + lh * WROW + toff;
-#pragma unroll 2
-        for (int m = 0; m < CK / 2; ++m) {
-          float a[AM], b[AN];
+    } else {
+      const int RP = (p.BH + 2) * p.PW, total = CK * RP;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);   // whole tensor: the channel tail falls out of range
 #pragma unroll
-          for (int am = 0; am < AM; ++am) a[am] = wrow[2 * m * BM + am * 32];
+      for (int s = 0; s < kXSlots; ++s) {
+        const int e = tid + 256 * s;
+        const int vcc = __umulhi((unsigned)e, p.magRP), rem = e - vcc * RP;
+        const int rr = __umulhi((unsigned)rem, p.magPW), cc = rem - rr * p.PW;
+        const int ci = chunk * CK + vcc, hh = h0 - 1 + rr, ww = w0 - 1 + cc;
+        const bool ok = e < total && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
+        xr[s] = buf_load(rs, ok ? ((unsigned)ci * (unsigned)p.ldX + (unsigned)hh * (unsigned)p.Wd + (unsigned)ww) * 4u : OOB);
+      }
+    }
+  };
+  // ---- input tile: registers -> LDS
+  auto store_x = [&]() {
+    int lane = lane0, tid = tid0;
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    if (MODE == 1) {
+      int row = wave, qb = 0;
 #pragma unroll
-          for (int an = 0; an < AN; ++an) b[an] = xrow[2 * m * WROW + bb[an]];
+      for (int s = 0; s < kXSlots; ++s) {
+        const int q = qb + lane;
+        if (row < CK && q < used1) Xs[row * WROW + q] = xr[s];
+        qb += 64;
+        if (qb >= used1) { qb = 0; row += 4; }
+      }
+    } else if (MODE == 3) {
+      const int st = p.stride, span = used1 * st, cpc = CK / st;
+      int cl = wave, eb = 0;
 #pragma unroll
-          for (int am = 0; am < AM; ++am)
+      for (int s = 0; s < kXSlots; ++s) {
+        const int e = eb + lane;
+        if (cl < cpc && e < span) { const int q = (st == 2) ? (e >> 1) : e / st; const int r = e - q * st; Xs[(cl * st + r) * WROW + q] = xr[s]; }
+        eb += 64;
+        if (eb >= span) { eb = 0; cl += 4; }
+      }
+    } else {
+      const int RP = (p.BH + 2) * p.PW, total = CK * RP;
 #pragma unroll
-            for (int an = 0; an < AN; ++an)
-              acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[am], b[an], acc[am][an], 0, 0, 0);
+      for (int s = 0; s < kXSlots; ++s) {
+        const int e = tid + 256 * s;
+        if (e < total) { const int vcc = __umulhi((unsigned)e, p.magRP); Xs[vcc * WROW + (e - vcc * RP)] = xr[s]; }
+      }
+    }
+  };
+  // ---- weight slab of (chunk, tap block): global -> registers -> LDS.  Rows past the slab / matrix read as zero; columns
+  //      past Wcols only feed output rows that are never stored.
+  auto load_w = [&](int chunk, int tb) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int ut = min(p.KT, p.ktaps - tb * p.KT);
+    const int rows = ut * CK;
+    const unsigned row0 = (unsigned)((chunk * p.ktaps + tb * p.KT) * CK);
+    if (wvec) {
+      constexpr int V4 = BM / 4;
+#pragma unroll
+      for (int s = 0; s < kWSlots / 4; ++s) {
+        const int e = tid + 256 * s;
+        const int rr = e / V4, c4 = (e - rr * V4) * 4;
+        const unsigned off = rr < rows ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c4)) * 4u : OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)off, 0, 0);
+        wr[4 * s] = __uint_as_float(v.x); wr[4 * s + 1] = __uint_as_float(v.y); wr[4 * s + 2] = __uint_as_float(v.z); wr[4 * s + 3] = __uint_as_float(v.w);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < kWSlots; ++s) {
+        const int e = tid + 256 * s;
+        const int rr = e / BM, c = e - rr * BM;
+        wr[s] = buf_load(wrs, (rr < rows && co0 + c < p.Wcols) ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c)) * 4u : OOB);
+      }
+    }
+  };
+  auto store_w = [&](int tb) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int ut = min(p.KT, p.ktaps - tb * p.KT);
+    const int rows = ut * CK;
+    if (wvec) {
+      constexpr int V4 = BM / 4;
+#pragma unroll
+      for (int s = 0; s < kWSlots / 4; ++s) {
+        const int e = tid + 256 * s;
+        const int rr = e / V4, c4 = (e - rr * V4) * 4;
+        if (rr < rows) *reinterpret_cast<float4*>(Ws + rr * BM + c4) = make_float4(wr[4 * s], wr[4 * s + 1], wr[4 * s + 2], wr[4 * s + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < kWSlots; ++s) {
+        const int e = tid + 256 * s;
+        const int rr = e / BM, c = e - rr * BM;
+        if (rr < rows) Ws[rr * BM + c] = wr[s];
+      }
+    }
+  };
+
+  load_x(0);
+  load_w(0, 0);
+  int chunk = 0, tb = 0;
+  for (int stg = 0; stg < nstages; ++stg) {
+    __syncthreads();                       // every wave is done reading the previous stage from LDS
+    if (tb == 0) store_x();
+    store_w(tb);
+    __syncthreads();
+    int nchunk2 = chunk, ntb2 = tb + 1;
+    if (ntb2 == ntb) { ntb2 = 0; nchunk2 = chunk + 1; }
+    if (stg + 1 < nstages) {               // prefetch the next stage; its latency hides under the MFMA loop below
+      if (ntb2 == 0) load_x(nchunk2);
+      load_w(nchunk2, ntb2);
+    }
+    const int ut = min(p.KT, p.ktaps - tb * p.KT);
+    for (int uu = 0; uu < ut; ++uu) {
+      const int u = tb * p.KT + uu;
+      int toff;
+      if (MODE == 2) toff = (u / 3) * p.PW + (u % 3);
+      else toff = u * p.dil;
+      const float* wrow = Ws + (uu * CK + lh) * BM + wm * AM * 32 + li;
+      const float* xrow = Xs + lh * WROW + toff;
+      for (int m = 0; m < CK / 2; ++m) {
+        float a[AM], b[AN];
+#pragma unroll
+        for (int am = 0; am < AM; ++am) a[am] = wrow[2 * m * BM + am * 32];
+#pragma unroll
+        for (int an = 0; an < AN; ++an) b[an] = xrow[2 * m * WROW + bb[an]];
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+          for (int an = 0; an < AN; ++an)
+            acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[am], b[an], acc[am][an], 0, 0, 0);
+      }
+    }
+    chunk = nchunk2; tb = ntb2;
+  }
+
+  // -------------------------------------------------------------------------- epilogue
+  // Two phases per accumulator row block: first every residual / accumulate operand is loaded (all loads in flight at once),
+  // then the results are computed and stored.  Interleaving loads with stores would serialise on vmcnt, which counts both.
+  const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
+  const float* R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
+  float* Y = p.Y + (long long)z * p.yBatch;
+  auto out_index = [&](int co, int ph, int n, long long& oidx) -> bool {
+    if (MODE == 2) {
+      if (p.up2) {
+        const int hh = n / p.Wd, ww = n - hh * p.Wd;
+        oidx = (long long)co * p.ldY + (long long)(2 * hh + (ph >> 1)) * (2 * p.Wd) + 2 * ww + (ph & 1);
+      } else {
+        oidx = (long long)co * p.ldY + n;
+      }
+      return true;
+    }
+    if (p.ostride == 1) { oidx = (long long)co * p.ldY + n; return true; }
+    const long long to = (long long)n * p.ostride + ph;
+    oidx = (long long)co * p.ldY + to;
+    return to < p.ldY;          // ldY doubles as the true output length for interleaved stores
+  };
+#if RVC_EPI_TWOPHASE
+#pragma unroll
+  for (int am = 0; am < AM; ++am) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {          // 4 accumulator registers (= 4 consecutive output rows) at a time
+      float rv[AN][4], yv[AN][4], bvv[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = co0 + (wm * AM + am) * 32 + rr + 8 * rg + 4 * lh;
+        const bool mok = m < p.Co;
+        const int co = mok ? m % p.orows : 0, ph = mok ? m / p.orows : 0;
+        bvv[rr] = (bias && mok) ? bias[co] : 0.f;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          long long oidx;
+          const bool ok = mok && n < p.Tout && out_index(co, ph, n, oidx);
+          rv[an][rr] = (ok && R) ? R[(long long)co * p.ldR + n] : 0.f;
+          yv[an][rr] = (ok && p.accumulate) ? Y[oidx] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = co0 + (wm * AM + am) * 32 + rr + 8 * rg + 4 * lh;
+        if (m >= p.Co) continue;
+        const int co = m % p.orows, ph = m / p.orows;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          long long oidx;
+          if (n >= p.Tout || !out_index(co, ph, n, oidx)) continue;
+          float v = acc[am][an][rg * 4 + rr] + bvv[rr];
+          if (p.act_before_res) v = apply_act(v, p.act, p.act_slope) + rv[an][rr];
+          else v = apply_act(v + rv[an][rr], p.act, p.act_slope);
+          Y[oidx] = v * p.out_scale + yv[an][rr];
         }
       }
     }
   }
-
-  // -------------------------------------------------------------------------- epilogue
-  const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
-  const float* __restrict__ R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
-  float* __restrict__ Y = p.Y + (long long)z * p.yBatch;
+}
+#else
 #pragma unroll
   for (int am = 0; am < AM; ++am) {
 #pragma unroll
@@ -213,31 +349,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
 #pragma unroll
       for (int an = 0; an < AN; ++an) {
         const int n = n0 + (wn * AN + an) * 32 + li;
-        if (n >= p.Tout) continue;
-        float v = acc[am][an][r] + bv;
         long long oidx;
-        if (MODE == 2) {
-          if (p.up2) {
-            const int hh = n / p.Wd, ww = n - hh * p.Wd;
-            oidx = (long long)co * p.ldY + (long long)(2 * hh + (ph >> 1)) * (2 * p.Wd) + 2 * ww + (ph & 1);
-          } else {
-            oidx = (long long)co * p.ldY + n;
-          }
-        } else {
-          if (p.ostride == 1) oidx = (long long)co * p.ldY + n;
-          else {
-            const long long to = (long long)n * p.ostride + ph;
-            if (to >= p.ldY) continue;   // ldY doubles as the true output length for interleaved stores
-            oidx = (long long)co * p.ldY + to;
-          }
-        }
-        if (p.act_before_res) {
-          v = apply_act(v, p.act, p.act_slope);
-          if (R) v += R[(long long)co * p.ldR + n];
-        } else {
-          if (R) v += R[(long long)co * p.ldR + n];
-          v = apply_act(v, p.act, p.act_slope);
-        }
+        if (n >= p.Tout || !out_index(co, ph, n, oidx)) continue;
+        float v = acc[am][an][r] + bv;
+        if (p.act_before_res) { v = apply_act(v, p.act, p.act_slope); if (R) v += R[(long long)co * p.ldR + n]; }
+        else { if (R) v += R[(long long)co * p.ldR + n]; v = apply_act(v, p.act, p.act_slope); }
         v *= p.out_scale;
         if (p.accumulate) v += Y[oidx];
         Y[oidx] = v;
@@ -245,6 +361,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
     }
   }
 }
+#endif
 
 // ============================================================================ host side
 float* dev_upload(const float* host, size_t n) {
@@ -445,11 +562,23 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
     const int used = BN + (a.ktaps - 1) * (a.stride == 1 ? a.dil : 1);
     a.WROW = used | 1;
   }
-  // taps per weight stage: keep the slab <= 48 KB
+  // taps per weight stage: the slab must fit the register prefetch slots (32 KB)
   int kt = a.ktaps;
-  const int maxrows = (48 * 1024 / 4) / BM;
+  const int maxrows = (kWSlots * 256) / BM;
   if (kt * a.CK > maxrows) kt = maxrows / a.CK > 0 ? maxrows / a.CK : 1;
   a.KT = kt;
+  if (mode == 2) {
+    const unsigned RP = (unsigned)((a.BH + 2) * a.PW);
+    a.magRP = (unsigned)((0x100000000ULL + RP - 1) / RP); a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
+    RVC_REQUIRE((a.CK * (int)RP + 255) / 256 <= kXSlots, "2-D input tile exceeds the register prefetch slots");
+  } else if (a.stride == 1) {
+    const int used = BN + (a.ktaps - 1) * a.dil;
+    RVC_REQUIRE(((a.CK + 3) / 4) * ((used + 63) / 64) <= kXSlots, "1-D input tile exceeds the register prefetch slots");
+  } else {
+    const int span = (BN + a.ktaps - 1) * a.stride;
+    RVC_REQUIRE(((a.CK / a.stride + 3) / 4) * ((span + 63) / 64) <= kXSlots, "strided input tile exceeds the register prefetch slots");
+  }
+  RVC_REQUIRE(a.KT * a.CK * BM <= kWSlots * 256, "weight slab exceeds the register prefetch slots");
   const size_t lds = ((size_t)((a.CK * a.WROW + 3) & ~3) + (size_t)a.KT * a.CK * BM) * sizeof(float);
   RVC_REQUIRE(lds <= 160 * 1024, "conv tile does not fit LDS");
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)batch);
@@ -459,6 +588,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
     cfg_id = ID_ + (mode == 2 ? 7 : 0);                                                         \
     if (g_prof_on) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); (void)hipEventRecord(rec.a, s); } \
     if (mode == 2) launch_cfg<WM_, WN_, AM_, AN_, 2>(a, grid, lds, s);                          \
+    else if (a.stride > 1) launch_cfg<WM_, WN_, AM_, AN_, 3>(a, grid, lds, s);                  \
     else launch_cfg<WM_, WN_, AM_, AN_, 1>(a, grid, lds, s);                                    \
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); } \
     return;                                                                                     \

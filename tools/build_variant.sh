@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/build_variant.sh NAME [extra hipcc flags...] : builds comfy-rvc_amd/csrc/variants/librvc_hip_NAME.so for A/B kernel timing
+set -e
+cd "$(dirname "$0")/../comfy-rvc_amd/csrc"
+name=$1; shift
+mkdir -p variants/obj_$name
+for f in conv_mfma ops model_synth model_hubert model_rmvpe rvc_api; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include "$@" -c $f.hip -o variants/obj_$name/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/librvc_hip_$name.so variants/obj_$name/*.o
+echo built variants/librvc_hip_$name.so
