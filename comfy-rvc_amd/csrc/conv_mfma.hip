@@ -21,6 +21,15 @@
 
 namespace rvc {
 
+#ifdef RVC_CONV_TIMING
+__device__ unsigned long long g_conv_timing[8];   // [0] blocks, [1] prologue, [2] stage sync+LDS fill, [3] prefetch issue, [4] MFMA loops, [5] epilogue, [6] total
+#define TICK() clock64()
+#define TACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_conv_timing[i], (unsigned long long)(v)); } while (0)
+#else
+#define TICK() 0ll
+#define TACC(i, v) do {} while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvArgsX : ConvArgs {
@@ -28,48 +37,44 @@ struct ConvArgsX : ConvArgs {
   int Wcols;       // valid columns in a weight row
   int Wrows;       // valid rows of the weight matrix
   unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
+  int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
-  switch (act) {
-    case ACT_LRELU: return v > 0.f ? v : v * slope;
-    case ACT_RELU: return v > 0.f ? v : 0.f;
-    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    case ACT_TANH: return tanhf(v);
-    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case ACT_LOGCLAMP: return logf(fmaxf(v, slope));
-    default: return v;
-  }
-}
-
-constexpr int kXSlots = 36;   // register slots (floats per thread) for the prefetched input tile
 constexpr int kWSlots = 32;   // register slots (floats per thread) for the prefetched weight slab (<= 32 KB / 256 threads)
+// register slots for the prefetched input tile, per tile width and mode (checked against the launch geometry on the host)
+__host__ __device__ constexpr int x_slots(int BN, int MODE) {
+  return MODE == 2 ? (BN >= 512 ? 26 : (BN >= 256 ? 18 : 14)) : (BN >= 512 ? 36 : (BN >= 256 ? 20 : 16));
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {   // out-of-range -> 0 (hardware bounds check)
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+// out-of-range offsets (>= the descriptor's extent; kOOB always is) read as 0 and drop stores: the hardware range check
+// supplies zero padding, channel tails and ragged edges without branches
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
 // Software pipeline: the global loads of stage s+1 (input tile with halo + weight slab) are issued into registers before the
 // MFMA loop of stage s and written to LDS after it, so HBM/L2 latency is covered by matrix work instead of a barrier wait.
-// Loads go through buffer descriptors: zero padding, channel tails and ragged edges come from the hardware range check.
 // MODE 1: 1-D stride 1, MODE 2: 2-D 3x3, MODE 3: 1-D strided (phase-decomposed rows).
+// In-kernel activations are the max(v, slope*v) family (identity / ReLU / leaky ReLU); GELU, tanh, sigmoid and log-clamp run as
+// a separate elementwise pass (act_res_inplace) so that this kernel stays small enough for the instruction cache.
 template <int WM, int WN, int AM, int AN, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32;
-  constexpr unsigned OOB = 0x80000000u;
+  constexpr int XS = x_slots(BN, MODE);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CK = p.CK, WROW = p.WROW;
   float* Xs = smem;
   float* Ws = smem + ((CK * WROW + 3) & ~3);
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
+  const int li = lane0 & 31, lh = lane0 >> 5;
   const int z = blockIdx.z;
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
@@ -99,60 +104,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   const int nstages = p.nchunk * ntb;
   const bool wvec = (p.ldW & 3) == 0 && (p.Wcols & 3) == 0 && ((((uintptr_t)W) & 15) == 0);
   const int used1 = BN + (p.ktaps - 1) * (MODE == 1 ? p.dil : 1);   // 1-D: LDS columns in use per row
+  const int span = MODE == 3 ? used1 * p.stride : used1;             // 1-D: input samples staged per (channel) row
+  const int nrows = MODE == 3 ? CK / p.stride : CK;                  // 1-D: rows fetched per chunk (channels)
+  const int bx = MODE == 3 ? n0 * p.stride - p.pad : n0 - p.pad;
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(W, (unsigned)p.Wrows * (unsigned)p.ldW * 4u);
-
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);   // channel tail falls out of range
   const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;   // input activation: leaky ReLU (slope 1 = identity)
-  float xr[kXSlots];
-  float wr[kWSlots];
-  const int lane0 = lane, tid0 = tid;   // re-materialised inside the staging lambdas (keeps their address math out of loop-invariant registers)
 
-  // ---- input tile: global -> registers
+  float xr[XS];
+  float wr[kWSlots];
+
+  // ---- input tile: global -> registers.  Slot s of wave w covers 64 columns of row (w + 4s) / ni (uniform scalar math).
   auto load_x = [&](int chunk) {
     int lane = lane0, tid = tid0;
-    asm volatile("" : "+v"(lane), "+v"(tid));
-    if (MODE == 1) {
-      int row = wave, qb = 0;
-      const int ci0 = chunk * CK;
-      __amdgpu_buffer_rsrc_t rs = make_rsrc(X + (long long)(ci0 + row) * p.ldX, (ci0 + row < p.Ci && row < CK) ? (unsigned)p.Tin * 4u : 0u);
+    asm volatile("" : "+v"(lane), "+v"(tid));      // keeps the address math out of loop-invariant registers
+    if (MODE != 2) {
 #pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
-        const int x = n0 - p.pad + qb + lane;
-        float v = buf_load(rs, x >= 0 ? (unsigned)x * 4u : OOB);
-        v = fmaxf(v, v * pre_slope);
-        xr[s] = v;
-        qb += 64;
-        if (qb >= used1) {
-          qb = 0; row += 4;
-          rs = make_rsrc(X + (long long)(ci0 + row) * p.ldX, (ci0 + row < p.Ci && row < CK) ? (unsigned)p.Tin * 4u : 0u);
-        }
-      }
-    } else if (MODE == 3) {
-      const int st = p.stride, span = used1 * st, cpc = CK / st, c0 = chunk * cpc;
-      int cl = wave, eb = 0;
-      __amdgpu_buffer_rsrc_t rs = make_rsrc(X + (long long)(c0 + cl) * p.ldX, (c0 + cl < p.Ci && cl < cpc) ? (unsigned)p.Tin * 4u : 0u);
-#pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
-        const int x = n0 * st - p.pad + eb + lane;
-        float v = buf_load(rs, x >= 0 ? (unsigned)x * 4u : OOB);
-        v = fmaxf(v, v * pre_slope);
-        xr[s] = v;
-        eb += 64;
-        if (eb >= span) {
-          eb = 0; cl += 4;
-          rs = make_rsrc(X + (long long)(c0 + cl) * p.ldX, (c0 + cl < p.Ci && cl < cpc) ? (unsigned)p.Tin * 4u : 0u);
-        }
+      for (int s = 0; s < XS; ++s) {
+        const unsigned g = (unsigned)(wave + 4 * s);
+        const int row = p.ni == 1 ? (int)g : (int)__umulhi(g, p.magNI), qb = ((int)g - row * p.ni) * 64;   // (2^32 / 1 does not fit the magic)
+        const int ci = chunk * nrows + row;
+        const int e = qb + lane, x = bx + e;
+        const bool ok = row < nrows && ci < p.Ci && e < span && x >= 0 && x < p.Tin;
+        float v = buf_load(xrs, ok ? (unsigned)x * 4u : kOOB, (unsigned)ci * (unsigned)p.ldX * 4u);
+        xr[s] = fmaxf(v, v * pre_slope);
       }
     } else {
       const int RP = (p.BH + 2) * p.PW, total = CK * RP;
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);   // whole tensor: the channel tail falls out of range
 #pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
+      for (int s = 0; s < XS; ++s) {
         const int e = tid + 256 * s;
         const int vcc = __umulhi((unsigned)e, p.magRP), rem = e - vcc * RP;
         const int rr = __umulhi((unsigned)rem, p.magPW), cc = rem - rr * p.PW;
         const int ci = chunk * CK + vcc, hh = h0 - 1 + rr, ww = w0 - 1 + cc;
         const bool ok = e < total && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
-        xr[s] = buf_load(rs, ok ? ((unsigned)ci * (unsigned)p.ldX + (unsigned)hh * (unsigned)p.Wd + (unsigned)ww) * 4u : OOB);
+        xr[s] = buf_load(xrs, ok ? ((unsigned)ci * (unsigned)p.ldX + (unsigned)hh * (unsigned)p.Wd + (unsigned)ww) * 4u : kOOB);
       }
     }
   };
@@ -160,29 +146,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   auto store_x = [&]() {
     int lane = lane0, tid = tid0;
     asm volatile("" : "+v"(lane), "+v"(tid));
-    if (MODE == 1) {
-      int row = wave, qb = 0;
+    if (MODE != 2) {
 #pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
-        const int q = qb + lane;
-        if (row < CK && q < used1) Xs[row * WROW + q] = xr[s];
-        qb += 64;
-        if (qb >= used1) { qb = 0; row += 4; }
-      }
-    } else if (MODE == 3) {
-      const int st = p.stride, span = used1 * st, cpc = CK / st;
-      int cl = wave, eb = 0;
-#pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
-        const int e = eb + lane;
-        if (cl < cpc && e < span) { const int q = (st == 2) ? (e >> 1) : e / st; const int r = e - q * st; Xs[(cl * st + r) * WROW + q] = xr[s]; }
-        eb += 64;
-        if (eb >= span) { eb = 0; cl += 4; }
+      for (int s = 0; s < XS; ++s) {
+        const unsigned g = (unsigned)(wave + 4 * s);
+        const int row = p.ni == 1 ? (int)g : (int)__umulhi(g, p.magNI), qb = ((int)g - row * p.ni) * 64;   // (2^32 / 1 does not fit the magic)
+        const int e = qb + lane;
+        if (row < nrows && e < span) {
+          if (MODE == 1) Xs[row * WROW + e] = xr[s];
+          else { const int st = p.stride; const int q = (st == 2) ? (e >> 1) : e / st; Xs[(row * st + (e - q * st)) * WROW + q] = xr[s]; }
+        }
       }
     } else {
       const int RP = (p.BH + 2) * p.PW, total = CK * RP;
 #pragma unroll
-      for (int s = 0; s < kXSlots; ++s) {
+      for (int s = 0; s < XS; ++s) {
         const int e = tid + 256 * s;
         if (e < total) { const int vcc = __umulhi((unsigned)e, p.magRP); Xs[vcc * WROW + (e - vcc * RP)] = xr[s]; }
       }
@@ -202,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
       for (int s = 0; s < kWSlots / 4; ++s) {
         const int e = tid + 256 * s;
         const int rr = e / V4, c4 = (e - rr * V4) * 4;
-        const unsigned off = rr < rows ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c4)) * 4u : OOB;
+        const unsigned off = rr < rows ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c4)) * 4u : kOOB;
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)off, 0, 0);
         wr[4 * s] = __uint_as_float(v.x); wr[4 * s + 1] = __uint_as_float(v.y); wr[4 * s + 2] = __uint_as_float(v.z); wr[4 * s + 3] = __uint_as_float(v.w);
       }
@@ -211,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
       for (int s = 0; s < kWSlots; ++s) {
         const int e = tid + 256 * s;
         const int rr = e / BM, c = e - rr * BM;
-        wr[s] = buf_load(wrs, (rr < rows && co0 + c < p.Wcols) ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c)) * 4u : OOB);
+        wr[s] = buf_load(wrs, (rr < rows && co0 + c < p.Wcols) ? ((row0 + rr) * (unsigned)p.ldW + (unsigned)(co0 + c)) * 4u : kOOB);
       }
     }
   };
@@ -238,132 +216,200 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
     }
   };
 
-  load_x(0);
-  load_w(0, 0);
-  int chunk = 0, tb = 0;
-  for (int stg = 0; stg < nstages; ++stg) {
-    __syncthreads();                       // every wave is done reading the previous stage from LDS
-    if (tb == 0) store_x();
-    store_w(tb);
-    __syncthreads();
-    int nchunk2 = chunk, ntb2 = tb + 1;
-    if (ntb2 == ntb) { ntb2 = 0; nchunk2 = chunk + 1; }
-    if (stg + 1 < nstages) {               // prefetch the next stage; its latency hides under the MFMA loop below
-      if (ntb2 == 0) load_x(nchunk2);
-      load_w(nchunk2, ntb2);
+  // Iteration `it` moves stage it-1 from registers to LDS, prefetches stage `it` into registers and runs the MFMAs of stage
+  // it-1 (one copy of every code section; the prefetch latency hides under the matrix work).
+  const long long t_begin = TICK();
+  int chunk = 0, tb = 0, pchunk = 0, ptb = 0;
+  for (int it = 0; it <= nstages; ++it) {
+    const long long ta = TICK();
+    if (it > 0) {
+      __syncthreads();                       // every wave is done reading the previous stage from LDS
+      if (ptb == 0) store_x();
+      store_w(ptb);
+      __syncthreads();
     }
-    const int ut = min(p.KT, p.ktaps - tb * p.KT);
-    for (int uu = 0; uu < ut; ++uu) {
-      const int u = tb * p.KT + uu;
-      int toff;
-      if (MODE == 2) toff = (u / 3) * p.PW + (u % 3);
-      else toff = u * p.dil;
-      const float* wrow = Ws + (uu * CK + lh) * BM + wm * AM * 32 + li;
-      const float* xrow = Xs + lh * WROW + toff;
-      for (int m = 0; m < CK / 2; ++m) {
-        float a[AM], b[AN];
+    const long long tb_ = TICK();
+    TACC(it <= 1 ? 1 : 2, tb_ - ta);
+    if (it < nstages) {
+      if (tb == 0) load_x(chunk);
+      load_w(chunk, tb);
+    }
+    const long long tc = TICK();
+    TACC(3, tc - tb_);
+    if (it > 0) {
+      const int ut = min(p.KT, p.ktaps - ptb * p.KT);
+      for (int uu = 0; uu < ut; ++uu) {
+        const int u = ptb * p.KT + uu;
+        int toff;
+        if (MODE == 2) toff = (u / 3) * p.PW + (u % 3);
+        else toff = u * (MODE == 1 ? p.dil : 1);
+        const float* wrow = Ws + (uu * CK + lh) * BM + wm * AM * 32 + li;
+        const float* xrow = Xs + lh * WROW + toff;
+        for (int m = 0; m < CK / 2; ++m) {
+          float a[AM], b[AN];
 #pragma unroll
-        for (int am = 0; am < AM; ++am) a[am] = wrow[2 * m * BM + am * 32];
+          for (int am = 0; am < AM; ++am) a[am] = wrow[2 * m * BM + am * 32];
 #pragma unroll
-        for (int an = 0; an < AN; ++an) b[an] = xrow[2 * m * WROW + bb[an]];
+          for (int an = 0; an < AN; ++an) b[an] = xrow[2 * m * WROW + bb[an]];
 #pragma unroll
-        for (int am = 0; am < AM; ++am)
+          for (int am = 0; am < AM; ++am)
 #pragma unroll
-          for (int an = 0; an < AN; ++an)
-            acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[am], b[an], acc[am][an], 0, 0, 0);
+            for (int an = 0; an < AN; ++an)
+              acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[am], b[an], acc[am][an], 0, 0, 0);
+        }
       }
     }
-    chunk = nchunk2; tb = ntb2;
+    TACC(4, TICK() - tc);
+    pchunk = chunk; ptb = tb;
+    if (++tb == ntb) { tb = 0; ++chunk; }
   }
+  (void)pchunk;
+  const long long t_epi = TICK();
 
   // -------------------------------------------------------------------------- epilogue
-  // Two phases per accumulator row block: first every residual / accumulate operand is loaded (all loads in flight at once),
-  // then the results are computed and stored.  Interleaving loads with stores would serialise on vmcnt, which counts both.
+  // v = acc + bias; act in {identity, ReLU, leaky ReLU} as max(v, slope * v), before or after the residual; * out_scale;
+  // (+ previous output).  Row r+1's residual / accumulate operands are requested before row r is stored.
   const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
   const float* R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
   float* Y = p.Y + (long long)z * p.yBatch;
-  auto out_index = [&](int co, int ph, int n, long long& oidx) -> bool {
-    if (MODE == 2) {
-      if (p.up2) {
-        const int hh = n / p.Wd, ww = n - hh * p.Wd;
-        oidx = (long long)co * p.ldY + (long long)(2 * hh + (ph >> 1)) * (2 * p.Wd) + 2 * ww + (ph & 1);
-      } else {
-        oidx = (long long)co * p.ldY + n;
-      }
-      return true;
-    }
-    if (p.ostride == 1) { oidx = (long long)co * p.ldY + n; return true; }
-    const long long to = (long long)n * p.ostride + ph;
-    oidx = (long long)co * p.ldY + to;
-    return to < p.ldY;          // ldY doubles as the true output length for interleaved stores
-  };
-#if RVC_EPI_TWOPHASE
+  const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
+  const float oscale = p.out_scale;
+  if (p.ostride == 1 && !p.up2) {
+    // dense rows: 32-bit element offsets through buffer descriptors (extents < 2^31 bytes, checked on the host)
+    const bool plain = p.orows == p.Co;
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R : Y, R ? (unsigned)p.orows * (unsigned)p.ldR * 4u : 0u);   // no residual: all loads read 0
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(Y, p.accumulate ? (unsigned)p.orows * (unsigned)p.ldY * 4u : 0u);
+    const bool abr = p.act_before_res != 0;
+    const bool need_loads = R != nullptr || p.accumulate;
+    auto row_info = [&](int am, int r, bool& mok, float& bv, unsigned& yrow, unsigned& rrow) {
+      const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      mok = m < p.Co;
+      const int co = plain ? m : m % p.orows;
+      bv = (bias && mok) ? bias[co] : 0.f;
+      yrow = (unsigned)co * (unsigned)p.ldY; rrow = (unsigned)co * (unsigned)p.ldR;
+    };
 #pragma unroll
-  for (int am = 0; am < AM; ++am) {
+    for (int am = 0; am < AM; ++am) {
+      float rv[AN], yv[AN], rvn[AN], yvn[AN];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {          // 4 accumulator registers (= 4 consecutive output rows) at a time
-      float rv[AN][4], yv[AN][4], bvv[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = co0 + (wm * AM + am) * 32 + rr + 8 * rg + 4 * lh;
-        const bool mok = m < p.Co;
-        const int co = mok ? m % p.orows : 0, ph = mok ? m / p.orows : 0;
-        bvv[rr] = (bias && mok) ? bias[co] : 0.f;
+      for (int an = 0; an < AN; ++an) { rv[an] = 0.f; yv[an] = 0.f; rvn[an] = 0.f; yvn[an] = 0.f; }
+      if (need_loads) {
+        bool mok; float bv; unsigned yrow, rrow;
+        row_info(am, 0, mok, bv, yrow, rrow);
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
           const int n = n0 + (wn * AN + an) * 32 + li;
-          long long oidx;
-          const bool ok = mok && n < p.Tout && out_index(co, ph, n, oidx);
-          rv[an][rr] = (ok && R) ? R[(long long)co * p.ldR + n] : 0.f;
-          yv[an][rr] = (ok && p.accumulate) ? Y[oidx] : 0.f;
+          const bool ok = mok && n < p.Tout;
+          rv[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
+          yv[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
         }
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = co0 + (wm * AM + am) * 32 + rr + 8 * rg + 4 * lh;
+      for (int r = 0; r < 16; ++r) {
+        if (need_loads && r + 1 < 16) {
+          bool mok; float bv; unsigned yrow, rrow;
+          row_info(am, r + 1, mok, bv, yrow, rrow);
+#pragma unroll
+          for (int an = 0; an < AN; ++an) {
+            const int n = n0 + (wn * AN + an) * 32 + li;
+            const bool ok = mok && n < p.Tout;
+            rvn[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
+            yvn[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
+          }
+        }
+        bool mok; float bv; unsigned yrow, rrow;
+        row_info(am, r, mok, bv, yrow, rrow);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const bool ok = mok && n < p.Tout;
+          float v = acc[am][an][r] + bv;
+          if (abr) v = fmaxf(v, v * lslope) + rv[an];
+          else { v += rv[an]; v = fmaxf(v, v * lslope); }
+          v = v * oscale + yv[an];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(ok ? (yrow + (unsigned)n) * 4u : kOOB), 0, 0);
+        }
+#pragma unroll
+        for (int an = 0; an < AN; ++an) { rv[an] = rvn[an]; yv[an] = yvn[an]; }
+      }
+    }
+  } else {
+    // interleaved stores (ConvTranspose1d phases, ConvTranspose2d 2x2 phases): generic 64-bit indexing, accumulate optional
+#pragma unroll
+    for (int am = 0; am < AM; ++am) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= p.Co) continue;
         const int co = m % p.orows, ph = m / p.orows;
+        const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
           const int n = n0 + (wn * AN + an) * 32 + li;
+          if (n >= p.Tout) continue;
           long long oidx;
-          if (n >= p.Tout || !out_index(co, ph, n, oidx)) continue;
-          float v = acc[am][an][rg * 4 + rr] + bvv[rr];
-          if (p.act_before_res) v = apply_act(v, p.act, p.act_slope) + rv[an][rr];
-          else v = apply_act(v + rv[an][rr], p.act, p.act_slope);
-          Y[oidx] = v * p.out_scale + yv[an][rr];
+          if (MODE == 2) {
+            const int hh = n / p.Wd, ww = n - hh * p.Wd;
+            oidx = (long long)co * p.ldY + (long long)(2 * hh + (ph >> 1)) * (2 * p.Wd) + 2 * ww + (ph & 1);
+          } else {
+            const long long to = (long long)n * p.ostride + ph;
+            if (to >= p.ldY) continue;   // ldY doubles as the true output length for interleaved stores
+            oidx = (long long)co * p.ldY + to;
+          }
+          float v = acc[am][an][r] + bv;
+          v = fmaxf(v, v * lslope) * oscale;
+          if (p.accumulate) v += Y[oidx];
+          Y[oidx] = v;
         }
       }
     }
   }
+  TACC(5, TICK() - t_epi); TACC(6, TICK() - t_begin); TACC(0, 1);
 }
-#else
-#pragma unroll
-  for (int am = 0; am < AM; ++am) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= p.Co) continue;
-      const int co = m % p.orows, ph = m / p.orows;
-      const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-      for (int an = 0; an < AN; ++an) {
-        const int n = n0 + (wn * AN + an) * 32 + li;
-        long long oidx;
-        if (n >= p.Tout || !out_index(co, ph, n, oidx)) continue;
-        float v = acc[am][an][r] + bv;
-        if (p.act_before_res) { v = apply_act(v, p.act, p.act_slope); if (R) v += R[(long long)co * p.ldR + n]; }
-        else { if (R) v += R[(long long)co * p.ldR + n]; v = apply_act(v, p.act, p.act_slope); }
-        v *= p.out_scale;
-        if (p.accumulate) v += Y[oidx];
-        Y[oidx] = v;
-      }
-    }
+
+// Elementwise pass for the activations kept out of the MFMA kernel: y = act(y) [+ r]  or  y = act(y + r)
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_LRELU: return v > 0.f ? v : v * slope;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_LOGCLAMP: return logf(fmaxf(v, slope));
+    default: return v;
   }
 }
-#endif
+__global__ void act_res_kernel(float* __restrict__ y, const float* __restrict__ r, int rows, int T, long long ldY, long long ldR, int act,
+                               float slope, int act_before_res) {
+  const long long n = (long long)rows * T;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const int c = (int)(i / T); const int t = (int)(i - (long long)c * T);
+    float v = y[(long long)c * ldY + t];
+    const float rv = r ? r[(long long)c * ldR + t] : 0.f;
+    v = act_before_res ? apply_act(v, act, slope) + rv : apply_act(v + rv, act, slope);
+    y[(long long)c * ldY + t] = v;
+  }
+}
+static void act_res_inplace(hipStream_t s, float* y, const float* r, int rows, int T, long long ldY, long long ldR, int act, float slope,
+                            int act_before_res) {
+  const long long n = (long long)rows * T;
+  int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(act_res_kernel, dim3(blocks), dim3(256), 0, s, y, r, rows, T, ldY, ldR, act, slope, act_before_res);
+}
 
 // ============================================================================ host side
+#ifdef RVC_CONV_TIMING
+void conv_timing_read(unsigned long long* out8, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof(z)); }
+}
+#else
+void conv_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 8; ++i) out8[i] = 0; }
+#endif
 float* dev_upload(const float* host, size_t n) {
   float* d = nullptr;
   RVC_HIP_CHECK(hipMalloc(&d, (n ? n : 1) * sizeof(float)));
@@ -548,9 +594,11 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
 }
 const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < 14) ? kCfgNames[i] : ""; }
 
-static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flops) {
-  TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
-  int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
+// Fills the tile-dependent launch geometry; returns false when the tile does not fit the register prefetch slots / LDS.
+static bool setup_tile(ConvArgsX& a, int mode, const TileCfg& t, size_t& lds) {
+  const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
+  const int kmode = mode == 2 ? 2 : (a.stride > 1 ? 3 : 1);
+  int need;
   if (mode == 2) {
     // tile must be whole rows or a power-of-two fraction of a row
     a.BWd = BN < a.Wd ? BN : a.Wd;
@@ -558,29 +606,46 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
     a.PW = a.BWd + 2;
     a.WROW = (a.BH + 2) * a.PW;
     if ((a.WROW & 1) == 0) a.WROW += 1;
+    const unsigned RP = (unsigned)((a.BH + 2) * a.PW);
+    a.magRP = (unsigned)((0x100000000ULL + RP - 1) / RP); a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
+    a.ni = 1; a.magNI = 0;
+    need = (a.CK * (int)RP + 255) / 256;
   } else {
     const int used = BN + (a.ktaps - 1) * (a.stride == 1 ? a.dil : 1);
     a.WROW = used | 1;
+    const int span = a.stride == 1 ? used : used * a.stride;
+    const int nrows = a.stride == 1 ? a.CK : a.CK / a.stride;
+    a.ni = (span + 63) / 64;
+    a.magNI = (unsigned)((0x100000000ULL + a.ni - 1) / a.ni);
+    need = (nrows * a.ni + 3) / 4;
   }
+  if (need > x_slots(BN, kmode)) return false;
   // taps per weight stage: the slab must fit the register prefetch slots (32 KB)
   int kt = a.ktaps;
   const int maxrows = (kWSlots * 256) / BM;
-  if (kt * a.CK > maxrows) kt = maxrows / a.CK > 0 ? maxrows / a.CK : 1;
+  if (a.CK > maxrows) return false;
+  if (kt * a.CK > maxrows) kt = maxrows / a.CK;
   a.KT = kt;
-  if (mode == 2) {
-    const unsigned RP = (unsigned)((a.BH + 2) * a.PW);
-    a.magRP = (unsigned)((0x100000000ULL + RP - 1) / RP); a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
-    RVC_REQUIRE((a.CK * (int)RP + 255) / 256 <= kXSlots, "2-D input tile exceeds the register prefetch slots");
-  } else if (a.stride == 1) {
-    const int used = BN + (a.ktaps - 1) * a.dil;
-    RVC_REQUIRE(((a.CK + 3) / 4) * ((used + 63) / 64) <= kXSlots, "1-D input tile exceeds the register prefetch slots");
-  } else {
-    const int span = (BN + a.ktaps - 1) * a.stride;
-    RVC_REQUIRE(((a.CK / a.stride + 3) / 4) * ((span + 63) / 64) <= kXSlots, "strided input tile exceeds the register prefetch slots");
+  lds = ((size_t)((a.CK * a.WROW + 3) & ~3) + (size_t)a.KT * a.CK * BM) * sizeof(float);
+  return lds <= 160 * 1024;
+}
+
+static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flops) {
+  RVC_REQUIRE(a.act == ACT_NONE || a.act == ACT_LRELU || a.act == ACT_RELU, "in-kernel activations are identity / ReLU / leaky ReLU");
+  RVC_REQUIRE(a.pre_act == ACT_NONE || a.pre_act == ACT_LRELU, "input activation must be identity or leaky ReLU");
+  TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
+  size_t lds = 0;
+  if (!setup_tile(a, mode, t, lds)) {
+    // fall back to narrower tiles (fewer staged columns per row)
+    const TileCfg alts[] = {{2, 2, 1, 2}, {2, 2, 1, 1}, {1, 4, 1, 1}};
+    bool ok = false;
+    for (const TileCfg& c : alts) { if (a.Co <= 32 && c.WM == 2) continue; t = c; if (setup_tile(a, mode, t, lds)) { ok = true; break; } }
+    if (!ok) { t = TileCfg{2, 2, 1, 1}; ok = setup_tile(a, mode, t, lds); }
+    RVC_REQUIRE(ok, "no tile configuration fits this convolution");
   }
-  RVC_REQUIRE(a.KT * a.CK * BM <= kWSlots * 256, "weight slab exceeds the register prefetch slots");
-  const size_t lds = ((size_t)((a.CK * a.WROW + 3) & ~3) + (size_t)a.KT * a.CK * BM) * sizeof(float);
-  RVC_REQUIRE(lds <= 160 * 1024, "conv tile does not fit LDS");
+  const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
+  RVC_REQUIRE((double)a.orows * (double)a.ldY * 4.0 < 2147483648.0 && (double)a.orows * (double)a.ldR * 4.0 < 2147483648.0 &&
+              (double)a.Ci * (double)a.ldX * 4.0 < 2147483648.0, "tensor extent exceeds the 32-bit buffer addressing of the conv kernel");
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)batch);
   ProfRec rec{}; int cfg_id = 0;
 #define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
@@ -604,6 +669,16 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   throw Error("no tile configuration matched");
 }
 
+static bool simple_act(int act) { return act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU; }
+// Activations outside the max(v, slope v) family are applied by a second elementwise pass over the conv output.
+static ConvEpilogue split_epilogue(const ConvEpilogue& e, bool& post) {
+  post = !simple_act(e.act);
+  if (!post) return e;
+  RVC_REQUIRE(e.out_scale == 1.f && !e.accumulate, "GELU/tanh/sigmoid/log epilogues do not combine with scale/accumulate");
+  ConvEpilogue c = e;
+  c.act = ACT_NONE; c.act_slope = 0.f; c.R = nullptr; c.ldR = 0;
+  return c;
+}
 static void fill_epilogue(ConvArgsX& a, const ConvEpilogue& e) {
   a.R = e.R; a.ldR = e.ldR; a.pre_act = e.pre_act; a.pre_slope = e.pre_slope; a.act = e.act; a.act_slope = e.act_slope;
   a.act_before_res = e.act_before_res; a.out_scale = e.out_scale; a.accumulate = e.accumulate;
@@ -615,8 +690,9 @@ int conv1d_out_len(const ConvLayer& L, int Tin) {
 }
 
 void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int Tin, float* Y, long long ldY,
-                const ConvEpilogue& e) {
+                const ConvEpilogue& e0) {
   RVC_REQUIRE(L.mode == 1 && L.Wd_, "conv1d_run on an uninitialised / non-1D layer");
+  bool post; const ConvEpilogue e = split_epilogue(e0, post);
   ConvArgsX a{};
   a.X = X; a.W = L.Wd_; a.bias = L.bd_; a.Y = Y;
   fill_epilogue(a, e);
@@ -641,11 +717,16 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
   run_conv(a, 1, L.groups, s, flops);
+  if (post) {
+    RVC_REQUIRE(L.tconv_u == 0, "post-activation on a transposed conv");
+    act_res_inplace(s, Y, e0.R, L.groups * L.Co, Tout, ldY, e0.ldR, e0.act, e0.act_slope, e0.act_before_res);
+  }
 }
 
 void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch, const float* B, long long ldB, long long bBatch,
                  float* Y, long long ldY, long long yBatch, int M, int N, int K, int batch, const float* bias, int biasBatch,
                  const ConvEpilogue& e) {
+  RVC_REQUIRE(simple_act(e.act), "gemm_tn_run supports identity / ReLU / leaky ReLU epilogues");
   ConvArgsX a{};
   a.X = B; a.W = A; a.bias = bias; a.Y = Y;
   fill_epilogue(a, e);
@@ -659,6 +740,7 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
 
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
                 const ConvEpilogue& e) {
+  RVC_REQUIRE(simple_act(e.act), "conv2d_run supports identity / ReLU / leaky ReLU epilogues");
   RVC_REQUIRE(L.mode == 2 && L.Wd_, "conv2d_run on an uninitialised / non-2D layer");
   RVC_REQUIRE((Wd & (Wd - 1)) == 0 && Wd >= 2, "width must be a power of two");
   ConvArgsX a{};

@@ -269,5 +269,6 @@ int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14) {
   RVC_CATCH
 }
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
+int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 
 }  // extern "C"

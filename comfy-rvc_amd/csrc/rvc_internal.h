@@ -110,6 +110,7 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
 void conv_prof_enable(bool on);
 int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of 14 (tile configuration x {1d, 2d})
 const char* conv_prof_cfg_name(int i);
+void conv_timing_read(unsigned long long* out8, bool reset);   // debug builds (-DRVC_CONV_TIMING): per-phase cycle sums
 
 // ----------------------------------------------------------------------------- device memory
 float* dev_upload(const float* host, size_t n);

@@ -151,6 +151,8 @@ int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev
 int rvc_prof_enable(int on);
 int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14);
 const char* rvc_prof_cfg_name(int i);
+/* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
+int rvc_debug_conv_timing(uint64_t* out8, int reset);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,9 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
 L.get_ctx(0)
-T = 3198
+import os
+T = int(os.environ.get('BENCH_T', 3198))
+NORES = os.environ.get('BENCH_NORES') == '1'
 CASES = [  # name, Ci, Co, Tin, k, stride, dil
     ("gen s1 C256 k3", 256, 256, 10 * T, 3, 1, 1), ("gen s1 C256 k11 d5", 256, 256, 10 * T, 11, 1, 5),
     ("gen s2 C128 k3", 128, 128, 100 * T, 3, 1, 1), ("gen s2 C128 k7 d3", 128, 128, 100 * T, 7, 1, 3), ("gen s2 C128 k11", 128, 128, 100 * T, 11, 1, 1),
@@ -23,7 +25,7 @@ for name, Ci, Co, Tin, k, s, d in CASES:
     x = torch.randn(Ci, Tin, device="cuda")
     Tout = (Tin + 2 * pad - d * (k - 1) - 1) // s + 1
     y = torch.empty(Co, Tout, device="cuda"); r = torch.randn(Co, Tout, device="cuda")
-    run = lambda: L.check(L.lib.rvc_conv1d_plan_run(plan, None, L.ptr(x), Tin, L.ptr(r), L.ptr(y), 1, 0.1, 0, 0.0))
+    run = lambda: L.check(L.lib.rvc_conv1d_plan_run(plan, None, L.ptr(x), Tin, None if NORES else L.ptr(r), L.ptr(y), 1, 0.1, 0, 0.0))
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -32,4 +34,7 @@ for name, Ci, Co, Tin, k, s, d in CASES:
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * Co * Tout * Ci * k
     print(f"{name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)")
+    tm = (C.c_uint64 * 8)(); L.lib.rvc_debug_conv_timing(tm, 1)
+    if tm[0]:
+        nb = tm[0]; print("      per block cycles: " + "  ".join(f"{n} {tm[i]/nb:.0f}" for i, n in ((1,"prologue"),(2,"fill"),(3,"issue"),(4,"mfma"),(5,"epilogue"),(6,"total"))) + f"  blocks/launch {nb/(reps+1):.0f}")
     L.lib.rvc_conv1d_plan_destroy(plan)
