@@ -77,6 +77,9 @@ SIGNATURES = {
                                 c_void_p, P(SynthTaps)]),
     "rvc_vc_segment": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
                                c_void_p, c_void_p, c_void_p]),
+    "rvc_vc_segment_feats": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
+    "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),
     "rvc_op_conv1d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                       [c_int, c_float, c_int, c_float, c_int, c_float, c_int]),
     "rvc_op_conv_transpose1d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int, c_float, c_int]),

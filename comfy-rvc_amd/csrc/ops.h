@@ -28,4 +28,6 @@ void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long 
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
                  int T, int upp, float sr, float lw, float lb, float* phase_out = nullptr);
 
+void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n1, int sr2, float rate, short* out, float* rms2, unsigned* maxbits);
+
 }  // namespace rvc

@@ -552,3 +552,66 @@ void sine_source(hipStream_t s, const float* f0, const float* noise, float* har,
 }
 
 }  // namespace rvc
+
+namespace rvc {
+// ---------------------------------------------------------------------------------------------- output post-processing on device
+// change_rms (reference lib/model_utils.py:39-57) + peak normalisation to int16 (reference vc_infer_pipeline.py:188-189).
+// RMS frames of the output: librosa.feature.rms semantics (zero centre-padding, frame = sr, hop = sr / 2), float32 result.
+__global__ __launch_bounds__(256) void rms_frames_kernel(const float* __restrict__ x, float* __restrict__ rms, long long N, int frame, int hop) {
+  __shared__ double red[4];
+  const long long start = (long long)blockIdx.x * hop - frame / 2;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < frame; i += 256) {
+    const long long j = start + i;
+    if (j >= 0 && j < N) { const float v = x[j]; s += (double)(v * v); }
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) rms[blockIdx.x] = sqrtf((float)((red[0] + red[1] + red[2] + red[3]) / (double)frame));
+}
+// F.interpolate(mode="linear", align_corners=False) source coordinate and weights
+template <typename T> __device__ __forceinline__ T interp_linear(const T* __restrict__ a, int n, long long i, T scale) {
+  T src = scale * ((T)i + (T)0.5) - (T)0.5;
+  if (src < (T)0) src = (T)0;
+  int i0 = (int)src; if (i0 > n - 1) i0 = n - 1;
+  const int i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  const T l1 = src - (T)i0, l0 = (T)1 - l1;
+  return l0 * a[i0] + l1 * a[i1];
+}
+__global__ void rms_mix_absmax_kernel(float* __restrict__ x, long long N, const double* __restrict__ rms1, int n1, const float* __restrict__ rms2, int n2,
+                                      double p1, double p2, int do_mix, unsigned* __restrict__ maxbits) {
+  float mx = 0.f;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  const double s1 = (double)n1 / (double)N; const float s2 = (float)n2 / (float)N;
+  for (; i < N; i += st) {
+    float v = x[i];
+    if (do_mix) {
+      const double r1 = interp_linear<double>(rms1, n1, i, s1);
+      const float r2 = fmaxf(interp_linear<float>(rms2, n2, i, s2), 1e-6f);
+      v = (float)((double)v * (pow(r1, p1) * (double)powf(r2, (float)p2)));
+      x[i] = v;
+    }
+    mx = fmaxf(mx, fabsf(v));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) atomicMax(maxbits, __float_as_uint(mx));
+}
+__global__ void to_int16_kernel(const float* __restrict__ x, short* __restrict__ y, long long N, const unsigned* __restrict__ maxbits) {
+  const float amax = __uint_as_float(*maxbits) / 0.99f;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < N; i += st) y[i] = (short)(x[i] * 32768.f / amax);     // C conversion truncates toward zero like ndarray.astype(int16)
+}
+void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n1, int sr2, float rate, short* out, float* rms2, unsigned* maxbits) {
+  const int frame = sr2 / 2 * 2, hop = sr2 / 2;
+  const int n2 = (int)(N / hop) + 1;
+  const int do_mix = rate < 1.f && rms1 != nullptr;
+  (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned), s);
+  if (do_mix) hipLaunchKernelGGL(rms_frames_kernel, dim3(n2), dim3(256), 0, s, x, rms2, N, frame, hop);
+  int blocks = (int)((N + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rms_mix_absmax_kernel, dim3(blocks), dim3(256), 0, s, x, N, rms1, n1, rms2, n2, (double)(1.f - rate), (double)(rate - 1.f), do_mix, maxbits);
+  hipLaunchKernelGGL(to_int16_kernel, dim3(blocks), dim3(256), 0, s, x, out, N, maxbits);
+}
+}  // namespace rvc

@@ -160,6 +160,37 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
   RVC_CATCH
 }
 
+int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, int64_t Th, int feat_dim, const int64_t* pitch, const float* pitchf, int sid,
+                         float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
+  RVC_TRY
+  RVC_REQUIRE(s && feats_cm && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = (int)(2 * Th);
+  float* fup = nullptr;
+  RVC_HIP_CHECK(hipMallocAsync((void**)&fup, (size_t)feat_dim * T * sizeof(float), st));
+  try {
+    feats_prepare(st, feats_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
+    synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
+    check_launch();
+  } catch (...) { (void)hipFreeAsync(fup, st); throw; }
+  RVC_HIP_CHECK(hipFreeAsync(fup, st));
+  RVC_CATCH
+}
+
+int rvc_postprocess(void* stream, float* wav, int64_t N, const double* rms1, int n1, int sr2, float rms_mix_rate, int16_t* out_i16) {
+  RVC_TRY
+  RVC_REQUIRE(wav && out_i16 && N > 0 && sr2 > 0, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* scratch = nullptr;
+  const int n2 = (int)(N / (sr2 / 2)) + 1;
+  RVC_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)(n2 + 4) * sizeof(float), st));
+  postprocess(st, wav, N, rms1, n1, sr2, rms_mix_rate, (short*)out_i16, scratch + 4, (unsigned*)scratch);
+  hipError_t e = hipGetLastError();
+  RVC_HIP_CHECK(hipFreeAsync(scratch, st));
+  RVC_HIP_CHECK(e);
+  RVC_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ single ops
 int rvc_op_conv1d(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int Tin, int k,
                   int stride, int pad, int dil, int groups, int pre_act, float pre_slope, int act, float act_slope, int act_before_res,

@@ -31,6 +31,7 @@ bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)   # 48 Hz zero-phase 
 class VC(FeatureExtractor):
     noise_fn = None        # optional callable(shape) -> CPU float tensor replacing the global-RNG draws (tests / replay)
     noise_on_device = False  # True: draw the synthesizer noise with the GPU generator (faster, not CPU-replayable)
+    overlap_streams = True   # HuBERT on a side stream while RMVPE runs (False: one stream, for per-kernel profiling)
 
     def _draw(self, shape):
         if self.noise_fn is not None:
@@ -108,6 +109,8 @@ class VC(FeatureExtractor):
                  f0_file=None, f0_min=50, f0_max=1600):
         index, big_npy = self.load_index(file_index)
         audio = signal.filtfilt(bh, ah, audio)
+        device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) and if_f0
+                       and index is None and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
         opt_ts = []
         if audio.shape[0] + self.window > self.t_max:
             # cut points: the quietest sample (|160-tap moving sum|) within +-t_query of every t_center (reference :127-135)
@@ -123,6 +126,9 @@ class VC(FeatureExtractor):
         audio_opt = []
         t = None
         audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        if device_path:
+            return self._pipeline_device(model, net_g, sid, audio, audio_pad, opt_ts, f0_up_key, f0_method, merge_type, filter_radius,
+                                         tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max)
         inp_f0 = None
         if f0_file is not None:
             try:
@@ -159,6 +165,81 @@ class VC(FeatureExtractor):
         audio_max = np.abs(audio_opt).max() / 0.99
         audio_opt = (audio_opt * MAX_INT16 / audio_max).astype(np.int16)
         return audio_opt
+
+
+def _frame_rms64(y, frame_length, hop_length):
+    y = np.pad(np.asarray(y), int(frame_length // 2), mode="constant")
+    n_frames = 1 + (y.shape[-1] - frame_length) // hop_length
+    cols = hop_length * np.arange(n_frames)[None, :] + np.arange(frame_length)[:, None]
+    return np.sqrt(np.mean(np.abs(y[cols]) ** 2, axis=-2))
+
+
+def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
+                     rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max):
+    """VC.pipeline with every per-sample stage on the GPU: HuBERT runs on a side stream while RMVPE produces the pitch, the
+    segments are synthesised from device-resident features, and change_rms + int16 normalisation (reference
+    vc_infer_pipeline.py:182-189) run as kernels; only the zero-phase high-pass, the cut search and the 100 fps pitch
+    post-processing stay on the host, exactly where the reference has them."""
+    dev = net_g.device
+    bounds, s0 = [], 0
+    for t in opt_ts:
+        t = t // self.window * self.window
+        bounds.append((s0, t + self.t_pad2 + self.window))
+        s0 = t
+    bounds.append((s0, audio_pad.shape[0]))
+    main = torch.cuda.current_stream(dev)
+    a_dev = torch.from_numpy(audio_pad.astype(np.float32)).to(dev)
+    if getattr(self, "_side", None) is None:
+        self._side = torch.cuda.Stream(dev)
+    side = self._side if self.overlap_streams else main
+    side.wait_stream(main)
+    feats = []
+    with torch.cuda.stream(side):
+        for (b0, b1) in bounds:
+            feats.append(model.extract_features(a_dev[b0:b1].view(1, -1), version=version, channel_major=True))
+    a_dev.record_stream(side)
+    # pitch on the main stream (RMVPE) + host post-processing at 100 fps
+    x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else audio_pad
+    pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
+                                f0_min, f0_max)
+    p_len = min(pitch.shape[0], pitchf.shape[0])
+    pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
+    pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
+    main.wait_stream(side)
+    sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
+    D = 256 if version == "v1" else 768
+    outs = []
+    for (b0, b1), f in zip(bounds, feats):
+        Th = f.shape[1]
+        T = 2 * Th
+        if self.noise_fn is None and not self.noise_on_device:
+            for _ in range(12):
+                torch.rand([])      # the reference's HuBERT draws one LayerDrop scalar per layer from the same global stream
+        nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
+        nz = nz.to(dev, torch.float32).contiguous()
+        ns = ns.to(dev, torch.float32).contiguous()
+        pc = pitch_d[b0 // self.window: b0 // self.window + T].contiguous()
+        pf = pitchf_d[b0 // self.window: b0 // self.window + T].contiguous()
+        assert pc.numel() == T, "pitch track shorter than the feature sequence"
+        out = torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
+                                                     float(protect), 1 if protect < 0.5 else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
+        outs.append(out[self.t_pad_tgt: out.numel() - self.t_pad_tgt])
+    wav = torch.cat(outs) if len(outs) > 1 else outs[0].contiguous()
+    N = wav.numel()
+    rms1 = None
+    if rms_mix_rate < 1:
+        rms1 = torch.from_numpy(_frame_rms64(audio, 16000 // 2 * 2, 16000 // 2)).to(dev)
+    i16 = torch.empty(N, dtype=torch.int16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib.rvc_postprocess(_lib.current_stream(), _lib.ptr(wav), N, _lib.ptr(rms1), 0 if rms1 is None else rms1.numel(),
+                                            int(tgt_sr), float(rms_mix_rate), _lib.ptr(i16)))
+    self.last_float = wav          # device tensor: waveform after change_rms, before the int16 normalisation
+    return i16.cpu().numpy()
+
+
+VC._pipeline_device = _pipeline_device
 
 
 def _synth_class(version, if_f0):

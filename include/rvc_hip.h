@@ -116,6 +116,16 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
                    const int64_t* pitch_dev, const float* pitchf_dev, int sid, float protect, int do_protect,
                    const float* noise_z_dev, const float* noise_src_dev, float* out_dev);
 
+/* Same, starting from HuBERT features that already live on the device (channel-major [feat_dim][T_h]); lets the caller run
+ * HuBERT on a second stream while RMVPE produces the pitch. */
+int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm_dev, int64_t T_h, int feat_dim, const int64_t* pitch_dev,
+                         const float* pitchf_dev, int sid, float protect, int do_protect, const float* noise_z_dev,
+                         const float* noise_src_dev, float* out_dev);
+/* Output post-processing of VC.pipeline on the device: change_rms (lib/model_utils.py:39-57; skipped when rms_mix_rate >= 1 or
+ * rms1_dev == NULL) followed by peak normalisation to int16 (vc_infer_pipeline.py:188-189).  wav_dev [N] float32 is modified in
+ * place; rms1_dev = RMS frames of the 16 kHz input (float64 [n1], hop 0.5 s); sr2 = output rate. */
+int rvc_postprocess(void* stream, float* wav_dev, int64_t N, const double* rms1_dev, int n1, int sr2, float rms_mix_rate, int16_t* out_i16_dev);
+
 /* ------------------------------------------------------------------ single ops (parity tests / kernel benchmarks) */
 /* Conv1d: x_dev [Ci][Tin], w_host [Co][Ci/groups][k], y_dev [Co][Tout]; act codes: 0 none 1 lrelu 2 relu 3 gelu 4 tanh 5 sigmoid */
 int rvc_op_conv1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
