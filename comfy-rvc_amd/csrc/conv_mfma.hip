@@ -43,7 +43,7 @@ struct ConvArgsX : ConvArgs {
 constexpr int kWSlots = 32;   // register slots (floats per thread) for the prefetched weight slab (<= 32 KB / 256 threads)
 // register slots for the prefetched input tile, per tile width and mode (checked against the launch geometry on the host)
 __host__ __device__ constexpr int x_slots(int BN, int MODE) {
-  return MODE == 2 ? (BN >= 512 ? 26 : (BN >= 256 ? 18 : 14)) : (BN >= 512 ? 36 : (BN >= 256 ? 20 : 16));
+  return MODE == 2 ? (BN >= 512 ? 26 : (BN >= 256 ? 18 : 14)) : (BN >= 512 ? 36 : (BN >= 256 ? 20 : (BN >= 128 ? 32 : 16)));
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -428,7 +428,8 @@ void Arena::ensure(size_t bytes) {
 void Arena::release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
 
 static int pick_ck(int V, int ktaps, int stride) {
-  int ck = ktaps >= 4 ? 8 : (ktaps >= 2 ? 16 : 32);
+  // k = 1 (GEMM): 64 channels per stage so that one stage of MFMA work outlasts the latency of the next stage's prefetch
+  int ck = ktaps >= 4 ? 8 : (ktaps >= 2 ? 16 : 64);
   if (stride > 1) { ck = ((ck + stride - 1) / stride) * stride; if (ck & 1) ck *= 2; }
   if (V < ck) { ck = stride > 1 ? ((V + stride - 1) / stride) * stride : V; if (ck & 1) ck += (stride > 1 ? stride : 1); if (ck < 2) ck = 2; }
   return ck;
@@ -634,6 +635,9 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   RVC_REQUIRE(a.act == ACT_NONE || a.act == ACT_LRELU || a.act == ACT_RELU, "in-kernel activations are identity / ReLU / leaky ReLU");
   RVC_REQUIRE(a.pre_act == ACT_NONE || a.pre_act == ACT_LRELU, "input activation must be identity or leaky ReLU");
   TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
+  if (const char* f = getenv("RVC_FORCE_TILE")) {   // experiments: "WM,WN,AM,AN"
+    int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
+  }
   size_t lds = 0;
   if (!setup_tile(a, mode, t, lds)) {
     // fall back to narrower tiles (fewer staged columns per row)
@@ -731,7 +735,7 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
   a.X = B; a.W = A; a.bias = bias; a.Y = Y;
   fill_epilogue(a, e);
   a.Ci = K; a.Co = M; a.CoP = M; a.Tin = N; a.Tout = N; a.Wd = 0; a.ktaps = 1; a.dil = 1; a.stride = 1; a.pad = 0;
-  a.CK = K >= 32 ? 32 : ((K + 1) & ~1); a.nchunk = (K + a.CK - 1) / a.CK;
+  a.CK = K >= 64 ? 64 : ((K + 1) & ~1); a.nchunk = (K + a.CK - 1) / a.CK;
   a.ldX = ldB; a.ldY = ldY; a.up2 = 0; a.ostride = 1; a.orows = M;
   a.ldW = ldA; a.Wcols = M; a.Wrows = K;
   a.xBatch = bBatch; a.wBatch = aBatch; a.yBatch = yBatch; a.rBatch = 0; a.bBatch = biasBatch;

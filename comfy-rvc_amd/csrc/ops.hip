@@ -23,30 +23,30 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm over channels
-// y[c][t] = (x[c][t] (+ r[c][t]) - mean_t) * rstd_t * gamma[c] + beta[c];  block = 64 columns x 4 channel slices.
+// y[c][t] = (x[c][t] (+ r[c][t]) - mean_t) * rstd_t * gamma[c] + beta[c];  block = 16 columns x 16 channel slices
+// (64-byte row segments keep the loads coalesced while a 1599-frame sequence still yields 100 workgroups).
 __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ y, int C, int T, long long ld, float eps) {
-  __shared__ float s_sum[4][64], s_sq[4][64];
-  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + col;
+  __shared__ float s_a[16][17], s_b[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col;
   const bool ok = t < T;
-  float sum = 0.f;
-  for (int c = sl; c < C; c += 4) {
-    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; sum += v; }
+  // single sweep: shifted sums (shift = first channel's value) keep the variance free of cancellation
+  const float shift = ok ? (x[t] + (r ? r[t] : 0.f)) : 0.f;
+  float sum = 0.f, sq = 0.f;
+  for (int c = sl; c < C; c += 16) {
+    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; v -= shift; sum += v; sq += v * v; }
   }
-  s_sum[sl][col] = sum;
+  s_a[sl][col] = sum; s_b[sl][col] = sq;
   __syncthreads();
-  const float mean = (s_sum[0][col] + s_sum[1][col] + s_sum[2][col] + s_sum[3][col]) / (float)C;
-  float sq = 0.f;
-  for (int c = sl; c < C; c += 4) {
-    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; v -= mean; sq += v * v; }
-  }
-  s_sq[sl][col] = sq;
-  __syncthreads();
-  const float var = (s_sq[0][col] + s_sq[1][col] + s_sq[2][col] + s_sq[3][col]) / (float)C;
-  const float rstd = rsqrtf(var + eps);
-  for (int c = sl; c < C; c += 4) {
+  float ts = 0.f, tq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ts += s_a[i][col]; tq += s_b[i][col]; }
+  const float md = ts / (float)C;                       // mean - shift
+  const float var = fmaxf(tq / (float)C - md * md, 0.f);
+  const float mean = md + shift, rstd = rsqrtf(var + eps);
+  for (int c = sl; c < C; c += 16) {
     if (ok) {
       float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t];
       y[(long long)c * ld + t] = (v - mean) * rstd * gamma[c] + beta[c];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
 }
 void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gamma, const float* beta, float* y, int C, int T,
                  long long ld, float eps) {
-  hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 63) / 64), dim3(256), 0, s, x, r, gamma, beta, y, C, T, ld, eps);
+  hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, r, gamma, beta, y, C, T, ld, eps);
 }
 
 // ---------------------------------------------------------------------------------------------- GroupNorm(C, C) over time + GELU
@@ -88,51 +88,51 @@ void groupnorm_t_gelu(hipStream_t s, float* x, const float* gamma, const float* 
 // ---------------------------------------------------------------------------------------------- column softmax of S^T [Tk][Tq]
 // Softmax over the key axis (rows) for every query column; optional relative-position bias
 // rel[(k - q + win)][q] for |k - q| <= win (enc_p, reference attentions.py:230-239) and optional gather of the banded
-// probabilities pb[r][q] = P[q][q + r - win] (reference attentions.py:260-267).  Block = 32 columns x 8 row slices.
+// probabilities pb[r][q] = P[q][q + r - win] (reference attentions.py:260-267).  Block = 16 columns x 16 row slices.
+// Two sweeps: online (max, sum) then normalise-and-store: 2 reads + 1 write of the score matrix.
 __global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ S, int Tk, int Tq, long long ld, long long batchS,
                                                            const float* __restrict__ rel, long long batchRel, int win,
                                                            float* __restrict__ pb, long long batchPb) {
-  __shared__ float red[8][32];
-  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int q = blockIdx.x * 32 + col;
+  __shared__ float s_m[16][17], s_s[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int q = blockIdx.x * 16 + col;
   const bool ok = q < Tq;
   float* Sb = S + (long long)blockIdx.y * batchS;
   const float* relb = rel ? rel + (long long)blockIdx.y * batchRel : nullptr;
-  float mx = -3.0e38f;
-  for (int k = sl; k < Tk; k += 8) {
+  float mx = -3.0e38f, sum = 0.f;
+  for (int k = sl; k < Tk; k += 16) {
     if (ok) {
       float v = Sb[(long long)k * ld + q];
-      if (relb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) { v += relb[(long long)d * Tq + q]; Sb[(long long)k * ld + q] = v; } }
-      mx = fmaxf(mx, v);
+      if (relb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) v += relb[(long long)d * Tq + q]; }
+      const float nm = fmaxf(mx, v);
+      sum = sum * expf(mx - nm) + expf(v - nm);
+      mx = nm;
     }
   }
-  red[sl][col] = mx;
+  s_m[sl][col] = mx; s_s[sl][col] = sum;
   __syncthreads();
-  mx = red[0][col];
+  float gm = -3.0e38f;
 #pragma unroll
-  for (int i = 1; i < 8; ++i) mx = fmaxf(mx, red[i][col]);
-  __syncthreads();
-  float sum = 0.f;
-  for (int k = sl; k < Tk; k += 8) {
-    if (ok) { const float e = expf(Sb[(long long)k * ld + q] - mx); Sb[(long long)k * ld + q] = e; sum += e; }
-  }
-  red[sl][col] = sum;
-  __syncthreads();
-  sum = 0.f;
+  for (int i = 0; i < 16; ++i) gm = fmaxf(gm, s_m[i][col]);
+  float gs = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sum += red[i][col];
-  const float inv = 1.f / sum;
-  for (int k = sl; k < Tk; k += 8) {
+  for (int i = 0; i < 16; ++i) gs += s_s[i][col] * expf(s_m[i][col] - gm);
+  const float inv = 1.f / gs;
+  for (int k = sl; k < Tk; k += 16) {
     if (ok) {
-      const float pv = Sb[(long long)k * ld + q] * inv;
+      float v = Sb[(long long)k * ld + q];
+      const int d = k - q + win;
+      const bool band = d >= 0 && d <= 2 * win;
+      if (relb && band) v += relb[(long long)d * Tq + q];
+      const float pv = expf(v - gm) * inv;
       Sb[(long long)k * ld + q] = pv;
-      if (pb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) pb[(long long)blockIdx.y * batchPb + (long long)d * Tq + q] = pv; }
+      if (pb && band) pb[(long long)blockIdx.y * batchPb + (long long)d * Tq + q] = pv;
     }
   }
 }
 void softmax_cols(hipStream_t s, float* S, int Tk, int Tq, long long ld, long long batchS, int batch, const float* rel,
                   long long batchRel, int win, float* pb, long long batchPb) {
-  hipLaunchKernelGGL(softmax_cols_kernel, dim3((Tq + 31) / 32, batch), dim3(256), 0, s, S, Tk, Tq, ld, batchS, rel, batchRel,
+  hipLaunchKernelGGL(softmax_cols_kernel, dim3((Tq + 15) / 16, batch), dim3(256), 0, s, S, Tk, Tq, ld, batchS, rel, batchRel,
                      win, pb, batchPb);
 }
 
