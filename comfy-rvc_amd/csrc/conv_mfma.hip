@@ -36,6 +36,7 @@ struct ConvArgsX : ConvArgs {
   long long ldW;   // pitch (floats) of one packed-weight row
   int Wcols;       // valid columns in a weight row
   int Wrows;       // valid rows of the weight matrix
+  int ksplit; float* partial; long long ldP;   // split-K: chunk ranges over blockIdx.z, raw accumulators to partial[ks][m][ldP]
   unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
   int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
 };
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane0 & 31, lh = lane0 >> 5;
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / p.ksplit, ks = blockIdx.z - z * p.ksplit;   // batch index, K-split index
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
 
@@ -101,7 +102,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
 
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
-  const int nstages = p.nchunk * ntb;
+  const int cps = (p.nchunk + p.ksplit - 1) / p.ksplit;                  // chunks per K split
+  const int chunk0 = ks * cps, chunk1 = min(p.nchunk, chunk0 + cps);
+  const int nstages = max(chunk1 - chunk0, 0) * ntb;
   const bool wvec = (p.ldW & 3) == 0 && (p.Wcols & 3) == 0 && ((((uintptr_t)W) & 15) == 0);
   const int used1 = BN + (p.ktaps - 1) * (MODE == 1 ? p.dil : 1);   // 1-D: LDS columns in use per row
   const int span = MODE == 3 ? used1 * p.stride : used1;             // 1-D: input samples staged per (channel) row
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   // Iteration `it` moves stage it-1 from registers to LDS, prefetches stage `it` into registers and runs the MFMAs of stage
   // it-1 (one copy of every code section; the prefetch latency hides under the matrix work).
   const long long t_begin = TICK();
-  int chunk = 0, tb = 0, pchunk = 0, ptb = 0;
+  int chunk = chunk0, tb = 0, pchunk = chunk0, ptb = 0;
   for (int it = 0; it <= nstages; ++it) {
     const long long ta = TICK();
     if (it > 0) {
@@ -274,7 +277,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   float* Y = p.Y + (long long)z * p.yBatch;
   const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
   const float oscale = p.out_scale;
-  if (p.ostride == 1 && !p.up2) {
+  if (p.ksplit > 1) {
+    // split-K: raw partial sums; bias / activation / residual are applied by splitk_reduce_kernel in a fixed order
+    float* P = p.partial + ((long long)blockIdx.z * p.Co) * p.ldP;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(P, (unsigned)p.Co * (unsigned)p.ldP * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const bool ok = m < p.Co && n < p.Tout;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), prs, (int)(ok ? ((unsigned)m * (unsigned)p.ldP + (unsigned)n) * 4u : kOOB), 0, 0);
+        }
+      }
+  } else if (p.ostride == 1 && !p.up2) {
     // dense rows: 32-bit element offsets through buffer descriptors (extents < 2^31 bytes, checked on the host)
     const bool plain = p.orows == p.Co;
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
@@ -398,6 +417,28 @@ static void act_res_inplace(hipStream_t s, float* y, const float* r, int rows, i
   const long long n = (long long)rows * T;
   int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(act_res_kernel, dim3(blocks), dim3(256), 0, s, y, r, rows, T, ldY, ldR, act, slope, act_before_res);
+}
+
+// Second pass of a split-K launch: sums the partials in a fixed order and applies the dense epilogue.
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, int S, int batch, int M, int N, long long ldP, const float* __restrict__ bias, int bBatch,
+                                     const float* __restrict__ R, long long ldR, long long rBatch, float* __restrict__ Y, long long ldY, long long yBatch,
+                                     int orows, float lslope, int abr, float oscale, int accumulate) {
+  const long long total = (long long)batch * M * N;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += st) {
+    const int n = (int)(i % N); const long long t = i / N; const int m = (int)(t % M); const int z = (int)(t / M);
+    float v = 0.f;
+    for (int k = 0; k < S; ++k) v += P[(((long long)z * S + k) * M + m) * ldP + n];
+    const int co = m % orows;
+    if (bias) v += bias[(long long)z * bBatch + co];
+    const float rv = R ? R[(long long)z * rBatch + (long long)co * ldR + n] : 0.f;
+    if (abr) v = fmaxf(v, v * lslope) + rv; else { v += rv; v = fmaxf(v, v * lslope); }
+    const long long o = (long long)z * yBatch + (long long)co * ldY + n;
+    v *= oscale;
+    if (accumulate) v += Y[o];
+    Y[o] = v;
+  }
 }
 
 // ============================================================================ host side
@@ -650,8 +691,34 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   RVC_REQUIRE((double)a.orows * (double)a.ldY * 4.0 < 2147483648.0 && (double)a.orows * (double)a.ldR * 4.0 < 2147483648.0 &&
               (double)a.Ci * (double)a.ldX * 4.0 < 2147483648.0, "tensor extent exceeds the 32-bit buffer addressing of the conv kernel");
-  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)batch);
+  // split-K: small grids (deep U-Net levels, 1599-frame GEMMs) leave most CUs idle and expose every stage's load latency;
+  // slicing the reduction over S workgroups restores occupancy.  Partials are reduced in a fixed order (deterministic).
+  const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM) * batch;
+  int S = 1;
+  static const int max_split = getenv("RVC_SPLITK") ? atoi(getenv("RVC_SPLITK")) : 8;
+  static const int split_blk = getenv("RVC_SPLITK_BLK") ? atoi(getenv("RVC_SPLITK_BLK")) : 400;
+  if (a.ostride == 1 && !a.up2 && nblk < split_blk) {
+    S = (int)((2 * split_blk + nblk - 1) / nblk);
+    if (S > max_split) S = max_split;
+    if (S > a.nchunk / 2) S = a.nchunk / 2;
+    if (S < 1) S = 1;
+    while (S > 1 && ((a.nchunk + S - 1) / S) * (S - 1) >= a.nchunk) --S;     // every split must own at least one chunk
+  }
+  a.ksplit = S; a.partial = nullptr; a.ldP = (a.Tout + 31) & ~31;
+  if (S > 1) RVC_HIP_CHECK(hipMallocAsync((void**)&a.partial, (size_t)S * batch * a.Co * a.ldP * sizeof(float), s));
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)(batch * S));
   ProfRec rec{}; int cfg_id = 0;
+  auto finish = [&]() {
+    if (S > 1) {
+      const long long total = (long long)batch * a.Co * a.Tout;
+      int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+      const float lslope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : a.act_slope);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, S, batch, a.Co, a.Tout, a.ldP, a.bias, a.bBatch, a.R, a.ldR,
+                         a.rBatch, a.Y, a.ldY, a.yBatch, a.orows, lslope, a.act_before_res, a.out_scale, a.accumulate);
+      (void)hipFreeAsync(a.partial, s);
+    }
+    if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); }
+  };
 #define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
   if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \
     cfg_id = ID_ + (mode == 2 ? 7 : 0);                                                         \
@@ -659,7 +726,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
     if (mode == 2) launch_cfg<WM_, WN_, AM_, AN_, 2>(a, grid, lds, s);                          \
     else if (a.stride > 1) launch_cfg<WM_, WN_, AM_, AN_, 3>(a, grid, lds, s);                  \
     else launch_cfg<WM_, WN_, AM_, AN_, 1>(a, grid, lds, s);                                    \
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); } \
+    finish();                                                                                   \
     return;                                                                                     \
   }
   RVC_LAUNCH(0, 1, 4, 1, 4)
