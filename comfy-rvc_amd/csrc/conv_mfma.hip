@@ -459,6 +459,21 @@ float* dev_upload(const float* host, size_t n) {
 }
 void dev_free(void* p) { if (p) (void)hipFree(p); }
 
+// Per-stream scratch buffers (slot 0: split-K partials, slot 1/2: pipeline temporaries).  Work on one stream is ordered, so a
+// buffer can be reused by consecutive launches; growing (warm-up only) synchronises, steady state never allocates.
+void* stream_scratch(hipStream_t s, int slot, size_t bytes) {
+  struct Buf { void* p = nullptr; size_t cap = 0; };
+  static std::map<std::pair<hipStream_t, int>, Buf> pool;
+  Buf& b = pool[{s, slot}];
+  if (bytes > b.cap) {
+    RVC_HIP_CHECK(hipDeviceSynchronize());
+    if (b.p) (void)hipFree(b.p);
+    b.cap = bytes + bytes / 4 + (1 << 20);
+    RVC_HIP_CHECK(hipMalloc(&b.p, b.cap));
+  }
+  return b.p;
+}
+
 void Arena::ensure(size_t bytes) {
   if (bytes <= cap) return;
   if (base) { RVC_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(base); base = nullptr; cap = 0; }
@@ -705,7 +720,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
     while (S > 1 && ((a.nchunk + S - 1) / S) * (S - 1) >= a.nchunk) --S;     // every split must own at least one chunk
   }
   a.ksplit = S; a.partial = nullptr; a.ldP = (a.Tout + 31) & ~31;
-  if (S > 1) RVC_HIP_CHECK(hipMallocAsync((void**)&a.partial, (size_t)S * batch * a.Co * a.ldP * sizeof(float), s));
+  if (S > 1) a.partial = (float*)stream_scratch(s, 0, (size_t)S * batch * a.Co * a.ldP * sizeof(float));
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)(batch * S));
   ProfRec rec{}; int cfg_id = 0;
   auto finish = [&]() {
@@ -715,7 +730,6 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
       const float lslope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : a.act_slope);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, S, batch, a.Co, a.Tout, a.ldP, a.bias, a.bBatch, a.R, a.ldR,
                          a.rBatch, a.Y, a.ldY, a.yBatch, a.orows, lslope, a.act_before_res, a.out_scale, a.accumulate);
-      (void)hipFreeAsync(a.partial, s);
     }
     if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); }
   };

@@ -146,17 +146,12 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
   const int D = version == 1 ? 256 : 768;
   const int T = (int)(2 * Th);
   // scratch for the channel-major features lives in two small allocations owned by this call's stream order
-  float* fcm = nullptr; float* fup = nullptr;
-  RVC_HIP_CHECK(hipMallocAsync((void**)&fcm, (size_t)D * Th * sizeof(float), st));
-  RVC_HIP_CHECK(hipMallocAsync((void**)&fup, (size_t)D * T * sizeof(float), st));
-  try {
-    hubert_forward(h->m, st, audio, L, version, 0, nullptr, fcm, nullptr);
-    feats_prepare(st, fcm, pitchf, fup, D, (int)Th, T, protect, do_protect);
-    synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
-    check_launch();
-  } catch (...) { (void)hipFreeAsync(fcm, st); (void)hipFreeAsync(fup, st); throw; }
-  RVC_HIP_CHECK(hipFreeAsync(fcm, st));
-  RVC_HIP_CHECK(hipFreeAsync(fup, st));
+  float* fcm = (float*)stream_scratch(st, 1, (size_t)D * Th * sizeof(float));
+  float* fup = (float*)stream_scratch(st, 2, (size_t)D * T * sizeof(float));
+  hubert_forward(h->m, st, audio, L, version, 0, nullptr, fcm, nullptr);
+  feats_prepare(st, fcm, pitchf, fup, D, (int)Th, T, protect, do_protect);
+  synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
+  check_launch();
   RVC_CATCH
 }
 
@@ -166,14 +161,10 @@ int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, int6
   RVC_REQUIRE(s && feats_cm && pitch && pitchf && noise_z && noise_src && out, "null argument");
   hipStream_t st = (hipStream_t)stream;
   const int T = (int)(2 * Th);
-  float* fup = nullptr;
-  RVC_HIP_CHECK(hipMallocAsync((void**)&fup, (size_t)feat_dim * T * sizeof(float), st));
-  try {
-    feats_prepare(st, feats_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
-    synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
-    check_launch();
-  } catch (...) { (void)hipFreeAsync(fup, st); throw; }
-  RVC_HIP_CHECK(hipFreeAsync(fup, st));
+  float* fup = (float*)stream_scratch(st, 2, (size_t)feat_dim * T * sizeof(float));
+  feats_prepare(st, feats_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
+  synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
+  check_launch();
   RVC_CATCH
 }
 
@@ -181,13 +172,10 @@ int rvc_postprocess(void* stream, float* wav, int64_t N, const double* rms1, int
   RVC_TRY
   RVC_REQUIRE(wav && out_i16 && N > 0 && sr2 > 0, "bad argument");
   hipStream_t st = (hipStream_t)stream;
-  float* scratch = nullptr;
   const int n2 = (int)(N / (sr2 / 2)) + 1;
-  RVC_HIP_CHECK(hipMallocAsync((void**)&scratch, (size_t)(n2 + 4) * sizeof(float), st));
+  float* scratch = (float*)stream_scratch(st, 1, (size_t)(n2 + 4) * sizeof(float));
   postprocess(st, wav, N, rms1, n1, sr2, rms_mix_rate, (short*)out_i16, scratch + 4, (unsigned*)scratch);
-  hipError_t e = hipGetLastError();
-  RVC_HIP_CHECK(hipFreeAsync(scratch, st));
-  RVC_HIP_CHECK(e);
+  check_launch();
   RVC_CATCH
 }
 

@@ -114,6 +114,7 @@ void conv_timing_read(unsigned long long* out8, bool reset);   // debug builds (
 
 // ----------------------------------------------------------------------------- device memory
 float* dev_upload(const float* host, size_t n);
+void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // persistent per-stream scratch (grows on demand)
 void dev_free(void* p);
 
 struct Arena {

@@ -180,6 +180,11 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
     segments are synthesised from device-resident features, and change_rms + int16 normalisation (reference
     vc_infer_pipeline.py:182-189) run as kernels; only the zero-phase high-pass, the cut search and the 100 fps pitch
     post-processing stay on the host, exactly where the reference has them."""
+    import time as _t
+    _tr = [("start", _t.perf_counter())] if os.environ.get("RVC_TRACE") else None
+    def _mark(n):
+        if _tr is not None:
+            _tr.append((n, _t.perf_counter()))
     dev = net_g.device
     bounds, s0 = [], 0
     for t in opt_ts:
@@ -198,10 +203,12 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
         for (b0, b1) in bounds:
             feats.append(model.extract_features(a_dev[b0:b1].view(1, -1), version=version, channel_major=True))
     a_dev.record_stream(side)
+    _mark("hubert enqueued")
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
     x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else audio_pad
     pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
                                 f0_min, f0_max)
+    _mark("f0 ready (rmvpe sync + host post)")
     p_len = min(pitch.shape[0], pitchf.shape[0])
     pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
     pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
@@ -226,6 +233,7 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
             _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
                                                      float(protect), 1 if protect < 0.5 else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
         outs.append(out[self.t_pad_tgt: out.numel() - self.t_pad_tgt])
+    _mark("synth enqueued")
     wav = torch.cat(outs) if len(outs) > 1 else outs[0].contiguous()
     N = wav.numel()
     rms1 = None
@@ -236,7 +244,12 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
         _lib.check(_lib.lib.rvc_postprocess(_lib.current_stream(), _lib.ptr(wav), N, _lib.ptr(rms1), 0 if rms1 is None else rms1.numel(),
                                             int(tgt_sr), float(rms_mix_rate), _lib.ptr(i16)))
     self.last_float = wav          # device tensor: waveform after change_rms, before the int16 normalisation
-    return i16.cpu().numpy()
+    _mark("post enqueued")
+    res = i16.cpu().numpy()
+    _mark("result on host")
+    if _tr is not None:
+        print("trace ms: " + " | ".join(f"{n} {1e3 * (t - _tr[i][1]):.1f}" for i, (n, t) in enumerate(_tr[1:])))
+    return res
 
 
 VC._pipeline_device = _pipeline_device
