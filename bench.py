@@ -120,14 +120,15 @@ def main():
         vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
         step()
         torch.cuda.synchronize()
-        ms = (C.c_double * 14)(); fl = (C.c_double * 14)(); ln = (C.c_int64 * 14)()
+        NCFG = 24   # RVC_PROF_CFGS
+        ms = (C.c_double * NCFG)(); fl = (C.c_double * NCFG)(); ln = (C.c_int64 * NCFG)()
         _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
         _lib.check(_lib.lib.rvc_prof_enable(0))
         vc.overlap_streams = True
         tot_ms, tot_fl, tot_l = sum(ms), sum(fl), sum(ln)
         per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
                                                             "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
-                   for i in range(14) if ln[i]}
+                   for i in range(NCFG) if ln[i]}
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,

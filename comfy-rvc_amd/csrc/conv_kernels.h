@@ -1,0 +1,118 @@
+// Device-side helpers and launch plumbing shared by the convolution kernels (conv_mfma.hip: fp32 MFMA,
+// conv_x3.hip: bf16x3 split MFMA).  Private to csrc/.
+#pragma once
+#include "rvc_internal.h"
+
+namespace rvc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsX : ConvArgs {
+  long long ldW;   // pitch (floats) of one packed-weight row
+  int Wcols;       // valid columns in a weight row
+  int Wrows;       // valid rows of the weight matrix
+  int ksplit; float* partial; long long ldP;   // split-K: chunk ranges over blockIdx.z, raw accumulators to partial[ks][m][ldP]
+  unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
+  int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
+  // bf16x3 kernel (conv_x3.hip): split weight image, its padded row count, X buffers in LDS (1 or 2)
+  const unsigned char* Wx; int CoPx; int xbufs; long long wxBatch;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// out-of-range offsets (>= the descriptor's extent; kOOB always is) read as 0 and drop stores: the hardware range check
+// supplies zero padding, channel tails and ragged edges without branches
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// Dense-row epilogue shared by the MFMA kernels (32x32 accumulator layout: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)):  v = acc + bias; act in {identity, ReLU, leaky ReLU} as max(v, slope v),
+// before or after the residual; * out_scale; (+ previous output).  Row r+1's residual / accumulate operands are requested
+// before row r is stored (vmcnt counts loads and stores alike).  32-bit element offsets through buffer descriptors.
+template <int WM, int WN, int AM, int AN>
+__device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)[AM][AN], int z, int co0, int n0, int wm, int wn, int li, int lh) {
+  const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
+  const float* R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
+  float* Y = p.Y + (long long)z * p.yBatch;
+  const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
+  const float oscale = p.out_scale;
+  const bool plain = p.orows == p.Co;
+  const __amdgpu_buffer_rsrc_t yrs = make_rsrc(Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
+  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R : Y, R ? (unsigned)p.orows * (unsigned)p.ldR * 4u : 0u);   // no residual: all loads read 0
+  const __amdgpu_buffer_rsrc_t ars = make_rsrc(Y, p.accumulate ? (unsigned)p.orows * (unsigned)p.ldY * 4u : 0u);
+  const bool abr = p.act_before_res != 0;
+  const bool need_loads = R != nullptr || p.accumulate;
+  auto row_info = [&](int am, int r, bool& mok, float& bv, unsigned& yrow, unsigned& rrow) {
+    const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    mok = m < p.Co;
+    const int co = plain ? m : m % p.orows;
+    bv = (bias && mok) ? bias[co] : 0.f;
+    yrow = (unsigned)co * (unsigned)p.ldY; rrow = (unsigned)co * (unsigned)p.ldR;
+  };
+#pragma unroll
+  for (int am = 0; am < AM; ++am) {
+    float rv[AN], yv[AN], rvn[AN], yvn[AN];
+#pragma unroll
+    for (int an = 0; an < AN; ++an) { rv[an] = 0.f; yv[an] = 0.f; rvn[an] = 0.f; yvn[an] = 0.f; }
+    if (need_loads) {
+      bool mok; float bv; unsigned yrow, rrow;
+      row_info(am, 0, mok, bv, yrow, rrow);
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        const bool ok = mok && n < p.Tout;
+        rv[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
+        yv[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (need_loads && r + 1 < 16) {
+        bool mok; float bv; unsigned yrow, rrow;
+        row_info(am, r + 1, mok, bv, yrow, rrow);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const bool ok = mok && n < p.Tout;
+          rvn[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
+          yvn[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
+        }
+      }
+      bool mok; float bv; unsigned yrow, rrow;
+      row_info(am, r, mok, bv, yrow, rrow);
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        const bool ok = mok && n < p.Tout;
+        float v = acc[am][an][r] + bv;
+        if (abr) v = fmaxf(v, v * lslope) + rv[an];
+        else { v += rv[an]; v = fmaxf(v, v * lslope); }
+        v = v * oscale + yv[an];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(ok ? (yrow + (unsigned)n) * 4u : kOOB), 0, 0);
+      }
+#pragma unroll
+      for (int an = 0; an < AN; ++an) { rv[an] = rvn[an]; yv[an] = yvn[an]; }
+    }
+  }
+}
+
+// ---- host side
+struct TileCfg { int WM, WN, AM, AN; };
+TileCfg choose_tile(int M, long long N, int batch);
+int tile_cfg_id(const TileCfg& t);            // 0..6, -1 if not an instantiated tiling
+
+// per-launch HIP-event profiling (cfg: 0..6 fp32 1-D, 7..13 fp32 2-D, 14..20 bf16x3 1-D)
+constexpr int kProfCfgs = 24;
+struct ProfTicket { hipEvent_t a = nullptr, b = nullptr; bool on = false; };
+ProfTicket conv_prof_begin(hipStream_t s);
+void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg);
+
+// bf16x3 path: returns false when the layer / geometry is not eligible (caller falls back to the fp32 kernel)
+bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops);
+bool conv_x3_enabled();
+
+}  // namespace rvc

@@ -13,7 +13,7 @@
 // MFMA 32x32x2 f32: A = Wp[kk][m] (lane i = m, lane half = kk parity), B = Xs[kk][n] (lane i = n);
 // both are single conflict-free ds_read_b32 per operand; fp32 accumulate, bitwise an fmaf chain.
 // Workgroup = 4 waves (WM x WN), each wave owns AM x AN accumulators of 32x32.
-#include "rvc_internal.h"
+#include "conv_kernels.h"
 
 #ifndef RVC_EPI_TWOPHASE
 #define RVC_EPI_TWOPHASE 0
@@ -30,32 +30,10 @@ __device__ unsigned long long g_conv_timing[8];   // [0] blocks, [1] prologue, [
 #define TACC(i, v) do {} while (0)
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgsX : ConvArgs {
-  long long ldW;   // pitch (floats) of one packed-weight row
-  int Wcols;       // valid columns in a weight row
-  int Wrows;       // valid rows of the weight matrix
-  int ksplit; float* partial; long long ldP;   // split-K: chunk ranges over blockIdx.z, raw accumulators to partial[ks][m][ldP]
-  unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
-  int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
-};
-
 constexpr int kWSlots = 32;   // register slots (floats per thread) for the prefetched weight slab (<= 32 KB / 256 threads)
 // register slots for the prefetched input tile, per tile width and mode (checked against the launch geometry on the host)
 __host__ __device__ constexpr int x_slots(int BN, int MODE) {
   return MODE == 2 ? (BN >= 512 ? 26 : (BN >= 256 ? 18 : 14)) : (BN >= 512 ? 36 : (BN >= 256 ? 20 : (BN >= 128 ? 32 : 16)));
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-// out-of-range offsets (>= the descriptor's extent; kOOB always is) read as 0 and drop stores: the hardware range check
-// supplies zero padding, channel tails and ragged edges without branches
-constexpr unsigned kOOB = 0x80000000u;
-__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff = 0) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
 // Software pipeline: the global loads of stage s+1 (input tile with halo + weight slab) are issued into registers before the
@@ -273,7 +251,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
   // v = acc + bias; act in {identity, ReLU, leaky ReLU} as max(v, slope * v), before or after the residual; * out_scale;
   // (+ previous output).  Row r+1's residual / accumulate operands are requested before row r is stored.
   const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
-  const float* R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
   float* Y = p.Y + (long long)z * p.yBatch;
   const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
   const float oscale = p.out_scale;
@@ -294,65 +271,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
         }
       }
   } else if (p.ostride == 1 && !p.up2) {
-    // dense rows: 32-bit element offsets through buffer descriptors (extents < 2^31 bytes, checked on the host)
-    const bool plain = p.orows == p.Co;
-    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
-    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R : Y, R ? (unsigned)p.orows * (unsigned)p.ldR * 4u : 0u);   // no residual: all loads read 0
-    const __amdgpu_buffer_rsrc_t ars = make_rsrc(Y, p.accumulate ? (unsigned)p.orows * (unsigned)p.ldY * 4u : 0u);
-    const bool abr = p.act_before_res != 0;
-    const bool need_loads = R != nullptr || p.accumulate;
-    auto row_info = [&](int am, int r, bool& mok, float& bv, unsigned& yrow, unsigned& rrow) {
-      const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      mok = m < p.Co;
-      const int co = plain ? m : m % p.orows;
-      bv = (bias && mok) ? bias[co] : 0.f;
-      yrow = (unsigned)co * (unsigned)p.ldY; rrow = (unsigned)co * (unsigned)p.ldR;
-    };
-#pragma unroll
-    for (int am = 0; am < AM; ++am) {
-      float rv[AN], yv[AN], rvn[AN], yvn[AN];
-#pragma unroll
-      for (int an = 0; an < AN; ++an) { rv[an] = 0.f; yv[an] = 0.f; rvn[an] = 0.f; yvn[an] = 0.f; }
-      if (need_loads) {
-        bool mok; float bv; unsigned yrow, rrow;
-        row_info(am, 0, mok, bv, yrow, rrow);
-#pragma unroll
-        for (int an = 0; an < AN; ++an) {
-          const int n = n0 + (wn * AN + an) * 32 + li;
-          const bool ok = mok && n < p.Tout;
-          rv[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
-          yv[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (need_loads && r + 1 < 16) {
-          bool mok; float bv; unsigned yrow, rrow;
-          row_info(am, r + 1, mok, bv, yrow, rrow);
-#pragma unroll
-          for (int an = 0; an < AN; ++an) {
-            const int n = n0 + (wn * AN + an) * 32 + li;
-            const bool ok = mok && n < p.Tout;
-            rvn[an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
-            yvn[an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
-          }
-        }
-        bool mok; float bv; unsigned yrow, rrow;
-        row_info(am, r, mok, bv, yrow, rrow);
-#pragma unroll
-        for (int an = 0; an < AN; ++an) {
-          const int n = n0 + (wn * AN + an) * 32 + li;
-          const bool ok = mok && n < p.Tout;
-          float v = acc[am][an][r] + bv;
-          if (abr) v = fmaxf(v, v * lslope) + rv[an];
-          else { v += rv[an]; v = fmaxf(v, v * lslope); }
-          v = v * oscale + yv[an];
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(ok ? (yrow + (unsigned)n) * 4u : kOOB), 0, 0);
-        }
-#pragma unroll
-        for (int an = 0; an < AN; ++an) { rv[an] = rvn[an]; yv[an] = yvn[an]; }
-      }
-    }
+    dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
   } else {
     // interleaved stores (ConvTranspose1d phases, ConvTranspose2d 2x2 phases): generic 64-bit indexing, accumulate optional
 #pragma unroll
@@ -496,7 +415,40 @@ static void upload_layer(ConvLayer& L, const std::vector<float>& packed, const f
   L.bd_ = bias ? dev_upload(bias, nbias) : nullptr;
 }
 
-void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); L.Wd_ = L.bd_ = nullptr; }
+void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); L.Wd_ = L.bd_ = nullptr; L.Wx_ = nullptr; }
+
+// bf16x3 weight image (conv_x3.hip): every fp32 weight is split w = hi + lo (both bf16, round-to-nearest-even) and stored
+// [16-channel chunk][tap][hi|lo][CoPx rows][16 channels] with the two 8-channel halves of a row swapped when bit 3 of the row
+// is set, so that the LDS copy (a linear global_load_lds image) is conflict-free for ds_read_b128.
+static uint16_t bf16_rne(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static bool g_x3_default = false;
+static int g_precision = 1;      // 0: fp32 kernel only, 1: layers initialised under conv_x3_set_default(true), 2: every eligible layer
+void conv_x3_set_default(bool on) { g_x3_default = on; }
+void conv_set_precision(int mode) { g_precision = mode; }
+static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
+  L.CoPx = (Co + 127) & ~127;
+  const int nch = Ci / 16;
+  L.wxBatch = (long long)nch * k * 2 * L.CoPx * 16;
+  std::vector<uint16_t> P((size_t)L.wxBatch, 0);
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int u = 0; u < k; ++u) {
+        const float v = w[((size_t)co * Ci + ci) * k + u];
+        const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+        const int chunk = ci >> 4, c16 = ci & 15;
+        const size_t col = (size_t)((((c16 >> 3) ^ ((co >> 3) & 1)) << 3) + (c16 & 7));
+        const size_t base = ((size_t)chunk * k + u) * 2;
+        P[((base + 0) * L.CoPx + co) * 16 + col] = hi;
+        P[((base + 1) * L.CoPx + co) * 16 + col] = lo;
+      }
+  RVC_HIP_CHECK(hipMalloc(&L.Wx_, P.size() * sizeof(uint16_t)));
+  RVC_HIP_CHECK(hipMemcpy(L.Wx_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+}
 
 void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci, int k, int stride, int pad,
                        int dil, int groups) {
@@ -522,6 +474,7 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
               w[((size_t)(g * Cog + co) * Cig + ci) * k + tap];
         }
   upload_layer(L, P, bias, Co);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && stride == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
 }
 
 void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci, int Co, int k, int u, int pad) {
@@ -597,8 +550,6 @@ void tconv2d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci,
 }
 
 // ---------------------------------------------------------------------------- launch
-struct TileCfg { int WM, WN, AM, AN; };
-
 template <int WM, int WN, int AM, int AN, int MODE>
 static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_mfma_kernel<WM, WN, AM, AN, MODE>;
@@ -610,7 +561,7 @@ static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s)
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
-static TileCfg choose_tile(int M, long long N, int batch, int mode, int Wd) {
+TileCfg choose_tile(int M, long long N, int batch) {
   // candidates ordered by preference for large problems; pick the first that yields enough workgroups
   const int Mp = (M + 31) / 32 * 32;
   TileCfg best{2, 2, 1, 1};
@@ -623,7 +574,6 @@ static TileCfg choose_tile(int M, long long N, int batch, int mode, int Wd) {
   if (Mp >= 128 && blocks(128, 128) >= 384) return TileCfg{2, 2, 2, 2};
   if (Mp <= 64 && blocks(64, 256) >= 384) return TileCfg{2, 2, 1, 4};
   if (blocks(64, 128) >= 384) return TileCfg{2, 2, 1, 2};
-  (void)mode; (void)Wd;
   return best;   // 64 x 64
 }
 
@@ -631,8 +581,10 @@ static TileCfg choose_tile(int M, long long N, int batch, int mode, int Wd) {
 struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static const char* kCfgNames[14] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
-                                    "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d"};
+static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
+                                           "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d",
+                                           "1x4x1x4/x3", "1x4x1x2/x3", "1x4x1x1/x3", "2x2x2x2/x3", "2x2x1x4/x3", "2x2x1x2/x3", "2x2x1x1/x3",
+                                           "", "", ""};
 void conv_prof_enable(bool on) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();
@@ -640,7 +592,7 @@ void conv_prof_enable(bool on) {
 }
 // Sums the event-timed conv launches recorded since conv_prof_enable(true).  Per tile configuration: ms, flops, launches.
 int conv_prof_collect(double* ms, double* flops, long long* launches) {
-  for (int i = 0; i < 14; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (int i = 0; i < kProfCfgs; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
@@ -649,7 +601,22 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
   }
   return (int)g_prof.size();
 }
-const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < 14) ? kCfgNames[i] : ""; }
+const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < kProfCfgs) ? kCfgNames[i] : ""; }
+ProfTicket conv_prof_begin(hipStream_t s) {
+  ProfTicket t; t.on = g_prof_on;
+  if (t.on) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); (void)hipEventRecord(t.a, s); }
+  return t;
+}
+void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg) {
+  if (!t.on) return;
+  (void)hipEventRecord(t.b, s);
+  g_prof.push_back(ProfRec{t.a, t.b, flops, cfg});
+}
+int tile_cfg_id(const TileCfg& t) {
+  static const TileCfg all[7] = {{1, 4, 1, 4}, {1, 4, 1, 2}, {1, 4, 1, 1}, {2, 2, 2, 2}, {2, 2, 1, 4}, {2, 2, 1, 2}, {2, 2, 1, 1}};
+  for (int i = 0; i < 7; ++i) if (all[i].WM == t.WM && all[i].WN == t.WN && all[i].AM == t.AM && all[i].AN == t.AN) return i;
+  return -1;
+}
 
 // Fills the tile-dependent launch geometry; returns false when the tile does not fit the register prefetch slots / LDS.
 static bool setup_tile(ConvArgsX& a, int mode, const TileCfg& t, size_t& lds) {
@@ -690,7 +657,7 @@ static bool setup_tile(ConvArgsX& a, int mode, const TileCfg& t, size_t& lds) {
 static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flops) {
   RVC_REQUIRE(a.act == ACT_NONE || a.act == ACT_LRELU || a.act == ACT_RELU, "in-kernel activations are identity / ReLU / leaky ReLU");
   RVC_REQUIRE(a.pre_act == ACT_NONE || a.pre_act == ACT_LRELU, "input activation must be identity or leaky ReLU");
-  TileCfg t = choose_tile(a.Co, a.Tout, batch, mode, a.Wd);
+  TileCfg t = choose_tile(a.Co, a.Tout, batch);
   if (const char* f = getenv("RVC_FORCE_TILE")) {   // experiments: "WM,WN,AM,AN"
     int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
   }
@@ -722,7 +689,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   a.ksplit = S; a.partial = nullptr; a.ldP = (a.Tout + 31) & ~31;
   if (S > 1) a.partial = (float*)stream_scratch(s, 0, (size_t)S * batch * a.Co * a.ldP * sizeof(float));
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)(batch * S));
-  ProfRec rec{}; int cfg_id = 0;
+  ProfTicket rec; int cfg_id = 0;
   auto finish = [&]() {
     if (S > 1) {
       const long long total = (long long)batch * a.Co * a.Tout;
@@ -731,12 +698,12 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, S, batch, a.Co, a.Tout, a.ldP, a.bias, a.bBatch, a.R, a.ldR,
                          a.rBatch, a.Y, a.ldY, a.yBatch, a.orows, lslope, a.act_before_res, a.out_scale, a.accumulate);
     }
-    if (g_prof_on) { (void)hipEventRecord(rec.b, s); rec.flops = flops; rec.cfg = cfg_id; g_prof.push_back(rec); }
+    conv_prof_end(rec, s, flops, cfg_id);
   };
 #define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
   if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \
     cfg_id = ID_ + (mode == 2 ? 7 : 0);                                                         \
-    if (g_prof_on) { (void)hipEventCreate(&rec.a); (void)hipEventCreate(&rec.b); (void)hipEventRecord(rec.a, s); } \
+    rec = conv_prof_begin(s);                                                                   \
     if (mode == 2) launch_cfg<WM_, WN_, AM_, AN_, 2>(a, grid, lds, s);                          \
     else if (a.stride > 1) launch_cfg<WM_, WN_, AM_, AN_, 3>(a, grid, lds, s);                  \
     else launch_cfg<WM_, WN_, AM_, AN_, 1>(a, grid, lds, s);                                    \
@@ -801,7 +768,8 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.bBatch = L.Co;
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
-  run_conv(a, 1, L.groups, s, flops);
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch;
+  if (!(L.Wx_ && L.tconv_u == 0 && conv_x3_try(a, L.groups, s, flops))) run_conv(a, 1, L.groups, s, flops);
   if (post) {
     RVC_REQUIRE(L.tconv_u == 0, "post-activation on a transposed conv");
     act_res_inplace(s, Y, e0.R, L.groups * L.Co, Tout, ldY, e0.ldR, e0.act, e0.act_slope, e0.act_before_res);

@@ -1,0 +1,255 @@
+// bf16x3 split-precision implicit-GEMM Conv1d on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16), gfx950 only.
+//
+// Every fp32 operand is split x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product is evaluated as
+// hi*hi + hi*lo + lo*hi with fp32 accumulation (the dropped lo*lo term is 2^-18 relative).  Three bf16 MFMAs do the work of
+// eight fp32 ones (32x32x16 vs 32x32x2 per instruction at twice the issue cost), so the generator's ResBlock convolutions run
+// at ~5x the fp32 matrix rate while the end-to-end synthesizer output stays within 3e-5 of the fp32 path (tolerance 1e-3).
+//
+// Same GEMM view, tiles and epilogue as conv_mfma.hip (stride-1 1-D convolutions only):
+//   Y[m][n] = sum_{chunk, tap, c16} W[m][chunk*16 + c16][tap] * X[chunk*16 + c16][n - pad + tap*dil]
+// One MFMA consumes 16 channels of one tap: lane (i, half) holds channels half*8 .. half*8+7 of row / position i.
+// LDS images (16 channels = 32 B per row, the two 16-B halves swapped when bit 3 of the row index is set, which makes every
+// ds_read_b128 lane group hit 16 distinct slots for any tap offset):
+//   X: [hi|lo][position q][16 ch] bf16, converted from the fp32 [C][T] activation while staging (registers -> ds_write_b128)
+//   W: [tap][hi|lo][row m][16 ch] bf16, a linear copy of the host-packed image by global_load_lds_dwordx4 (no registers),
+//      double-buffered so that the DMA of stage s+1 runs under the MFMAs of stage s; one barrier per stage.
+#include "conv_kernels.h"
+
+namespace rvc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
+__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 5 : (BN >= 256 ? 3 : (BN >= 128 ? 2 : 1)); }
+
+__device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
+
+template <int WM, int WN, int AM, int AN>
+__global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
+  const int P = p.WROW;                     // staged positions: BN + (ktaps - 1) * dil
+  const int xplane = P * 32;                // bytes of one hi / lo plane
+  const int wbuf = p.KT * 2 * BM * 32;      // bytes of one weight buffer
+  unsigned char* Xs = smem3;
+  unsigned char* Ws = smem3 + ((p.xbufs * 2 * xplane + 1023) & ~1023);
+
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane0 & 31, lh = lane0 >> 5;
+  const int z = blockIdx.z;
+  const int co0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const float* __restrict__ X = p.X + (long long)z * p.xBatch;
+  const unsigned char* __restrict__ Wg = p.Wx + (long long)z * p.wxBatch * 2;
+
+  f32x16 acc[AM][AN];
+#pragma unroll
+  for (int am = 0; am < AM; ++am)
+#pragma unroll
+    for (int an = 0; an < AN; ++an)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+
+  const int ntb = (p.ktaps + p.KT - 1) / p.KT;
+  const int nstages = p.nchunk * ntb;
+  const int bx = n0 - p.pad;
+  const int ni = p.ni;                                                      // 64-position groups per plane row set
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
+  const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;      // input activation: leaky ReLU (slope 1 = identity)
+
+  float xr[XS][8];
+
+  // ---- input tile: global -> registers.  Slot s of wave w covers 64 positions x 8 channels (one 16-B half of the LDS rows).
+  auto load_x = [&](int chunk) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const int g = wave + 4 * s;
+      const int hb = g >= ni ? 1 : 0;
+      const int q = (g - hb * ni) * 64 + lane, x = bx + q;
+      const bool ok = g < 2 * ni && q < P && x >= 0 && x < p.Tin;
+      const unsigned voff = ok ? (unsigned)x * 4u : kOOB;
+      const unsigned c0 = (unsigned)(chunk * 16 + hb * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
+        xr[s][j] = fmaxf(v, v * pre_slope);
+      }
+    }
+  };
+  // ---- input tile: registers -> hi/lo bf16 -> LDS
+  auto store_x = [&](int xb) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    unsigned char* xbase = Xs + xb * 2 * xplane;
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const int g = wave + 4 * s;
+      const int hb = g >= ni ? 1 : 0;
+      const int q = (g - hb * ni) * 64 + lane;
+      if (g < 2 * ni && q < P) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = xr[s][2 * j], b = xr[s][2 * j + 1];
+          const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+          const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
+          hi[j] = bf16_bits(ah) | (bf16_bits(bh) << 16);
+          lo[j] = bf16_bits(al) | (bf16_bits(bl) << 16);
+        }
+        const int off = q * 32 + ((hb ^ ((q >> 3) & 1)) << 4);
+        *reinterpret_cast<u32x4*>(xbase + off) = hi;
+        *reinterpret_cast<u32x4*>(xbase + xplane + off) = lo;
+      }
+    }
+  };
+  // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
+  auto issue_w = [&](int chunk, int tb, int buf) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int ut = min(p.KT, p.ktaps - tb * p.KT);
+    const int npieces = ut * 2 * RB;
+    for (int pi = wave; pi < npieces; pi += 4) {
+      const int j = pi / RB, rblk = pi - j * RB;            // j = (tap in block) * 2 + (hi | lo)
+      const long long row = ((long long)(chunk * p.ktaps + tb * p.KT + (j >> 1)) * 2 + (j & 1)) * p.CoPx + co0 + rblk * 32;
+      const unsigned char* src = Wg + row * 32 + lane * 16;
+      unsigned char* dst = Ws + buf * wbuf + pi * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  int aoff[AM], bq[AN];
+#pragma unroll
+  for (int am = 0; am < AM; ++am) { const int m = (wm * AM + am) * 32 + li; aoff[am] = m * 32 + ((lh ^ ((m >> 3) & 1)) << 4); }
+#pragma unroll
+  for (int an = 0; an < AN; ++an) bq[an] = (wn * AN + an) * 32 + li;
+
+  int chunk = 0, tb = 0;
+  issue_w(0, 0, 0);
+  load_x(0);
+  for (int it = 0; it < nstages; ++it) {
+    const int buf = it & 1;
+    const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
+    if (tb == 0) {
+      if (p.xbufs == 1 && it > 0) __syncthreads();       // single X buffer: every wave is done with the previous chunk
+      store_x(xb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stage's weight DMA has landed
+    __syncthreads();
+    int ntb_ = tb + 1, nchunk_ = chunk;
+    if (ntb_ == ntb) { ntb_ = 0; ++nchunk_; }
+    if (it + 1 < nstages) {
+      issue_w(nchunk_, ntb_, buf ^ 1);
+      if (ntb_ == 0) load_x(nchunk_);
+    }
+    // ---- MFMAs of this stage
+    const int ut = min(p.KT, p.ktaps - tb * p.KT);
+    const unsigned char* wb = Ws + buf * wbuf;
+    const unsigned char* xp = Xs + xb * 2 * xplane;
+    for (int uu = 0; uu < ut; ++uu) {
+      const int toff = (tb * p.KT + uu) * p.dil;
+      const unsigned char* wt = wb + uu * 2 * BM * 32;
+      u32x4 ah[AM], al[AM], bh[AN], bl[AN];
+#pragma unroll
+      for (int am = 0; am < AM; ++am) {
+        ah[am] = *reinterpret_cast<const u32x4*>(wt + aoff[am]);
+        al[am] = *reinterpret_cast<const u32x4*>(wt + BM * 32 + aoff[am]);
+      }
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int q = bq[an] + toff;
+        const int off = q * 32 + ((lh ^ ((q >> 3) & 1)) << 4);
+        bh[an] = *reinterpret_cast<const u32x4*>(xp + off);
+        bl[an] = *reinterpret_cast<const u32x4*>(xp + xplane + off);
+      }
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+    }
+    tb = ntb_; chunk = nchunk_;
+  }
+
+  dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
+}
+
+// ============================================================================ host side
+bool conv_x3_enabled() {
+  static const bool on = !(getenv("RVC_X3") && atoi(getenv("RVC_X3")) == 0);
+  return on;
+}
+
+template <int WM, int WN, int AM, int AN>
+static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_x3_kernel<WM, WN, AM, AN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
+
+bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
+  if (!conv_x3_enabled() || !a0.Wx) return false;
+  if (a0.stride != 1 || a0.ostride != 1 || a0.up2 || (a0.Ci & 15) || batch != 1) return false;
+  if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
+  if ((double)a0.orows * (double)a0.ldY * 4.0 >= 2147483648.0 || (double)a0.orows * (double)a0.ldR * 4.0 >= 2147483648.0 ||
+      (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;
+  ConvArgsX a = a0;
+  TileCfg t = choose_tile(a.Co, a.Tout, batch);
+  if (const char* f = getenv("RVC_FORCE_TILE")) {
+    int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
+  }
+  const int id = tile_cfg_id(t);
+  if (id < 0) return false;
+  const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
+  const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
+  static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 400;
+  if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
+  const int P = BN + (a.ktaps - 1) * a.dil;
+  a.ni = (P + 63) / 64;
+  if ((2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  // LDS budget: <= 80 KiB per workgroup (two workgroups per CU); X double-buffered when that still leaves >= 2 taps per stage
+  const int budget = 80 * 1024;
+  const int per_tap = 2 * 2 * BM * 32;                    // two buffers x {hi, lo} x BM rows x 32 B
+  int xbufs = 2;
+  int xbytes = (xbufs * 2 * P * 32 + 1023) & ~1023;
+  int ktmax = (budget - xbytes) / per_tap;
+  if (ktmax < 2 && a.ktaps > ktmax) { xbufs = 1; xbytes = (2 * P * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
+  if (ktmax < 1) return false;
+  if (ktmax > a.ktaps) ktmax = a.ktaps;
+  const int ntb = (a.ktaps + ktmax - 1) / ktmax;
+  a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
+  a.CK = 16; a.nchunk = a.Ci / 16; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
+  const size_t lds = (size_t)xbytes + (size_t)2 * a.KT * 2 * BM * 32;
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1u);
+  ProfTicket tk = conv_prof_begin(s);
+  switch (id) {
+    case 0: launch_x3<1, 4, 1, 4>(a, grid, lds, s); break;
+    case 1: launch_x3<1, 4, 1, 2>(a, grid, lds, s); break;
+    case 2: launch_x3<1, 4, 1, 1>(a, grid, lds, s); break;
+    case 3: launch_x3<2, 2, 2, 2>(a, grid, lds, s); break;
+    case 4: launch_x3<2, 2, 1, 4>(a, grid, lds, s); break;
+    case 5: launch_x3<2, 2, 1, 2>(a, grid, lds, s); break;
+    default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
+  }
+  conv_prof_end(tk, s, flops, 14 + id);
+  return true;
+}
+
+}  // namespace rvc

@@ -173,6 +173,7 @@ void synth_finalize(Synth* S) {
     const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
     // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
     conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
+    conv_x3_set_default(true);      // generator ResBlocks (70 % of the clip's FLOPs): bf16x3 split MFMA, see conv_x3.hip
     for (int j = 0; j < 3; ++j) {
       const std::string rb = "dec.resblocks." + std::to_string(i * 3 + j) + ".";
       const int k = S->rb_k[j];
@@ -182,6 +183,7 @@ void synth_finalize(Synth* S) {
         st.rb[j].c2[m] = make_conv1d(ts, rb + "convs2." + std::to_string(m), 1, (k - 1) / 2, 1, true);
       }
     }
+    conv_x3_set_default(false);
   }
   S->ts.clear();
   S->ready = true;

@@ -1,6 +1,7 @@
 // extern "C" layer of librvc_hip.so (see include/rvc_hip.h).  Every entry point converts C++ exceptions into a status code
 // plus a thread-local message; nothing here has a CPU fallback.
 #include "models.h"
+#include "conv_kernels.h"
 
 namespace rvc {
 static thread_local std::string g_err;
@@ -280,11 +281,18 @@ int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float*
 }
 
 int rvc_prof_enable(int on) { RVC_TRY conv_prof_enable(on != 0); RVC_CATCH }
-int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14) {
+int rvc_set_conv_precision(int mode) {
   RVC_TRY
-  long long l[14];
-  conv_prof_collect(ms14, flops14, l);
-  for (int i = 0; i < 14; ++i) launches14[i] = l[i];
+  RVC_REQUIRE(mode >= 0 && mode <= 2, "precision mode must be 0, 1 or 2");
+  conv_set_precision(mode);
+  RVC_CATCH
+}
+int rvc_prof_collect(double* ms, double* flops, int64_t* launches) {
+  RVC_TRY
+  static_assert(RVC_PROF_CFGS == kProfCfgs, "profiling table size");
+  long long l[RVC_PROF_CFGS];
+  conv_prof_collect(ms, flops, l);
+  for (int i = 0; i < RVC_PROF_CFGS; ++i) launches[i] = l[i];
   RVC_CATCH
 }
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }

@@ -73,6 +73,8 @@ struct ConvLayer {
   int up2 = 0;             // 2-D ConvTranspose (k3 s2 p1 op1) as 4 phase convs
   int conv_pad = 0;        // ConvTranspose1d: left pad of the equivalent stride-1 conv
   long long wBatch = 0;    // packed elements per group
+  uint16_t* Wx_ = nullptr; // bf16x3 split image (conv_x3.hip), null when the layer only runs on the fp32 kernel
+  int CoPx = 0; long long wxBatch = 0;
 };
 
 struct ConvEpilogue {
@@ -93,6 +95,10 @@ void conv2d3x3_layer_init(ConvLayer& L, const float* w /*[Co][Ci][3][3]*/, const
 void conv2d1x1_layer_init(ConvLayer& L, const float* w /*[Co][Ci]*/, const float* bias, int Co, int Ci);
 void tconv2d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][3][3]*/, const float* bias, int Ci, int Co);
 void conv_layer_free(ConvLayer& L);
+// Layers initialised while this is on also get a bf16x3 split weight image and run on conv_x3_kernel when eligible
+// (stride 1, groups 1, Ci % 16 == 0): 3 bf16 MFMAs per fp32 product, fp32 accumulate, ~1e-5 relative error.
+void conv_x3_set_default(bool on);
+void conv_set_precision(int mode);   // 0: fp32 only, 1: model default (generator convolutions), 2: every eligible layer
 
 // launches.  1-D: X [Ci][Tin] with channel stride ldX, Y [Co][Tout] with channel stride ldY.
 int conv1d_out_len(const ConvLayer& L, int Tin);
@@ -108,7 +114,7 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
 
 // per-launch HIP-event profiling of the conv kernels (bench.py's roofline leg)
 void conv_prof_enable(bool on);
-int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of 14 (tile configuration x {1d, 2d})
+int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of RVC_PROF_CFGS (tile configuration x {fp32 1-D, fp32 2-D, bf16x3})
 const char* conv_prof_cfg_name(int i);
 void conv_timing_read(unsigned long long* out8, bool reset);   // debug builds (-DRVC_CONV_TIMING): per-phase cycle sums
 

@@ -155,11 +155,20 @@ int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, c
 int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev, float* har_dev, float* sine_dev, int T, int upp, float sr,
                        float lin_w, float lin_b, float* rad_dev, float* tmp_dev, float* phase_dev);
 
+/* Matrix-core arithmetic of the Conv1d layers created AFTER the call (process-wide; models read it at *_finalize):
+ *   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32; bitwise an fp32 FMA chain)
+ *   1  default: the synthesizer's generator convolutions use the bf16x3 split (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on
+ *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; ~1e-5 relative error per layer), everything else fp32
+ *   2  bf16x3 for every eligible layer (stride 1, groups 1, Ci % 16 == 0), including rvc_op_conv1d / plans (parity tests) */
+int rvc_set_conv_precision(int mode);
+
 /* ------------------------------------------------------------------ kernel profiling (bench.py roofline leg) */
-/* While enabled, every launch of the MFMA convolution kernel is bracketed by HIP events on its own stream and tagged with its
- * algorithmic FLOPs.  rvc_prof_collect sums them per tile configuration (14 = 7 tilings x {1-D, 2-D}); names via rvc_prof_cfg_name. */
+/* While enabled, every launch of the MFMA convolution kernels is bracketed by HIP events on its own stream and tagged with its
+ * algorithmic FLOPs.  rvc_prof_collect sums them per kernel configuration into arrays of RVC_PROF_CFGS entries
+ * (7 tilings x {fp32 1-D, fp32 2-D, bf16x3 1-D}, rest unused); names via rvc_prof_cfg_name. */
+#define RVC_PROF_CFGS 24
 int rvc_prof_enable(int on);
-int rvc_prof_collect(double* ms14, double* flops14, int64_t* launches14);
+int rvc_prof_collect(double* ms, double* flops, int64_t* launches);
 const char* rvc_prof_cfg_name(int i);
 /* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
 int rvc_debug_conv_timing(uint64_t* out8, int reset);

@@ -75,6 +75,63 @@ def test_conv1d(L, case):
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
+X3_CONV1D = [
+    # Ci, Co, T, k, pad, dil, pre, act, res, out_scale, accumulate      (grids >= 400 workgroups so that the bf16x3 kernel is chosen)
+    (128, 128, 60001, 11, 25, 5, "lrelu", "none", False, 1.0, False),
+    (128, 128, 55555, 3, 1, 1, "lrelu", "none", True, 1.0, False),
+    (256, 256, 26000, 7, 9, 3, "lrelu", "none", True, 1.0 / 3, True),
+    (64, 64, 131000, 11, 5, 1, "lrelu", "lrelu", False, 1.0, False),
+    (64, 64, 140001, 7, 15, 5, "none", "none", True, 1.0, False),
+    (32, 32, 300007, 11, 25, 5, "lrelu", "none", True, 1.0 / 3, True),
+    (32, 32, 260000, 3, 3, 3, "lrelu", "none", False, 1.0, False),
+    (192, 192, 52000, 5, 2, 1, "none", "none", False, 1.0, False),
+    (16, 96, 120000, 4, 1, 1, "none", "relu", False, 1.0, False),
+]
+
+
+@pytest.mark.parametrize("case", X3_CONV1D, ids=[f"x{i}" for i in range(len(X3_CONV1D))])
+def test_conv1d_bf16x3(L, case):
+    """bf16x3 split-MFMA Conv1d (conv_x3.hip) against an fp64 torch reference: error of a few 1e-6, far inside the 1e-3 budget."""
+    Ci, Co, T, k, pad, dil, pre, act, res, scale, accum = case
+    g = torch.Generator().manual_seed(hash(case) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / np.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv1d(_act(x, pre, 0.1).double()[None], w.double(), b.double(), padding=pad, dilation=dil)[0]
+    Tout = ref.shape[1]
+    r = torch.randn(Co, Tout, generator=g) if res else None
+    if r is not None:
+        ref = ref + r
+    ref = _act(ref, act, 0.1) * scale
+    y0 = torch.randn(Co, Tout, generator=g)
+    if accum:
+        ref = ref + y0
+    y = dev(y0)
+    wc, bc = w.contiguous().numpy(), b.contiguous().numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    ms = (C.c_double * 24)(); fl = (C.c_double * 24)(); ln = (C.c_int64 * 24)()
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, T, k, 1,
+                                    pad, dil, 1, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
+        L.check(L.lib.rvc_prof_collect(ms, fl, ln))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert sum(ln[14:21]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+    # the same layer on the fp32 kernel: both must agree with the reference, bf16x3 within a small factor of fp32's own error
+    L.check(L.lib.rvc_set_conv_precision(0))
+    y32 = dev(y0)
+    try:
+        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y32), Ci, Co, T, k, 1,
+                                    pad, dil, 1, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert rel_err(y32.cpu().double(), ref) < 2e-6
+
+
 TCONV1D = [(512, 256, 30, 16, 10, 3), (64, 32, 100, 4, 2, 1), (128, 64, 33, 24, 12, 6), (256, 128, 40, 20, 10, 5)]
 
 

@@ -7,6 +7,7 @@ L.get_ctx(0)
 import os
 T = int(os.environ.get('BENCH_T', 3198))
 NORES = os.environ.get('BENCH_NORES') == '1'
+L.check(L.lib.rvc_set_conv_precision(int(os.environ.get('BENCH_PRECISION', 2))))   # 0: fp32 MFMA, 2: bf16x3 where eligible
 CASES = [  # name, Ci, Co, Tin, k, stride, dil
     ("gen s1 C256 k3", 256, 256, 10 * T, 3, 1, 1), ("gen s1 C256 k11 d5", 256, 256, 10 * T, 11, 1, 5),
     ("gen s2 C128 k3", 128, 128, 100 * T, 3, 1, 1), ("gen s2 C128 k7 d3", 128, 128, 100 * T, 7, 1, 3), ("gen s2 C128 k11", 128, 128, 100 * T, 11, 1, 1),
