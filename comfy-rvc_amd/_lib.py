@@ -79,6 +79,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p]),
     "rvc_vc_segment_feats": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
                                      c_void_p]),
+    "rvc_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                             c_void_p, c_int]),
     "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),
     "rvc_op_conv1d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                       [c_int, c_float, c_int, c_float, c_int, c_float, c_int]),

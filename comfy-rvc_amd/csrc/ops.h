@@ -28,6 +28,8 @@ void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long 
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
                  int T, int upp, float sr, float lw, float lb, float* phase_out = nullptr);
 
+void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch);
 void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n1, int sr2, float rate, short* out, float* rms2, unsigned* maxbits);
 
 }  // namespace rvc

@@ -615,3 +615,121 @@ void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n
   hipLaunchKernelGGL(to_int16_kernel, dim3(blocks), dim3(256), 0, s, x, out, N, maxbits);
 }
 }  // namespace rvc
+
+// ================================================================================================ input pre-processing
+// Zero-phase IIR high-pass of VC.pipeline (vc_infer_pipeline.py:121, scipy.signal.filtfilt(bh, ah, audio): odd extension by
+// padlen = 3 * max(len(a), len(b)) samples, lfilter_zi initial conditions, direct form II transposed in float64, forward then
+// backward), the reflect padding of :141 with the float32 cast the networks see, and the 0.5 s-hop RMS frames of the filtered
+// signal that change_rms needs (lib/model_utils.py:45).
+// The recurrence is sequential, but the filter forgets: its slowest pole has radius 0.9942, so a run that starts W = 8192 samples
+// early from a zero state has converged to the true state (|A^W| = 4e-14, far below the rounding noise) at its chunk.  Every
+// thread therefore filters W warm-up samples + its own L-sample chunk (overlap-discard); the first chunks start at sample 0 with
+// filtfilt's lfilter_zi initial conditions.  float64, same direct-form-II-transposed update as scipy.  This 5th-order high-pass
+// at 0.006 Nyquist amplifies rounding noise ~3e8 x: two float64 evaluations that differ only in rounding order (e.g. scipy's C
+// loop and a literal Python transcription of it) already differ by 4e-8 of full scale, and so does this one - about one float32
+// ulp of the signal the networks consume.
+namespace rvc {
+
+constexpr int kIirOrder = 5;
+struct IirArgs {
+  double b[kIirOrder + 1], a[kIirOrder + 1], zi[kIirOrder];
+  const void* x; int is64;        // input samples (float32 or float64)
+  long long n, N; int padlen;     // input length, extended length n + 2 padlen
+  double* yf;                     // forward output [N]
+  double* filt;                   // final output [n]
+  int L, W, nchunks;
+};
+
+__device__ __forceinline__ double iir_input(const IirArgs& p, long long i) {
+  // odd extension, evaluated in the input's own precision like scipy's odd_ext
+  const long long n = p.n; const int pl = p.padlen;
+  if (p.is64) {
+    const double* x = (const double*)p.x;
+    if (i < pl) return 2.0 * x[0] - x[pl - i];
+    if (i >= n + pl) return 2.0 * x[n - 1] - x[n - 2 - (i - (n + pl))];
+    return x[i - pl];
+  }
+  const float* x = (const float*)p.x;
+  if (i < pl) return (double)__fsub_rn(2.f * x[0], x[pl - i]);
+  if (i >= n + pl) return (double)__fsub_rn(2.f * x[n - 1], x[n - 2 - (i - (n + pl))]);
+  return (double)x[i - pl];
+}
+template <int DIR>
+__device__ __forceinline__ double iir_src(const IirArgs& p, long long j) { return DIR == 0 ? iir_input(p, j) : p.yf[p.N - 1 - j]; }
+
+__device__ __forceinline__ double iir_step(const IirArgs& p, double (&z)[kIirOrder], double x) {
+  const double y = fma(p.b[0], x, z[0]);
+#pragma unroll
+  for (int i = 0; i < kIirOrder - 1; ++i) z[i] = fma(-p.a[i + 1], y, fma(p.b[i + 1], x, z[i + 1]));
+  z[kIirOrder - 1] = fma(-p.a[kIirOrder], y, p.b[kIirOrder] * x);
+  return y;
+}
+
+// DIR 0: forward over the odd-extended input -> yf.  DIR 1: backward over yf -> filt (un-reversed, extension dropped).
+template <int DIR>
+__global__ void iir_chunk_kernel(const IirArgs p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.nchunks) return;
+  const long long j0 = (long long)c * p.L, j1 = min(j0 + p.L, p.N);
+  long long js = j0 - p.W;
+  double z[kIirOrder];
+  if (js <= 0) {
+    js = 0;
+    const double x0 = iir_src<DIR>(p, 0);
+#pragma unroll
+    for (int i = 0; i < kIirOrder; ++i) z[i] = p.zi[i] * x0;
+  } else {
+#pragma unroll
+    for (int i = 0; i < kIirOrder; ++i) z[i] = 0.0;
+  }
+  for (long long j = js; j < j0; ++j) (void)iir_step(p, z, iir_src<DIR>(p, j));
+  for (long long j = j0; j < j1; ++j) {
+    const double y = iir_step(p, z, iir_src<DIR>(p, j));
+    if (DIR == 0) p.yf[j] = y;
+    else { const long long i = p.N - 1 - j - p.padlen; if (i >= 0 && i < p.n) p.filt[i] = y; }
+  }
+}
+
+__global__ void pad_reflect_f32_kernel(const double* __restrict__ x, long long n, int t_pad, float* __restrict__ out) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n + 2LL * t_pad) return;
+  long long i = j - t_pad;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  out[j] = (float)x[i];
+}
+
+// librosa.feature.rms(y, frame_length, hop_length) on a float64 signal: centred frames, zero padding
+__global__ __launch_bounds__(256) void rms_frames_f64_kernel(const double* __restrict__ x, long long n, int frame, int hop, double* __restrict__ rms) {
+  __shared__ double red[256];
+  const long long start = (long long)blockIdx.x * hop - frame / 2;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < frame; i += 256) {
+    const long long j = start + i;
+    if (j >= 0 && j < n) { const double v = x[j]; s = fma(v, v, s); }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) rms[blockIdx.x] = sqrt(red[0] / frame);
+}
+
+void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* n + 2 padlen */) {
+  IirArgs p{};
+  for (int i = 0; i <= kIirOrder; ++i) { p.b[i] = b[i] / a[0]; p.a[i] = a[i] / a[0]; }
+  for (int i = 0; i < kIirOrder; ++i) p.zi[i] = zi[i];
+  p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen;
+  p.L = 1024; p.W = 8192; p.nchunks = (int)((p.N + p.L - 1) / p.L);
+  p.yf = scratch; p.filt = filt;
+  const dim3 grid((p.nchunks + 63) / 64), blk(64);
+  hipLaunchKernelGGL((iir_chunk_kernel<0>), grid, blk, 0, s, p);
+  hipLaunchKernelGGL((iir_chunk_kernel<1>), grid, blk, 0, s, p);
+  if (padded) {
+    const long long np = n + 2LL * t_pad;
+    hipLaunchKernelGGL(pad_reflect_f32_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, filt, n, t_pad, padded);
+  }
+  if (rms1 && n1 > 0) hipLaunchKernelGGL(rms_frames_f64_kernel, dim3(n1), dim3(256), 0, s, filt, n, frame, hop, rms1);
+}
+
+}  // namespace rvc

@@ -169,6 +169,18 @@ int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, int6
   RVC_CATCH
 }
 
+int rvc_preprocess(void* stream, const void* audio, int is_f64, int64_t n, const double* b6, const double* a6, const double* zi5, int t_pad,
+                   double* filt, float* padded, double* rms1, int n1) {
+  RVC_TRY
+  RVC_REQUIRE(audio && b6 && a6 && zi5 && filt && n > 3 * 6 + 1 && t_pad >= 0 && t_pad < n, "bad argument");
+  RVC_REQUIRE(a6[0] != 0.0, "a[0] must be non-zero");
+  RVC_REQUIRE(rms1 == nullptr || n1 == (int)(n / 8000) + 1, "rms1 must hold n / 8000 + 1 frames");
+  hipStream_t st = (hipStream_t)stream;
+  double* scratch = (double*)stream_scratch(st, 2, (size_t)(n + 36 + 16) * sizeof(double));
+  preprocess(st, audio, is_f64, n, b6, a6, zi5, t_pad, filt, padded, rms1, n1, 16000, 8000, scratch);
+  check_launch();
+  RVC_CATCH
+}
 int rvc_postprocess(void* stream, float* wav, int64_t N, const double* rms1, int n1, int sr2, float rms_mix_rate, int16_t* out_i16) {
   RVC_TRY
   RVC_REQUIRE(wav && out_i16 && N > 0 && sr2 > 0, "bad argument");

@@ -26,6 +26,8 @@ from .lib.utils import gc_collect
 from .pitch_extraction import FeatureExtractor
 
 bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)   # 48 Hz zero-phase high-pass (reference :21)
+_BH, _AH = np.ascontiguousarray(bh, dtype=np.float64), np.ascontiguousarray(ah, dtype=np.float64)
+_ZI = np.ascontiguousarray(signal.lfilter_zi(bh, ah), dtype=np.float64)   # filtfilt's initial conditions (device path)
 
 
 class VC(FeatureExtractor):
@@ -104,17 +106,11 @@ class VC(FeatureExtractor):
                 audio1 = net_g.infer(feats, p_len_t, sid)[0][0, 0].data.cpu().float().numpy()
         return audio1
 
-    def pipeline(self, model, net_g, sid, audio, times, f0_up_key, f0_method, merge_type, file_index, index_rate, if_f0,
-                 filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx,
-                 f0_file=None, f0_min=50, f0_max=1600):
-        index, big_npy = self.load_index(file_index)
-        audio = signal.filtfilt(bh, ah, audio)
-        device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) and if_f0
-                       and index is None and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
+    def _cut_points(self, audio):
+        """Cut points of a long clip: the quietest sample (|160-tap moving sum|) within +-t_query of every t_center (reference
+        :127-135).  160 sequential adds on purpose: a cumulative-sum shortcut would change the rounding and could move a cut."""
         opt_ts = []
         if audio.shape[0] + self.window > self.t_max:
-            # cut points: the quietest sample (|160-tap moving sum|) within +-t_query of every t_center (reference :127-135)
-            # (160 sequential adds on purpose: a cumulative-sum shortcut would change the rounding and could move a cut)
             audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
             audio_sum = np.zeros_like(audio)
             for i in range(self.window):
@@ -122,13 +118,23 @@ class VC(FeatureExtractor):
             for t in range(self.t_center, audio.shape[0], self.t_center):
                 seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
                 opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+        return opt_ts
+
+    def pipeline(self, model, net_g, sid, audio, times, f0_up_key, f0_method, merge_type, file_index, index_rate, if_f0,
+                 filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx,
+                 f0_file=None, f0_min=50, f0_max=1600):
+        index, big_npy = self.load_index(file_index)
+        device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) and if_f0
+                       and index is None and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
+        if device_path:
+            return self._pipeline_device(model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius,
+                                         tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max)
+        audio = signal.filtfilt(bh, ah, audio)
+        opt_ts = self._cut_points(audio)
         s = 0
         audio_opt = []
         t = None
         audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
-        if device_path:
-            return self._pipeline_device(model, net_g, sid, audio, audio_pad, opt_ts, f0_up_key, f0_method, merge_type, filter_radius,
-                                         tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max)
         inp_f0 = None
         if f0_file is not None:
             try:
@@ -167,33 +173,39 @@ class VC(FeatureExtractor):
         return audio_opt
 
 
-def _frame_rms64(y, frame_length, hop_length):
-    y = np.pad(np.asarray(y), int(frame_length // 2), mode="constant")
-    n_frames = 1 + (y.shape[-1] - frame_length) // hop_length
-    cols = hop_length * np.arange(n_frames)[None, :] + np.arange(frame_length)[:, None]
-    return np.sqrt(np.mean(np.abs(y[cols]) ** 2, axis=-2))
-
-
-def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
+def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
                      rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max):
-    """VC.pipeline with every per-sample stage on the GPU: HuBERT runs on a side stream while RMVPE produces the pitch, the
-    segments are synthesised from device-resident features, and change_rms + int16 normalisation (reference
-    vc_infer_pipeline.py:182-189) run as kernels; only the zero-phase high-pass, the cut search and the 100 fps pitch
-    post-processing stay on the host, exactly where the reference has them."""
+    """VC.pipeline with every per-sample stage on the GPU: the zero-phase high-pass, reflect padding and input RMS frames
+    (rvc_preprocess), HuBERT on a side stream while RMVPE produces the pitch, the segments synthesised from device-resident
+    features, and change_rms + int16 normalisation (reference vc_infer_pipeline.py:182-189) as kernels; only the cut search of
+    long clips and the 100 fps pitch post-processing stay on the host, exactly where the reference has them."""
     import time as _t
     _tr = [("start", _t.perf_counter())] if os.environ.get("RVC_TRACE") else None
     def _mark(n):
         if _tr is not None:
             _tr.append((n, _t.perf_counter()))
     dev = net_g.device
+    main = torch.cuda.current_stream(dev)
+    audio = np.ascontiguousarray(audio)
+    if audio.dtype not in (np.float32, np.float64):
+        audio = audio.astype(np.float64)
+    n = int(audio.shape[0])
+    raw_d = torch.from_numpy(audio).to(dev)
+    filt_d = torch.empty(n, dtype=torch.float64, device=dev)            # signal.filtfilt(bh, ah, audio)
+    a_dev = torch.empty(n + 2 * self.t_pad, dtype=torch.float32, device=dev)
+    rms1 = torch.empty(n // 8000 + 1, dtype=torch.float64, device=dev) if rms_mix_rate < 1 else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib.rvc_preprocess(_lib.current_stream(), _lib.ptr(raw_d), 1 if audio.dtype == np.float64 else 0, n, _lib.ptr(_BH),
+                                           _lib.ptr(_AH), _lib.ptr(_ZI), int(self.t_pad), _lib.ptr(filt_d), _lib.ptr(a_dev), _lib.ptr(rms1),
+                                           0 if rms1 is None else rms1.numel()))
+    opt_ts = self._cut_points(filt_d.cpu().numpy()) if n + self.window > self.t_max else []
     bounds, s0 = [], 0
     for t in opt_ts:
         t = t // self.window * self.window
         bounds.append((s0, t + self.t_pad2 + self.window))
         s0 = t
-    bounds.append((s0, audio_pad.shape[0]))
-    main = torch.cuda.current_stream(dev)
-    a_dev = torch.from_numpy(audio_pad.astype(np.float32)).to(dev)
+    bounds.append((s0, a_dev.shape[0]))
+    _mark("preprocess enqueued")
     if getattr(self, "_side", None) is None:
         self._side = torch.cuda.Stream(dev)
     side = self._side if self.overlap_streams else main
@@ -205,7 +217,7 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
     a_dev.record_stream(side)
     _mark("hubert enqueued")
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
-    x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else audio_pad
+    x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
     pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
                                 f0_min, f0_max)
     _mark("f0 ready (rmvpe sync + host post)")
@@ -236,9 +248,6 @@ def _pipeline_device(self, model, net_g, sid, audio, audio_pad, opt_ts, f0_up_ke
     _mark("synth enqueued")
     wav = torch.cat(outs) if len(outs) > 1 else outs[0].contiguous()
     N = wav.numel()
-    rms1 = None
-    if rms_mix_rate < 1:
-        rms1 = torch.from_numpy(_frame_rms64(audio, 16000 // 2 * 2, 16000 // 2)).to(dev)
     i16 = torch.empty(N, dtype=torch.int16, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib.rvc_postprocess(_lib.current_stream(), _lib.ptr(wav), N, _lib.ptr(rms1), 0 if rms1 is None else rms1.numel(),

@@ -121,6 +121,14 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
 int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm_dev, int64_t T_h, int feat_dim, const int64_t* pitch_dev,
                          const float* pitchf_dev, int sid, float protect, int do_protect, const float* noise_z_dev,
                          const float* noise_src_dev, float* out_dev);
+/* Input pre-processing of VC.pipeline on the device: the zero-phase 5th-order high-pass (vc_infer_pipeline.py:19,121:
+ * scipy.signal.filtfilt(bh, ah, audio) - odd extension by 18 samples, lfilter_zi initial conditions, float64), the reflect
+ * padding by t_pad with the float32 cast the networks consume (:141) and the RMS frames of the filtered input that change_rms
+ * uses (lib/model_utils.py:45; frame 1 s, hop 0.5 s at 16 kHz, n1 = n / 8000 + 1; may be NULL).
+ * audio_dev [n] float32 (is_f64 = 0) or float64 (1); b6 / a6 / zi5 are HOST arrays (butter coefficients, lfilter_zi);
+ * filt_dev [n] float64 = filtered signal, padded_dev [n + 2 t_pad] float32 (may be NULL). */
+int rvc_preprocess(void* stream, const void* audio_dev, int is_f64, int64_t n, const double* b6_host, const double* a6_host,
+                   const double* zi5_host, int t_pad, double* filt_dev, float* padded_dev, double* rms1_dev, int n1);
 /* Output post-processing of VC.pipeline on the device: change_rms (lib/model_utils.py:39-57; skipped when rms_mix_rate >= 1 or
  * rms1_dev == NULL) followed by peak normalisation to int16 (vc_infer_pipeline.py:188-189).  wav_dev [N] float32 is modified in
  * place; rms1_dev = RMS frames of the 16 kHz input (float64 [n1], hop 0.5 s); sr2 = output rate. */

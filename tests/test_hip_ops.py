@@ -221,3 +221,34 @@ def test_sine_source_matches_oracle(L, upp, sr, T):
     # 1e-3 of the sine amplitude (0.1); the phase itself is an fp64 running sum on both sides
     assert float((sine.cpu() - taps["sine_waves"][0, :, 0]).abs().max()) < 1e-4
     assert float((har.cpu() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("n,dtype,t_pad", [(48000, np.float32, 16000), (160001, np.float64, 16000), (5003, np.float32, 800), (700000, np.float32, 16000)])
+def test_preprocess_filtfilt_pad_rms(L, n, dtype, t_pad):
+    """rvc_preprocess (overlap-discard float64 IIR on the device) against scipy.signal.filtfilt + np.pad + the oracle's framed RMS.
+    The filter amplifies float64 rounding noise to ~4e-8 of full scale (a literal Python transcription of scipy's loop differs
+    from scipy by that much), so that is the agreement any re-ordered evaluation can reach: about one float32 ulp."""
+    from scipy import signal
+    from comfy_rvc_amd.vc_infer_pipeline import _AH, _BH, _ZI, ah, bh
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 16000.0
+    x = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.05 * rng.standard_normal(n) + 0.2).astype(dtype)     # DC offset: the high-pass has work to do
+    ref = signal.filtfilt(bh, ah, x)
+    xd = torch.from_numpy(x).cuda()
+    filt = torch.empty(n, dtype=torch.float64, device="cuda")
+    padded = torch.empty(n + 2 * t_pad, dtype=torch.float32, device="cuda")
+    n1 = n // 8000 + 1
+    rms1 = torch.empty(n1, dtype=torch.float64, device="cuda")
+    L.check(L.lib.rvc_preprocess(None, L.ptr(xd), int(dtype == np.float64), n, L.ptr(_BH), L.ptr(_AH), L.ptr(_ZI), t_pad, L.ptr(filt),
+                                 L.ptr(padded), L.ptr(rms1), n1))
+    torch.cuda.synchronize()
+    got = filt.cpu().numpy()
+    assert np.abs(got - ref).max() <= 3e-7 * np.abs(ref).max()
+    ref_pad = np.pad(ref, (t_pad, t_pad), mode="reflect").astype(np.float32)
+    gp = padded.cpu().numpy()
+    assert np.array_equal(gp, np.pad(got, (t_pad, t_pad), mode="reflect").astype(np.float32))      # padding + cast are exact
+    assert np.abs(gp - ref_pad).max() <= 4e-7 * np.abs(ref_pad).max()
+    yp = np.pad(ref, 8000, mode="constant")
+    cols = 8000 * np.arange(n1)[None, :] + np.arange(16000)[:, None]
+    ref_rms = np.sqrt(np.mean(np.abs(yp[cols]) ** 2, axis=0))
+    assert np.allclose(rms1.cpu().numpy(), ref_rms, rtol=1e-6, atol=0)
