@@ -621,41 +621,44 @@ void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n
 // padlen = 3 * max(len(a), len(b)) samples, lfilter_zi initial conditions, direct form II transposed in float64, forward then
 // backward), the reflect padding of :141 with the float32 cast the networks see, and the 0.5 s-hop RMS frames of the filtered
 // signal that change_rms needs (lib/model_utils.py:45).
-// The recurrence is sequential, but the filter forgets: its slowest pole has radius 0.9942, so a run that starts W = 8192 samples
-// early from a zero state has converged to the true state (|A^W| = 4e-14, far below the rounding noise) at its chunk.  Every
-// thread therefore filters W warm-up samples + its own L-sample chunk (overlap-discard); the first chunks start at sample 0 with
-// filtfilt's lfilter_zi initial conditions.  float64, same direct-form-II-transposed update as scipy.  This 5th-order high-pass
-// at 0.006 Nyquist amplifies rounding noise ~3e8 x: two float64 evaluations that differ only in rounding order (e.g. scipy's C
-// loop and a literal Python transcription of it) already differ by 4e-8 of full scale, and so does this one - about one float32
-// ulp of the signal the networks consume.
+// The recurrence is sequential, but the filter forgets: a run that starts W samples early from a zero state differs from the true
+// response by at most sum_{k >= W} |h_k| * max|x| (h = impulse response) = 2.3e-13 for W = 5120, so every thread filters W warm-up
+// samples + its own L-sample chunk (overlap-discard); the first chunks start at sample 0 with filtfilt's lfilter_zi initial
+// conditions.  float64, same direct-form-II-transposed update as scipy.  This 5th-order high-pass at 0.006 Nyquist amplifies
+// rounding noise ~3e8 x: two float64 evaluations that differ only in rounding order (scipy's C loop and a literal Python
+// transcription of it) already differ by 4e-8 of full scale, and so does this one - about one float32 ulp of the signal the
+// networks consume.  Each lane streams its own window with 64-byte loads issued eight steps ahead of their use.
 namespace rvc {
 
 constexpr int kIirOrder = 5;
 struct IirArgs {
   double b[kIirOrder + 1], a[kIirOrder + 1], zi[kIirOrder];
   const void* x; int is64;        // input samples (float32 or float64)
-  long long n, N; int padlen;     // input length, extended length n + 2 padlen
-  double* yf;                     // forward output [N]
+  long long n, N, Np; int padlen; // input length, extended length n + 2 padlen, Np = N rounded up to 8
+  double* ext;                    // odd-extended input [Np]
+  double* yr;                     // forward output, time-reversed [Np]: yr[N - 1 - j] = y_fwd[j]
   double* filt;                   // final output [n]
   int L, W, nchunks;
 };
 
-__device__ __forceinline__ double iir_input(const IirArgs& p, long long i) {
-  // odd extension, evaluated in the input's own precision like scipy's odd_ext
+// odd extension, evaluated in the input's own precision like scipy's odd_ext; zero fill up to Np
+__global__ void iir_extend_kernel(const IirArgs p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.Np) return;
   const long long n = p.n; const int pl = p.padlen;
-  if (p.is64) {
-    const double* x = (const double*)p.x;
-    if (i < pl) return 2.0 * x[0] - x[pl - i];
-    if (i >= n + pl) return 2.0 * x[n - 1] - x[n - 2 - (i - (n + pl))];
-    return x[i - pl];
+  double v = 0.0;
+  if (i < p.N) {
+    if (p.is64) {
+      const double* x = (const double*)p.x;
+      v = i < pl ? 2.0 * x[0] - x[pl - i] : (i >= n + pl ? 2.0 * x[n - 1] - x[n - 2 - (i - (n + pl))] : x[i - pl]);
+    } else {
+      const float* x = (const float*)p.x;
+      v = i < pl ? (double)__fsub_rn(2.f * x[0], x[pl - i]) : (i >= n + pl ? (double)__fsub_rn(2.f * x[n - 1], x[n - 2 - (i - (n + pl))]) : (double)x[i - pl]);
+    }
   }
-  const float* x = (const float*)p.x;
-  if (i < pl) return (double)__fsub_rn(2.f * x[0], x[pl - i]);
-  if (i >= n + pl) return (double)__fsub_rn(2.f * x[n - 1], x[n - 2 - (i - (n + pl))]);
-  return (double)x[i - pl];
+  p.ext[i] = v;
+  if (i >= p.N) p.yr[i] = 0.0;
 }
-template <int DIR>
-__device__ __forceinline__ double iir_src(const IirArgs& p, long long j) { return DIR == 0 ? iir_input(p, j) : p.yf[p.N - 1 - j]; }
 
 __device__ __forceinline__ double iir_step(const IirArgs& p, double (&z)[kIirOrder], double x) {
   const double y = fma(p.b[0], x, z[0]);
@@ -665,28 +668,50 @@ __device__ __forceinline__ double iir_step(const IirArgs& p, double (&z)[kIirOrd
   return y;
 }
 
-// DIR 0: forward over the odd-extended input -> yf.  DIR 1: backward over yf -> filt (un-reversed, extension dropped).
+// DIR 0: forward over ext -> yr (reversed).  DIR 1: forward over yr (= backward in time) -> filt (un-reversed, extension dropped).
 template <int DIR>
 __global__ void iir_chunk_kernel(const IirArgs p) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.nchunks) return;
-  const long long j0 = (long long)c * p.L, j1 = min(j0 + p.L, p.N);
+  const double* __restrict__ src = DIR == 0 ? p.ext : p.yr;
+  const long long j0 = (long long)c * p.L, j1 = min(j0 + p.L, p.Np);
   long long js = j0 - p.W;
   double z[kIirOrder];
   if (js <= 0) {
     js = 0;
-    const double x0 = iir_src<DIR>(p, 0);
+    const double x0 = src[0];
 #pragma unroll
     for (int i = 0; i < kIirOrder; ++i) z[i] = p.zi[i] * x0;
   } else {
 #pragma unroll
     for (int i = 0; i < kIirOrder; ++i) z[i] = 0.0;
   }
-  for (long long j = js; j < j0; ++j) (void)iir_step(p, z, iir_src<DIR>(p, j));
-  for (long long j = j0; j < j1; ++j) {
-    const double y = iir_step(p, z, iir_src<DIR>(p, j));
-    if (DIR == 0) p.yf[j] = y;
-    else { const long long i = p.N - 1 - j - p.padlen; if (i >= 0 && i < p.n) p.filt[i] = y; }
+  // js, j0, j1 are multiples of 8: groups of eight samples, the next group in flight while the current one is filtered
+  double2 cur[4], nxt[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const double2*>(src + js + 2 * q);
+  for (long long j = js; j < j1; j += 8) {
+    const long long jn = j + 8 < j1 ? j + 8 : j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const double2*>(src + jn + 2 * q);
+    double y[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { y[2 * q] = iir_step(p, z, cur[q].x); y[2 * q + 1] = iir_step(p, z, cur[q].y); }
+    if (j >= j0) {
+      if (DIR == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // yr[N - 1 - (j + e)] = y[e]; out-of-range slots (j + e >= N) fall below index 0: skip
+          const long long e0 = p.N - 1 - (j + 2 * q);
+          if (e0 >= 0) p.yr[e0] = y[2 * q];
+          if (e0 - 1 >= 0) p.yr[e0 - 1] = y[2 * q + 1];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const long long i = p.N - 1 - (j + e) - p.padlen; if (i >= 0 && i < p.n) p.filt[i] = y[e]; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
   }
 }
 
@@ -715,13 +740,14 @@ __global__ __launch_bounds__(256) void rms_frames_f64_kernel(const double* __res
 }
 
 void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
-                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* n + 2 padlen */) {
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* 2 * (n + 2 padlen + 8) */) {
   IirArgs p{};
   for (int i = 0; i <= kIirOrder; ++i) { p.b[i] = b[i] / a[0]; p.a[i] = a[i] / a[0]; }
   for (int i = 0; i < kIirOrder; ++i) p.zi[i] = zi[i];
-  p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen;
-  p.L = 1024; p.W = 8192; p.nchunks = (int)((p.N + p.L - 1) / p.L);
-  p.yf = scratch; p.filt = filt;
+  p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen; p.Np = (p.N + 7) & ~7LL;
+  p.L = 512; p.W = 5120; p.nchunks = (int)((p.Np + p.L - 1) / p.L);
+  p.ext = scratch; p.yr = scratch + p.Np; p.filt = filt;
+  hipLaunchKernelGGL(iir_extend_kernel, dim3((unsigned)((p.Np + 255) / 256)), dim3(256), 0, s, p);
   const dim3 grid((p.nchunks + 63) / 64), blk(64);
   hipLaunchKernelGGL((iir_chunk_kernel<0>), grid, blk, 0, s, p);
   hipLaunchKernelGGL((iir_chunk_kernel<1>), grid, blk, 0, s, p);

@@ -176,7 +176,7 @@ int rvc_preprocess(void* stream, const void* audio, int is_f64, int64_t n, const
   RVC_REQUIRE(a6[0] != 0.0, "a[0] must be non-zero");
   RVC_REQUIRE(rms1 == nullptr || n1 == (int)(n / 8000) + 1, "rms1 must hold n / 8000 + 1 frames");
   hipStream_t st = (hipStream_t)stream;
-  double* scratch = (double*)stream_scratch(st, 2, (size_t)(n + 36 + 16) * sizeof(double));
+  double* scratch = (double*)stream_scratch(st, 2, (size_t)(2 * (n + 36 + 8)) * sizeof(double));
   preprocess(st, audio, is_f64, n, b6, a6, zi5, t_pad, filt, padded, rms1, n1, 16000, 8000, scratch);
   check_launch();
   RVC_CATCH
