@@ -10,9 +10,10 @@
 // One MFMA consumes 16 channels of one tap: lane (i, half) holds channels half*8 .. half*8+7 of row / position i.
 // LDS images (16 channels = 32 B per row, the two 16-B halves swapped when bit 3 of the row index is set, which makes every
 // ds_read_b128 lane group hit 16 distinct slots for any tap offset):
-//   X: [hi|lo][position q][16 ch] bf16, converted from the fp32 [C][T] activation while staging (registers -> ds_write_b128)
-//   W: [tap][hi|lo][row m][16 ch] bf16, a linear copy of the host-packed image by global_load_lds_dwordx4 (no registers),
+//   X: [chunk][hi|lo][position q][16 ch] bf16, converted from the fp32 [C][T] activation while staging (registers -> ds_write_b128)
+//   W: [chunk][tap][hi|lo][row m][16 ch] bf16, a linear copy of the host-packed image by global_load_lds_dwordx4 (no registers),
 //      double-buffered so that the DMA of stage s+1 runs under the MFMAs of stage s; one barrier per stage.
+// A stage is NC 16-channel chunks x KT taps: NC = 1 for the wide dilated kernels of the generator, up to 4 for k = 1 (GEMM).
 #include "conv_kernels.h"
 
 namespace rvc {
@@ -20,7 +21,7 @@ namespace rvc {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
-__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 5 : (BN >= 256 ? 3 : (BN >= 128 ? 2 : 1)); }
+__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 256 ? 5 : (BN >= 128 ? 4 : 2); }
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 
@@ -29,10 +30,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged positions: BN + (ktaps - 1) * dil
+  const int NC = p.NC;                      // 16-channel chunks per stage
   const int xplane = P * 32;                // bytes of one hi / lo plane
-  const int wbuf = p.KT * 2 * BM * 32;      // bytes of one weight buffer
+  const int xbuf = NC * 2 * xplane;         // bytes of one X buffer
+  const int wbuf = NC * p.KT * 2 * BM * 32; // bytes of one weight buffer
   unsigned char* Xs = smem3;
-  unsigned char* Ws = smem3 + ((p.xbufs * 2 * xplane + 1023) & ~1023);
+  unsigned char* Ws = smem3 + ((p.xbufs * xbuf + 1023) & ~1023);
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
 
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
-  const int nstages = p.nchunk * ntb;
+  const int nstages = (p.nchunk / NC) * ntb;          // p.nchunk is a multiple of NC (host)
   const int bx = n0 - p.pad;
   const int ni = p.ni;                                                      // 64-position groups per plane row set
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
@@ -62,17 +65,19 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   float xr[XS][8];
 
   // ---- input tile: global -> registers.  Slot s of wave w covers 64 positions x 8 channels (one 16-B half of the LDS rows).
-  auto load_x = [&](int chunk) {
+  auto load_x = [&](int grp) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
-      const int g = wave + 4 * s;
+      const int t = wave + 4 * s;
+      const int cc = (t >= 2 * ni) + (t >= 4 * ni) + (t >= 6 * ni);       // NC <= 4
+      const int g = t - cc * 2 * ni;
       const int hb = g >= ni ? 1 : 0;
       const int q = (g - hb * ni) * 64 + lane, x = bx + q;
-      const bool ok = g < 2 * ni && q < P && x >= 0 && x < p.Tin;
+      const bool ok = cc < NC && q < P && x >= 0 && x < p.Tin;
       const unsigned voff = ok ? (unsigned)x * 4u : kOOB;
-      const unsigned c0 = (unsigned)(chunk * 16 + hb * 8);
+      const unsigned c0 = (unsigned)((grp * NC + cc) * 16 + hb * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
@@ -84,13 +89,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   auto store_x = [&](int xb) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    unsigned char* xbase = Xs + xb * 2 * xplane;
+    unsigned char* xbase0 = Xs + xb * xbuf;
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
-      const int g = wave + 4 * s;
+      const int t = wave + 4 * s;
+      const int cc = (t >= 2 * ni) + (t >= 4 * ni) + (t >= 6 * ni);
+      const int g = t - cc * 2 * ni;
       const int hb = g >= ni ? 1 : 0;
       const int q = (g - hb * ni) * 64 + lane;
-      if (g < 2 * ni && q < P) {
+      unsigned char* xbase = xbase0 + cc * 2 * xplane;
+      if (cc < NC && q < P) {
         u32x4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -107,14 +115,15 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
     }
   };
   // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
-  auto issue_w = [&](int chunk, int tb, int buf) {
+  auto issue_w = [&](int grp, int tb, int buf) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
-    const int npieces = ut * 2 * RB;
+    const int npieces = NC * ut * 2 * RB;
     for (int pi = wave; pi < npieces; pi += 4) {
-      const int j = pi / RB, rblk = pi - j * RB;            // j = (tap in block) * 2 + (hi | lo)
-      const long long row = ((long long)(chunk * p.ktaps + tb * p.KT + (j >> 1)) * 2 + (j & 1)) * p.CoPx + co0 + rblk * 32;
+      const int j = pi / RB, rblk = pi - j * RB;            // j = ((chunk in group) * ut + tap in block) * 2 + (hi | lo)
+      const int cc = j / (2 * ut), jr = j - cc * 2 * ut;
+      const long long row = ((long long)((grp * NC + cc) * p.ktaps + tb * p.KT + (jr >> 1)) * 2 + (jr & 1)) * p.CoPx + co0 + rblk * 32;
       const unsigned char* src = Wg + row * 32 + lane * 16;
       unsigned char* dst = Ws + buf * wbuf + pi * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -148,10 +157,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
     // ---- MFMAs of this stage
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
     const unsigned char* wb = Ws + buf * wbuf;
-    const unsigned char* xp = Xs + xb * 2 * xplane;
-    for (int uu = 0; uu < ut; ++uu) {
+    for (int cu = 0; cu < NC * ut; ++cu) {
+      const int cc = cu / ut, uu = cu - cc * ut;
+      const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
       const int toff = (tb * p.KT + uu) * p.dil;
-      const unsigned char* wt = wb + uu * 2 * BM * 32;
+      const unsigned char* wt = wb + cu * 2 * BM * 32;
       u32x4 ah[AM], al[AM], bh[AN], bl[AN];
 #pragma unroll
       for (int am = 0; am < AM; ++am) {
@@ -219,24 +229,32 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (id < 0) return false;
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
-  static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 400;
+  static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
   if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
   const int P = BN + (a.ktaps - 1) * a.dil;
   a.ni = (P + 63) / 64;
-  if ((2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  const int nchunk = a.Ci / 16;
+  // chunks per stage: short reductions per chunk (k <= 3) take several chunks per stage so that a stage outlasts its DMA
+  int NC = a.ktaps == 1 ? 4 : (a.ktaps <= 3 ? 2 : 1);
+  while (NC > 1 && (nchunk % NC != 0 || (NC * 2 * a.ni + 3) / 4 > x3_slots(BN))) NC >>= 1;
+  if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
   // LDS budget: <= 80 KiB per workgroup (two workgroups per CU); X double-buffered when that still leaves >= 2 taps per stage
   const int budget = 80 * 1024;
-  const int per_tap = 2 * 2 * BM * 32;                    // two buffers x {hi, lo} x BM rows x 32 B
-  int xbufs = 2;
-  int xbytes = (xbufs * 2 * P * 32 + 1023) & ~1023;
-  int ktmax = (budget - xbytes) / per_tap;
-  if (ktmax < 2 && a.ktaps > ktmax) { xbufs = 1; xbytes = (2 * P * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
+  int xbufs = 2, xbytes = 0, ktmax = 0;
+  for (;;) {
+    const int per_tap = 2 * NC * 2 * BM * 32;               // two buffers x NC chunks x {hi, lo} x BM rows x 32 B
+    xbufs = 2; xbytes = (xbufs * NC * 2 * P * 32 + 1023) & ~1023;
+    ktmax = (budget - xbytes) / per_tap;
+    if (ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * P * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
+    if (ktmax >= 1 || NC == 1) break;
+    NC >>= 1;
+  }
   if (ktmax < 1) return false;
   if (ktmax > a.ktaps) ktmax = a.ktaps;
   const int ntb = (a.ktaps + ktmax - 1) / ktmax;
   a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
-  a.CK = 16; a.nchunk = a.Ci / 16; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
-  const size_t lds = (size_t)xbytes + (size_t)2 * a.KT * 2 * BM * 32;
+  a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
+  const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1u);
   ProfTicket tk = conv_prof_begin(s);
   switch (id) {

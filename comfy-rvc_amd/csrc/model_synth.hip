@@ -93,6 +93,9 @@ int synth_upp(const Synth* S) { return S->upp; }
 void synth_finalize(Synth* S) {
   const TensorStore& ts = S->ts;
   synth_free(*S);
+  // every eligible Conv1d (stride 1, groups 1, Ci % 16 == 0) also gets a bf16x3 split weight image: the generator ResBlocks
+  // (70 % of a clip's FLOPs), flow WaveNet, enc_p projections; conv_x3.hip, ~1e-5 relative error per layer
+  struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
   const int C = S->hidden, kc = C / S->n_heads;
   {
     const HostTensor& w = ts.get("enc_p.emb_phone.weight", {C, S->feat_dim});
@@ -173,7 +176,6 @@ void synth_finalize(Synth* S) {
     const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
     // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
     conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
-    conv_x3_set_default(true);      // generator ResBlocks (70 % of the clip's FLOPs): bf16x3 split MFMA, see conv_x3.hip
     for (int j = 0; j < 3; ++j) {
       const std::string rb = "dec.resblocks." + std::to_string(i * 3 + j) + ".";
       const int k = S->rb_k[j];
@@ -183,7 +185,6 @@ void synth_finalize(Synth* S) {
         st.rb[j].c2[m] = make_conv1d(ts, rb + "convs2." + std::to_string(m), 1, (k - 1) / 2, 1, true);
       }
     }
-    conv_x3_set_default(false);
   }
   S->ts.clear();
   S->ready = true;

@@ -86,6 +86,14 @@ X3_CONV1D = [
     (32, 32, 260000, 3, 3, 3, "lrelu", "none", False, 1.0, False),
     (192, 192, 52000, 5, 2, 1, "none", "none", False, 1.0, False),
     (16, 96, 120000, 4, 1, 1, "none", "relu", False, 1.0, False),
+    (768, 768, 1499, 1, 0, 1, "none", "none", True, 1.0, False),        # HuBERT projections: k = 1, 4 chunks per stage
+    (768, 3072, 1499, 1, 0, 1, "none", "none", False, 1.0, False),
+    (3072, 768, 1499, 1, 0, 1, "none", "none", True, 1.0, False),
+    (512, 768, 1499, 1, 0, 1, "none", "none", False, 1.0, False),
+    (96, 192, 40000, 1, 0, 1, "none", "none", False, 1.0, False),       # 6 chunks: 2 per stage
+    (80, 128, 40000, 3, 2, 2, "lrelu", "none", False, 1.0, False),      # 5 chunks: 1 per stage
+    (192, 384, 3000, 5, 2, 1, "none", "none", False, 1.0, False),       # flow WaveNet in_layer
+    (128, 128, 52001, 3, 3, 3, "lrelu", "none", True, 1.0, False),      # k = 3: 2 chunks per stage
 ]
 
 
