@@ -16,7 +16,7 @@ struct ConvArgsX : ConvArgs {
   unsigned magRP, magPW;   // 2-D: ceil(2^32 / d) for d = (BH+2)*PW and d = PW (exact division of small tile indices)
   int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
   // bf16x3 kernel (conv_x3.hip): split weight image, its padded row count, X buffers in LDS (1 or 2)
-  const unsigned char* Wx; int CoPx; int xbufs; int NC; long long wxBatch;
+  const unsigned char* Wx; int CoPx; int xbufs; int NC; int kreal; long long wxBatch;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -474,7 +474,7 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
               w[((size_t)(g * Cog + co) * Cig + ci) * k + tap];
         }
   upload_layer(L, P, bias, Co);
-  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && stride == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
 }
 
 void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci, int Co, int k, int u, int pad) {
@@ -768,7 +768,7 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.bBatch = L.Co;
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
-  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch;
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.k;
   if (!(L.Wx_ && L.tconv_u == 0 && conv_x3_try(a, L.groups, s, flops))) run_conv(a, 1, L.groups, s, flops);
   if (post) {
     RVC_REQUIRE(L.tconv_u == 0, "post-activation on a transposed conv");

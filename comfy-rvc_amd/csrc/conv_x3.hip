@@ -21,7 +21,7 @@ namespace rvc {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
-__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 256 ? 5 : (BN >= 128 ? 4 : 2); }
+__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 128 ? 5 : 2; }
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 
@@ -29,9 +29,11 @@ template <int WM, int WN, int AM, int AN>
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
-  const int P = p.WROW;                     // staged positions: BN + (ktaps - 1) * dil
+  const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
   const int NC = p.NC;                      // 16-channel chunks per stage
-  const int xplane = P * 32;                // bytes of one hi / lo plane
+  const int st = p.stride;                  // strided convs keep one sub-plane per input phase (position mod stride): unit-stride reads
+  const int Pm = (P + st - 1) / st;         // rows per phase sub-plane
+  const int xplane = st * Pm * 32;          // bytes of one hi / lo plane
   const int xbuf = NC * 2 * xplane;         // bytes of one X buffer
   const int wbuf = NC * p.KT * 2 * BM * 32; // bytes of one weight buffer
   unsigned char* Xs = smem3;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
 
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
   const int nstages = (p.nchunk / NC) * ntb;          // p.nchunk is a multiple of NC (host)
-  const int bx = n0 - p.pad;
+  const int bx = n0 * st - p.pad;
   const int ni = p.ni;                                                      // 64-position groups per plane row set
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
   const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;      // input activation: leaky ReLU (slope 1 = identity)
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
           hi[j] = bf16_bits(ah) | (bf16_bits(bh) << 16);
           lo[j] = bf16_bits(al) | (bf16_bits(bl) << 16);
         }
-        const int off = q * 32 + ((hb ^ ((q >> 3) & 1)) << 4);
+        const int ph = st == 1 ? 0 : (st == 2 ? (q & 1) : q % st), m = st == 1 ? q : (st == 2 ? (q >> 1) : q / st);
+        const int off = (ph * Pm + m) * 32 + ((hb ^ ((m >> 3) & 1)) << 4);
         *reinterpret_cast<u32x4*>(xbase + off) = hi;
         *reinterpret_cast<u32x4*>(xbase + xplane + off) = lo;
       }
@@ -160,7 +163,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
     for (int cu = 0; cu < NC * ut; ++cu) {
       const int cc = cu / ut, uu = cu - cc * ut;
       const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
-      const int toff = (tb * p.KT + uu) * p.dil;
+      const int u = tb * p.KT + uu;
+      const int toff = st == 1 ? u * p.dil : u / st;                 // row offset inside the (phase) plane
+      if (st > 1) xp += (u - toff * st) * Pm * 32;
       const unsigned char* wt = wb + cu * 2 * BM * 32;
       u32x4 ah[AM], al[AM], bh[AN], bl[AN];
 #pragma unroll
@@ -216,11 +221,12 @@ static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) 
 
 bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (!conv_x3_enabled() || !a0.Wx) return false;
-  if (a0.stride != 1 || a0.ostride != 1 || a0.up2 || (a0.Ci & 15) || batch != 1) return false;
+  if ((a0.stride != 1 && a0.dil != 1) || a0.ostride != 1 || a0.up2 || (a0.Ci & 15) || batch != 1) return false;
   if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
   if ((double)a0.orows * (double)a0.ldY * 4.0 >= 2147483648.0 || (double)a0.orows * (double)a0.ldR * 4.0 >= 2147483648.0 ||
       (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;
   ConvArgsX a = a0;
+  a.ktaps = a0.kreal;                                     // true taps (the fp32 kernel folds the stride phases into virtual channels)
   TileCfg t = choose_tile(a.Co, a.Tout, batch);
   if (const char* f = getenv("RVC_FORCE_TILE")) {
     int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
@@ -231,7 +237,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
   if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
-  const int P = BN + (a.ktaps - 1) * a.dil;
+  const int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1, Pm = (P + a.stride - 1) / a.stride;
   a.ni = (P + 63) / 64;
   const int nchunk = a.Ci / 16;
   // chunks per stage: short reductions per chunk (k <= 3) take several chunks per stage so that a stage outlasts its DMA
@@ -243,9 +249,9 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   int xbufs = 2, xbytes = 0, ktmax = 0;
   for (;;) {
     const int per_tap = 2 * NC * 2 * BM * 32;               // two buffers x NC chunks x {hi, lo} x BM rows x 32 B
-    xbufs = 2; xbytes = (xbufs * NC * 2 * P * 32 + 1023) & ~1023;
+    xbufs = 2; xbytes = (xbufs * NC * 2 * a.stride * Pm * 32 + 1023) & ~1023;
     ktmax = (budget - xbytes) / per_tap;
-    if (ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * P * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
+    if (ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * a.stride * Pm * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
     if (ktmax >= 1 || NC == 1) break;
     NC >>= 1;
   }

@@ -94,18 +94,23 @@ X3_CONV1D = [
     (80, 128, 40000, 3, 2, 2, "lrelu", "none", False, 1.0, False),      # 5 chunks: 1 per stage
     (192, 384, 3000, 5, 2, 1, "none", "none", False, 1.0, False),       # flow WaveNet in_layer
     (128, 128, 52001, 3, 3, 3, "lrelu", "none", True, 1.0, False),      # k = 3: 2 chunks per stage
+    (64, 64, 140000, 3, 0, 1, "none", "none", False, 1.0, False, 2),    # stride 2 (HuBERT feature encoder): phase sub-planes in LDS
+    (128, 128, 70001, 2, 0, 1, "none", "gelu", False, 1.0, False, 2),
+    (512, 512, 20001, 3, 0, 1, "none", "gelu", False, 1.0, False, 2),
+    (48, 64, 100000, 5, 2, 1, "lrelu", "none", False, 1.0, False, 3),
 ]
 
 
 @pytest.mark.parametrize("case", X3_CONV1D, ids=[f"x{i}" for i in range(len(X3_CONV1D))])
 def test_conv1d_bf16x3(L, case):
     """bf16x3 split-MFMA Conv1d (conv_x3.hip) against an fp64 torch reference: error of a few 1e-6, far inside the 1e-3 budget."""
-    Ci, Co, T, k, pad, dil, pre, act, res, scale, accum = case
+    Ci, Co, T, k, pad, dil, pre, act, res, scale, accum = case[:11]
+    stride = case[11] if len(case) > 11 else 1
     g = torch.Generator().manual_seed(hash(case) % 10000)
     x = torch.randn(Ci, T, generator=g)
     w = torch.randn(Co, Ci, k, generator=g) / np.sqrt(Ci * k)
     b = torch.randn(Co, generator=g) * 0.1
-    ref = F.conv1d(_act(x, pre, 0.1).double()[None], w.double(), b.double(), padding=pad, dilation=dil)[0]
+    ref = F.conv1d(_act(x, pre, 0.1).double()[None], w.double(), b.double(), stride=stride, padding=pad, dilation=dil)[0]
     Tout = ref.shape[1]
     r = torch.randn(Co, Tout, generator=g) if res else None
     if r is not None:
@@ -121,7 +126,7 @@ def test_conv1d_bf16x3(L, case):
     L.check(L.lib.rvc_set_conv_precision(2))
     try:
         L.check(L.lib.rvc_prof_enable(1))
-        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, T, k, 1,
+        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, T, k, stride,
                                     pad, dil, 1, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
         L.check(L.lib.rvc_prof_collect(ms, fl, ln))
     finally:
@@ -133,7 +138,7 @@ def test_conv1d_bf16x3(L, case):
     L.check(L.lib.rvc_set_conv_precision(0))
     y32 = dev(y0)
     try:
-        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y32), Ci, Co, T, k, 1,
+        L.check(L.lib.rvc_op_conv1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y32), Ci, Co, T, k, stride,
                                     pad, dil, 1, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
     finally:
         L.check(L.lib.rvc_set_conv_precision(1))
