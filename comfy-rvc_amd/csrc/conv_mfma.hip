@@ -362,10 +362,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, int S, int bat
 
 // ============================================================================ host side
 #ifdef RVC_CONV_TIMING
+void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 8);
   if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof(z)); }
+  unsigned long long x3[8]; conv_x3_timing_read(x3, reset);
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
 }
 #else
 void conv_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 8; ++i) out8[i] = 0; }
@@ -496,6 +499,18 @@ void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci,
           const int chunk = ci / L.CK, vcc = ci % L.CK;
           P[(((size_t)chunk * L.ktaps + j) * L.CK + vcc) * L.CoP + (size_t)r * Co + co] = w[((size_t)ci * Co + co) * k + kk];
         }
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0 && L.Co >= 32) {
+    // bf16x3 image of the equivalent stride-1 convolution: Weq[r * Co + co][ci][j]
+    std::vector<float> Weq((size_t)L.Co * Ci * L.ktaps, 0.f);
+    for (int r = 0; r < u; ++r)
+      for (int co = 0; co < Co; ++co)
+        for (int ci = 0; ci < Ci; ++ci)
+          for (int j = 0; j < L.ktaps; ++j) {
+            const int kk = (E2 - j) * u + r + pad;
+            if (kk >= 0 && kk < k) Weq[(((size_t)r * Co + co) * Ci + ci) * L.ktaps + j] = w[((size_t)ci * Co + co) * k + kk];
+          }
+    pack_x3(L, Weq.data(), L.Co, Ci, L.ktaps);
+  }
   // remember the true transposed-conv geometry for the output length
   L.k = k; L.pad = pad;
   L.dil = 1;
@@ -598,6 +613,7 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     ms[r.cfg] += t; flops[r.cfg] += r.flops; launches[r.cfg] += 1;
+    if (getenv("RVC_PROF_DUMP")) fprintf(stderr, "conv launch %-12s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", kCfgNames[r.cfg], t * 1e3, r.flops / 1e9, r.flops / t / 1e9);
   }
   return (int)g_prof.size();
 }
@@ -768,8 +784,8 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.bBatch = L.Co;
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
-  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.k;
-  if (!(L.Wx_ && L.tconv_u == 0 && conv_x3_try(a, L.groups, s, flops))) run_conv(a, 1, L.groups, s, flops);
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.tconv_u > 0 ? L.ktaps : L.k;
+  if (!(L.Wx_ && conv_x3_try(a, L.groups, s, flops))) run_conv(a, 1, L.groups, s, flops);
   if (post) {
     RVC_REQUIRE(L.tconv_u == 0, "post-activation on a transposed conv");
     act_res_inplace(s, Y, e0.R, L.groups * L.Co, Tout, ldY, e0.ldR, e0.act, e0.act_slope, e0.act_before_res);

@@ -20,6 +20,20 @@ namespace rvc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef RVC_CONV_TIMING
+__device__ unsigned long long g_x3_timing[8];   // [0] blocks, [1] prologue, [2] X store + DMA wait + barrier, [3] prefetch issue, [4] MFMA loops, [5] epilogue, [6] total
+#define X3TICK() clock64()
+#define X3TACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_x3_timing[i], (unsigned long long)(v)); } while (0)
+void conv_x3_timing_read(unsigned long long* out8, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x3_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_timing), z, sizeof(z)); }
+}
+#else
+#define X3TICK() 0ll
+#define X3TACC(i, v) do {} while (0)
+#endif
+
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
 __host__ __device__ constexpr int x3_slots(int BN) { return BN >= 128 ? 5 : 2; }
 
@@ -68,6 +82,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
 
   // ---- input tile: global -> registers.  Slot s of wave w covers 64 positions x 8 channels (one 16-B half of the LDS rows).
   auto load_x = [&](int grp) {
+#ifdef RVC_X3_NOX
+    return;
+#endif
     int lane = lane0;
     asm volatile("" : "+v"(lane));
 #pragma unroll
@@ -89,6 +106,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   };
   // ---- input tile: registers -> hi/lo bf16 -> LDS
   auto store_x = [&](int xb) {
+#ifdef RVC_X3_NOX
+    return;
+#endif
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     unsigned char* xbase0 = Xs + xb * xbuf;
@@ -119,6 +139,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   };
   // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
   auto issue_w = [&](int grp, int tb, int buf) {
+#ifdef RVC_X3_NOW
+    return;
+#endif
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
@@ -140,9 +163,12 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
   for (int an = 0; an < AN; ++an) bq[an] = (wn * AN + an) * 32 + li;
 
   int chunk = 0, tb = 0;
+  const long long t_begin = X3TICK();
   issue_w(0, 0, 0);
   load_x(0);
+  X3TACC(1, X3TICK() - t_begin);
   for (int it = 0; it < nstages; ++it) {
+    const long long ta = X3TICK();
     const int buf = it & 1;
     const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
     if (tb == 0) {
@@ -151,16 +177,24 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stage's weight DMA has landed
     __syncthreads();
+    const long long tb_ = X3TICK();
+    X3TACC(2, tb_ - ta);
     int ntb_ = tb + 1, nchunk_ = chunk;
     if (ntb_ == ntb) { ntb_ = 0; ++nchunk_; }
     if (it + 1 < nstages) {
       issue_w(nchunk_, ntb_, buf ^ 1);
       if (ntb_ == 0) load_x(nchunk_);
     }
+    const long long tc = X3TICK();
+    X3TACC(3, tc - tb_);
     // ---- MFMAs of this stage
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
     const unsigned char* wb = Ws + buf * wbuf;
+#ifdef RVC_X3_NOMFMA
+    for (int cu = 0; cu < 0; ++cu) {
+#else
     for (int cu = 0; cu < NC * ut; ++cu) {
+#endif
       const int cc = cu / ut, uu = cu - cc * ut;
       const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
       const int u = tb * p.KT + uu;
@@ -197,9 +231,42 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
           acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
     }
     tb = ntb_; chunk = nchunk_;
+    X3TACC(4, X3TICK() - tc);
   }
-
-  dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
+  const long long t_epi = X3TICK();
+#ifdef RVC_X3_NOEPI
+  if (acc[0][0][0] == 12345.678f)
+#endif
+  if (p.ostride == 1) {
+    dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
+  } else {
+    // interleaved store of the ConvTranspose1d phases: row m = phase * orows + co goes to Y[co][n * ostride + phase]
+    const float* __restrict__ bias = p.bias;
+    float* Y = p.Y;
+    const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
+#pragma unroll
+    for (int am = 0; am < AM; ++am) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.Co) continue;
+        const int ph = m / p.orows, co = m - ph * p.orows;
+        const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const long long to = (long long)n * p.ostride + ph;
+          if (n >= p.Tout || to >= p.ldY) continue;   // ldY doubles as the true output length for interleaved stores
+          const long long oidx = (long long)co * p.ldY + to;
+          float v = acc[am][an][r] + bv;
+          v = fmaxf(v, v * lslope) * p.out_scale;
+          if (p.accumulate) v += Y[oidx];
+          Y[oidx] = v;
+        }
+      }
+    }
+  }
+  X3TACC(5, X3TICK() - t_epi); X3TACC(6, X3TICK() - t_begin); X3TACC(0, 1);
 }
 
 // ============================================================================ host side
@@ -221,7 +288,7 @@ static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) 
 
 bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (!conv_x3_enabled() || !a0.Wx) return false;
-  if ((a0.stride != 1 && a0.dil != 1) || a0.ostride != 1 || a0.up2 || (a0.Ci & 15) || batch != 1) return false;
+  if ((a0.stride != 1 && a0.dil != 1) || a0.up2 || (a0.ostride != 1 && a0.R) || (a0.Ci & 15) || batch != 1) return false;
   if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
   if ((double)a0.orows * (double)a0.ldY * 4.0 >= 2147483648.0 || (double)a0.orows * (double)a0.ldR * 4.0 >= 2147483648.0 ||
       (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;

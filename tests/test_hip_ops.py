@@ -164,6 +164,29 @@ def test_conv_transpose1d(L, case):
     assert rel_err(y.cpu(), ref + y0) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(128, 64, 60000, 4, 2, 1), (256, 128, 30001, 16, 10, 3), (64, 32, 300000, 4, 2, 1), (512, 256, 3000, 16, 10, 3)])
+def test_conv_transpose1d_bf16x3(L, case):
+    """The generator's upsampling layers on the bf16x3 kernel (polyphase rows, interleaved store)."""
+    Ci, Co, T, k, u, pad = case
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Ci, Co, k, generator=g) / np.sqrt(Ci * k / u)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1).double()[None], w.double(), b.double(), stride=u, padding=pad)[0]
+    y, xd, wc, bc = torch.zeros(ref.shape, device="cuda"), dev(x), w.contiguous().numpy(), b.numpy()
+    ms = (C.c_double * 24)(); fl = (C.c_double * 24)(); ln = (C.c_int64 * 24)()
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_op_conv_transpose1d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(y), Ci, Co, T, k, u, pad, 1, 0.1, 0))
+        L.check(L.lib.rvc_prof_collect(ms, fl, ln))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert sum(ln[14:21]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 CONV2D = [(1, 16, 64, 128), (16, 16, 96, 128), (32, 64, 48, 32), (128, 128, 12, 16), (256, 512, 6, 4), (16, 3, 64, 128), (512, 512, 3, 4)]
 
 
