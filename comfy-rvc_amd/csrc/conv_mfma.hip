@@ -599,7 +599,7 @@ static std::vector<ProfRec> g_prof;
 static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
                                            "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d",
                                            "1x4x1x4/x3", "1x4x1x2/x3", "1x4x1x1/x3", "2x2x2x2/x3", "2x2x1x4/x3", "2x2x1x2/x3", "2x2x1x1/x3",
-                                           "", "", ""};
+                                           "2x2x2x4/x3", "1x4x2x4/x3", ""};
 void conv_prof_enable(bool on) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();

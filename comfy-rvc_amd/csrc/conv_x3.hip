@@ -40,7 +40,7 @@ __host__ __device__ constexpr int x3_slots(int BN) { return BN >= 128 ? 5 : 2; }
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 
 template <int WM, int WN, int AM, int AN>
-__global__ __launch_bounds__(256) void conv_x3_kernel(const ConvArgsX p) {
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
@@ -295,10 +295,23 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   ConvArgsX a = a0;
   a.ktaps = a0.kreal;                                     // true taps (the fp32 kernel folds the stride phases into virtual channels)
   TileCfg t = choose_tile(a.Co, a.Tout, batch);
+  {
+    // wide tiles (8 accumulators per wave): every workgroup re-fetches the whole weight image from L2, so the L2 -> LDS stream
+    // per output halves with twice the positions per workgroup; taken when the grid still fills the chip several times over
+    // (measured: C128 k11 610 -> 470 us; deeper weight buffering instead of wider tiles was slower)
+    static const int wide_blk = getenv("RVC_X3_WIDE") ? atoi(getenv("RVC_X3_WIDE")) : 600;
+    auto blocks = [&](int bm, int bn) { return (long long)((a.Co + bm - 1) / bm) * ((a.Tout + bn - 1) / bn); };
+    if (wide_blk > 0 && a.stride == 1) {
+      if (a.Co > 64 && blocks(128, 256) >= wide_blk) t = TileCfg{2, 2, 2, 4};
+      else if (a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
+    }
+  }
   if (const char* f = getenv("RVC_FORCE_TILE")) {
     int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
   }
-  const int id = tile_cfg_id(t);
+  int id = tile_cfg_id(t);
+  if (t.WM == 2 && t.WN == 2 && t.AM == 2 && t.AN == 4) id = 7;
+  if (t.WM == 1 && t.WN == 4 && t.AM == 2 && t.AN == 4) id = 8;
   if (id < 0) return false;
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
@@ -337,6 +350,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     case 3: launch_x3<2, 2, 2, 2>(a, grid, lds, s); break;
     case 4: launch_x3<2, 2, 1, 4>(a, grid, lds, s); break;
     case 5: launch_x3<2, 2, 1, 2>(a, grid, lds, s); break;
+    case 7: launch_x3<2, 2, 2, 4>(a, grid, lds, s); break;
+    case 8: launch_x3<1, 4, 2, 4>(a, grid, lds, s); break;
     default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
   }
   conv_prof_end(tk, s, flops, 14 + id);

@@ -98,6 +98,8 @@ X3_CONV1D = [
     (128, 128, 70001, 2, 0, 1, "none", "gelu", False, 1.0, False, 2),
     (512, 512, 20001, 3, 0, 1, "none", "gelu", False, 1.0, False, 2),
     (48, 64, 100000, 5, 2, 1, "lrelu", "none", False, 1.0, False, 3),
+    (128, 128, 160001, 7, 9, 3, "lrelu", "none", True, 1.0, False),     # >= 600 workgroups of 128 x 256: wide tile 2x2x2x4
+    (64, 64, 310000, 11, 25, 5, "lrelu", "none", True, 1.0 / 3, True),  # wide tile 1x4x2x4 (64 x 512)
 ]
 
 
@@ -132,7 +134,7 @@ def test_conv1d_bf16x3(L, case):
     finally:
         L.check(L.lib.rvc_prof_enable(0))
         L.check(L.lib.rvc_set_conv_precision(1))
-    assert sum(ln[14:21]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert sum(ln[14:24]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
     assert rel_err(y.cpu().double(), ref) < 2e-5
     # the same layer on the fp32 kernel: both must agree with the reference, bf16x3 within a small factor of fp32's own error
     L.check(L.lib.rvc_set_conv_precision(0))
@@ -183,7 +185,7 @@ def test_conv_transpose1d_bf16x3(L, case):
     finally:
         L.check(L.lib.rvc_prof_enable(0))
         L.check(L.lib.rvc_set_conv_precision(1))
-    assert sum(ln[14:21]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert sum(ln[14:24]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
     assert rel_err(y.cpu().double(), ref) < 2e-5
 
 
