@@ -8,7 +8,7 @@ One "step" = every rank converts ONE synthetic 30 s / 16 kHz clip end to end thr
 int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz) and the
 int16 waveforms are gathered on rank 0 over RCCL (the path's only exchange step).  Clips are independent, so the work
 shards one-clip-per-GPU with no data-path collective besides that gather: weak scaling.  Weights are procedural
-(comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32 on the MFMA units.
+(comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32 (fp32 MFMA, or the bf16x3 split with fp32 accumulation).
 Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
 """
 import argparse
@@ -27,6 +27,7 @@ import torch         # noqa: E402
 
 CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 
 
 def cpu_baseline(seconds=3.0):
@@ -125,17 +126,39 @@ def main():
         _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
         _lib.check(_lib.lib.rvc_prof_enable(0))
         vc.overlap_streams = True
-        tot_ms, tot_fl, tot_l = sum(ms), sum(fl), sum(ln)
         per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
                                                             "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
                    for i in range(NCFG) if ln[i]}
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (all instantiations; fp32 v_mfma_f32_32x32x2_f32)",
-                    "launches_per_clip": int(tot_l), "avg_launch_us": round(tot_ms * 1e3 / max(tot_l, 1), 2),
-                    "algorithmic_gflop_per_launch": round(tot_fl / max(tot_l, 1) / 1e9, 3),
-                    "kernel_ms_per_clip": round(tot_ms, 2), "algorithmic_tflop_per_clip": round(tot_fl / 1e12, 3), "per_tile_config": per_cfg}
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            pass
+
+        def family(idx, kernel, desc, peak, note):
+            t, f_, l_ = sum(ms[i] for i in idx), sum(fl[i] for i in idx), sum(ln[i] for i in idx)
+            if l_ == 0:
+                return None
+            ach = f_ / (t * 1e-3) / 1e12
+            tr = traffic.get(kernel)
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                    "traffic_note": None if tr is None else "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
+                                                            "(profiles/r1_pmc_traffic.json, tools/pmc_traffic.py)",
+                    "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
+                    "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "kernel_ms_per_clip": round(t, 2),
+                    "algorithmic_tflop_per_clip": round(f_ / 1e12, 3)}
+        r_x3 = family(range(14, NCFG), "rvc::conv_x3_kernel",
+                      "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)",
+                      round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product")
+        r_f32 = family(range(0, 14), "rvc::conv_mfma_kernel",
+                       "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak")
+        fams = [r for r in (r_x3, r_f32) if r]
+        fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant kernel = the one with the most time per clip
+        roofline = fams[0]
+        roofline["per_tile_config"] = per_cfg
+        roofline["other_kernels"] = fams[1:]
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -145,6 +168,7 @@ def main():
             "metric": "audio-sec/wall-sec (xRT), 40k_v2 end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
             "config": {"workload": f"Full VC 40k_v2 (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clip per GPU "
                                    "per step, vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
                        "clips_per_step": world, "audio_seconds_delivered_per_clip": round(delivered, 3),

@@ -532,6 +532,7 @@ void conv2d3x3_layer_init(ConvLayer& L, const float* w, const float* bias, int C
         P[(((size_t)chunk * 9 + u) * L.CK + vcc) * L.CoP + co] = w[((size_t)co * Ci + ci) * 9 + u];
       }
   upload_layer(L, P, bias, Co);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0 && Co >= 16) pack_x3(L, w, Co, Ci, 9);
 }
 
 void conv2d1x1_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci) {
@@ -820,7 +821,9 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.ldX = ldX; a.ldY = ldY; a.up2 = L.up2; a.ostride = 1; a.orows = L.up2 ? L.co_real : L.Co;
   a.ldW = L.CoP; a.Wcols = L.CoP; a.Wrows = L.nchunk * 9 * L.CK;
   a.xBatch = 0; a.wBatch = 0; a.yBatch = 0; a.rBatch = 0; a.bBatch = 0;
-  run_conv(a, 2, 1, s, 2.0 * H * (double)Wd * 9 * L.Ci * (L.up2 ? L.co_real : L.Co));
+  const double flops = 2.0 * H * (double)Wd * 9 * L.Ci * (L.up2 ? L.co_real : L.Co);
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = 9;
+  if (!(L.Wx_ && !L.up2 && conv_x3_try(a, 1, s, flops))) run_conv(a, 2, 1, s, flops);
 }
 
 }  // namespace rvc

@@ -35,7 +35,7 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset) {
 #endif
 
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
-__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 128 ? 5 : 2; }
+__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 7 : (BN >= 128 ? 5 : 2); }
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
   const int nstages = (p.nchunk / NC) * ntb;          // p.nchunk is a multiple of NC (host)
   const int bx = n0 * st - p.pad;
+  // 2-D 3x3 (p.Wd > 0): the tile is BH image rows x BWd columns; the staged "positions" are the (BH + 2) x PW halo patch in
+  // row-major order, tap (dh, dw) is the position offset dh * PW + dw
+  const bool two_d = p.Wd > 0;
+  int h0 = 0, w0 = 0;
+  if (two_d) { h0 = n0 / p.Wd; w0 = n0 - h0 * p.Wd; }
   const int ni = p.ni;                                                      // 64-position groups per plane row set
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
   const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;      // input activation: leaky ReLU (slope 1 = identity)
@@ -93,8 +98,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       const int cc = (t >= 2 * ni) + (t >= 4 * ni) + (t >= 6 * ni);       // NC <= 4
       const int g = t - cc * 2 * ni;
       const int hb = g >= ni ? 1 : 0;
-      const int q = (g - hb * ni) * 64 + lane, x = bx + q;
-      const bool ok = cc < NC && q < P && x >= 0 && x < p.Tin;
+      const int q = (g - hb * ni) * 64 + lane;
+      int x = bx + q;
+      bool ok = cc < NC && q < P && x >= 0 && x < p.Tin;
+      if (two_d) {
+        const int rr = (int)__umulhi((unsigned)q, p.magPW), cw = q - rr * p.PW;
+        const int hh = h0 - 1 + rr, ww = w0 - 1 + cw;
+        ok = cc < NC && q < P && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
+        x = hh * p.Wd + ww;
+      }
       const unsigned voff = ok ? (unsigned)x * 4u : kOOB;
       const unsigned c0 = (unsigned)((grp * NC + cc) * 16 + hb * 8);
 #pragma unroll
@@ -160,7 +172,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
 #pragma unroll
   for (int am = 0; am < AM; ++am) { const int m = (wm * AM + am) * 32 + li; aoff[am] = m * 32 + ((lh ^ ((m >> 3) & 1)) << 4); }
 #pragma unroll
-  for (int an = 0; an < AN; ++an) bq[an] = (wn * AN + an) * 32 + li;
+  for (int an = 0; an < AN; ++an) {
+    const int nl = (wn * AN + an) * 32 + li;
+    bq[an] = two_d ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl;
+  }
 
   int chunk = 0, tb = 0;
   const long long t_begin = X3TICK();
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       const int cc = cu / ut, uu = cu - cc * ut;
       const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
       const int u = tb * p.KT + uu;
-      const int toff = st == 1 ? u * p.dil : u / st;                 // row offset inside the (phase) plane
+      const int toff = two_d ? (u / 3) * p.PW + (u % 3) : (st == 1 ? u * p.dil : u / st);   // row offset inside the (phase) plane
       if (st > 1) xp += (u - toff * st) * Pm * 32;
       const unsigned char* wt = wb + cu * 2 * BM * 32;
       u32x4 ah[AM], al[AM], bh[AN], bl[AN];
@@ -288,12 +303,13 @@ static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) 
 
 bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (!conv_x3_enabled() || !a0.Wx) return false;
+  if (a0.Wd > 0 && (a0.ktaps != 9 || a0.stride != 1)) return false;
   if ((a0.stride != 1 && a0.dil != 1) || a0.up2 || (a0.ostride != 1 && a0.R) || (a0.Ci & 15) || batch != 1) return false;
   if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
   if ((double)a0.orows * (double)a0.ldY * 4.0 >= 2147483648.0 || (double)a0.orows * (double)a0.ldR * 4.0 >= 2147483648.0 ||
       (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;
   ConvArgsX a = a0;
-  a.ktaps = a0.kreal;                                     // true taps (the fp32 kernel folds the stride phases into virtual channels)
+  if (a.Wd == 0) a.ktaps = a0.kreal;                      // true taps (the fp32 kernel folds the stride phases into virtual channels)
   TileCfg t = choose_tile(a.Co, a.Tout, batch);
   {
     // wide tiles (8 accumulators per wave): every workgroup re-fetches the whole weight image from L2, so the L2 -> LDS stream
@@ -301,7 +317,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     // (measured: C128 k11 610 -> 470 us; deeper weight buffering instead of wider tiles was slower)
     static const int wide_blk = getenv("RVC_X3_WIDE") ? atoi(getenv("RVC_X3_WIDE")) : 600;
     auto blocks = [&](int bm, int bn) { return (long long)((a.Co + bm - 1) / bm) * ((a.Tout + bn - 1) / bn); };
-    if (wide_blk > 0 && a.stride == 1) {
+    if (wide_blk > 0 && a.stride == 1 && a.Wd == 0) {
       if (a.Co > 64 && blocks(128, 256) >= wide_blk) t = TileCfg{2, 2, 2, 4};
       else if (a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
@@ -317,7 +333,14 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
   if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
-  const int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1, Pm = (P + a.stride - 1) / a.stride;
+  int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1;
+  if (a.Wd > 0) {
+    // tile = whole image rows or a power-of-two fraction of one row (Wd is a power of two)
+    a.BWd = BN < a.Wd ? BN : a.Wd; a.BH = BN < a.Wd ? 1 : BN / a.Wd; a.PW = a.BWd + 2;
+    P = (a.BH + 2) * a.PW;
+    a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
+  }
+  const int Pm = (P + a.stride - 1) / a.stride;
   a.ni = (P + 63) / 64;
   const int nchunk = a.Ci / 16;
   // chunks per stage: short reductions per chunk (k <= 3) take several chunks per stage so that a stage outlasts its DMA

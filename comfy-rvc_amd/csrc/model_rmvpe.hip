@@ -71,6 +71,8 @@ static void make_cbr(CBR& B, const TensorStore& ts, const std::string& p, int ci
 }
 
 void rmvpe_finalize(Rmvpe* R) {
+  // 3x3 convolutions with Ci % 16 == 0 also get a bf16x3 split weight image (conv_x3.hip); Ci = 1 / transposed convs stay fp32
+  struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
   const TensorStore& ts = R->ts;
   rmvpe_free(*R);
   conv1d_layer_init(R->stft, ts.get("stft.forward_basis", {1026, 1024}).data.data(), nullptr, 1026, 1024, 1, 1, 0, 1, 1);

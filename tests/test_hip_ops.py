@@ -206,6 +206,31 @@ def test_conv2d3x3_relu_residual(L, case):
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(16, 16, 3232, 128), (32, 32, 1616, 64), (64, 32, 1617, 64), (64, 64, 808, 32), (128, 64, 803, 32), (16, 32, 1000, 128),
+                                  (48, 16, 2000, 128)])
+def test_conv2d3x3_bf16x3(L, case):
+    """RMVPE U-Net 3x3 convolutions on the bf16x3 kernel (halo patch staged per tile of image rows)."""
+    Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / np.sqrt(Ci * 9)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double()[None], w.double(), b.double(), padding=1)[0]) + r
+    y, xd, rd, wc, bc = torch.empty(Co, H, W, device="cuda"), dev(x), dev(r), w.contiguous().numpy(), b.numpy()
+    ms = (C.c_double * 24)(); fl = (C.c_double * 24)(); ln = (C.c_int64 * 24)()
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_op_conv2d3x3(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(rd), L.ptr(y), Ci, Co, H, W, 1))
+        L.check(L.lib.rvc_prof_collect(ms, fl, ln))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert sum(ln[14:24]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("case", [(512, 256, 3, 4), (32, 16, 32, 64), (64, 32, 16, 32)])
 def test_conv_transpose2d(L, case):
     Ci, Co, H, W = case
