@@ -88,20 +88,34 @@ void groupnorm_t_gelu(hipStream_t s, float* x, const float* gamma, const float* 
 // ---------------------------------------------------------------------------------------------- column softmax of S^T [Tk][Tq]
 // Softmax over the key axis (rows) for every query column; optional relative-position bias
 // rel[(k - q + win)][q] for |k - q| <= win (enc_p, reference attentions.py:230-239) and optional gather of the banded
-// probabilities pb[r][q] = P[q][q + r - win] (reference attentions.py:260-267).  Block = 16 columns x 16 row slices.
-// Two sweeps: online (max, sum) then normalise-and-store: 2 reads + 1 write of the score matrix.
-__global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ S, int Tk, int Tq, long long ld, long long batchS,
-                                                           const float* __restrict__ rel, long long batchRel, int win,
-                                                           float* __restrict__ pb, long long batchPb) {
-  __shared__ float s_m[16][17], s_s[16][17];
-  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int q = blockIdx.x * 16 + col;
+// probabilities pb[r][q] = P[q][q + r - win] (reference attentions.py:260-267).  Block = 64 columns x 16 row slices: every
+// wave touches 256 contiguous bytes of a row.  Two sweeps: online (max, sum) then normalise-and-store: 2 reads + 1 write of the
+// score matrix (the second read comes from the 256 MB memory-side cache).
+__global__ __launch_bounds__(1024) void softmax_cols_kernel(float* __restrict__ S, int Tk, int Tq, long long ld, long long batchS,
+                                                            const float* __restrict__ rel, long long batchRel, int win,
+                                                            float* __restrict__ pb, long long batchPb) {
+  __shared__ float s_m[16][64], s_s[16][64];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + col;
   const bool ok = q < Tq;
   float* Sb = S + (long long)blockIdx.y * batchS;
   const float* relb = rel ? rel + (long long)blockIdx.y * batchRel : nullptr;
   float mx = -3.0e38f, sum = 0.f;
-  for (int k = sl; k < Tk; k += 16) {
-    if (ok) {
+  if (ok) {
+    int k = sl;
+    for (; k + 48 < Tk; k += 64) {           // four rows in flight per thread
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = Sb[(long long)(k + 16 * j) * ld + q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (relb) { const int d = k + 16 * j - q + win; if (d >= 0 && d <= 2 * win) v[j] += relb[(long long)d * Tq + q]; }
+        const float nm = fmaxf(mx, v[j]);
+        sum = sum * expf(mx - nm) + expf(v[j] - nm);
+        mx = nm;
+      }
+    }
+    for (; k < Tk; k += 16) {
       float v = Sb[(long long)k * ld + q];
       if (relb) { const int d = k - q + win; if (d >= 0 && d <= 2 * win) v += relb[(long long)d * Tq + q]; }
       const float nm = fmaxf(mx, v);
@@ -118,21 +132,28 @@ __global__ __launch_bounds__(256) void softmax_cols_kernel(float* __restrict__ S
 #pragma unroll
   for (int i = 0; i < 16; ++i) gs += s_s[i][col] * expf(s_m[i][col] - gm);
   const float inv = 1.f / gs;
-  for (int k = sl; k < Tk; k += 16) {
-    if (ok) {
-      float v = Sb[(long long)k * ld + q];
-      const int d = k - q + win;
-      const bool band = d >= 0 && d <= 2 * win;
-      if (relb && band) v += relb[(long long)d * Tq + q];
-      const float pv = expf(v - gm) * inv;
-      Sb[(long long)k * ld + q] = pv;
-      if (pb && band) pb[(long long)blockIdx.y * batchPb + (long long)d * Tq + q] = pv;
-    }
+  if (!ok) return;
+  auto emit = [&](int k, float v) {
+    const int d = k - q + win;
+    const bool band = d >= 0 && d <= 2 * win;
+    if (relb && band) v += relb[(long long)d * Tq + q];
+    const float pv = expf(v - gm) * inv;
+    Sb[(long long)k * ld + q] = pv;
+    if (pb && band) pb[(long long)blockIdx.y * batchPb + (long long)d * Tq + q] = pv;
+  };
+  int k = sl;
+  for (; k + 48 < Tk; k += 64) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = Sb[(long long)(k + 16 * j) * ld + q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) emit(k + 16 * j, v[j]);
   }
+  for (; k < Tk; k += 16) emit(k, Sb[(long long)k * ld + q]);
 }
 void softmax_cols(hipStream_t s, float* S, int Tk, int Tq, long long ld, long long batchS, int batch, const float* rel,
                   long long batchRel, int win, float* pb, long long batchPb) {
-  hipLaunchKernelGGL(softmax_cols_kernel, dim3((Tq + 15) / 16, batch), dim3(256), 0, s, S, Tk, Tq, ld, batchS, rel, batchRel,
+  hipLaunchKernelGGL(softmax_cols_kernel, dim3((Tq + 63) / 64, batch), dim3(1024), 0, s, S, Tk, Tq, ld, batchS, rel, batchRel,
                      win, pb, batchPb);
 }
 
@@ -330,14 +351,20 @@ void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long
 // 16 workgroups: (direction, slice of 32 hidden units).  Each keeps its 96 x 256 block of W_hh in registers
 // (2 threads per row, 128 weights each).  h_t is exchanged through 8-byte {step tag, value} granules written with
 // agent-scope relaxed atomics (write-through) into a 2-deep ring and gathered by polling (bounded spin).
+// Placement: workgroups are dealt round-robin to the 8 XCDs, so the launch is 64 workgroups of which those with
+// blockIdx % 8 == 0 (direction 0) and == 4 (direction 1) work and the rest exit: the 8 slices of one direction then share one
+// XCD (measured: 6.3 -> 5.0 ms for 3200 steps).  Agent-scope loads are correct for any placement; workgroup-scope (sc0) polling
+// was tried for an L2-local hand-off and never observes the remote store (it is served from the CU's L1).
 // gi: [T][1536] = W_ih x + (bias added here); out: channel-major [512][T].   nn.GRU gate order r, z, n.
 __global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                        const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                        float* __restrict__ out, unsigned long long* xbuf, int* err, int T) {
-  constexpr int H = 256, NS = 8, HS = 32;
+  constexpr int H = 256, HS = 32;
   __shared__ __attribute__((aligned(16))) float hs[H];
   __shared__ float ghs[96];
-  const int dir = blockIdx.x / NS, sl = blockIdx.x % NS;
+  const int xcd = blockIdx.x & 7;
+  if (xcd != 0 && xcd != 4) return;
+  const int dir = xcd >> 2, sl = blockIdx.x >> 3;
   const int tid = threadIdx.x;
   const float* W = w_hh + (long long)dir * 3 * H * H;
   const float* BH = b_hh + dir * 3 * H;
@@ -413,7 +440,7 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
               unsigned long long* xbuf, int* err, int T) {
   (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
   (void)hipMemsetAsync(err, 0, sizeof(int), s);
-  hipLaunchKernelGGL(gru_scan_kernel, dim3(16), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T);
+  hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T);
 }
 
 // ---------------------------------------------------------------------------------------------- RMVPE decode
