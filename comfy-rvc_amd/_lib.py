@@ -77,8 +77,13 @@ SIGNATURES = {
                                 c_void_p, P(SynthTaps)]),
     "rvc_vc_segment": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int,
                                c_void_p, c_void_p, c_void_p]),
-    "rvc_vc_segment_feats": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
-                                     c_void_p]),
+    "rvc_vc_segment_feats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p,
+                                     c_void_p, c_void_p]),
+    "rvc_index_create": (c_int, [c_void_p, c_void_p, c_int64, c_int, P(c_void_p)]),
+    "rvc_index_destroy": (c_int, [c_void_p]),
+    "rvc_index_ntotal": (c_int64, [c_void_p]),
+    "rvc_index_search": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rvc_index_blend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rvc_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_int]),
     "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -111,6 +111,9 @@ struct ProfTicket { hipEvent_t a = nullptr, b = nullptr; bool on = false; };
 ProfTicket conv_prof_begin(hipStream_t s);
 void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg);
 
+// second pass of a split-K launch (conv_mfma.hip): fixed-order sum of the partials + dense epilogue
+void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s);
+
 // bf16x3 path: returns false when the layer / geometry is not eligible (caller falls back to the fp32 kernel)
 bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops);
 bool conv_x3_enabled();

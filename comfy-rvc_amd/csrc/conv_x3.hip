@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane0 & 31, lh = lane0 >> 5;
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / p.ksplit, ks = blockIdx.z - z * p.ksplit;   // batch index, K-split index
   const int co0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   const float* __restrict__ X = p.X + (long long)z * p.xBatch;
@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
 
   const int ntb = (p.ktaps + p.KT - 1) / p.KT;
-  const int nstages = (p.nchunk / NC) * ntb;          // p.nchunk is a multiple of NC (host)
+  const int ngroups = p.nchunk / NC;                  // p.nchunk is a multiple of NC (host)
+  const int gps = (ngroups + p.ksplit - 1) / p.ksplit;        // chunk groups per K split
+  const int g0 = ks * gps, g1 = min(ngroups, g0 + gps);
+  const int nstages = max(g1 - g0, 0) * ntb;
   const int bx = n0 * st - p.pad;
   // 2-D 3x3 (p.Wd > 0): the tile is BH image rows x BWd columns; the staged "positions" are the (BH + 2) x PW halo patch in
   // row-major order, tap (dh, dw) is the position offset dh * PW + dw
@@ -177,10 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     bq[an] = two_d ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl;
   }
 
-  int chunk = 0, tb = 0;
+  int chunk = g0, tb = 0;
   const long long t_begin = X3TICK();
-  issue_w(0, 0, 0);
-  load_x(0);
+  if (nstages > 0) { issue_w(g0, 0, 0); load_x(g0); }
   X3TACC(1, X3TICK() - t_begin);
   for (int it = 0; it < nstages; ++it) {
     const long long ta = X3TICK();
@@ -252,7 +254,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
 #ifdef RVC_X3_NOEPI
   if (acc[0][0][0] == 12345.678f)
 #endif
-  if (p.ostride == 1) {
+  if (p.ksplit > 1) {
+    // split-K: raw partial sums; bias / activation / residual are applied by splitk_reduce_kernel in a fixed order
+    float* Pp = p.partial + ((long long)blockIdx.z * p.Co) * p.ldP;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(Pp, (unsigned)p.Co * (unsigned)p.ldP * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const bool ok = m < p.Co && n < p.Tout;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), prs, (int)(ok ? ((unsigned)m * (unsigned)p.ldP + (unsigned)n) * 4u : kOOB), 0, 0);
+        }
+      }
+  } else if (p.ostride == 1) {
     dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
   } else {
     // interleaved store of the ConvTranspose1d phases: row m = phase * orows + co goes to Y[co][n * ostride + phase]
@@ -333,6 +351,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
   if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
+  static const int x3_split_blk = getenv("RVC_X3_SPLITK_BLK") ? atoi(getenv("RVC_X3_SPLITK_BLK")) : 0;
   int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1;
   if (a.Wd > 0) {
     // tile = whole image rows or a power-of-two fraction of one row (Wd is a power of two)
@@ -363,8 +382,21 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const int ntb = (a.ktaps + ktmax - 1) / ktmax;
   a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
+  // split-K (k = 1 GEMMs on small grids): every stage of such a workgroup is a dependent global -> LDS round trip, so slicing the
+  // reduction over S workgroups shortens the chain and puts more of them on a CU; partials are reduced in a fixed order
+  int S = 1;
+  if (x3_split_blk > 0 && a.ostride == 1 && a.Wd == 0 && a.ktaps == 1 && nblk < x3_split_blk) {
+    const int ngroups = nchunk / NC;
+    S = (int)((2LL * x3_split_blk + nblk - 1) / nblk);
+    if (S > 8) S = 8;
+    if (S > ngroups / 3) S = ngroups / 3;
+    if (S < 1) S = 1;
+    while (S > 1 && ((ngroups + S - 1) / S) * (S - 1) >= ngroups) --S;
+  }
+  a.ksplit = S; a.ldP = (a.Tout + 31) & ~31;
+  if (S > 1) a.partial = (float*)stream_scratch(s, 0, (size_t)S * a.Co * a.ldP * sizeof(float));
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
-  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1u);
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
   ProfTicket tk = conv_prof_begin(s);
   switch (id) {
     case 0: launch_x3<1, 4, 1, 4>(a, grid, lds, s); break;
@@ -377,6 +409,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     case 8: launch_x3<1, 4, 2, 4>(a, grid, lds, s); break;
     default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
   }
+  if (S > 1) splitk_reduce_launch(a, S, 1, s);
   conv_prof_end(tk, s, flops, 14 + id);
   return true;
 }

@@ -38,6 +38,15 @@ void rmvpe_finalize(Rmvpe* R);
 void rmvpe_forward(Rmvpe* R, hipStream_t s, const float* audio, long long L, float thred, float* mel_out, float* salience_out, double* f0_out,
                    const RmvpeTaps* taps);
 
+// feature retrieval (index.hip): exact nearest neighbour over big_npy [N][D]
+struct FeatIndex;
+FeatIndex* index_create(Ctx* ctx, const float* big_npy, long long N, int D);
+void index_destroy(FeatIndex* I);
+long long index_size(const FeatIndex* I);
+int index_dim(const FeatIndex* I);
+void index_search(FeatIndex* I, hipStream_t s, const float* feats_cm, int T, long long* idx, float* score);
+void index_blend(FeatIndex* I, hipStream_t s, const float* feats_cm, const long long* idx, int T, float rate, float* out_cm);
+
 void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, float thred, double* f0);
 size_t synth_workspace(const Synth* S);
 size_t hubert_workspace(const Hubert* H);

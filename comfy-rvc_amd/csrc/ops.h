@@ -17,7 +17,8 @@ void flip_c(hipStream_t s, const float* x, float* y, int C, int T);
 void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitch, int C, int T);
 void transpose(hipStream_t s, const float* in, float* out, int R, int C, long long ldin, long long ldout, int batch, long long bin,
                long long bout);
-void feats_prepare(hipStream_t s, const float* f, const float* pitchf, float* out, int D, int Th, int T, float protect, int do_protect);
+void feats_prepare(hipStream_t s, const float* f, const float* f0, const float* pitchf, float* out, int D, int Th, int T, float protect,
+                   int do_protect);
 void frames(hipStream_t s, const float* src, float* out, int L, int k, int stride, int pad, int Tout, int reflect);
 void magnitude(hipStream_t s, const float* ft, float* mag, int F, int T);
 void mel_to_unet(hipStream_t s, const float* mel, float* x, int n, int Tr, float a, float b);

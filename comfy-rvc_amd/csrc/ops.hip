@@ -256,8 +256,9 @@ void transpose(hipStream_t s, const float* in, float* out, int R, int C, long lo
 }
 
 // features for the synthesizer: nearest x2 upsample of [D][Th] and the protect blend (reference vc_infer_pipeline.py:77-95)
-__global__ void feats_prepare_kernel(const float* __restrict__ f, const float* __restrict__ pitchf, float* __restrict__ out, int D,
-                                     int Th, int T, float protect, int do_protect) {
+// f0 = features before index retrieval (feats0 of the reference); null when no index is used (then feats0 == feats)
+__global__ void feats_prepare_kernel(const float* __restrict__ f, const float* __restrict__ f0, const float* __restrict__ pitchf,
+                                     float* __restrict__ out, int D, int Th, int T, float protect, int do_protect) {
   const long long n = (long long)D * T;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long st = (long long)gridDim.x * blockDim.x;
@@ -270,14 +271,16 @@ __global__ void feats_prepare_kernel(const float* __restrict__ f, const float* _
       float w = pf;
       if (pf > 0.f) w = 1.f;
       if (pf < 1.f) w = protect;
-      o = v * w + v * (1.f - w);
+      const float v0 = f0 ? f0[(long long)c * Th + (t >> 1)] : v;
+      o = v * w + v0 * (1.f - w);
     }
     out[i] = o;
   }
 }
-void feats_prepare(hipStream_t s, const float* f, const float* pitchf, float* out, int D, int Th, int T, float protect, int do_protect) {
+void feats_prepare(hipStream_t s, const float* f, const float* f0, const float* pitchf, float* out, int D, int Th, int T, float protect,
+                   int do_protect) {
   long long n = (long long)D * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(feats_prepare_kernel, dim3(blocks), dim3(256), 0, s, f, pitchf, out, D, Th, T, protect, do_protect);
+  hipLaunchKernelGGL(feats_prepare_kernel, dim3(blocks), dim3(256), 0, s, f, f0, pitchf, out, D, Th, T, protect, do_protect);
 }
 
 // ---------------------------------------------------------------------------------------------- im2col for single-channel convs

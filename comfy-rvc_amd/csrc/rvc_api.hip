@@ -150,21 +150,48 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
   float* fcm = (float*)stream_scratch(st, 1, (size_t)D * Th * sizeof(float));
   float* fup = (float*)stream_scratch(st, 2, (size_t)D * T * sizeof(float));
   hubert_forward(h->m, st, audio, L, version, 0, nullptr, fcm, nullptr);
-  feats_prepare(st, fcm, pitchf, fup, D, (int)Th, T, protect, do_protect);
+  feats_prepare(st, fcm, nullptr, pitchf, fup, D, (int)Th, T, protect, do_protect);
   synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
   check_launch();
   RVC_CATCH
 }
 
-int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, int64_t Th, int feat_dim, const int64_t* pitch, const float* pitchf, int sid,
-                         float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
+int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, const float* feats0_cm, int64_t Th, int feat_dim, const int64_t* pitch,
+                         const float* pitchf, int sid, float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
   RVC_TRY
   RVC_REQUIRE(s && feats_cm && pitch && pitchf && noise_z && noise_src && out, "null argument");
   hipStream_t st = (hipStream_t)stream;
   const int T = (int)(2 * Th);
   float* fup = (float*)stream_scratch(st, 2, (size_t)feat_dim * T * sizeof(float));
-  feats_prepare(st, feats_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
+  feats_prepare(st, feats_cm, feats0_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
   synth_infer(s->m, st, fup, 1, (const long long*)pitch, pitchf, sid, noise_z, noise_src, T, out, nullptr);
+  check_launch();
+  RVC_CATCH
+}
+
+// ------------------------------------------------------------------------------------------------ feature retrieval
+struct rvc_index { FeatIndex* m; };
+int rvc_index_create(rvc_ctx* ctx, const float* big_npy, int64_t N, int D, rvc_index** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && out, "null argument");
+  rvc_index* h = new rvc_index();
+  try { h->m = index_create(&ctx->c, big_npy, N, D); } catch (...) { delete h; throw; }
+  *out = h;
+  RVC_CATCH
+}
+int rvc_index_destroy(rvc_index* h) { if (h) { index_destroy(h->m); delete h; } return 0; }
+int64_t rvc_index_ntotal(const rvc_index* h) { return h ? index_size(h->m) : 0; }
+int rvc_index_search(rvc_index* h, void* stream, const float* feats_cm, int64_t T, int64_t* idx, float* score) {
+  RVC_TRY
+  RVC_REQUIRE(h && feats_cm && idx && T > 0, "bad argument");
+  index_search(h->m, (hipStream_t)stream, feats_cm, (int)T, (long long*)idx, score);
+  check_launch();
+  RVC_CATCH
+}
+int rvc_index_blend(rvc_index* h, void* stream, const float* feats_cm, const int64_t* idx, int64_t T, float index_rate, float* out_cm) {
+  RVC_TRY
+  RVC_REQUIRE(h && feats_cm && idx && out_cm && T > 0, "bad argument");
+  index_blend(h->m, (hipStream_t)stream, feats_cm, (const long long*)idx, (int)T, index_rate, out_cm);
   check_launch();
   RVC_CATCH
 }

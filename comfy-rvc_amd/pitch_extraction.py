@@ -52,10 +52,35 @@ class FeatureExtractor:
                 pass
 
     def load_index(self, file_index):
-        """Index retrieval (faiss) is the first 'next' row of the scope table; without it the reference runs index-free too."""
-        if isinstance(file_index, tuple):
-            return file_index
-        return None, None
+        """(index, big_npy) for feature retrieval (reference :52-73).  Accepts the reference's preloaded tuple, "" (no index),
+        a `.npy` file holding big_npy [N, D] (what `train_index` saves next to the faiss file as total_fea.npy), or a faiss
+        `.index` file when faiss is importable; the search object is always a device-resident exact index (lib/feature_index.py).
+        Errors are printed and turn into "no index", as in the reference."""
+        index = big_npy = None
+        try:
+            if isinstance(file_index, tuple):
+                index, big_npy = file_index
+                if index is not None and not hasattr(index, "search_device") and big_npy is not None:
+                    index = self._device_index(big_npy)          # a faiss object from the caller: keep its vectors, search on the GPU
+            elif file_index == "" or file_index is None:
+                pass
+            elif str(file_index).endswith(".npy"):
+                big_npy = np.load(file_index).astype(np.float32)
+                index = self._device_index(big_npy)
+            else:
+                import faiss   # noqa: PLC0415 - optional, absent offline
+                fidx = faiss.read_index(file_index)
+                big_npy = fidx.reconstruct_n(0, fidx.ntotal)
+                index = self._device_index(big_npy)
+        except Exception as e:   # noqa: BLE001 - reference behaviour
+            print(f"Could not open Faiss index file for reading. {e}")
+            index = big_npy = None
+        return index, big_npy
+
+    def _device_index(self, big_npy):
+        from .lib.feature_index import DeviceIndex   # noqa: PLC0415
+        dev = self.device if str(self.device).startswith("cuda") else "cuda:0"
+        return DeviceIndex(big_npy, device=dev)
 
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):

@@ -55,10 +55,9 @@ class VC(FeatureExtractor):
             feats = feats.mean(-1)
         assert feats.dim() == 1, feats.dim()
         feats = feats.view(1, -1)
-        if index is not None and big_npy is not None and index_rate > 0:
-            raise NotImplementedError("index retrieval (faiss) is a 'next' row of the scope table")
+        use_index = index is not None and big_npy is not None and index_rate > 0
         fused = isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) \
-            and pitch is not None and pitchf is not None
+            and pitch is not None and pitchf is not None and not use_index
         if fused:
             L = feats.shape[1]
             Th = model.num_frames(L)
@@ -83,6 +82,14 @@ class VC(FeatureExtractor):
         dev = self.device
         feats = model.extract_features(version=version, source=feats.to(dev), padding_mask=None, output_layer=9 if version == "v1" else 12)
         feats0 = feats.clone() if (protect < 0.5 and pitch is not None and pitchf is not None) else None
+        if use_index:
+            # nearest training feature per frame, blended in with weight index_rate (reference :60-75)
+            npy = feats[0].cpu().numpy().astype("float32")
+            score, ix = index.search(npy, k=1)
+            weight = np.square(1 / score)
+            weight /= weight.sum(axis=1, keepdims=True)
+            npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
+            feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0).to(feats.device) * index_rate + (1 - index_rate) * feats
         feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
         if feats0 is not None:
             feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
@@ -124,11 +131,14 @@ class VC(FeatureExtractor):
                  filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx,
                  f0_file=None, f0_min=50, f0_max=1600):
         index, big_npy = self.load_index(file_index)
+        use_index = index is not None and big_npy is not None and index_rate > 0
         device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) and if_f0
-                       and index is None and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
+                       and (not use_index or hasattr(index, "blend_device"))
+                       and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
         if device_path:
             return self._pipeline_device(model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius,
-                                         tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max)
+                                         tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max,
+                                         index if use_index else None, index_rate)
         audio = signal.filtfilt(bh, ah, audio)
         opt_ts = self._cut_points(audio)
         s = 0
@@ -174,7 +184,7 @@ class VC(FeatureExtractor):
 
 
 def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
-                     rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max):
+                     rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max, index=None, index_rate=0.0):
     """VC.pipeline with every per-sample stage on the GPU: the zero-phase high-pass, reflect padding and input RMS frames
     (rvc_preprocess), HuBERT on a side stream while RMVPE produces the pitch, the segments synthesised from device-resident
     features, and change_rms + int16 normalisation (reference vc_infer_pipeline.py:182-189) as kernels; only the cut search of
@@ -210,10 +220,17 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
         self._side = torch.cuda.Stream(dev)
     side = self._side if self.overlap_streams else main
     side.wait_stream(main)
-    feats = []
+    feats, feats0 = [], []
     with torch.cuda.stream(side):
         for (b0, b1) in bounds:
-            feats.append(model.extract_features(a_dev[b0:b1].view(1, -1), version=version, channel_major=True))
+            f = model.extract_features(a_dev[b0:b1].view(1, -1), version=version, channel_major=True)
+            if index is not None:
+                # feature retrieval on the device, still on the side stream (reference :60-75); feats0 feeds the protect blend
+                feats0.append(f if protect < 0.5 else None)
+                f = index.blend_device(f.contiguous(), index_rate)
+            else:
+                feats0.append(None)
+            feats.append(f)
     a_dev.record_stream(side)
     _mark("hubert enqueued")
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
@@ -228,7 +245,7 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
     D = 256 if version == "v1" else 768
     outs = []
-    for (b0, b1), f in zip(bounds, feats):
+    for (b0, b1), f, f0c in zip(bounds, feats, feats0):
         Th = f.shape[1]
         T = 2 * Th
         if self.noise_fn is None and not self.noise_on_device:
@@ -242,7 +259,7 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
         assert pc.numel() == T, "pitch track shorter than the feature sequence"
         out = torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
+            _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), _lib.ptr(f0c), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
                                                      float(protect), 1 if protect < 0.5 else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
         outs.append(out[self.t_pad_tgt: out.numel() - self.t_pad_tgt])
     _mark("synth enqueued")
@@ -285,9 +302,14 @@ def get_vc(model_path, file_index=None, config=config, device=None):
     net_g.load_state_dict(cpt["weight"], strict=False)
     net_g.eval()
     vc = VC(tgt_sr, config)
+    # preload the retrieval index (reference :230-246): the dict then carries the (index, big_npy) tuple
     if file_index and os.path.exists(str(file_index)):
-        sys.stdout.write(f"{file_index}: index retrieval is not built yet, continuing without it\n")
-    return {"vc": vc, "cpt": cpt, "net_g": net_g, "model_name": model_name, "file_index": "", "sr": cpt["config"][-1]}
+        sys.stdout.write(f"Attempting to load {file_index}....\n")
+        index, big_npy = vc.load_index(str(file_index))
+        file_index = (index, big_npy) if index is not None else ""
+    else:
+        file_index = ""
+    return {"vc": vc, "cpt": cpt, "net_g": net_g, "model_name": model_name, "file_index": file_index, "sr": cpt["config"][-1]}
 
 
 def vc_single(cpt=None, net_g=None, vc=None, hubert_model=None, sid=0, input_audio=None, input_audio_path=None, f0_up_key=0,

@@ -118,9 +118,24 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
 
 /* Same, starting from HuBERT features that already live on the device (channel-major [feat_dim][T_h]); lets the caller run
  * HuBERT on a second stream while RMVPE produces the pitch. */
-int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm_dev, int64_t T_h, int feat_dim, const int64_t* pitch_dev,
-                         const float* pitchf_dev, int sid, float protect, int do_protect, const float* noise_z_dev,
-                         const float* noise_src_dev, float* out_dev);
+int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm_dev, const float* feats0_cm_dev, int64_t T_h, int feat_dim,
+                         const int64_t* pitch_dev, const float* pitchf_dev, int sid, float protect, int do_protect,
+                         const float* noise_z_dev, const float* noise_src_dev, float* out_dev);
+/* feats0_cm_dev: the features before index retrieval (the reference's feats0 of the protect blend, :58-59,:89-95) or NULL when
+ * no index is used. */
+
+/* ------------------------------------------------------------------ feature retrieval (vc_infer_pipeline.py:60-75) */
+/* The reference looks every HuBERT frame up in a faiss IVF-Flat index over the training features big_npy [N][D]
+ * (index.search(npy, k=1); pitch_extraction.py:52-73 loads it, custom_nodes/rvc_nodes.py:500-554 builds it) and blends the
+ * neighbour in with weight index_rate.  rvc_index_* is the exact L2 nearest-neighbour search over the same big_npy, device
+ * resident: search returns idx [T] (and optionally the squared distances faiss would report), blend writes
+ * out = index_rate * big_npy[idx] + (1 - index_rate) * feats.  Features are channel-major [D][T]. */
+typedef struct rvc_index rvc_index;
+int rvc_index_create(rvc_ctx* ctx, const float* big_npy_host, int64_t N, int D, rvc_index** out);
+int rvc_index_destroy(rvc_index* h);
+int64_t rvc_index_ntotal(const rvc_index* h);
+int rvc_index_search(rvc_index* h, void* stream, const float* feats_cm_dev, int64_t T, int64_t* idx_dev, float* score_dev /* may be NULL */);
+int rvc_index_blend(rvc_index* h, void* stream, const float* feats_cm_dev, const int64_t* idx_dev, int64_t T, float index_rate, float* out_cm_dev);
 /* Input pre-processing of VC.pipeline on the device: the zero-phase 5th-order high-pass (vc_infer_pipeline.py:19,121:
  * scipy.signal.filtfilt(bh, ah, audio) - odd extension by 18 samples, lfilter_zi initial conditions, float64), the reflect
  * padding by t_pad with the float32 cast the networks consume (:141) and the RMS frames of the filtered input that change_rms

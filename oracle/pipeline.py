@@ -107,12 +107,30 @@ def segment_points(audio, c):
     return opt_ts
 
 
+def index_search(npy, big_npy):
+    """Exact k = 1 nearest neighbour in squared L2, the quantity a faiss Flat/IVF-Flat L2 index reports (reference
+    vc_infer_pipeline.py:65; faiss itself is absent offline, its IVF probe approximates this).  float64 distances so that the
+    arg-min is the true one; returns (score float32 [T, 1], ix int64 [T, 1])."""
+    a = np.asarray(npy, dtype=np.float64)
+    b = np.asarray(big_npy, dtype=np.float64)
+    d = (a * a).sum(1)[:, None] - 2.0 * (a @ b.T) + (b * b).sum(1)[None, :]
+    ix = d.argmin(1)
+    return d[np.arange(a.shape[0]), ix].astype(np.float32)[:, None], ix.astype(np.int64)[:, None]
+
+
 def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf, protect, noise_fn, c,
-               n_hubert_layers=None):
-    """VC.vc without index retrieval (reference vc_infer_pipeline.py:25-114)."""
+               n_hubert_layers=None, big_npy=None, index_rate=0.0):
+    """VC.vc (reference vc_infer_pipeline.py:25-114); index retrieval as an exact search over big_npy when given."""
     feats = torch.from_numpy(audio0).float().view(1, -1)
     feats = nets.hubert_extract_features(hubert_sd, feats, version, n_layers=n_hubert_layers)
     feats0 = feats.clone()
+    if big_npy is not None and index_rate > 0:
+        npy = feats[0].numpy().astype("float32")
+        score, ix = index_search(npy, big_npy)
+        weight = np.square(1 / score)
+        weight /= weight.sum(axis=1, keepdims=True)
+        npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
+        feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0) * index_rate + (1 - index_rate) * feats
     feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
     feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
     p_len = min(audio0.shape[0] // c.window, feats.shape[1])
@@ -133,8 +151,8 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
 
 def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up_key=0, f0_method="rmvpe",
              rms_mix_rate=0.25, protect=0.33, f0_autotune=False, noise_fn=None, f0_override=None,
-             x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None):
-    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for if_f0=1, no index, resample_sr=0.
+             x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None, big_npy=None, index_rate=0.0):
+    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for if_f0=1, resample_sr=0; optional exact index retrieval.
 
     audio: 16 kHz mono float32 (already remixed).  Returns int16 [N] at tgt_sr (and the float waveform
     before normalisation if return_float).  f0_override(audio_pad) -> f0 replaces the pitch front-end.
@@ -161,13 +179,13 @@ def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up
         ps = pitch[:, s // c.window: (t + c.t_pad2) // c.window + 1]
         pfs = pitchf[:, s // c.window: (t + c.t_pad2) // c.window + 1]
         out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
-                              n_hubert_layers)[c.t_pad_tgt: -c.t_pad_tgt])
+                              n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
         s = t
     a = audio_pad[t:]
     ps = pitch[:, t // c.window:] if t is not None else pitch
     pfs = pitchf[:, t // c.window:] if t is not None else pitchf
     out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
-                          n_hubert_layers)[c.t_pad_tgt: -c.t_pad_tgt])
+                          n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
     audio_opt = np.concatenate(out)
     if rms_mix_rate < 1:
         audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)

@@ -86,3 +86,70 @@ def test_generic_callee_path_equals_fused_path(models, noise_tape):
         outs.append(vc.vc(m, vcd["net_g"], torch.tensor([0]), audio, pitch, pitchf, [0, 0, 0], None, None, 0.0, "v2", 0.33))
     assert outs[0].shape == outs[1].shape == (T * 400,)
     assert np.max(np.abs(outs[0] - outs[1])) < 1e-5
+
+
+# ------------------------------------------------------------------ feature retrieval
+def _big_npy(hub, n=3000, seed=3):
+    """A synthetic training-feature matrix: HuBERT features of other clips plus jitter (the faiss index's `big_npy`)."""
+    rng = np.random.default_rng(seed)
+    feats = [hub.extract_features(torch.from_numpy(S.synth_audio(2.0, seed=50 + i))[None], version="v2")[0].cpu().numpy() for i in range(4)]
+    base = np.concatenate(feats, 0)
+    rows = base[rng.integers(0, base.shape[0], n)] + 0.05 * rng.standard_normal((n, base.shape[1])).astype(np.float32)
+    return np.ascontiguousarray(rows, dtype=np.float32)
+
+
+def test_device_index_search_and_blend_match_brute_force(models):
+    from comfy_rvc_amd.lib.feature_index import DeviceIndex
+    from oracle.pipeline import index_search
+    hub, _, _ = models
+    big = _big_npy(hub, n=40000)                   # > one 32768-row chunk: exercises the running arg-max across chunks
+    q = hub.extract_features(torch.from_numpy(S.synth_audio(1.5, seed=9))[None], version="v2")[0].cpu().numpy()
+    idx = DeviceIndex(big)
+    score, ix = idx.search(q, k=1)
+    rscore, rix = index_search(q, big)
+    same = ix[:, 0] == rix[:, 0]
+    # a different row may only win on a numerical tie of the two distances
+    d_other = ((q[~same].astype(np.float64) - big[ix[~same, 0]].astype(np.float64)) ** 2).sum(1)
+    assert same.mean() > 0.99 and np.allclose(d_other, rscore[~same, 0], rtol=1e-5)
+    assert np.allclose(score[:, 0], rscore[:, 0], rtol=2e-4, atol=1e-4)
+    f_cm = torch.from_numpy(q).cuda().t().contiguous()
+    out = idx.blend_device(f_cm, 0.75).t().cpu().numpy()
+    ref = big[ix[:, 0]] * 0.75 + 0.25 * q
+    assert np.max(np.abs(out - ref)) < 1e-5
+    # exact members of the index are found with distance ~0 (the reference's 1/score^2 weight then degenerates; behaviour kept)
+    s2, i2 = idx.search(big[[5, 39999]], k=1)
+    assert list(i2[:, 0]) == [5, 39999] and np.all(np.abs(s2) < 1e-2)
+
+
+def test_pipeline_with_index_matches_oracle(models, noise_tape):
+    """vc_single with a retrieval index (device path: search + blend on the side stream, feats0 into the protect blend) against
+    the CPU oracle with its brute-force search; also the generic VC.vc path with the faiss-like search() surface."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.feature_index import DeviceIndex
+    from comfy_rvc_amd.vc_infer_pipeline import VC, vc_single
+    from oracle import pipeline as opl
+    hub, vcd, rm = models
+    big = _big_npy(hub)
+    audio = S.synth_audio(2.0, seed=21)
+    f0fn = lambda x, **k: S.designed_f0(x.shape[0] // 160 + 1, seed=0).astype(np.float64)   # noqa: E731
+    g = torch.Generator().manual_seed(11)
+    tape = []
+
+    def rec(shape):
+        t = torch.randn(shape, generator=g); tape.append(t); return t
+    ref = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0), S.CONFIG_40K_V2, "v2", audio,
+                       rms_mix_rate=0.25, protect=0.33, noise_fn=rec, f0_override=f0fn, big_npy=big, index_rate=0.75)
+    vc = VC(40000, Config())
+    vc.model_rmvpe = rm
+    vc.f0_method_dict["pm"] = f0fn
+    it = iter(tape)
+    vc.noise_fn = lambda shape: next(it)
+    out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
+                    file_index=(DeviceIndex(big), big), index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
+    assert out is not None and out[0].shape == ref.shape
+    assert np.max(np.abs(out[0].astype(np.int32) - ref.astype(np.int32))) <= LSB
+    # without the index the result is different (the blend is really applied)
+    it = iter(tape)
+    out0 = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
+                     file_index="", index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
+    assert np.max(np.abs(out0[0].astype(np.int32) - ref.astype(np.int32))) > 10 * LSB
