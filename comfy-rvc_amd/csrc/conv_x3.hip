@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
         }
       }
   } else if (p.ostride == 1) {
-    dense_epilogue<WM, WN, AM, AN>(p, acc, z, co0, n0, wm, wn, li, lh);
+    dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(p, acc, z, co0, n0, wm, wn, li, lh);
   } else {
     // interleaved store of the ConvTranspose1d phases: row m = phase * orows + co goes to Y[co][n * ostride + phase]
     const float* __restrict__ bias = p.bias;
