@@ -19,9 +19,29 @@ def main():
         assert P.shard_indices(5) == list(range(rank, 5, world))
         res = P.convert_clips(clips, lambda c: (c * 3).astype(np.int16)[: c.shape[0] - rank], device="cpu")
         single = P.gather_waveforms(np.arange(10 + rank, dtype=np.int16), "cpu")
+        # training-prep feature dump: files are sharded rank::world with no collective (stub network: host logic only)
+        import torch
+        from scipy.io import wavfile
+        from comfy_rvc_amd.preprocessing_utils import FeatureInput
+        d = os.path.dirname(sys.argv[1])
+
+        class Stub:
+            def extract_features(self, version, source, **kw):
+                return torch.full((1, source.shape[1] // 320, 768), float(rank))
         if rank == 0:
+            for i in range(5):
+                wavfile.write(os.path.join(d, f"c{i}.wav"), 16000, np.zeros(3200 * (i + 1), dtype=np.int16))
+        dist.barrier()
+        paths = [(os.path.join(d, f"c{i}.wav"), os.path.join(d, f"a{i}"), os.path.join(d, f"b{i}"), os.path.join(d, f"f{i}")) for i in range(5)]
+        fi = FeatureInput(Stub(), "rmvpe", None, device="cpu", version="v2", if_f0=False)
+        n_done = fi.go(paths)
+        assert n_done == len(range(rank, 5, world))
+        dist.barrier()
+        if rank == 0:
+            owners = [int(np.load(os.path.join(d, f"f{i}.npy"))[0, 0]) for i in range(5)]
+            shapes = [list(np.load(os.path.join(d, f"f{i}.npy")).shape) for i in range(5)]
             with open(sys.argv[1], "w") as f:
-                json.dump({"res": [r.tolist() for r in res], "single": [s.tolist() for s in single]}, f)
+                json.dump({"res": [r.tolist() for r in res], "single": [s.tolist() for s in single], "owners": owners, "shapes": shapes}, f)
         else:
             assert res is None and single is None
     finally:

@@ -29,3 +29,6 @@ def test_shard_and_gather_world2(tmp_path):
         n = 100 + 37 * i - (i % 2)          # odd clips were converted by rank 1, which trims one sample
         assert wav == [3 * i] * n
     assert r["single"] == [list(range(10)), list(range(11))]
+    # feature dump: clip i was written by rank i mod 2, every file exactly once, [T_h, 768] each
+    assert r["owners"] == [0, 1, 0, 1, 0]
+    assert r["shapes"] == [[10 * (i + 1), 768] for i in range(5)]
