@@ -28,6 +28,7 @@ import torch         # noqa: E402
 CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
+HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
 def cpu_baseline(seconds=3.0):
@@ -123,6 +124,10 @@ def main():
         torch.cuda.synchronize()
         NCFG = 24   # RVC_PROF_CFGS
         ms = (C.c_double * NCFG)(); fl = (C.c_double * NCFG)(); ln = (C.c_int64 * NCFG)()
+        ex = (C.c_double * (NCFG * 8))()
+        ridge_f32 = FP32_MFMA_PEAK_TFLOPS * 1e12 / HBM_PEAK_BPS
+        ridge_x3 = BF16_MFMA_PEAK_TFLOPS / 3.0 * 1e12 / HBM_PEAK_BPS
+        _lib.check(_lib.lib.rvc_prof_collect_ex(ex, ridge_f32, ridge_x3))
         _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
         _lib.check(_lib.lib.rvc_prof_enable(0))
         vc.overlap_streams = True
@@ -136,26 +141,38 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
 
-        def family(idx, kernel, desc, peak, note):
-            t, f_, l_ = sum(ms[i] for i in idx), sum(fl[i] for i in idx), sum(ln[i] for i in idx)
+        def family(idx, regime, kernel, desc, peak_tf, note):
+            """One roofline entry: the launches of a kernel family in one regime (0: MFMA-bound, 4: HBM-bound by arithmetic intensity)."""
+            t = sum(ex[i * 8 + regime] for i in idx); f_ = sum(ex[i * 8 + regime + 1] for i in idx)
+            by = sum(ex[i * 8 + regime + 2] for i in idx); l_ = sum(ex[i * 8 + regime + 3] for i in idx)
             if l_ == 0:
                 return None
-            ach = f_ / (t * 1e-3) / 1e12
             tr = traffic.get(kernel)
-            return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                    "traffic_note": None if tr is None else "HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
-                                                            "(profiles/r1_pmc_traffic.json, tools/pmc_traffic.py)",
-                    "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
-                    "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "kernel_ms_per_clip": round(t, 2),
-                    "algorithmic_tflop_per_clip": round(f_ / 1e12, 3)}
-        r_x3 = family(range(14, NCFG), "rvc::conv_x3_kernel",
-                      "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)",
-                      round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product")
-        r_f32 = family(range(0, 14), "rvc::conv_mfma_kernel",
-                       "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak")
-        fams = [r for r in (r_x3, r_f32) if r]
-        fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant kernel = the one with the most time per clip
+            e = {"bound": "mfma" if regime == 0 else "hbm"}
+            if regime == 0:
+                ach = f_ / (t * 1e-3) / 1e12
+                e.update({"achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4)})
+            else:
+                ach = by / (t * 1e-3) / 1e9
+                e.update({"achieved": round(ach, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(ach / (HBM_PEAK_BPS / 1e9), 4)})
+            e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                      "traffic_note": None if tr is None else "HBM bytes per launch averaged over ALL launches of this kernel: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                                                              "WRITE_SIZE, separate passes (profiles/r1_pmc_traffic.json, tools/pmc_traffic.py)",
+                      "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
+                      "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "algorithmic_mbytes_per_launch": round(by / l_ / 1e6, 2),
+                      "kernel_ms_per_clip": round(t, 2), "algorithmic_tflop_per_clip": round(f_ / 1e12, 3)})
+            return e
+        X3 = "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)"
+        F32 = "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)"
+        x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+        split_note = ("launches are split by arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the ridge peak FLOP/s / 8 TB/s: "
+                      "this entry holds the %s-bound ones")
+        fams = [family(range(14, NCFG), 0, "rvc::conv_x3_kernel", X3, x3_peak, "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product; " + split_note % "MFMA"),
+                family(range(14, NCFG), 4, "rvc::conv_x3_kernel", X3, x3_peak, "HBM 8 TB/s; " + split_note % "HBM"),
+                family(range(0, 14), 0, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak; " + split_note % "MFMA"),
+                family(range(0, 14), 4, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "HBM 8 TB/s; " + split_note % "HBM")]
+        fams = [r for r in fams if r]
+        fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant entry = the one with the most kernel time per clip
         roofline = fams[0]
         roofline["per_tile_config"] = per_cfg
         roofline["other_kernels"] = fams[1:]

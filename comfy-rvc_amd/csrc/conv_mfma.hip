@@ -602,7 +602,7 @@ TileCfg choose_tile(int M, long long N, int batch) {
 }
 
 // ---------------------------------------------------------------------------- optional per-launch profiling (HIP events)
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; };
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
@@ -632,10 +632,33 @@ ProfTicket conv_prof_begin(hipStream_t s) {
   if (t.on) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); (void)hipEventRecord(t.a, s); }
   return t;
 }
-void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg) {
+void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes) {
   if (!t.on) return;
   (void)hipEventRecord(t.b, s);
-  g_prof.push_back(ProfRec{t.a, t.b, flops, cfg});
+  g_prof.push_back(ProfRec{t.a, t.b, flops, cfg, bytes});
+}
+// algorithmic HBM bytes of one launch: input + output (+ residual, + previous output when accumulating) + weights, fp32
+double conv_alg_bytes(const ConvArgsX& a, int batch) {
+  const double in = (double)a.Ci * (a.Wd > 0 ? (double)a.Tin * a.Wd : (double)a.Tin);
+  const double out = (double)a.Co * a.Tout;
+  const double w = (double)a.Co * a.Ci * (a.kreal > 0 ? a.kreal : a.ktaps);
+  return 4.0 * (batch * (in + out * (1.0 + (a.R ? 1.0 : 0.0) + (a.accumulate ? 1.0 : 0.0))) + w);
+}
+// Per kernel configuration and roofline regime.  A launch counts as HBM-bound when its arithmetic intensity is below the ridge of
+// its kernel (peak FLOP/s / 8 TB/s): out[cfg][0..3] = {ms, flops, bytes, launches} of the MFMA-bound launches, [4..7] of the
+// HBM-bound ones.
+int conv_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) {
+  for (int i = 0; i < kProfCfgs * 8; ++i) out[i] = 0;
+  for (auto& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    const double ridge = r.cfg >= 14 ? ridge_x3 : ridge_fp32;
+    const int o = (r.bytes > 0 && r.flops / r.bytes < ridge) ? 4 : 0;
+    double* q = out + r.cfg * 8 + o;
+    q[0] += t; q[1] += r.flops; q[2] += r.bytes; q[3] += 1;
+  }
+  return (int)g_prof.size();
 }
 int tile_cfg_id(const TileCfg& t) {
   static const TileCfg all[7] = {{1, 4, 1, 4}, {1, 4, 1, 2}, {1, 4, 1, 1}, {2, 2, 2, 2}, {2, 2, 1, 4}, {2, 2, 1, 2}, {2, 2, 1, 1}};
@@ -721,7 +744,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
       (void)total;
       splitk_reduce_launch(a, S, batch, s);
     }
-    conv_prof_end(rec, s, flops, cfg_id);
+    conv_prof_end(rec, s, flops, cfg_id, conv_alg_bytes(a, batch));
   };
 #define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
   if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \

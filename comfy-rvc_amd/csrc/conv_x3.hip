@@ -410,7 +410,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
   }
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
-  conv_prof_end(tk, s, flops, 14 + id);
+  conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch));
   return true;
 }
 

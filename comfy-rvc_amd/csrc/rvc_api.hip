@@ -334,6 +334,7 @@ int rvc_prof_collect(double* ms, double* flops, int64_t* launches) {
   for (int i = 0; i < RVC_PROF_CFGS; ++i) launches[i] = l[i];
   RVC_CATCH
 }
+int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) { RVC_TRY conv_prof_collect_ex(out, ridge_fp32, ridge_x3); RVC_CATCH }
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 

@@ -192,6 +192,10 @@ int rvc_set_conv_precision(int mode);
 #define RVC_PROF_CFGS 24
 int rvc_prof_enable(int on);
 int rvc_prof_collect(double* ms, double* flops, int64_t* launches);
+/* Same records split by roofline regime: out[cfg][0..3] = {ms, FLOPs, algorithmic HBM bytes, launches} of the launches whose
+ * arithmetic intensity (FLOP per algorithmic byte: input + output + residual / accumulate operands + weights) is at or above the
+ * given ridge (peak FLOP/s over peak HBM B/s of the kernel family), out[cfg][4..7] of those below it.  RVC_PROF_CFGS * 8 doubles. */
+int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_bf16x3);
 const char* rvc_prof_cfg_name(int i);
 /* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
 int rvc_debug_conv_timing(uint64_t* out8, int reset);
