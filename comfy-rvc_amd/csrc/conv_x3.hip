@@ -366,8 +366,11 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   int NC = a.ktaps == 1 ? 4 : (a.ktaps <= 3 ? 2 : 1);
   while (NC > 1 && (nchunk % NC != 0 || (NC * 2 * a.ni + 3) / 4 > x3_slots(BN))) NC >>= 1;
   if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
-  // LDS budget: <= 80 KiB per workgroup (two workgroups per CU); X double-buffered when that still leaves >= 2 taps per stage
-  const int budget = 80 * 1024;
+  // LDS budget per workgroup: 53 KiB = three workgroups per CU for the tiles whose registers allow it (<= 170 VGPRs), two for the
+  // 8-accumulator tiles.  Measured: occupancy matters more than stage length (one 156 KiB workgroup per CU with 3x longer stages:
+  // +32 % time; three 128x128 workgroups instead of two: -12 %).  X double-buffered when that still leaves >= 2 taps per stage.
+  static const int budget_kb = getenv("RVC_X3_LDS_KB") ? atoi(getenv("RVC_X3_LDS_KB")) : 53;
+  const int budget = budget_kb * 1024;
   int xbufs = 2, xbytes = 0, ktmax = 0;
   for (;;) {
     const int per_tap = 2 * NC * 2 * BM * 32;               // two buffers x NC chunks x {hi, lo} x BM rows x 32 B
