@@ -154,7 +154,6 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
     const size_t mark = A.off;
     float* qk = A.alloc<float>((size_t)1536 * T);
     float* vr = A.alloc<float>((size_t)T * 768);
-    float* Sc = A.alloc<float>((size_t)12 * T * T);
     float* attn = A.alloc<float>((size_t)768 * T);
     float* ff = A.alloc<float>((size_t)3072 * T);
     if (!dry) {
@@ -164,9 +163,8 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
         if (taps && l == 8) tap(taps->hidden_8, h, (size_t)768 * T);
         conv1d_run(Y.qk, s, h, T, T, qk, T, E0);
         gemm_tn_run(s, h, T, 0, Y.wvT.p, 768, 0, vr, 768, 0, T, 768, 768, 1, nullptr, 0, E0);
-        gemm_tn_run(s, qk + (size_t)768 * T, T, 64LL * T, qk, T, 64LL * T, Sc, T, (long long)T * T, T, T, 64, 12, nullptr, 0, E0);
-        softmax_cols(s, Sc, T, T, T, (long long)T * T, 12, nullptr, 0, 0, nullptr, 0);
-        gemm_tn_run(s, vr, 768, 64, Sc, T, (long long)T * T, attn, T, 64LL * T, 64, T, T, 12, Y.bv.p, 64, E0);
+        // softmax(K^T Q) V + bv without materialising the [12][T][T] scores (attention.hip)
+        attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, attn, T, 12, 64, T);
         ConvEpilogue Er; Er.R = h; Er.ldR = T;
         conv1d_run(Y.o, s, attn, T, T, hb, T, Er);
         layernorm_c(s, hb, nullptr, Y.g1.p, Y.b1.p, h, 768, T, T, 1e-5f);

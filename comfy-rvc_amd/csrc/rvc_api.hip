@@ -294,6 +294,12 @@ int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x, int Ti
   RVC_CATCH
 }
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
+int rvc_op_attention(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, float* out, int heads, int T) {
+  RVC_TRY
+  attention_fused((hipStream_t)stream, q, k, T, v_rm, (long long)heads * 64, bv, out, T, heads, 64, T);
+  check_launch();
+  RVC_CATCH
+}
 int rvc_op_layernorm_c(void* stream, const float* x, const float* res, const float* gamma, const float* beta, float* y, int C, int T) {
   RVC_TRY
   layernorm_c((hipStream_t)stream, x, res, gamma, beta, y, C, T, T, 1e-5f);

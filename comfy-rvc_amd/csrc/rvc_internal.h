@@ -112,6 +112,10 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
                 const ConvEpilogue& e);
 
+// fused multi-head attention (attention.hip): Q, K channel-major [heads*64][T], V row-major [T][heads*64], out channel-major
+void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
+                     float* out, long long ldo, int heads, int dhead, int T);
+
 // per-launch HIP-event profiling of the conv kernels (bench.py's roofline leg)
 void conv_prof_enable(bool on);
 int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of RVC_PROF_CFGS (tile configuration x {fp32 1-D, fp32 2-D, bf16x3})

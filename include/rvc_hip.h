@@ -172,6 +172,10 @@ int rvc_conv1d_plan_create(const float* w_host, const float* bias_host, int Ci, 
 int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x_dev, int Tin, const float* res_dev, float* y_dev, int pre_act,
                         float pre_slope, int act, float act_slope);
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
+/* fused softmax(K^T Q) V + bias for head dimension 64: q_dev, k_dev channel-major [heads*64][T] (q pre-scaled), v_rm_dev row-major
+ * [T][heads*64], bv_dev [heads*64] or NULL, out_dev channel-major [heads*64][T] */
+int rvc_op_attention(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, float* out_dev,
+                     int heads, int T);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                        int C, int T);
 /* optional debug outputs: rad_dev [T] per-frame phase increment, tmp_dev [T] scaled frame cumsum, phase_dev [T*upp] running phase (cycles) */

@@ -1,5 +1,6 @@
 """GPU parity of the single HIP ops (through the C ABI) against the same torch-CPU fp32 ops the oracle is built from."""
 import ctypes as C
+import zlib
 
 import numpy as np
 import pytest
@@ -53,7 +54,7 @@ CONV1D = [
 @pytest.mark.parametrize("case", CONV1D, ids=[f"c{i}" for i in range(len(CONV1D))])
 def test_conv1d(L, case):
     Ci, Co, T, k, s, pad, dil, groups, pre, act, res, scale, accum = case
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)     # (hash() of a tuple with strings changes per process)
     x = torch.randn(Ci, T, generator=g)
     w = torch.randn(Co, Ci // groups, k, generator=g) / np.sqrt(Ci // groups * k)
     b = torch.randn(Co, generator=g) * 0.1
@@ -108,7 +109,7 @@ def test_conv1d_bf16x3(L, case):
     """bf16x3 split-MFMA Conv1d (conv_x3.hip) against an fp64 torch reference: error of a few 1e-6, far inside the 1e-3 budget."""
     Ci, Co, T, k, pad, dil, pre, act, res, scale, accum = case[:11]
     stride = case[11] if len(case) > 11 else 1
-    g = torch.Generator().manual_seed(hash(case) % 10000)
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)     # (hash() of a tuple with strings changes per process)
     x = torch.randn(Ci, T, generator=g)
     w = torch.randn(Co, Ci, k, generator=g) / np.sqrt(Ci * k)
     b = torch.randn(Co, generator=g) * 0.1
@@ -144,7 +145,7 @@ def test_conv1d_bf16x3(L, case):
                                     pad, dil, 1, ACT[pre], 0.1, ACT[act], 0.1, 0, scale, int(accum)))
     finally:
         L.check(L.lib.rvc_set_conv_precision(1))
-    assert rel_err(y32.cpu().double(), ref) < 2e-6
+    assert rel_err(y32.cpu().double(), ref) < 4e-6
 
 
 TCONV1D = [(512, 256, 30, 16, 10, 3), (64, 32, 100, 4, 2, 1), (128, 64, 33, 24, 12, 6), (256, 128, 40, 20, 10, 5)]
@@ -255,6 +256,24 @@ def test_gemm_tn(L, case):
     L.check(L.lib.rvc_op_gemm_tn(None, L.ptr(ad), L.ptr(bd), L.ptr(y), M, N, K, B))
     torch.cuda.synchronize()
     assert rel_err(y.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("heads,T", [(12, 1599), (12, 100), (3, 64), (2, 777)])
+def test_fused_attention(L, heads, T):
+    """softmax(K^T Q) V + bias without the score matrix (attention.hip) against torch's attention in float64."""
+    g = torch.Generator().manual_seed(23)
+    D = 64
+    q = torch.randn(heads * D, T, generator=g) * 0.35          # pre-scaled queries, logits of a few units like HuBERT's
+    k = torch.randn(heads * D, T, generator=g)
+    v = torch.randn(T, heads * D, generator=g)
+    bv = torch.randn(heads * D, generator=g) * 0.1
+    qh = q.double().view(heads, D, T); kh = k.double().view(heads, D, T); vh = v.double().view(T, heads, D).permute(1, 0, 2)
+    p = torch.softmax(torch.einsum("hdq,hdk->hqk", qh, kh), dim=-1)
+    ref = torch.einsum("hqk,hkd->hdq", p, vh).reshape(heads * D, T) + bv.double()[:, None]
+    out, qd, kd, vd, bd = torch.empty(heads * D, T, device="cuda"), dev(q), dev(k), dev(v), dev(bv)
+    L.check(L.lib.rvc_op_attention(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), L.ptr(out), heads, T))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().double(), ref) < 2e-5
 
 
 def test_layernorm_channels(L):
