@@ -371,11 +371,14 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s) {
 // ============================================================================ host side
 #ifdef RVC_CONV_TIMING
 void conv_x3_timing_read(unsigned long long* out8, bool reset);
+void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 8);
   if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof(z)); }
   unsigned long long x3[8]; conv_x3_timing_read(x3, reset);
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  attention_timing_read(x3, reset);
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
 }
 #else
