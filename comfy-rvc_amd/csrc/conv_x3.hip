@@ -350,7 +350,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
-  if (nblk < min_blk) return false;                       // under-filled grids go to the fp32 kernel's split-K path
+  static const int min_blk2d = getenv("RVC_X3_MINBLK2D") ? atoi(getenv("RVC_X3_MINBLK2D")) : 20;   // deep U-Net levels: bf16x3 + split-K beats fp32 + split-K
+  if (nblk < (a.Wd > 0 ? min_blk2d : min_blk)) return false;   // under-filled grids go to the fp32 kernel's split-K path
   static const int x3_split_blk = getenv("RVC_X3_SPLITK_BLK") ? atoi(getenv("RVC_X3_SPLITK_BLK")) : 600;
   int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1;
   if (a.Wd > 0) {
@@ -389,11 +390,13 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   // reduction over S workgroups shortens the chain and puts more of them on a CU; partials are reduced in a fixed order
   int S = 1;
   // (measured on the HuBERT projections: K = 3072 203 -> 120 us, K = 768 unchanged or worse: only deep reductions are split)
-  if (x3_split_blk > 0 && a.ostride == 1 && a.Wd == 0 && a.ktaps == 1 && a.Ci >= 2048 && nblk < x3_split_blk) {
+  static const int split_blk2d = getenv("RVC_X3_SPLITK_BLK2D") ? atoi(getenv("RVC_X3_SPLITK_BLK2D")) : 400;
+  const int split_blk = a.Wd > 0 ? split_blk2d : x3_split_blk;
+  if (split_blk > 0 && a.ostride == 1 && ((a.Wd == 0 && a.ktaps == 1 && a.Ci >= 2048) || (a.Wd > 0 && a.Ci >= 64)) && nblk < split_blk) {
     const int ngroups = nchunk / NC;
-    S = (int)((2LL * x3_split_blk + nblk - 1) / nblk);
+    S = (int)((2LL * split_blk + nblk - 1) / nblk);
     if (S > 8) S = 8;
-    if (S > ngroups / 3) S = ngroups / 3;
+    if (S > ngroups / (a.Wd > 0 ? 1 : 3)) S = ngroups / (a.Wd > 0 ? 1 : 3);
     if (S < 1) S = 1;
     while (S > 1 && ((ngroups + S - 1) / S) * (S - 1) >= ngroups) --S;
   }
