@@ -429,7 +429,7 @@ static void upload_layer(ConvLayer& L, const std::vector<float>& packed, const f
   L.bd_ = bias ? dev_upload(bias, nbias) : nullptr;
 }
 
-void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); L.Wd_ = L.bd_ = nullptr; L.Wx_ = nullptr; }
+void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); dev_free(L.bd4_); L.Wd_ = L.bd_ = L.bd4_ = nullptr; L.Wx_ = nullptr; }
 
 // bf16x3 weight image (conv_x3.hip): every fp32 weight is split w = hi + lo (both bf16, round-to-nearest-even) and stored
 // [16-channel chunk][tap][hi|lo][CoPx rows][16 channels] with the two 8-channel halves of a row swapped when bit 3 of the row
@@ -574,6 +574,40 @@ void tconv2d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci,
                   w[(((size_t)ci * Co + co) * 3 + kh) * 3 + kw];
             }
   upload_layer(L, P, bias, Co);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0) {
+    // bf16x3 path: the same phase-major 3x3 convolution as a dense launch (split-K capable) into a [4 Co][H W] scratch, followed
+    // by a phase interleave; needs the weights as [4 Co][Ci][9] and the bias once per phase row
+    std::vector<float> Weq((size_t)4 * Co * Ci * 9, 0.f);
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int co = 0; co < Co; ++co)
+          for (int ci = 0; ci < Ci; ++ci)
+            for (int dh = 0; dh < 2; ++dh)
+              for (int dw = 0; dw < 2; ++dw) {
+                const int kh = a + 1 - 2 * dh, kw = b + 1 - 2 * dw;
+                if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+                Weq[(((size_t)(a * 2 + b) * Co + co) * Ci + ci) * 9 + (dh + 1) * 3 + (dw + 1)] = w[(((size_t)ci * Co + co) * 3 + kh) * 3 + kw];
+              }
+    pack_x3(L, Weq.data(), 4 * Co, Ci, 9);
+    if (bias) {
+      std::vector<float> b4((size_t)4 * Co);
+      for (int ph = 0; ph < 4; ++ph) for (int co = 0; co < Co; ++co) b4[(size_t)ph * Co + co] = bias[co];
+      L.bd4_ = dev_upload(b4.data(), b4.size());
+    }
+  }
+}
+
+// out[co][2h + a][2w + b] = ph[(a * 2 + b) * Co + co][h][w]
+__global__ void interleave2x2_kernel(const float* __restrict__ ph, float* __restrict__ out, int Co, int H, int Wd) {
+  const long long n = (long long)Co * H * Wd * 4;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  const int W2 = 2 * Wd; const long long plane = (long long)4 * H * Wd;
+  for (; i < n; i += st) {
+    const int co = (int)(i / plane); const long long rem = i - (long long)co * plane;
+    const int y = (int)(rem / W2), x = (int)(rem - (long long)y * W2);
+    out[i] = ph[((long long)((y & 1) * 2 + (x & 1)) * Co + co) * ((long long)H * Wd) + (long long)(y >> 1) * Wd + (x >> 1)];
+  }
 }
 
 // ---------------------------------------------------------------------------- launch
@@ -855,6 +889,18 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   a.xBatch = 0; a.wBatch = 0; a.yBatch = 0; a.rBatch = 0; a.bBatch = 0;
   const double flops = 2.0 * H * (double)Wd * 9 * L.Ci * (L.up2 ? L.co_real : L.Co);
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = 9;
+  if (L.up2 && L.Wx_ && !e.R && !e.accumulate) {
+    // ConvTranspose2d on the bf16x3 kernel: dense phase-major rows, then the 2x2 interleave
+    ConvArgsX d = a;
+    float* tmp = (float*)stream_scratch(s, 4, (size_t)L.Co * H * Wd * sizeof(float));
+    d.Y = tmp; d.ldY = (long long)H * Wd; d.up2 = 0; d.orows = L.Co; d.bias = L.bd4_;
+    if (conv_x3_try(d, 1, s, flops)) {
+      const long long n = (long long)L.Co * H * Wd;
+      int blocks = (int)((n + 255) / 256); if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(interleave2x2_kernel, dim3(blocks), dim3(256), 0, s, tmp, Y, L.co_real, H, Wd);
+      return;
+    }
+  }
   if (!(L.Wx_ && !L.up2 && conv_x3_try(a, 1, s, flops))) run_conv(a, 2, 1, s, flops);
 }
 

@@ -64,6 +64,7 @@ struct ConvArgs {
 struct ConvLayer {
   float* Wd_ = nullptr;    // packed weights (device)
   float* bd_ = nullptr;    // bias (device) or null
+  float* bd4_ = nullptr;   // ConvTranspose2d on the bf16x3 path: bias repeated per output phase
   int mode = 1;            // 1: 1-D, 2: 2-D 3x3
   int Ci = 0, Co = 0, CoP = 0, groups = 1;
   int k = 1, stride = 1, dil = 1, pad = 0;

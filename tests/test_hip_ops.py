@@ -245,6 +245,29 @@ def test_conv_transpose2d(L, case):
     assert rel_err(y.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(512, 256, 101, 4), (256, 128, 202, 8), (128, 64, 404, 16), (64, 32, 808, 32), (32, 16, 1616, 64)])
+def test_conv_transpose2d_bf16x3(L, case):
+    """RMVPE decoder up-convolutions on the bf16x3 kernel: dense phase-major 3x3 conv (split-K on the deep levels) + 2x2 interleave."""
+    Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(Ci, H, W, generator=g)
+    w = torch.randn(Ci, Co, 3, 3, generator=g) / np.sqrt(Ci * 9 / 4)
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x.double()[None], w.double(), b.double(), stride=2, padding=1, output_padding=1)[0])
+    y, xd, wc, bc = torch.empty(Co, 2 * H, 2 * W, device="cuda"), dev(x), w.contiguous().numpy(), b.numpy()
+    ms = (C.c_double * 24)(); fl = (C.c_double * 24)(); ln = (C.c_int64 * 24)()
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_op_conv_transpose2d(None, L.ptr(xd), L.ptr(wc), L.ptr(bc), L.ptr(y), Ci, Co, H, W, 1))
+        L.check(L.lib.rvc_prof_collect(ms, fl, ln))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert sum(ln[14:24]) == 1 and sum(ln[:14]) == 0, "the launch did not go through conv_x3_kernel"
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("case", [(49, 49, 64, 12), (64, 49, 49, 12), (100, 192, 192, 1), (1536, 70, 384, 1), (96, 333, 333, 2), (333, 333, 96, 2)])
 def test_gemm_tn(L, case):
     M, N, K, B = case
