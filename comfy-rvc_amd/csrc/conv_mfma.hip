@@ -543,7 +543,7 @@ void conv2d3x3_layer_init(ConvLayer& L, const float* w, const float* bias, int C
         P[(((size_t)chunk * 9 + u) * L.CK + vcc) * L.CoP + co] = w[((size_t)co * Ci + ci) * 9 + u];
       }
   upload_layer(L, P, bias, Co);
-  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0 && Co >= 16) pack_x3(L, w, Co, Ci, 9);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0) pack_x3(L, w, Co, Ci, 9);
 }
 
 void conv2d1x1_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci) {
