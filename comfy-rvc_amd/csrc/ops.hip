@@ -492,14 +492,22 @@ __global__ __launch_bounds__(1024) void sine_frame_kernel(const float* __restric
 }
 
 __device__ __forceinline__ float sine_interp(const float* __restrict__ tmp, int T, float scale, long long i) {
-  const float src = scale * (float)i;
+  // torch's CPU upsample evaluates, each step rounded to float32 on its own:
+  //   src = scale * i;  l1 = src - floor(src);  l0 = 1 - l1;  v = fma(l0, in0, fl(l1 * in1))
+  // On flat (unvoiced) stretches the last-bit jitter of this expression is what trips the reference's wrap detector, and on a
+  // 40 s segment thousands of its decisions change if `src - i0` is taken from the unrounded product, so the exact rounding
+  // sequence is part of the algorithm.  hipcc contracts a * b - c into an fma even through __fmul_rn / __fsub_rn (they are plain
+  // operators in the HIP headers): contraction is switched off for this function and the product is pinned in a register.
+#pragma clang fp contract(off)
+  float src = scale * (float)i;
+  asm volatile("" : "+v"(src));
   int i0 = (int)src;
   const int i1 = i0 + (i0 < T - 1 ? 1 : 0);
   float l1 = src - (float)i0; l1 = fminf(fmaxf(l1, 0.f), 1.f);
   const float l0 = 1.f - l1;
-  // torch's CPU upsample evaluates fma(w0, in0, fl(w1 * in1)); on flat (unvoiced) stretches the last-bit jitter of this
-  // expression is what trips the reference's wrap detector, so the exact rounding sequence is part of the algorithm.
-  const float v = __fmaf_rn(l0, tmp[i0], __fmul_rn(l1, tmp[i1]));
+  float p1 = l1 * tmp[i1];
+  asm volatile("" : "+v"(p1));
+  const float v = __builtin_fmaf(l0, tmp[i0], p1);
   return fmodf(v, 1.f);
 }
 __device__ __forceinline__ float sine_incr(const float* __restrict__ rad, const float* __restrict__ tmp, int T, int upp, float scale, long long i) {

@@ -310,6 +310,29 @@ def test_layernorm_channels(L):
     assert rel_err(y.cpu(), ref) < 1e-5
 
 
+def test_sine_source_phase_is_exact_on_a_long_segment(L):
+    """41 s segment: the running phase (cycles) must equal torch's sample for sample.  The wrap detector of SineGen reacts to single
+    ulps of the interpolated frame phase; with `scale * i - floor` contracted into an fma the device made ~8000 different (integer)
+    wrap decisions over this segment and the fp32 sine argument lost 3e-3 of accuracy - found on a 45 s clip, 54 LSB end to end."""
+    from comfy_rvc_amd import synthetic as S
+    T, upp, sr = 4100, 400, 40000
+    f0 = torch.from_numpy(S.designed_f0(T, seed=0)).view(1, T)
+    f = f0[:, None].transpose(1, 2)
+    rad = (f / sr) % 1
+    tmp = torch.cumsum(rad, 1); tmp *= upp
+    tmpi = F.interpolate(tmp.transpose(2, 1), scale_factor=float(upp), mode="linear", align_corners=True).transpose(2, 1)
+    radu = F.interpolate(rad.transpose(2, 1), scale_factor=float(upp), mode="nearest").transpose(2, 1)
+    tm1 = tmpi % 1
+    shift = torch.zeros_like(radu); shift[:, 1:, :] = ((tm1[:, 1:, :] - tm1[:, :-1, :]) < 0) * -1.0
+    c = torch.cumsum(radu + shift, dim=1)[0, :, 0]
+    N = T * upp
+    har, sine, ph = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    fd, nd = dev(f0.view(-1)), torch.zeros(N, device="cuda")
+    L.check(L.lib.rvc_op_sine_source(None, L.ptr(fd), L.ptr(nd), L.ptr(har), L.ptr(sine), T, upp, float(sr), 0.9, 0.01, None, None, L.ptr(ph)))
+    torch.cuda.synchronize()
+    assert torch.equal(ph.cpu(), c)
+
+
 @pytest.mark.parametrize("upp,sr,T", [(400, 40000, 320), (480, 48000, 200)])
 def test_sine_source_matches_oracle(L, upp, sr, T):
     from oracle import nets
