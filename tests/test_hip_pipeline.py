@@ -153,3 +153,36 @@ def test_pipeline_with_index_matches_oracle(models, noise_tape):
     out0 = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
                      file_index="", index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
     assert np.max(np.abs(out0[0].astype(np.int32) - ref.astype(np.int32))) > 10 * LSB
+
+
+@pytest.mark.parametrize("variant", ["48k_v2", "40k_v1"])
+def test_pipeline_variants_match_oracle(variant):
+    """End to end for the other generator shape (48 kHz: upsample 12,10,2,2) and the v1 layout (256-d features from HuBERT layer 9
+    + final_proj) against the CPU oracle on a 2 s clip."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.rmvpe import RMVPE
+    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+    from oracle import pipeline as opl
+    cfg_l, ver = {"48k_v2": (S.CONFIG_48K_V2, "v2"), "40k_v1": (S.CONFIG_40K_V1, "v1")}[variant]
+    audio = S.synth_audio(2.0, seed=31)
+    f0fn = lambda x, **k: S.designed_f0(x.shape[0] // 160 + 1, seed=0).astype(np.float64)   # noqa: E731
+    g = torch.Generator().manual_seed(12)
+    tape = []
+
+    def rec(shape):
+        t = torch.randn(shape, generator=g); tape.append(t); return t
+    ref = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(cfg_l, ver, 0), cfg_l, ver, audio,
+                       rms_mix_rate=0.25, protect=0.33, noise_fn=rec, f0_override=f0fn)
+    cfg = Config()
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    vcd = get_vc(S.synth_checkpoint(cfg_l, ver, 0), config=cfg)
+    vc = VC(cfg_l[-1], cfg)
+    vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0))
+    vc.f0_method_dict["pm"] = f0fn
+    it = iter(tape)
+    vc.noise_fn = lambda shape: next(it)
+    out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
+                    index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
+    assert out is not None and out[1] == cfg_l[-1] and out[0].shape == ref.shape
+    assert np.max(np.abs(out[0].astype(np.int32) - ref.astype(np.int32))) <= LSB
