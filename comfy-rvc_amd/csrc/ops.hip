@@ -753,12 +753,15 @@ __global__ void iir_chunk_kernel(const IirArgs p) {
   }
 }
 
+// np.pad(x, t_pad, mode="reflect") + float32 cast; pads wider than the signal reflect repeatedly (period 2 (n - 1)), as numpy does
+// for clips shorter than the 1 s pad
 __global__ void pad_reflect_f32_kernel(const double* __restrict__ x, long long n, int t_pad, float* __restrict__ out) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n + 2LL * t_pad) return;
-  long long i = j - t_pad;
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * (n - 1) - i;
+  const long long period = 2 * (n - 1);
+  long long i = (j - t_pad) % period;
+  if (i < 0) i += period;
+  if (i >= n) i = period - i;
   out[j] = (float)x[i];
 }
 

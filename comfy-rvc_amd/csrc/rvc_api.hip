@@ -199,7 +199,7 @@ int rvc_index_blend(rvc_index* h, void* stream, const float* feats_cm, const int
 int rvc_preprocess(void* stream, const void* audio, int is_f64, int64_t n, const double* b6, const double* a6, const double* zi5, int t_pad,
                    double* filt, float* padded, double* rms1, int n1) {
   RVC_TRY
-  RVC_REQUIRE(audio && b6 && a6 && zi5 && filt && n > 3 * 6 + 1 && t_pad >= 0 && t_pad < n, "bad argument");
+  RVC_REQUIRE(audio && b6 && a6 && zi5 && filt && n > 3 * 6 + 1 && t_pad >= 0, "bad argument");
   RVC_REQUIRE(a6[0] != 0.0, "a[0] must be non-zero");
   RVC_REQUIRE(rms1 == nullptr || n1 == (int)(n / 8000) + 1, "rms1 must hold n / 8000 + 1 frames");
   hipStream_t st = (hipStream_t)stream;

@@ -351,7 +351,8 @@ def test_sine_source_matches_oracle(L, upp, sr, T):
     assert float((har.cpu() - ref).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("n,dtype,t_pad", [(48000, np.float32, 16000), (160001, np.float64, 16000), (5003, np.float32, 800), (700000, np.float32, 16000)])
+@pytest.mark.parametrize("n,dtype,t_pad", [(48000, np.float32, 16000), (160001, np.float64, 16000), (5003, np.float32, 800), (700000, np.float32, 16000),
+                                           (16000, np.float32, 16000), (1920, np.float32, 16000)])     # pad wider than the clip: repeated reflection
 def test_preprocess_filtfilt_pad_rms(L, n, dtype, t_pad):
     """rvc_preprocess (overlap-discard float64 IIR on the device) against scipy.signal.filtfilt + np.pad + the oracle's framed RMS.
     The filter amplifies float64 rounding noise to ~4e-8 of full scale (a literal Python transcription of scipy's loop differs

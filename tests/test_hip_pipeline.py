@@ -186,3 +186,36 @@ def test_pipeline_variants_match_oracle(variant):
                     index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
     assert out is not None and out[1] == cfg_l[-1] and out[0].shape == ref.shape
     assert np.max(np.abs(out[0].astype(np.int32) - ref.astype(np.int32))) <= LSB
+
+
+@pytest.mark.parametrize("case", ["short_0.4s", "short_0.12s", "silence", "loud", "stereo", "float64"])
+def test_pipeline_edge_inputs_match_oracle(models, case):
+    """Clips shorter than the 1 s reflect pad (repeated reflection), all-zero input, peak > 1 (remix_audio rescales), stereo input
+    and float64 input through vc_single against the CPU oracle."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.audio import remix_audio
+    from comfy_rvc_amd.vc_infer_pipeline import VC, vc_single
+    from oracle import pipeline as opl
+    hub, vcd, rm = models
+    audio_in = {"short_0.4s": S.synth_audio(0.4, seed=1), "short_0.12s": S.synth_audio(0.12, seed=1), "silence": np.zeros(16000, np.float32),
+                "loud": (S.synth_audio(1.0, seed=2) * 6).astype(np.float32),
+                "stereo": np.stack([S.synth_audio(1.0, seed=3), S.synth_audio(1.0, seed=4)], 0),
+                "float64": S.synth_audio(1.0, seed=6).astype(np.float64)}[case]
+    a16, _ = remix_audio((audio_in, 16000), target_sr=16000)
+    g = torch.Generator().manual_seed(3)
+    tape = []
+
+    def rec(shape):
+        t = torch.randn(shape, generator=g); tape.append(t); return t
+    with np.errstate(all="ignore"):
+        ref = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0), S.CONFIG_40K_V2, "v2", a16,
+                           rms_mix_rate=0.25, protect=0.33, noise_fn=rec)
+    vc = VC(40000, Config())
+    vc.model_rmvpe = rm
+    it = iter(tape)
+    vc.noise_fn = lambda shape: next(it)
+    out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio_in, 16000), sid=0, f0_up_key=0, f0_method="rmvpe",
+                    index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
+    assert out is not None and out[0].shape == ref.shape
+    d = np.abs(out[0].astype(np.int32) - ref.astype(np.int32))
+    assert np.mean(d <= LSB) > 0.995
