@@ -55,8 +55,9 @@ def _list_models(folder, exts):
 _memo = {}
 
 
-def _memoised(kind, path, loader):
-    key = (kind, path, os.path.getmtime(path) if path and os.path.isfile(path) else None)
+def _memoised(kind, path, loader, extra=None):
+    mt = lambda f: os.path.getmtime(f) if f and os.path.isfile(f) else None   # noqa: E731
+    key = (kind, path, mt(path), extra, mt(extra))
     if key not in _memo:
         _memo[key] = loader()
     return _memo[key]
@@ -104,7 +105,8 @@ class LoadRVCModelNode:
     @classmethod
     def INPUT_TYPES(cls):
         models = [f"RVC/{m}" for m in _list_models("RVC", ("pth",))] or [""]
-        index = [""] + [f"RVC/.index/{m}" for m in _list_models(os.path.join("RVC", ".index"), ("index",))]
+        # faiss .index files (readable when faiss is installed) and big_npy .npy matrices (the vectors the index is built from)
+        index = [""] + [f"RVC/.index/{m}" for m in _list_models(os.path.join("RVC", ".index"), ("index", "npy"))]
         return {"required": {"model": (models, {"default": models[0]})}, "optional": {"index": (index, {"default": ""})}}
 
     RETURN_TYPES = ("RVC_MODEL", "STRING")
@@ -115,7 +117,7 @@ class LoadRVCModelNode:
     def load_model(self, model, index=""):
         path = os.path.join(BASE_MODELS_DIR, os.path.dirname(model), os.path.basename(model))
         file_index = os.path.join(BASE_MODELS_DIR, os.path.dirname(model), ".index", os.path.basename(index)) if index else None
-        return (lambda: _memoised("rvc", path, lambda: get_vc(path, file_index)), os.path.basename(model).split(".")[0])
+        return (lambda: _memoised("rvc", path, lambda: get_vc(path, file_index), extra=file_index), os.path.basename(model).split(".")[0])
 
 
 class RVCNode:
