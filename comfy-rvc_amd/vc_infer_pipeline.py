@@ -233,6 +233,17 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
             feats.append(f)
     a_dev.record_stream(side)
     _mark("hubert enqueued")
+    # the synthesizer's noise does not depend on the pitch: draw it now, so that nothing but the pitch upload sits between "f0 ready"
+    # and the first synthesizer kernel (get_f0 draws no random numbers, the order of the RNG stream is unchanged)
+    noises = []
+    for f in feats:
+        T = 2 * f.shape[1]
+        if self.noise_fn is None and not self.noise_on_device:
+            for _ in range(12):
+                torch.rand([])      # the reference's HuBERT draws one LayerDrop scalar per layer from the same global stream
+        nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
+        noises.append((nz.to(dev, torch.float32).contiguous(), ns.to(dev, torch.float32).contiguous(),
+                       torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)))
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
     x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
     pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
@@ -245,19 +256,12 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
     D = 256 if version == "v1" else 768
     outs = []
-    for (b0, b1), f, f0c in zip(bounds, feats, feats0):
+    for (b0, b1), f, f0c, (nz, ns, out) in zip(bounds, feats, feats0, noises):
         Th = f.shape[1]
         T = 2 * Th
-        if self.noise_fn is None and not self.noise_on_device:
-            for _ in range(12):
-                torch.rand([])      # the reference's HuBERT draws one LayerDrop scalar per layer from the same global stream
-        nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
-        nz = nz.to(dev, torch.float32).contiguous()
-        ns = ns.to(dev, torch.float32).contiguous()
         pc = pitch_d[b0 // self.window: b0 // self.window + T].contiguous()
         pf = pitchf_d[b0 // self.window: b0 // self.window + T].contiguous()
         assert pc.numel() == T, "pitch track shorter than the feature sequence"
-        out = torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), _lib.ptr(f0c), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
                                                      float(protect), 1 if protect < 0.5 else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
