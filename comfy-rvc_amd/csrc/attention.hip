@@ -34,12 +34,17 @@ void attention_timing_read(unsigned long long* out8, bool reset) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kAD = 64;        // head dimension
-constexpr int kAP = 65;        // LDS row pitch (floats): odd -> the 32-lane row / column reads are conflict-free
+constexpr int kAP = 68;        // LDS row pitch (floats): 16-byte aligned rows, 4-bank shift per row -> conflict-free ds_read_b128
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS tiles are stored with the MFMA reduction index contiguous:  Qs[query][d], Ks[key][d], Vs[d][key], Ps[query][key].
+// An MFMA step consumes the index pair (i, 32 + i) - lane half 0 takes i, half 1 takes 32 + i; any pairing is valid as long as A and
+// B agree - so each lane reads its 32 values of a row as eight ds_read_b128, one per four MFMA steps.
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ Q, const float* __restrict__ K, long long ldqk,
                                                         const float* __restrict__ V, long long ldv, const float* __restrict__ bv,
                                                         float* __restrict__ out, long long ldo, int T) {
-  __shared__ float Qs[kAD * kAP], Ks[kAD * kAP], Vs[64 * kAP], Ps[64 * kAP];
+  __shared__ __attribute__((aligned(16))) float Qs[64 * kAP], Ks[64 * kAP], Vs[kAD * kAP], Ps[64 * kAP];
   __shared__ float red[2][2][64];          // [stat: max | sum][wm][query]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -49,36 +54,45 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   const float* Kh = K + (long long)h * kAD * ldqk;
   const float* Vh = V + h * kAD;
 
-  // Q tile: rows d, columns queries (coalesced along the queries)
-  for (int e = tid; e < kAD * 64; e += 256) {
-    const int d = e >> 6, j = e & 63;
-    Qs[d * kAP + j] = (q0 + j < T) ? Qh[(long long)d * ldqk + q0 + j] : 0.f;
+  // Q tile -> Qs[query][d]: a thread takes 4 consecutive d of one query (4 coalesced loads) and writes them as one 16-byte store
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int e = tid + 256 * s, j = e & 63, d0 = (e >> 6) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (q0 + j < T) ? Qh[(long long)(d0 + i) * ldqk + q0 + j] : 0.f;
+    *reinterpret_cast<f32x4*>(Qs + j * kAP + d0) = v;
   }
-  float kr[16], vr[16];
+  f32x4 kr[4], vr[4];
   auto load_kv = [&](int k0) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int e = tid + 256 * s;
-      const int r = e >> 6, j = e & 63;                    // K: r = d, j = key;  V: r = key, j = d
-      kr[s] = (k0 + j < T) ? Kh[(long long)r * ldqk + k0 + j] : 0.f;
-      vr[s] = (k0 + r < T) ? Vh[(long long)(k0 + r) * ldv + j] : 0.f;
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + 256 * s, j = e & 63, g4 = (e >> 6) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kr[s][i] = (k0 + j < T) ? Kh[(long long)(g4 + i) * ldqk + k0 + j] : 0.f;            // K[d = g4 + i][key = j]
+        vr[s][i] = (k0 + g4 + i < T) ? Vh[(long long)(k0 + g4 + i) * ldv + j] : 0.f;        // V[key = g4 + i][d = j]
+      }
     }
   };
   auto store_kv = [&]() {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int e = tid + 256 * s;
-      const int r = e >> 6, j = e & 63;
-      Ks[r * kAP + j] = kr[s];
-      Vs[r * kAP + j] = vr[s];
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + 256 * s, j = e & 63, g4 = (e >> 6) * 4;
+      *reinterpret_cast<f32x4*>(Ks + j * kAP + g4) = kr[s];       // Ks[key j][d g4..]
+      *reinterpret_cast<f32x4*>(Vs + j * kAP + g4) = vr[s];       // Vs[d j][key g4..]
     }
   };
 
-  f32x16 o, o1;                             // two independent accumulation chains (even / odd key pairs), summed at the end
+  f32x16 o, o1;                             // two independent accumulation chains, summed at the end
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1.0e30f, l_run = 0.f;       // per query column wn*32 + li (identical in the lanes / waves that share a column)
   const int ntiles = (T + 63) / 64;
+  const float* arow_s = Ks + (wm * 32 + li) * kAP + lh * 32;     // A of S: key row
+  const float* brow_s = Qs + (wn * 32 + li) * kAP + lh * 32;     // B of S: query row
+  const float* arow_o = Vs + (wm * 32 + li) * kAP + lh * 32;     // A of O: d row
+  const float* brow_o = Ps + (wn * 32 + li) * kAP + lh * 32;     // B of O: query row
   const unsigned long long t_begin = ATICK();
   load_kv(0);
   for (int it = 0; it < ntiles; ++it) {
@@ -94,12 +108,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     f32x16 sacc, sacc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sacc1[r] = 0.f; }
-#pragma unroll 4
-    for (int kk = 0; kk < kAD; kk += 4) {
-      const float a0 = Ks[(kk + lh) * kAP + wm * 32 + li], a1 = Ks[(kk + 2 + lh) * kAP + wm * 32 + li];
-      const float b0 = Qs[(kk + lh) * kAP + wn * 32 + li], b1 = Qs[(kk + 2 + lh) * kAP + wn * 32 + li];
-      sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, sacc, 0, 0, 0);
-      sacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, sacc1, 0, 0, 0);
+    {
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] = *reinterpret_cast<const f32x4*>(arow_s + 4 * c); b[c] = *reinterpret_cast<const f32x4*>(brow_s + 4 * c); }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], b[c][0], sacc, 0, 0, 0);
+        sacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], b[c][1], sacc1, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][2], b[c][2], sacc, 0, 0, 0);
+        sacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][3], b[c][3], sacc1, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r];
@@ -124,10 +143,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const float alpha = expf(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = expf(sacc[r] - m_new);             // masked keys: exp(-1e30 - m) = 0
-      ps += pv;
-      Ps[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * kAP + wn * 32 + li] = pv;
+    for (int g = 0; g < 4; ++g) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pv[i] = expf(sacc[4 * g + i] - m_new); ps += pv[i]; }     // masked keys: exp(-1e30 - m) = 0
+      *reinterpret_cast<f32x4*>(Ps + (wn * 32 + li) * kAP + wm * 32 + 8 * g + 4 * lh) = pv;   // Ps[query][key .. key + 3]
     }
     ps += __shfl_xor(ps, 32);
     if (lh == 0) red[1][wm][wn * 32 + li] = ps;
@@ -139,12 +159,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const unsigned long long t3 = ATICK();
     ATACC(3, t3 - t2);
     // ---- O += V^T P : rows d = wm*32 + .., columns queries wn*32 + li
-#pragma unroll 4
-    for (int kk = 0; kk < 64; kk += 4) {
-      const float a0 = Vs[(kk + lh) * kAP + wm * 32 + li], a1 = Vs[(kk + 2 + lh) * kAP + wm * 32 + li];
-      const float b0 = Ps[(kk + lh) * kAP + wn * 32 + li], b1 = Ps[(kk + 2 + lh) * kAP + wn * 32 + li];
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, o, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, o1, 0, 0, 0);
+    {
+      f32x4 a[8], b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] = *reinterpret_cast<const f32x4*>(arow_o + 4 * c); b[c] = *reinterpret_cast<const f32x4*>(brow_o + 4 * c); }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][0], b[c][0], o, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][1], b[c][1], o1, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][2], b[c][2], o, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][3], b[c][3], o1, 0, 0, 0);
+      }
     }
     ATACC(4, ATICK() - t3);
   }
