@@ -192,4 +192,200 @@ void attention_fused(hipStream_t s, const float* Q, const float* K, long long ld
   hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T);
 }
 
+// ================================================================================================ key-split variant
+// attention_ks_kernel<D, WK, REL>: one workgroup = 32 queries of one head, WK waves; wave w owns keys [32 w, 32 w + 32) of every
+// 32 WK-key tile and keeps its OWN online-softmax state (m, l, O) over that key subset, so an iteration needs no cross-wave
+// exchange at all - only the two barriers around the shared K / V tile.  The WK partial results are merged once at the end:
+//   m = max_w m_w,  l = sum_w l_w e^(m_w - m),  O = sum_w O_w e^(m_w - m).
+// REL adds the windowed relative-position terms of the synthesizer's text encoder (reference attentions.py:230-267): scores of keys
+// within +-win of the query get rel[k - q + win][q] added (rel = Q . E_k, computed by a 21-row projection beforehand), and the
+// normalised probabilities of that band are returned as pb[r][q] = P[q][q + r - win] for the value-side projection.  Band scores are
+// kept raw in LDS and normalised with the final (m, l), so the online rescaling never touches them.
+template <int D, int WK, bool REL>
+__global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __restrict__ Q, const float* __restrict__ K, long long ldqk,
+                                                               const float* __restrict__ V, long long ldv, const float* __restrict__ bv,
+                                                               const float* __restrict__ rel, float* __restrict__ pb, int win,
+                                                               float* __restrict__ out, long long ldo, int T) {
+  constexpr int NT = 64 * WK, KT = 32 * WK, DP = D + 4, VP = KT + 4, PP = 36, DT = D / 32, OP = 33;
+  constexpr int kQs = 32 * DP, kKs = KT * DP, kVs = D * VP, kPs = WK * 32 * PP, kSb = REL ? 21 * 32 : 0;
+  static_assert(WK * (D * OP + 64) <= kKs + kVs, "merge buffers must fit the K / V tiles");
+  extern __shared__ __attribute__((aligned(16))) float smem_att[];
+  float* Qs = smem_att; float* Ks = Qs + kQs; float* Vs = Ks + kKs; float* Ps = Vs + kVs; float* sb = Ps + kPs;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int h = blockIdx.y, q0 = blockIdx.x * 32;
+  const float* Qh = Q + (long long)h * D * ldqk;
+  const float* Kh = K + (long long)h * D * ldqk;
+  const float* Vh = V + h * D;
+  const float* relh = REL ? rel + (long long)h * (2 * win + 1) * T : nullptr;
+
+  // Q tile -> Qs[query][d]
+  for (int e = tid; e < 32 * D / 4; e += NT) {
+    const int j = e & 31, d0 = (e >> 5) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (q0 + j < T) ? Qh[(long long)(d0 + i) * ldqk + q0 + j] : 0.f;
+    *reinterpret_cast<f32x4*>(Qs + j * DP + d0) = v;
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+  const float* arow_s = Ks + (w * 32 + li) * DP + lh * (D / 2);
+  const float* brow_s = Qs + li * DP + lh * (D / 2);
+  float* prow = Ps + (w * 32 + li) * PP;
+  const int q = q0 + li;
+  const int ntiles = (T + KT - 1) / KT;
+  for (int it = 0; it < ntiles; ++it) {
+    const int k0 = it * KT;
+    lds_barrier();                          // previous tile's Ks / Vs reads are done
+    // K tile -> Ks[key][d] (4 consecutive d of one key per task), V tile -> Vs[d][key] (4 consecutive keys of one d per task)
+    for (int e = tid; e < KT * D / 4; e += NT) {
+      const int j = e % KT, d0 = (e / KT) * 4;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (k0 + j < T) ? Kh[(long long)(d0 + i) * ldqk + k0 + j] : 0.f;
+      *reinterpret_cast<f32x4*>(Ks + j * DP + d0) = v;
+    }
+    for (int e = tid; e < KT * D / 4; e += NT) {
+      const int j = e % D, g4 = (e / D) * 4;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (k0 + g4 + i < T) ? Vh[(long long)(k0 + g4 + i) * ldv + j] : 0.f;
+      *reinterpret_cast<f32x4*>(Vs + j * VP + g4) = v;
+    }
+    lds_barrier();
+    const int kw = k0 + w * 32;             // first key of this wave's slice
+    if (kw < T) {                           // (wave-uniform) slices past the end contribute nothing
+      // ---- S = K^T Q : 32 keys x 32 queries, reduction over d with the pairing (i, D/2 + i)
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < D / 8; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow_s + 4 * c), b = *reinterpret_cast<const f32x4*>(brow_s + 4 * c);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], s1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[r] += s1[r];
+      // rows: key = kw + (r&3) + 8(r>>2) + 4 lh; column: query q
+      if (REL && kw + 32 + win > q0 && kw < q0 + 32 + win + 1) {          // slice intersects the band of this query group
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kw + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int rr = key - q + win;
+          if (rr >= 0 && rr <= 2 * win && key < T && q < T) {
+            s0[r] += relh[(long long)rr * T + q];
+            sb[rr * 32 + li] = s0[r];
+          }
+        }
+      }
+      if (kw + 32 > T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) if (kw + (r & 3) + 8 * (r >> 2) + 4 * lh >= T) s0[r] = -1.0e30f;
+      }
+      float mx = -1.0e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 pv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pv[i] = expf(s0[4 * g + i] - m_new); ps += pv[i]; }
+        *reinterpret_cast<f32x4*>(prow + 8 * g + 4 * lh) = pv;           // Ps[w][query][key_local .. + 3]
+      }
+      ps += __shfl_xor(ps, 32);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this wave's P is in LDS (wave-private region)
+      // ---- O[d][q] += V[d][keys of this slice] . P : reduction over the slice's 32 keys with the pairing (i, 16 + i)
+      f32x4 pb4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pb4[c] = *reinterpret_cast<const f32x4*>(prow + lh * 16 + 4 * c);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const float* vrow = Vs + (t * 32 + li) * VP + w * 32 + lh * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(vrow + 4 * c);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], pb4[c][i], o[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- merge the WK partial states: O_w, m_w, l_w through LDS (re-using the K / V tiles)
+  lds_barrier();
+  float* Oc = Ks;                                   // [WK][D][OP]
+  float* ml = Ks + WK * D * OP;                     // [WK][2][32]
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Oc[(w * D + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * OP + li] = o[t][r];
+  if (lh == 0) { ml[(w * 2 + 0) * 32 + li] = m_run; ml[(w * 2 + 1) * 32 + li] = l_run; }
+  lds_barrier();
+  for (int e = tid; e < D * 32; e += NT) {
+    const int d = e >> 5, j = e & 31;
+    float m = -1.0e30f;
+#pragma unroll
+    for (int x = 0; x < WK; ++x) m = fmaxf(m, ml[(x * 2) * 32 + j]);
+    float l = 0.f, acc = 0.f;
+#pragma unroll
+    for (int x = 0; x < WK; ++x) {
+      const float sc = expf(ml[(x * 2) * 32 + j] - m);
+      l += ml[(x * 2 + 1) * 32 + j] * sc;
+      acc += Oc[(x * D + d) * OP + j] * sc;
+    }
+    if (q0 + j < T) out[(long long)(h * D + d) * ldo + q0 + j] = acc / l + (bv ? bv[h * D + d] : 0.f);
+  }
+  if (REL) {
+    for (int e = tid; e < (2 * win + 1) * 32; e += NT) {
+      const int rr = e >> 5, j = e & 31;
+      const int qq = q0 + j, key = qq + rr - win;
+      if (qq >= T) continue;
+      float m = -1.0e30f, l = 0.f;
+#pragma unroll
+      for (int x = 0; x < WK; ++x) m = fmaxf(m, ml[(x * 2) * 32 + j]);
+#pragma unroll
+      for (int x = 0; x < WK; ++x) l += ml[(x * 2 + 1) * 32 + j] * expf(ml[(x * 2) * 32 + j] - m);
+      pb[((long long)h * (2 * win + 1) + rr) * T + qq] = (key >= 0 && key < T) ? expf(sb[rr * 32 + j] - m) / l : 0.f;
+    }
+  }
+}
+
+template <int D, int WK, bool REL>
+static void launch_att_ks(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
+                          const float* rel, float* pb, int win, float* out, long long ldo, int heads, int T) {
+  constexpr int KT = 32 * WK;
+  const size_t lds = sizeof(float) * (32 * (D + 4) + KT * (D + 4) + D * (KT + 4) + WK * 32 * 36 + (REL ? 21 * 32 : 0));
+  auto kern = attention_ks_kernel<D, WK, REL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((T + 31) / 32, heads), dim3(64 * WK), lds, s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, T);
+}
+
+// Text-encoder attention of the synthesizer (2 heads x 96): relative-position bias rel [heads][2 win + 1][T] in, banded probabilities
+// pb [heads][2 win + 1][T] out.  Q, K channel-major (Q pre-scaled), V row-major, out channel-major.
+void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
+                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T) {
+  RVC_REQUIRE(dhead == 96 && win == 10 && rel && pb, "fused relative-position attention is built for head dimension 96, window 10");
+  launch_att_ks<96, 4, true>(s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, heads, T);
+}
+
 }  // namespace rvc

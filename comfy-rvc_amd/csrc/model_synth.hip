@@ -219,7 +219,9 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     const size_t mark = A.off;
     float* qk = A.alloc<float>((size_t)2 * C * T);
     float* vr = A.alloc<float>((size_t)T * C);
-    float* Sc = A.alloc<float>((size_t)H * T * T);
+    static const bool fused_env = [] { const char* e = getenv("RVC_ENCP_FUSED"); return !e || atoi(e) != 0; }();
+    const bool fused_att = fused_env && kc == 96;
+    float* Sc = fused_att ? nullptr : A.alloc<float>((size_t)H * T * T);
     float* relk = A.alloc<float>((size_t)H * 21 * T);
     float* pb = A.alloc<float>((size_t)H * 21 * T);
     float* attn = A.alloc<float>((size_t)C * T);
@@ -229,11 +231,16 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
         EncLayer& e = S->enc[l];
         conv1d_run(e.qk, s, x, T, T, qk, T, E0);
         gemm_tn_run(s, x, T, 0, e.wvT.p, C, 0, vr, C, 0, T, C, C, 1, nullptr, 0, E0);                       // V row-major [T][C] (bias later)
-        gemm_tn_run(s, qk + (size_t)C * T, T, (long long)kc * T, qk, T, (long long)kc * T, Sc, T, (long long)T * T, T, T, kc, H, nullptr, 0, E0);
         for (int h = 0; h < H; ++h) conv1d_run(e.relk, s, qk + (size_t)h * kc * T, T, T, relk + (size_t)h * 21 * T, T, E0);
-        fill(s, pb, 0.f, (long long)H * 21 * T);
-        softmax_cols(s, Sc, T, T, T, (long long)T * T, H, relk, 21LL * T, 10, pb, 21LL * T);
-        gemm_tn_run(s, vr, C, kc, Sc, T, (long long)T * T, attn, T, (long long)kc * T, kc, T, T, H, e.bv.p, kc, E0);
+        if (fused_att) {
+          // softmax(K^T Q + banded rel-k bias) V + bv in one kernel; the band of probabilities comes back in pb for the rel-v projection
+          attention_rel_fused(s, qk, qk + (size_t)C * T, T, vr, C, e.bv.p, relk, pb, 10, attn, T, H, kc, T);
+        } else {
+          gemm_tn_run(s, qk + (size_t)C * T, T, (long long)kc * T, qk, T, (long long)kc * T, Sc, T, (long long)T * T, T, T, kc, H, nullptr, 0, E0);
+          fill(s, pb, 0.f, (long long)H * 21 * T);
+          softmax_cols(s, Sc, T, T, T, (long long)T * T, H, relk, 21LL * T, 10, pb, 21LL * T);
+          gemm_tn_run(s, vr, C, kc, Sc, T, (long long)T * T, attn, T, (long long)kc * T, kc, T, T, H, e.bv.p, kc, E0);
+        }
         ConvEpilogue Ea; Ea.accumulate = 1;
         for (int h = 0; h < H; ++h) conv1d_run(e.relv, s, pb + (size_t)h * 21 * T, T, T, attn + (size_t)h * kc * T, T, Ea);
         ConvEpilogue Er; Er.R = x; Er.ldR = T;

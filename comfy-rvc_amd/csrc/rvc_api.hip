@@ -300,6 +300,13 @@ int rvc_op_attention(void* stream, const float* q, const float* k, const float* 
   check_launch();
   RVC_CATCH
 }
+int rvc_op_attention_rel(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, const float* rel, float* pb,
+                         float* out, int heads, int T) {
+  RVC_TRY
+  attention_rel_fused((hipStream_t)stream, q, k, T, v_rm, (long long)heads * 96, bv, rel, pb, 10, out, T, heads, 96, T);
+  check_launch();
+  RVC_CATCH
+}
 int rvc_op_layernorm_c(void* stream, const float* x, const float* res, const float* gamma, const float* beta, float* y, int C, int T) {
   RVC_TRY
   layernorm_c((hipStream_t)stream, x, res, gamma, beta, y, C, T, T, 1e-5f);

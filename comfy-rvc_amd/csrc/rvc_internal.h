@@ -117,6 +117,9 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                      float* out, long long ldo, int heads, int dhead, int T);
 
+void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
+                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T);
+
 // per-launch HIP-event profiling of the conv kernels (bench.py's roofline leg)
 void conv_prof_enable(bool on);
 int conv_prof_collect(double* ms, double* flops, long long* launches);   // arrays of RVC_PROF_CFGS (tile configuration x {fp32 1-D, fp32 2-D, bf16x3})

@@ -176,6 +176,11 @@ int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
  * [T][heads*64], bv_dev [heads*64] or NULL, out_dev channel-major [heads*64][T] */
 int rvc_op_attention(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, float* out_dev,
                      int heads, int T);
+/* the synthesizer text encoder's attention (reference lib/infer_pack/attentions.py:230-267), head dimension 96, window 10:
+ * softmax over keys of K^T Q + rel[k - q + 10][q] (|k - q| <= 10), times V, + bv.  rel_dev [heads][21][T] in (the Q . emb_rel_k
+ * projection), pb_dev [heads][21][T] out: pb[r][q] = P[q][q + r - 10] (0 outside the sequence), the input of the rel-v projection. */
+int rvc_op_attention_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, const float* rel_dev,
+                         float* pb_dev, float* out_dev, int heads, int T);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                        int C, int T);
 /* optional debug outputs: rad_dev [T] per-frame phase increment, tmp_dev [T] scaled frame cumsum, phase_dev [T*upp] running phase (cycles) */

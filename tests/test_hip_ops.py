@@ -299,6 +299,40 @@ def test_fused_attention(L, heads, T):
     assert rel_err(out.cpu().double(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("heads,T", [(2, 3001), (2, 150), (2, 20), (3, 129), (2, 5)])
+def test_fused_relative_attention(L, heads, T):
+    """The text encoder's windowed relative-position attention in one kernel (reference attentions.py:230-267): scores of keys within
+    +-10 of the query get the rel-k bias; the normalised band comes back for the rel-v projection.  float64 torch restatement."""
+    g = torch.Generator().manual_seed(29)
+    D, W = 96, 10
+    q = torch.randn(heads * D, T, generator=g) * 0.3
+    k = torch.randn(heads * D, T, generator=g)
+    v = torch.randn(T, heads * D, generator=g)
+    bv = torch.randn(heads * D, generator=g) * 0.1
+    rel = torch.randn(heads, 2 * W + 1, T, generator=g) * 2.0
+    qh = q.double().view(heads, D, T); kh = k.double().view(heads, D, T); vh = v.double().view(T, heads, D).permute(1, 0, 2)
+    sc = torch.einsum("hdq,hdk->hqk", qh, kh)
+    qi = torch.arange(T)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        sc[:, qi[ok], ki[ok]] += rel.double()[:, r, qi[ok]]
+    p = torch.softmax(sc, dim=-1)
+    ref = torch.einsum("hqk,hkd->hdq", p, vh).reshape(heads * D, T) + bv.double()[:, None]
+    pb_ref = torch.zeros(heads, 2 * W + 1, T, dtype=torch.float64)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        pb_ref[:, r, qi[ok]] = p[:, qi[ok], ki[ok]]
+    out = torch.empty(heads * D, T, device="cuda")
+    pb = torch.full((heads, 2 * W + 1, T), 7.0, device="cuda")            # every entry must be written (zeros outside the sequence)
+    qd, kd, vd, bd, rd = dev(q), dev(k), dev(v), dev(bv), dev(rel)
+    L.check(L.lib.rvc_op_attention_rel(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), L.ptr(rd), L.ptr(pb), L.ptr(out), heads, T))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().double(), ref) < 2e-5
+    assert (pb.cpu().double() - pb_ref).abs().max() < 2e-6
+
+
 def test_layernorm_channels(L):
     g = torch.Generator().manual_seed(19)
     x, r = torch.randn(192, 333, generator=g), torch.randn(192, 333, generator=g)
