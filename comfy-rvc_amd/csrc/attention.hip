@@ -238,25 +238,46 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
   float* prow = Ps + (w * 32 + li) * PP;
   const int q = q0 + li;
   const int ntiles = (T + KT - 1) / KT;
+  // K / V tiles travel global -> registers -> LDS; the registers of tile it + 1 are requested before tile it is consumed, so the
+  // HBM / L2 latency hides behind the two MFMA chains (one workgroup per CU: nothing else would cover it)
+  constexpr int NL = KT * D / 4 / NT;
+  static_assert(KT * D / 4 % NT == 0, "tile tasks must divide evenly");
+  f32x4 kr[NL], vr[NL];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int x = 0; x < NL; ++x) {
+      const int e = tid + NT * x;
+      const int j = e % KT, d0 = (e / KT) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kr[x][i] = (k0 + j < T) ? Kh[(long long)(d0 + i) * ldqk + k0 + j] : 0.f;
+    }
+#pragma unroll
+    for (int x = 0; x < NL; ++x) {
+      const int e = tid + NT * x;
+      const int j = e % D, g4 = (e / D) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vr[x][i] = (k0 + g4 + i < T) ? Vh[(long long)(k0 + g4 + i) * ldv + j] : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int x = 0; x < NL; ++x) {
+      const int e = tid + NT * x;
+      *reinterpret_cast<f32x4*>(Ks + (e % KT) * DP + (e / KT) * 4) = kr[x];      // Ks[key][d .. d + 3]
+    }
+#pragma unroll
+    for (int x = 0; x < NL; ++x) {
+      const int e = tid + NT * x;
+      *reinterpret_cast<f32x4*>(Vs + (e % D) * VP + (e / D) * 4) = vr[x];        // Vs[d][key .. key + 3]
+    }
+  };
+  load_tile(0);
   for (int it = 0; it < ntiles; ++it) {
     const int k0 = it * KT;
     lds_barrier();                          // previous tile's Ks / Vs reads are done
-    // K tile -> Ks[key][d] (4 consecutive d of one key per task), V tile -> Vs[d][key] (4 consecutive keys of one d per task)
-    for (int e = tid; e < KT * D / 4; e += NT) {
-      const int j = e % KT, d0 = (e / KT) * 4;
-      f32x4 v;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = (k0 + j < T) ? Kh[(long long)(d0 + i) * ldqk + k0 + j] : 0.f;
-      *reinterpret_cast<f32x4*>(Ks + j * DP + d0) = v;
-    }
-    for (int e = tid; e < KT * D / 4; e += NT) {
-      const int j = e % D, g4 = (e / D) * 4;
-      f32x4 v;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = (k0 + g4 + i < T) ? Vh[(long long)(k0 + g4 + i) * ldv + j] : 0.f;
-      *reinterpret_cast<f32x4*>(Vs + j * VP + g4) = v;
-    }
+    store_tile();
     lds_barrier();
+    if (it + 1 < ntiles) load_tile(k0 + KT);
     const int kw = k0 + w * 32;             // first key of this wave's slice
     if (kw < T) {                           // (wave-uniform) slices past the end contribute nothing
       // ---- S = K^T Q : 32 keys x 32 queries, reduction over d with the pairing (i, D/2 + i)
