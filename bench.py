@@ -4,10 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = every rank converts ONE synthetic 30 s / 16 kHz clip end to end through `vc_single` (host float32 array in,
-int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz) and the
-int16 waveforms are gathered on rank 0 over RCCL (the path's only exchange step).  Clips are independent, so the work
-shards one-clip-per-GPU with no data-path collective besides that gather: weak scaling.  Weights are procedural
+One "step" = every rank converts LANES (default 2) synthetic 30 s / 16 kHz clips end to end through `vc_single` (host float32
+array in, int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz), the
+clips of a rank in flight concurrently on its GPU (parallel.ClipLanes: one host thread, stream set and model replica per lane -
+a batch-1 clip cannot fill 256 CUs in its narrow stages), and the int16 waveforms are gathered on rank 0 over RCCL (the path's
+only exchange step).  `--lanes 1` is the strictly sequential one-clip-at-a-time rate.  Clips are independent, so the work shards
+clip-per-GPU with no data-path collective besides that gather: weak scaling.  Weights are procedural
 (comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32 (fp32 MFMA, or the bf16x3 split with fp32 accumulation).
 Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
 """
@@ -54,6 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "2")), help="clips in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -79,20 +82,37 @@ def main():
     from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
 
     cfg = Config(device=dev)
-    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
-    vcd = get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0), config=cfg, device=dev)
-    vc = VC(40000, cfg)
-    vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
-    vc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
+    from comfy_rvc_amd.parallel import ClipLanes
     audio = S.synth_audio(args.seconds, seed=100 + rank)
     params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
+    n_lanes = max(1, args.lanes)
 
-    def step():
-        out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), config=cfg, **params)
-        assert out is not None, "vc_single failed"
-        wav = out[0]
-        if world > 1:
-            gather_waveforms(wav, dev)
+    def make_lane():
+        hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
+        vcd = get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0), config=cfg, device=dev)
+        vc = VC(40000, cfg)
+        vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
+        vc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
+
+        def convert(clip, i=0):
+            out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(clip, 16000), config=cfg, **params)
+            assert out is not None, "vc_single failed"
+            return out[0]
+        return convert, vc
+    lanes = [make_lane() for _ in range(n_lanes)]
+    vc = lanes[0][1]
+    pool = ClipLanes([fn for fn, _ in lanes], device=dev)
+
+    def step():                            # single clip on lane 0, caller's thread and stream (warm-up, roofline pass)
+        return lanes[0][0](audio)
+
+    def run_steps(k):
+        """k steps = k * LANES clips of this rank through the lanes (a free lane pulls the next clip); the waveforms are handed to the
+        gather in clip order as they complete."""
+        wav = None
+        for wav in pool.imap([audio] * (k * n_lanes)):
+            if world > 1:
+                gather_waveforms(wav, dev)
         return wav
 
     def sync():
@@ -100,20 +120,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        wav = step()
+    for fn, _ in lanes:                    # every lane sizes its workspaces once, sequentially
+        fn(audio)
+    wav = run_steps(args.warmup) if args.warmup > 0 else step()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wav = step()
+    wav = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    delivered = wav.shape[0] / 40000.0                       # audio seconds one rank delivers per step
-    value = delivered * world * args.steps / dt
+    delivered = wav.shape[0] / 40000.0                       # audio seconds of one converted clip
+    value = delivered * n_lanes * world * args.steps / dt
+
+    # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    alone_ms = (time.perf_counter() - t1) / 3 * 1e3
+    sync()
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -186,11 +215,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
-            "config": {"workload": f"Full VC 40k_v2 (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clip per GPU "
-                                   "per step, vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
-                       "clips_per_step": world, "audio_seconds_delivered_per_clip": round(delivered, 3),
+            "config": {"workload": f"Full VC 40k_v2 (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_lanes} per GPU "
+                                   "per step (in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
+                       "clips_per_step": world * n_lanes, "clips_in_flight_per_gpu": n_lanes, "audio_seconds_delivered_per_clip": round(delivered, 3),
+                       "one_clip_alone_ms": round(alone_ms, 2), "one_clip_alone_xrt": round(delivered / alone_ms * 1e3, 1),
                        "weights": "procedural (comfy-rvc_amd/synthetic.py)", "noise": "device generator",
-                       "parallelism": f"clip-per-GPU x{world}, RCCL gather of int16 waveforms"},
+                       "parallelism": f"clip-per-GPU x{world} ({n_lanes} lanes each), RCCL gather of int16 waveforms"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

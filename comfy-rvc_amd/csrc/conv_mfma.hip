@@ -397,6 +397,8 @@ void dev_free(void* p) { if (p) (void)hipFree(p); }
 void* stream_scratch(hipStream_t s, int slot, size_t bytes) {
   struct Buf { void* p = nullptr; size_t cap = 0; };
   static std::map<std::pair<hipStream_t, int>, Buf> pool;
+  static std::mutex mu;                       // several host threads drive their own streams (one clip in flight per worker)
+  std::lock_guard<std::mutex> lk(mu);
   Buf& b = pool[{s, slot}];
   if (bytes > b.cap) {
     RVC_HIP_CHECK(hipDeviceSynchronize());
@@ -642,11 +644,13 @@ TileCfg choose_tile(int M, long long N, int batch) {
 struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
 static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
                                            "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d",
                                            "1x4x1x4/x3", "1x4x1x2/x3", "1x4x1x1/x3", "2x2x2x2/x3", "2x2x1x4/x3", "2x2x1x2/x3", "2x2x1x1/x3",
                                            "2x2x2x4/x3", "1x4x2x4/x3", ""};
 void conv_prof_enable(bool on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();
   g_prof_on = on;
@@ -672,6 +676,7 @@ ProfTicket conv_prof_begin(hipStream_t s) {
 void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes) {
   if (!t.on) return;
   (void)hipEventRecord(t.b, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(ProfRec{t.a, t.b, flops, cfg, bytes});
 }
 // algorithmic HBM bytes of one launch: input + output (+ residual, + previous output when accumulating) + weights, fp32

@@ -18,6 +18,13 @@ def main():
         clips = [np.full(100 + 37 * i, i, dtype=np.float32) for i in range(5)]       # ragged lengths, 5 clips over 2 ranks
         assert P.shard_indices(5) == list(range(rank, 5, world))
         res = P.convert_clips(clips, lambda c: (c * 3).astype(np.int16)[: c.shape[0] - rank], device="cpu")
+        # the same through two conversion lanes per rank (threads); lane functions see the GLOBAL clip index
+        lanes = P.ClipLanes([lambda c, i: (c * 3).astype(np.int16)[: c.shape[0] - rank] + 0 * i for _ in range(2)])
+        res_l = P.convert_clips(clips, lanes, device="cpu")
+        assert (res_l is None) == (res is None) and (res is None or all(np.array_equal(a, b) for a, b in zip(res, res_l)))
+        seen = []
+        P.convert_clips(clips, P.ClipLanes([lambda c, i: (seen.append(i), np.zeros(1, np.int16))[1]]), device="cpu")
+        assert sorted(seen) == list(range(rank, 5, world))
         single = P.gather_waveforms(np.arange(10 + rank, dtype=np.int16), "cpu")
         # training-prep feature dump: files are sharded rank::world with no collective (stub network: host logic only)
         import torch

@@ -219,3 +219,35 @@ def test_pipeline_edge_inputs_match_oracle(models, case):
     assert out is not None and out[0].shape == ref.shape
     d = np.abs(out[0].astype(np.int32) - ref.astype(np.int32))
     assert np.mean(d <= LSB) > 0.995
+
+
+def test_two_lanes_in_flight_equal_sequential_conversion(models):
+    """ClipLanes: two clips in flight on one GPU (own threads, streams and model replicas) give bit-identical int16 audio to
+    converting the same clips one after another; the noise is derived from the clip index, so lane assignment cannot matter."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.rmvpe import RMVPE
+    from comfy_rvc_amd.parallel import ClipLanes
+    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+
+    def lane(hub, vcd, rm):
+        vc = VC(40000, Config())
+        vc.model_rmvpe = rm
+
+        def fn(clip, i):
+            gen = torch.Generator().manual_seed(1000 + i)
+            vc.noise_fn = lambda shape: torch.randn(shape, generator=gen)
+            out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(clip, 16000), sid=0, f0_up_key=i % 3,
+                            f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
+            assert out is not None
+            return out[0]
+        return fn
+    first = lane(*models)
+    second = lane(HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG), get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0), config=Config()),
+                  RMVPE(S.rmvpe_state_dict(0)))
+    clips = [S.synth_audio(1.0 + 0.7 * (i % 4), seed=60 + i) for i in range(8)]      # ragged lengths
+    seq = [first(c, i) for i, c in enumerate(clips)]
+    par = ClipLanes([first, second], device="cuda").map(clips)
+    assert len(par) == len(seq)
+    for a, b in zip(seq, par):
+        assert a.shape == b.shape and np.array_equal(a, b)

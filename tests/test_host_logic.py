@@ -1,5 +1,6 @@
 """CPU: the product's host-side logic (no GPU compute) against the golden vectors captured from the reference."""
 import numpy as np
+import pytest
 
 from conftest import golden, rel_err
 
@@ -66,3 +67,36 @@ def test_node_surface_matches_reference():
     assert params["f0_method"] == "rmvpe" and params["protect"] == .25
     a = N.to_audio_dict(np.zeros(100, dtype=np.float32), 40000)
     assert tuple(a["waveform"].shape) == (1, 100, 1) and a["sample_rate"] == 40000
+
+
+def test_clip_lanes_keep_order_overlap_and_propagate_errors():
+    """ClipLanes (two clips in flight per GPU): results come back in clip order whichever lane converts them, the lanes really
+    run concurrently, and a failing clip raises on the consumer side instead of hanging it."""
+    import threading
+    import time
+    from comfy_rvc_amd.parallel import ClipLanes
+    active, peak, lock, lane_of = [0], [0], threading.Lock(), {}
+
+    def make(k):
+        def fn(clip, i):
+            with lock:
+                active[0] += 1
+                peak[0] = max(peak[0], active[0])
+                lane_of[i] = k
+            time.sleep(0.02 if i % 2 else 0.005)          # uneven durations: a free lane pulls the next clip
+            with lock:
+                active[0] -= 1
+            return np.full(3, clip + i, dtype=np.int16)
+        return fn
+    pool = ClipLanes([make(0), make(1)])
+    out = pool.map(list(range(10, 20)))
+    assert [int(o[0]) for o in out] == [10 + 2 * i for i in range(10)]
+    assert peak[0] == 2 and set(lane_of.values()) == {0, 1}
+    assert pool.map([]) == []
+
+    def bad(clip, i):
+        if i == 3:
+            raise ValueError("clip 3 is broken")
+        return np.zeros(1, dtype=np.int16)
+    with pytest.raises(ValueError, match="clip 3"):
+        ClipLanes([bad, bad]).map(list(range(8)))
