@@ -82,6 +82,8 @@ class ClipLanes:
         self.device = torch.device(device) if device is not None else None
         self._streams = None
         if self.device is not None and self.device.type == "cuda":
+            if self.device.index is None:
+                self.device = torch.device("cuda", torch.cuda.current_device())
             self._streams = [torch.cuda.Stream(self.device) for _ in self.lanes]
 
     def imap(self, clips):
@@ -91,30 +93,33 @@ class ClipLanes:
         lock, errors, counter = threading.Lock(), [], iter(range(n))
 
         def work(k):
-            def loop():
-                while True:
-                    with lock:
-                        i = next(counter, None)
-                    if i is None or errors:
-                        return
-                    try:
-                        results[i] = self.lanes[k](clips[i], i)
-                    except BaseException as e:      # noqa: BLE001 - re-raised on the consumer side
-                        errors.append(e)
-                    finally:
-                        done[i].set()
             try:
                 if self._streams is not None:
                     torch.cuda.set_device(self.device)
                     with torch.cuda.stream(self._streams[k]):
-                        loop()
+                        loop(k)
                         self._streams[k].synchronize()
                 else:
-                    loop()
+                    loop(k)
+            except BaseException as e:              # noqa: BLE001 - anything outside a conversion (device setup ...) fails the whole map
+                errors.append(e)
             finally:
                 if errors:
                     for d in done:
                         d.set()
+
+        def loop(k):
+            while True:
+                with lock:
+                    i = next(counter, None)
+                if i is None or errors:
+                    return
+                try:
+                    results[i] = self.lanes[k](clips[i], i)
+                except BaseException as e:          # noqa: BLE001 - re-raised on the consumer side
+                    errors.append(e)
+                finally:
+                    done[i].set()
 
         threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(min(len(self.lanes), max(n, 1)))]
         for t in threads:

@@ -100,3 +100,14 @@ def test_clip_lanes_keep_order_overlap_and_propagate_errors():
         return np.zeros(1, dtype=np.int16)
     with pytest.raises(ValueError, match="clip 3"):
         ClipLanes([bad, bad]).map(list(range(8)))
+
+
+def test_clip_lanes_fail_instead_of_hanging_when_a_lane_cannot_start(monkeypatch):
+    """A lane thread that dies outside a conversion (device setup) must fail the map, not leave the consumer waiting."""
+    from comfy_rvc_amd import parallel as P
+    pool = P.ClipLanes([lambda c, i: np.zeros(1, np.int16)] * 2)
+    pool._streams = [None, None]                       # pretend to be a GPU pool whose device cannot be selected
+    pool.device = "cuda:0"
+    monkeypatch.setattr(P.torch.cuda, "set_device", lambda d: (_ for _ in ()).throw(RuntimeError("no such device")))
+    with pytest.raises(RuntimeError, match="no such device"):
+        pool.map([1, 2, 3])
