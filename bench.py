@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per busy stream (see comfy-rvc_amd/__init__.py); before HIP initialises
+
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
