@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = every rank converts LANES (default 2) synthetic 30 s / 16 kHz clips end to end through `vc_single` (host float32
+One "step" = every rank converts LANES (default 3) synthetic 30 s / 16 kHz clips end to end through `vc_single` (host float32
 array in, int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz), the
 clips of a rank in flight concurrently on its GPU (parallel.ClipLanes: one host thread, stream set and model replica per lane -
 a batch-1 clip cannot fill 256 CUs in its narrow stages), and the int16 waveforms are gathered on rank 0 over RCCL (the path's
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "2")), help="clips in flight per GPU")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
