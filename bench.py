@@ -68,12 +68,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dist = None
+    backend = os.environ.get("RVC_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:      # debugging the N > 1 control flow on a 1-GPU box: RVC_BENCH_BACKEND=gloo with LOCAL_RANK=0 on every rank
+            dist.init_process_group(backend=backend)
     dev = f"cuda:{local_rank}"
+    coll_dev = dev if backend == "nccl" else "cpu"      # where the collectives' tensors live
     torch.cuda.set_device(local_rank)
 
     from comfy_rvc_amd import _lib, synthetic as S
@@ -114,7 +119,7 @@ def main():
         wav = None
         for wav in pool.imap([audio] * (k * n_lanes)):
             if world > 1:
-                gather_waveforms(wav, dev)
+                gather_waveforms(wav, coll_dev)
         return wav
 
     def sync():
@@ -131,7 +136,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     delivered = wav.shape[0] / 40000.0                       # audio seconds of one converted clip
