@@ -21,6 +21,14 @@ CONFIG_40K_V2 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5
                  [10, 10, 2, 2], 512, [16, 16, 4, 4], 109, 256, 40000]
 CONFIG_48K_V2 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
                  [12, 10, 2, 2], 512, [24, 20, 4, 4], 109, 256, 48000]
+# the remaining shipped generator shapes (reference configs/32k.json, 48k.json: five upsampling stages down to 16 channels, transposed
+# convolutions whose kernel is not a multiple of the stride; configs/32k_v2.json)
+CONFIG_32K_V1 = [513, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [10, 4, 2, 2, 2], 512, [16, 16, 4, 4, 4], 109, 256, 32000]
+CONFIG_48K_V1 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [10, 6, 2, 2, 2], 512, [16, 16, 4, 4, 4], 109, 256, 48000]
+CONFIG_32K_V2 = [513, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                 [10, 8, 2, 2], 512, [20, 16, 4, 4], 109, 256, 32000]
 CONFIG_40K_V1 = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
                  [10, 10, 2, 2], 512, [16, 16, 4, 4], 109, 256, 40000]
 

@@ -258,6 +258,10 @@ def main():
         gen_synth(ns, S.CONFIG_40K_V2, "v2", "40k_v2", T=16, full_taps=True)
         gen_synth(ns, S.CONFIG_48K_V2, "v2", "48k_v2", T=12)
         gen_synth(ns, S.CONFIG_40K_V1, "v1", "40k_v1", T=12)
+    if "synth_shapes" in which:      # the other shipped generator shapes (added later; does not touch the vectors above)
+        gen_synth(ns, S.CONFIG_32K_V1, "v1", "32k_v1", T=12)
+        gen_synth(ns, S.CONFIG_48K_V1, "v1", "48k_v1", T=12)
+        gen_synth(ns, S.CONFIG_32K_V2, "v2", "32k_v2", T=12)
     if "pipeline" in which:
         gen_pipeline(ns)
 

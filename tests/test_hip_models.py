@@ -91,7 +91,8 @@ def test_rmvpe_matches_oracle_other_length(rmvpe):
 
 
 @pytest.mark.parametrize("name,config,version", [("synth_40k_v2.npz", S.CONFIG_40K_V2, "v2"), ("synth_48k_v2.npz", S.CONFIG_48K_V2, "v2"),
-                                                 ("synth_40k_v1.npz", S.CONFIG_40K_V1, "v1")])
+                                                 ("synth_40k_v1.npz", S.CONFIG_40K_V1, "v1"), ("synth_32k_v1.npz", S.CONFIG_32K_V1, "v1"),
+                                                 ("synth_48k_v1.npz", S.CONFIG_48K_V1, "v1"), ("synth_32k_v2.npz", S.CONFIG_32K_V2, "v2")])
 def test_synth_matches_reference_golden(name, config, version):
     g = golden(name)
     net = make_synth(config, version)

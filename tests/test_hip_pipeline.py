@@ -155,16 +155,18 @@ def test_pipeline_with_index_matches_oracle(models, noise_tape):
     assert np.max(np.abs(out0[0].astype(np.int32) - ref.astype(np.int32))) > 10 * LSB
 
 
-@pytest.mark.parametrize("variant", ["48k_v2", "40k_v1"])
+@pytest.mark.parametrize("variant", ["48k_v2", "40k_v1", "32k_v1", "48k_v1", "32k_v2"])
 def test_pipeline_variants_match_oracle(variant):
-    """End to end for the other generator shape (48 kHz: upsample 12,10,2,2) and the v1 layout (256-d features from HuBERT layer 9
-    + final_proj) against the CPU oracle on a 2 s clip."""
+    """End to end for every shipped generator shape (reference configs/*.json: 48k_v2 12,10,2,2; 32k_v2 10,8,2,2; the five-stage v1
+    shapes 10,4,2,2,2 and 10,6,2,2,2 that end at 16 channels) and the v1 layout (256-d features from HuBERT layer 9 + final_proj)
+    against the CPU oracle on a 2 s clip."""
     from comfy_rvc_amd.config import Config
     from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
     from comfy_rvc_amd.lib.rmvpe import RMVPE
     from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
     from oracle import pipeline as opl
-    cfg_l, ver = {"48k_v2": (S.CONFIG_48K_V2, "v2"), "40k_v1": (S.CONFIG_40K_V1, "v1")}[variant]
+    cfg_l, ver = {"48k_v2": (S.CONFIG_48K_V2, "v2"), "40k_v1": (S.CONFIG_40K_V1, "v1"), "32k_v1": (S.CONFIG_32K_V1, "v1"),
+                  "48k_v1": (S.CONFIG_48K_V1, "v1"), "32k_v2": (S.CONFIG_32K_V2, "v2")}[variant]
     audio = S.synth_audio(2.0, seed=31)
     f0fn = lambda x, **k: S.designed_f0(x.shape[0] // 160 + 1, seed=0).astype(np.float64)   # noqa: E731
     g = torch.Generator().manual_seed(12)

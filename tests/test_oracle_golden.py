@@ -68,7 +68,9 @@ def test_synth_40k_v2_oracle_matches_reference(noise_tape):
 
 
 def test_synth_48k_v2_and_v1_oracle_match_reference():
-    for name, cfg, ver in (("synth_48k_v2.npz", S.CONFIG_48K_V2, "v2"), ("synth_40k_v1.npz", S.CONFIG_40K_V1, "v1")):
+    for name, cfg, ver in (("synth_48k_v2.npz", S.CONFIG_48K_V2, "v2"), ("synth_40k_v1.npz", S.CONFIG_40K_V1, "v1"),
+                           ("synth_32k_v1.npz", S.CONFIG_32K_V1, "v1"), ("synth_48k_v1.npz", S.CONFIG_48K_V1, "v1"),
+                           ("synth_32k_v2.npz", S.CONFIG_32K_V2, "v2")):     # every generator shape of reference configs/*.json
         g, taps, wav = _synth_case(name, cfg, ver)
         assert rel_err(taps["z"], g["z"]) < 2e-5
         assert rel_err(wav, g["wav"]) < 1e-4, name

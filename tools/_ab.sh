@@ -1,3 +1,5 @@
-for r in 0 1; do RANK=$r WORLD_SIZE=2 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RVC_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -2 | cut -c1-400 & done; wait
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 300 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "x3 or conv" 2>&1 | tail -2
+echo "== pipe"; timeout 120 python tools/bench_conv.py gen hubert 2>&1 | grep -v "^ "
+echo "== nopipe"; RVC_HIP_LIB=comfy-rvc_amd/csrc/variants/librvc_hip_nopipe.so timeout 120 python tools/bench_conv.py gen hubert 2>&1 | grep -v "^ "
+for i in 1 2; do
+for v in "" comfy-rvc_amd/csrc/variants/librvc_hip_nopipe.so; do RVC_HIP_LIB=$v timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('LIB=$v', d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"; done; done
