@@ -289,10 +289,15 @@ def synth_spec(config, version="v2"):
     return s
 
 
-def synth_state_dict(config, version="v2", seed=0, fp16_round=True):
+F0_ONLY_KEYS = ("enc_p.emb_pitch.", "dec.m_source.", "dec.noise_convs.")   # absent from the *_nono (no-f0) synthesizers
+
+
+def synth_state_dict(config, version="v2", seed=0, fp16_round=True, f0=True):
     spec = synth_spec(config, version)
     sd = OrderedDict()
     for name, shape in spec.items():
+        if not f0 and name.startswith(F0_ONLY_KEYS):
+            continue
         if name.endswith("weight_g"):
             vshape = spec[name[:-1] + "v"]
             fan = int(np.prod(vshape[1:]))
@@ -340,10 +345,10 @@ def synth_state_dict(config, version="v2", seed=0, fp16_round=True):
     return sd
 
 
-def synth_checkpoint(config=None, version="v2", seed=0):
+def synth_checkpoint(config=None, version="v2", seed=0, f0=1):
     """The `cpt` dict layout `get_vc` reads (reference vc_infer_pipeline.py:199-221), as numpy arrays."""
     config = list(CONFIG_40K_V2 if config is None else config)
-    return {"weight": synth_state_dict(config, version, seed), "config": config, "f0": 1, "version": version,
+    return {"weight": synth_state_dict(config, version, seed, f0=bool(f0)), "config": config, "f0": int(f0), "version": version,
             "sr": {32000: "32k", 40000: "40k", 48000: "48k"}[config[-1]], "info": "synthetic"}
 
 

@@ -116,6 +116,26 @@ def gen_rmvpe(ns):
     print("rmvpe_1s mel", mel.shape, "sal", hidden.shape, "f0 range", f0.min(), f0.max(), "voiced", (f0 > 0).mean())
 
 
+def gen_synth_nono(ns, config, version, tag, T=12):
+    """SynthesizerTrnMs{256,768}NSFsid_nono.infer(phone, phone_lengths, sid) - the no-f0 model family (one randn_like draw)."""
+    cls = ns.models.SynthesizerTrnMs768NSFsid_nono if version == "v2" else ns.models.SynthesizerTrnMs256NSFsid_nono
+    net = cls(*config)
+    del net.enc_q
+    net.load_state_dict(to_torch_sd(S.synth_state_dict(config, version, 0, f0=False)), strict=True)
+    net.eval()
+    rng = np.random.default_rng(22)
+    D = 768 if version == "v2" else 256
+    phone = torch.from_numpy(rng.standard_normal((1, T, D)).astype(np.float32) * 0.5)
+    tape = NoiseTape(4321)
+    with torch.no_grad(), patched_randn_like(tape):
+        o, x_mask, (z, z_p, m_p, logs_p) = net.infer(phone, torch.LongTensor([T]), torch.LongTensor([2]))
+    assert tape.shapes == [(1, config[2], T)], tape.shapes
+    tape2 = NoiseTape(4321)
+    np.savez_compressed(os.path.join(OUT, f"synth_{tag}.npz"), phone=np_(phone), sid=np.int64(2), noise_seed=np.int64(4321),
+                        noise_z=np_(tape2((1, config[2], T))), m_p=np_(m_p), logs_p=np_(logs_p), z_p=np_(z_p), z=np_(z), wav=np_(o))
+    print(f"synth_{tag}", o.shape, "wav rms", float(o.pow(2).mean().sqrt()), "max", float(o.abs().max()))
+
+
 def gen_synth(ns, config, version, tag, T=16, full_taps=False):
     cls = ns.models.SynthesizerTrnMs768NSFsid if version == "v2" else ns.models.SynthesizerTrnMs256NSFsid
     net = cls(*config, is_half=False)
@@ -262,6 +282,9 @@ def main():
         gen_synth(ns, S.CONFIG_32K_V1, "v1", "32k_v1", T=12)
         gen_synth(ns, S.CONFIG_48K_V1, "v1", "48k_v1", T=12)
         gen_synth(ns, S.CONFIG_32K_V2, "v2", "32k_v2", T=12)
+    if "synth_nono" in which:        # the no-f0 model family
+        gen_synth_nono(ns, S.CONFIG_40K_V2, "v2", "40k_v2_nono")
+        gen_synth_nono(ns, S.CONFIG_40K_V1, "v1", "40k_v1_nono")
     if "pipeline" in which:
         gen_pipeline(ns)
 

@@ -327,7 +327,9 @@ def enc_p_forward(sd, config, phone, pitch, taps=None):
     """TextEncoder{256,768}.forward with lengths == T (reference lib/infer_pack/models.py:43-58,:90-105;
     attentions.Encoder.forward :57-69; FFN.forward :387-395).  phone [1,T,D], pitch int64 [1,T] -> m_p, logs_p [1,192,T]."""
     hidden, n_heads, n_layers, ksz = config[3], config[5], config[6], config[7]
-    x = F.linear(phone, sd["enc_p.emb_phone.weight"], sd["enc_p.emb_phone.bias"]) + F.embedding(pitch, sd["enc_p.emb_pitch.weight"])
+    x = F.linear(phone, sd["enc_p.emb_phone.weight"], sd["enc_p.emb_phone.bias"])
+    if pitch is not None:                                   # TextEncoder*(f0=False) of the *_nono synthesizers has no emb_pitch (models.py:47-50)
+        x = x + F.embedding(pitch, sd["enc_p.emb_pitch.weight"])
     x = x * math.sqrt(hidden)
     x = F.leaky_relu(x, 0.1)
     x = torch.transpose(x, 1, -1)
@@ -412,12 +414,15 @@ def sine_source(sd, f0, upp, sr, noise_src, taps=None):
 
 
 def generator_forward(sd, config, z, f0, g, noise_src, taps=None):
-    """GeneratorNSF.forward (reference models.py:542-564) + ResBlock1.forward (modules.py:295-308)."""
+    """GeneratorNSF.forward (reference models.py:542-564) + ResBlock1.forward (modules.py:295-308); f0 None = the plain
+    Generator of the *_nono synthesizers (models.py:292-311): no harmonic source, no noise convs."""
     rb_k, rb_d, up_rates, up_init, up_k, sr = config[10], config[11], config[12], config[13], config[14], config[17]
     upp = int(np.prod(up_rates))
-    har = sine_source(sd, f0, upp, sr, noise_src, taps).transpose(1, 2)
-    if taps is not None:
-        taps["har_source"] = har
+    har = None
+    if f0 is not None:
+        har = sine_source(sd, f0, upp, sr, noise_src, taps).transpose(1, 2)
+        if taps is not None:
+            taps["har_source"] = har
     x = F.conv1d(z, sd["dec.conv_pre.weight"], sd["dec.conv_pre.bias"], padding=3)
     x = x + F.conv1d(g, sd["dec.cond.weight"], sd["dec.cond.bias"])
     nk = len(rb_k)
@@ -425,12 +430,13 @@ def generator_forward(sd, config, z, f0, g, noise_src, taps=None):
         x = F.leaky_relu(x, LRELU_SLOPE)
         w = weight_norm_fold(sd[f"dec.ups.{i}.weight_v"], sd[f"dec.ups.{i}.weight_g"])
         x = F.conv_transpose1d(x, w, sd[f"dec.ups.{i}.bias"], stride=u, padding=(k - u) // 2)
-        if i + 1 < len(up_rates):
-            sf0 = int(np.prod(up_rates[i + 1:]))
-            xs_ = F.conv1d(har, sd[f"dec.noise_convs.{i}.weight"], sd[f"dec.noise_convs.{i}.bias"], stride=sf0, padding=sf0 // 2)
-        else:
-            xs_ = F.conv1d(har, sd[f"dec.noise_convs.{i}.weight"], sd[f"dec.noise_convs.{i}.bias"])
-        x = x + xs_
+        if har is not None:
+            if i + 1 < len(up_rates):
+                sf0 = int(np.prod(up_rates[i + 1:]))
+                xs_ = F.conv1d(har, sd[f"dec.noise_convs.{i}.weight"], sd[f"dec.noise_convs.{i}.bias"], stride=sf0, padding=sf0 // 2)
+            else:
+                xs_ = F.conv1d(har, sd[f"dec.noise_convs.{i}.weight"], sd[f"dec.noise_convs.{i}.bias"])
+            x = x + xs_
         if taps is not None:
             taps[f"gen_ups{i}"] = x
         xs = None
@@ -460,10 +466,12 @@ def synth_infer(sd, config, phone, pitch, nsff0, sid, noise_z, noise_src, taps=N
 
     phone [1,T,D] f32, pitch int64 [1,T], nsff0 f32 [1,T], sid int; noise_z [1,192,T] and
     noise_src [1,T*upp,1] are the two torch.randn_like draws in the reference's order.  -> [1,1,T*upp].
+    pitch = nsff0 = noise_src = None: SynthesizerTrnMs{256,768}NSFsid_nono.infer (models.py:905-916,:1011-1022), one draw.
     """
     sd = tensors(sd)
-    phone, pitch, nsff0 = _t(phone).float(), _t(pitch).long(), _t(nsff0).float()
-    noise_z, noise_src = _t(noise_z).float(), _t(noise_src).float()
+    phone, noise_z = _t(phone).float(), _t(noise_z).float()
+    if pitch is not None:
+        pitch, nsff0, noise_src = _t(pitch).long(), _t(nsff0).float(), _t(noise_src).float()
     with torch.no_grad():
         g = sd["emb_g.weight"][int(sid)].view(1, -1, 1)
         m_p, logs_p = enc_p_forward(sd, config, phone, pitch, taps)

@@ -134,6 +134,11 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
     feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
     feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
     p_len = min(audio0.shape[0] // c.window, feats.shape[1])
+    upp = int(np.prod(config[12]))
+    T = feats.shape[1]
+    if pitch is None:                                       # no-f0 model (reference :84,:105-108): no protect blend, one noise draw
+        o = nets.synth_infer(synth_sd, config, feats, None, None, sid, noise_fn((1, config[2], T)), None)
+        return o[0, 0].float().numpy()
     pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
     if protect < 0.5:
         pitchff = pitchf.clone()
@@ -141,8 +146,6 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
         pitchff[pitchf < 1] = protect
         pitchff = pitchff.unsqueeze(-1)
         feats = feats * pitchff + feats0 * (1 - pitchff)
-    upp = int(np.prod(config[12]))
-    T = feats.shape[1]
     noise_z = noise_fn((1, config[2], T))
     noise_src = noise_fn((1, T * upp, 1))
     o = nets.synth_infer(synth_sd, config, feats, pitch, pitchf, sid, noise_z, noise_src)
@@ -151,8 +154,10 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
 
 def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up_key=0, f0_method="rmvpe",
              rms_mix_rate=0.25, protect=0.33, f0_autotune=False, noise_fn=None, f0_override=None,
-             x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None, big_npy=None, index_rate=0.0):
-    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for if_f0=1, resample_sr=0; optional exact index retrieval.
+             x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None, big_npy=None, index_rate=0.0,
+             if_f0=1):
+    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for resample_sr=0; optional exact index retrieval; if_f0=0 is the
+    no-pitch model family (*_nono): no f0 front-end, pitch None all the way (:151-152,:172-179).
 
     audio: 16 kHz mono float32 (already remixed).  Returns int16 [N] at tgt_sr (and the float waveform
     before normalisation if return_float).  f0_override(audio_pad) -> f0 replaces the pitch front-end.
@@ -162,28 +167,30 @@ def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up
     audio = signal.filtfilt(BH, AH, audio)
     opt_ts = segment_points(audio, c)
     audio_pad = np.pad(audio, (c.t_pad, c.t_pad), mode="reflect")
-    if f0_override is not None:
-        f0 = np.asarray(f0_override(audio_pad), dtype=np.float64)
-    else:
-        f0 = nets.rmvpe_infer_from_audio(rmvpe_sd, audio_pad, thred=0.03)
-        if f0_method == "rmvpe+":
-            f0 = np.clip(f0, a_min=50, a_max=1600)   # infer_from_audio_with_pitch (lib/rmvpe.py:649-659)
-    pitch, pitchf = f0_postprocess(f0, f0_up_key, f0_autotune)
-    p_len = min(pitch.shape[0], pitchf.shape[0])
-    pitch = torch.from_numpy(pitch[:p_len].astype(np.int64)).unsqueeze(0)
-    pitchf = torch.from_numpy(pitchf[:p_len].astype(np.float32)).unsqueeze(0)
+    pitch = pitchf = None
+    if if_f0:
+        if f0_override is not None:
+            f0 = np.asarray(f0_override(audio_pad), dtype=np.float64)
+        else:
+            f0 = nets.rmvpe_infer_from_audio(rmvpe_sd, audio_pad, thred=0.03)
+            if f0_method == "rmvpe+":
+                f0 = np.clip(f0, a_min=50, a_max=1600)   # infer_from_audio_with_pitch (lib/rmvpe.py:649-659)
+        pitch, pitchf = f0_postprocess(f0, f0_up_key, f0_autotune)
+        p_len = min(pitch.shape[0], pitchf.shape[0])
+        pitch = torch.from_numpy(pitch[:p_len].astype(np.int64)).unsqueeze(0)
+        pitchf = torch.from_numpy(pitchf[:p_len].astype(np.float32)).unsqueeze(0)
     s, t, out = 0, None, []
     for t in opt_ts:
         t = t // c.window * c.window
         a = audio_pad[s: t + c.t_pad2 + c.window]
-        ps = pitch[:, s // c.window: (t + c.t_pad2) // c.window + 1]
-        pfs = pitchf[:, s // c.window: (t + c.t_pad2) // c.window + 1]
+        ps = pitch[:, s // c.window: (t + c.t_pad2) // c.window + 1] if if_f0 else None
+        pfs = pitchf[:, s // c.window: (t + c.t_pad2) // c.window + 1] if if_f0 else None
         out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
                               n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
         s = t
     a = audio_pad[t:]
-    ps = pitch[:, t // c.window:] if t is not None else pitch
-    pfs = pitchf[:, t // c.window:] if t is not None else pitchf
+    ps = pitch[:, t // c.window:] if if_f0 and t is not None else pitch
+    pfs = pitchf[:, t // c.window:] if if_f0 and t is not None else pitchf
     out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
                           n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
     audio_opt = np.concatenate(out)

@@ -104,3 +104,15 @@ def test_pipeline_segmentation_oracle_matches_reference(noise_tape):
     assert int(g["n_segments"]) == 4
     assert out.shape == g["out_i16"].shape
     assert np.max(np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))) <= 33
+
+
+def test_synth_nono_oracle_matches_reference():
+    """The no-f0 model family (SynthesizerTrnMs{256,768}NSFsid_nono.infer, reference models.py:905-916,:1011-1022): text encoder
+    without the pitch embedding, plain Generator without harmonic source / noise convs, one noise draw."""
+    for name, cfg, ver in (("synth_40k_v2_nono.npz", S.CONFIG_40K_V2, "v2"), ("synth_40k_v1_nono.npz", S.CONFIG_40K_V1, "v1")):
+        g = golden(name)
+        taps = {}
+        wav = nets.synth_infer(S.synth_state_dict(cfg, ver, 0, f0=False), cfg, g["phone"], None, None, int(g["sid"]), g["noise_z"], None, taps=taps)
+        for k in ("m_p", "logs_p", "z_p", "z"):
+            assert rel_err(taps[k], g[k]) < 2e-5, (name, k)
+        assert rel_err(wav, g["wav"]) < 1e-4, name
