@@ -73,6 +73,7 @@ SIGNATURES = {
     "rvc_synth_finalize": (c_int, [c_void_p]),
     "rvc_synth_destroy": (c_int, [c_void_p]),
     "rvc_synth_upp": (c_int, [c_void_p]),
+    "rvc_synth_has_f0": (c_int, [c_void_p]),
     "rvc_synth_infer": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                 c_void_p, P(SynthTaps)]),
     "rvc_vc_segment": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int,

@@ -59,6 +59,7 @@ struct Synth {
   DevVec dec_cond_w, dec_cond_b;
   std::vector<GenStage> stages;
   float lin_w = 1.f, lin_b = 0.f;
+  bool f0 = true;        // false: the *_nono family (no pitch embedding, plain Generator: reference models.py:244-311,:812-1022)
 };
 
 static void synth_free(Synth& S) {
@@ -89,6 +90,7 @@ Synth* synth_create(Ctx* ctx, const SynthConfig& c) {
 void synth_destroy(Synth* S) { if (S) { synth_free(*S); S->arena.release(); delete S; } }
 void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim) { S->ts.set(name, d, shape, ndim); }
 int synth_upp(const Synth* S) { return S->upp; }
+bool synth_has_f0(const Synth* S) { return S->f0; }
 
 void synth_finalize(Synth* S) {
   const TensorStore& ts = S->ts;
@@ -101,7 +103,9 @@ void synth_finalize(Synth* S) {
     const HostTensor& w = ts.get("enc_p.emb_phone.weight", {C, S->feat_dim});
     S->emb_phone_wT.upload(transpose2d(w.data.data(), C, S->feat_dim));
     S->emb_phone_b.upload(ts.get("enc_p.emb_phone.bias", {C}).data);
-    S->emb_pitch.upload(ts.get("enc_p.emb_pitch.weight", {256, C}).data);
+    // the checkpoint decides the family, like `cpt["f0"]` does in the reference (vc_infer_pipeline.py:202-218)
+    S->f0 = ts.has("enc_p.emb_pitch.weight");
+    if (S->f0) S->emb_pitch.upload(ts.get("enc_p.emb_pitch.weight", {256, C}).data);
     S->emb_g.upload(ts.get("emb_g.weight").data);
     S->n_spk = (int)ts.get("emb_g.weight").shape[0];
   }
@@ -157,8 +161,10 @@ void synth_finalize(Synth* S) {
   S->conv_post = make_conv1d(ts, "dec.conv_post", 1, 3, 1, false, false);
   S->dec_cond_w.upload(ts.get("dec.cond.weight").data);
   S->dec_cond_b.upload(ts.get("dec.cond.bias").data);
-  S->lin_w = ts.get("dec.m_source.l_linear.weight").data[0];
-  S->lin_b = ts.get("dec.m_source.l_linear.bias").data[0];
+  if (S->f0) {
+    S->lin_w = ts.get("dec.m_source.l_linear.weight").data[0];
+    S->lin_b = ts.get("dec.m_source.l_linear.bias").data[0];
+  }
   const int nu = (int)S->up_rates.size();
   S->stages.resize(nu);
   for (int i = 0; i < nu; ++i) {
@@ -173,9 +179,11 @@ void synth_finalize(Synth* S) {
     for (int j = i + 1; j < nu; ++j) sf0 *= S->up_rates[j];
     const std::string nc = "dec.noise_convs." + std::to_string(i);
     if (i + 1 < nu) { st.noise_k = 2 * sf0; st.noise_s = sf0; } else { st.noise_k = 1; st.noise_s = 1; }
-    const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
-    // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
-    conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
+    if (S->f0) {
+      const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
+      // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
+      conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
+    }
     for (int j = 0; j < 3; ++j) {
       const std::string rb = "dec.resblocks." + std::to_string(i * 3 + j) + ".";
       const int k = S->rb_k[j];
@@ -213,7 +221,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   float* xb = A.alloc<float>((size_t)C * T);
   if (!dry) {
     gemm_tn_run(s, S->emb_phone_wT.p, C, 0, feat_cm, T, 0, x, T, 0, C, T, S->feat_dim, 1, S->emb_phone_b.p, 0, E0);
-    encp_embed(s, x, S->emb_pitch.p, pitch, C, T);
+    encp_embed(s, x, S->f0 ? S->emb_pitch.p : nullptr, pitch, C, T);
   }
   {
     const size_t mark = A.off;
@@ -296,8 +304,8 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   }
   // ---- generator
   const long long N = (long long)T * S->upp;
-  float* har = A.alloc<float>((size_t)N);
-  {
+  float* har = S->f0 ? A.alloc<float>((size_t)N) : nullptr;
+  if (S->f0) {
     float* rad = A.alloc<float>((size_t)T);
     float* tmp = A.alloc<float>((size_t)T);
     double* bsum = A.alloc<double>((size_t)((N + 1023) / 1024));
@@ -319,16 +327,18 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     float* ya = A.alloc<float>((size_t)Cc * Tn);
     float* yb = A.alloc<float>((size_t)Cc * Tn);
     float* xs = A.alloc<float>((size_t)Cc * Tn);
-    float* fr = st.noise_k > 1 ? A.alloc<float>((size_t)st.noise_k * Tn) : nullptr;
+    float* fr = (S->f0 && st.noise_k > 1) ? A.alloc<float>((size_t)st.noise_k * Tn) : nullptr;
     if (!dry) {
       RVC_REQUIRE(conv1d_out_len(st.up, Tc) == Tn, "ConvTranspose1d geometry must give T_out = u * T_in");
-      if (st.noise_k > 1) {
+      if (!S->f0) {
+        // plain Generator: nothing is added to the up-sampled signal
+      } else if (st.noise_k > 1) {
         frames(s, har, fr, (int)N, st.noise_k, st.noise_s, st.noise_s / 2, Tn, 0);
         conv1d_run(st.noise, s, fr, Tn, Tn, up, Tn, E0);
       } else {
         conv1d_run(st.noise, s, har, Tn, Tn, up, Tn, E0);
       }
-      ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f; Eu.accumulate = 1;
+      ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f; Eu.accumulate = S->f0 ? 1 : 0;
       conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
       if (taps && i == 0) tap(taps->gen_ups0, up, (size_t)Cc * Tn);
       for (int j = 0; j < 3; ++j) {

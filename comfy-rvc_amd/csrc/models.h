@@ -16,6 +16,7 @@ void synth_destroy(Synth* S);
 void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim);
 void synth_finalize(Synth* S);
 int synth_upp(const Synth* S);
+bool synth_has_f0(const Synth* S);      // false: *_nono family (decided by the checkpoint: no enc_p.emb_pitch)
 void synth_infer(Synth* S, hipStream_t s, const float* feat, int feat_channel_major, const long long* pitch, const float* pitchf, int sid,
                  const float* noise_z, const float* noise_src, int T, float* out, const SynthTaps* taps);
 

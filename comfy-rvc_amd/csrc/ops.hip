@@ -230,7 +230,7 @@ __global__ void encp_embed_kernel(float* __restrict__ x, const float* __restrict
   const long long st = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += st) {
     const int c = (int)(i / T); const int t = (int)(i - (long long)c * T);
-    float v = (x[i] + emb[pitch[t] * C + c]) * scale;
+    float v = (x[i] + (emb ? emb[pitch[t] * C + c] : 0.f)) * scale;        // emb null: text encoder without pitch embedding (no-f0 models)
     x[i] = v > 0.f ? v : v * 0.1f;
   }
 }

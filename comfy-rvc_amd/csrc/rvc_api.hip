@@ -129,10 +129,20 @@ int rvc_synth_set_tensor(rvc_synth* s, const char* name, const float* d, const i
 int rvc_synth_finalize(rvc_synth* s) { RVC_TRY RVC_HIP_CHECK(hipSetDevice(s->ctx->c.device)); synth_finalize(s->m); RVC_CATCH }
 int rvc_synth_destroy(rvc_synth* s) { if (s) { synth_destroy(s->m); delete s; } return 0; }
 int rvc_synth_upp(rvc_synth* s) { return s ? synth_upp(s->m) : 0; }
+int rvc_synth_has_f0(rvc_synth* s) { return (s && synth_has_f0(s->m)) ? 1 : 0; }
+// pitch / pitchf / noise_src belong to the f0 family only: a no-f0 model takes (and must be given) NULL for all three
+static void check_pitch_args(rvc_synth* s, const void* pitch, const void* pitchf, const void* noise_src, int do_protect) {
+  if (synth_has_f0(s->m)) {
+    RVC_REQUIRE(pitch && pitchf && noise_src, "this model was trained with f0: pitch, pitchf and the source noise are required");
+  } else {
+    RVC_REQUIRE(!pitch && !pitchf && !noise_src && !do_protect, "no-f0 model: pitch, pitchf, source noise must be NULL and protect off");
+  }
+}
 int rvc_synth_infer(rvc_synth* s, void* stream, const float* phone, int phone_cm, const int64_t* pitch, const float* pitchf, int sid,
                     const float* noise_z, const float* noise_src, int64_t T, float* out, const rvc_synth_taps* taps) {
   RVC_TRY
-  RVC_REQUIRE(s && phone && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  RVC_REQUIRE(s && phone && noise_z && out, "null argument");
+  check_pitch_args(s, pitch, pitchf, noise_src, 0);
   synth_infer(s->m, (hipStream_t)stream, phone, phone_cm, (const long long*)pitch, pitchf, sid, noise_z, noise_src, (int)T, out, taps);
   check_launch();
   RVC_CATCH
@@ -141,7 +151,8 @@ int rvc_synth_infer(rvc_synth* s, void* stream, const float* phone, int phone_cm
 int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio, int64_t L, int version, const int64_t* pitch,
                    const float* pitchf, int sid, float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
   RVC_TRY
-  RVC_REQUIRE(h && s && audio && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  RVC_REQUIRE(h && s && audio && noise_z && out, "null argument");
+  check_pitch_args(s, pitch, pitchf, noise_src, do_protect);
   hipStream_t st = (hipStream_t)stream;
   const long long Th = hubert_num_frames(L);
   const int D = version == 1 ? 256 : 768;
@@ -159,7 +170,8 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
 int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, const float* feats0_cm, int64_t Th, int feat_dim, const int64_t* pitch,
                          const float* pitchf, int sid, float protect, int do_protect, const float* noise_z, const float* noise_src, float* out) {
   RVC_TRY
-  RVC_REQUIRE(s && feats_cm && pitch && pitchf && noise_z && noise_src && out, "null argument");
+  RVC_REQUIRE(s && feats_cm && noise_z && out, "null argument");
+  check_pitch_args(s, pitch, pitchf, noise_src, do_protect);
   hipStream_t st = (hipStream_t)stream;
   const int T = (int)(2 * Th);
   float* fup = (float*)stream_scratch(st, 2, (size_t)feat_dim * T * sizeof(float));

@@ -17,6 +17,7 @@ from ... import _lib
 
 class _SynthesizerNSFsid:
     FEAT_DIM = 768
+    HAS_F0 = True
 
     def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads, n_layers,
                  kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
@@ -61,6 +62,10 @@ class _SynthesizerNSFsid:
         with torch.cuda.device(self.device):
             _lib.set_tensors(_lib.lib.rvc_synth_set_tensor, self._h, sd)
             _lib.check(_lib.lib.rvc_synth_finalize(self._h))
+        has_f0 = bool(_lib.lib.rvc_synth_has_f0(self._h))
+        if has_f0 != self.HAS_F0:      # the reference would fail in load_state_dict(strict) / at the first infer call
+            raise ValueError(f"{type(self).__name__} expects a checkpoint trained {'with' if self.HAS_F0 else 'without'} f0 "
+                             f"(cpt['f0'] = {int(self.HAS_F0)}), this one is the other family")
         self._loaded = True
         return self
 
@@ -120,6 +125,50 @@ class _SynthesizerNSFsid:
             taps.update(tbuf)
         x_mask = torch.ones(1, 1, T, dtype=torch.float32, device=dev)
         return out, x_mask, (tbuf.get("z"), tbuf.get("z_p"), tbuf.get("m_p"), tbuf.get("logs_p"))
+
+
+class _SynthesizerNSFsid_nono(_SynthesizerNSFsid):
+    """No-f0 family (reference lib/infer_pack/models.py:812-1022): text encoder without pitch embedding, plain HiFi-GAN Generator.
+    The reference's constructor has `sr=None` last (:833,:939); `infer(phone, phone_lengths, sid, rate=None)` draws one randn_like."""
+    HAS_F0 = False
+
+    def __init__(self, *config, sr=None, **kwargs):
+        if len(config) == 18:
+            config, sr = config[:17], config[17]
+        super().__init__(*config, sr if sr is not None else 40000, **kwargs)
+
+    def infer(self, phone, phone_lengths, sid, rate=None, noise=None, taps=None, phone_channel_major=False):
+        assert self._loaded, "load_state_dict first"
+        assert rate is None, "`rate` is unused by every caller of the reference (SURVEY 8a9)"
+        dev = self.device
+        T = int(phone.shape[-1]) if phone_channel_major else int(phone.shape[1])
+        ph = phone.to(dev, torch.float32).contiguous()
+        assert int(torch.as_tensor(phone_lengths).reshape(-1)[0]) == T, "only full-length sequences (the reference always passes p_len = T)"
+        noise_z = torch.randn(1, self.inter_channels, T) if noise is None else (noise[0] if isinstance(noise, (tuple, list)) else noise)
+        nz = torch.as_tensor(noise_z).to(dev, torch.float32).contiguous().view(self.inter_channels, T)
+        out = torch.empty(1, 1, T * self.upp, dtype=torch.float32, device=dev)
+        tp, tbuf = None, {}
+        if taps is not None:
+            C_ = self.inter_channels
+            sizes = {"enc_p_layer0": (self.hidden_channels, T), "m_p": (C_, T), "logs_p": (C_, T), "z_p": (C_, T), "z": (C_, T)}
+            tbuf = {n: torch.empty(sizes[n], dtype=torch.float32, device=dev) for n in taps if n in sizes}
+            tp = _lib.SynthTaps(*[_lib.ptr(tbuf.get(n)) for n, _ in _lib.SynthTaps._fields_])
+        sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib.rvc_synth_infer(self._h, _lib.current_stream(), _lib.ptr(ph), 1 if phone_channel_major else 0, None, None, sid_i,
+                                                _lib.ptr(nz), None, T, _lib.ptr(out), C.byref(tp) if tp is not None else None))
+        if taps is not None:
+            taps.update(tbuf)
+        x_mask = torch.ones(1, 1, T, dtype=torch.float32, device=dev)
+        return out, x_mask, (tbuf.get("z"), tbuf.get("z_p"), tbuf.get("m_p"), tbuf.get("logs_p"))
+
+
+class SynthesizerTrnMs768NSFsid_nono(_SynthesizerNSFsid_nono):
+    FEAT_DIM = 768
+
+
+class SynthesizerTrnMs256NSFsid_nono(_SynthesizerNSFsid_nono):
+    FEAT_DIM = 256
 
 
 class SynthesizerTrnMs768NSFsid(_SynthesizerNSFsid):

@@ -20,7 +20,8 @@ from . import _lib
 from .config import config
 from .lib.audio import MAX_INT16, remix_audio
 from .lib.infer_pack.loaders import HubertModelWithFinalProj
-from .lib.infer_pack.models import SynthesizerTrnMs256NSFsid, SynthesizerTrnMs768NSFsid, _SynthesizerNSFsid
+from .lib.infer_pack.models import (SynthesizerTrnMs256NSFsid, SynthesizerTrnMs256NSFsid_nono, SynthesizerTrnMs768NSFsid,
+                                    SynthesizerTrnMs768NSFsid_nono, _SynthesizerNSFsid)
 from .lib.model_utils import change_rms, load_hubert
 from .lib.utils import gc_collect
 from .pitch_extraction import FeatureExtractor
@@ -110,7 +111,10 @@ class VC(FeatureExtractor):
                     kw["noise"] = self._noise(net_g.inter_channels, p_len, net_g.upp)
                 audio1 = net_g.infer(feats, p_len_t, pitch, pitchf, sid, **kw)[0][0, 0].data.cpu().float().numpy()
             else:
-                audio1 = net_g.infer(feats, p_len_t, sid)[0][0, 0].data.cpu().float().numpy()
+                kw = {}
+                if isinstance(net_g, _SynthesizerNSFsid):      # the no-f0 family draws one randn_like (reference models.py:908,:1014)
+                    kw["noise"] = self._draw((1, net_g.inter_channels, p_len))
+                audio1 = net_g.infer(feats, p_len_t, sid, **kw)[0][0, 0].data.cpu().float().numpy()
         return audio1
 
     def _cut_points(self, audio):
@@ -132,13 +136,14 @@ class VC(FeatureExtractor):
                  f0_file=None, f0_min=50, f0_max=1600):
         index, big_npy = self.load_index(file_index)
         use_index = index is not None and big_npy is not None and index_rate > 0
-        device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid) and if_f0
+        assert bool(if_f0) == bool(getattr(net_g, "HAS_F0", if_f0)), "if_f0 must match the model family (cpt['f0'])"
+        device_path = (isinstance(model, HubertModelWithFinalProj) and isinstance(net_g, _SynthesizerNSFsid)
                        and (not use_index or hasattr(index, "blend_device"))
                        and not (resample_sr >= 16000 and tgt_sr != resample_sr) and f0_file is None)
         if device_path:
             return self._pipeline_device(model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius,
                                          tgt_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max,
-                                         index if use_index else None, index_rate)
+                                         index if use_index else None, index_rate, bool(if_f0))
         audio = signal.filtfilt(bh, ah, audio)
         opt_ts = self._cut_points(audio)
         s = 0
@@ -184,7 +189,8 @@ class VC(FeatureExtractor):
 
 
 def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
-                     rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max, index=None, index_rate=0.0):
+                     rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max, index=None, index_rate=0.0,
+                     if_f0=True):
     """VC.pipeline with every per-sample stage on the GPU: the zero-phase high-pass, reflect padding and input RMS frames
     (rvc_preprocess), HuBERT on a side stream while RMVPE produces the pitch, the segments synthesised from device-resident
     features, and change_rms + int16 normalisation (reference vc_infer_pipeline.py:182-189) as kernels; only the cut search of
@@ -226,7 +232,7 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
             f = model.extract_features(a_dev[b0:b1].view(1, -1), version=version, channel_major=True)
             if index is not None:
                 # feature retrieval on the device, still on the side stream (reference :60-75); feats0 feeds the protect blend
-                feats0.append(f if protect < 0.5 else None)
+                feats0.append(f if (protect < 0.5 and if_f0) else None)
                 f = index.blend_device(f.contiguous(), index_rate)
             else:
                 feats0.append(None)
@@ -241,17 +247,22 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
         if self.noise_fn is None and not self.noise_on_device:
             for _ in range(12):
                 torch.rand([])      # the reference's HuBERT draws one LayerDrop scalar per layer from the same global stream
-        nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
-        noises.append((nz.to(dev, torch.float32).contiguous(), ns.to(dev, torch.float32).contiguous(),
-                       torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)))
+        if if_f0:
+            nz, ns = self._noise(net_g.inter_channels, T, net_g.upp)
+            ns = ns.to(dev, torch.float32).contiguous()
+        else:
+            nz, ns = self._draw((1, net_g.inter_channels, T)), None          # no-f0 family: one draw, no source noise
+        noises.append((nz.to(dev, torch.float32).contiguous(), ns, torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)))
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
-    x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
-    pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
-                                f0_min, f0_max)
-    _mark("f0 ready (rmvpe sync + host post)")
-    p_len = min(pitch.shape[0], pitchf.shape[0])
-    pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
-    pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
+    pitch_d = pitchf_d = None
+    if if_f0:
+        x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
+        pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
+                                    f0_min, f0_max)
+        _mark("f0 ready (rmvpe sync + host post)")
+        p_len = min(pitch.shape[0], pitchf.shape[0])
+        pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
+        pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
     main.wait_stream(side)
     sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
     D = 256 if version == "v1" else 768
@@ -259,12 +270,14 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     for (b0, b1), f, f0c, (nz, ns, out) in zip(bounds, feats, feats0, noises):
         Th = f.shape[1]
         T = 2 * Th
-        pc = pitch_d[b0 // self.window: b0 // self.window + T].contiguous()
-        pf = pitchf_d[b0 // self.window: b0 // self.window + T].contiguous()
-        assert pc.numel() == T, "pitch track shorter than the feature sequence"
+        pc = pf = None
+        if if_f0:
+            pc = pitch_d[b0 // self.window: b0 // self.window + T].contiguous()
+            pf = pitchf_d[b0 // self.window: b0 // self.window + T].contiguous()
+            assert pc.numel() == T, "pitch track shorter than the feature sequence"
         with torch.cuda.device(dev):
             _lib.check(_lib.lib.rvc_vc_segment_feats(net_g._h, _lib.current_stream(), _lib.ptr(f), _lib.ptr(f0c), Th, D, _lib.ptr(pc), _lib.ptr(pf), sid_i,
-                                                     float(protect), 1 if protect < 0.5 else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
+                                                     float(protect), 1 if (protect < 0.5 and if_f0) else 0, _lib.ptr(nz), _lib.ptr(ns), _lib.ptr(out)))
         outs.append(out[self.t_pad_tgt: out.numel() - self.t_pad_tgt])
     _mark("synth enqueued")
     wav = torch.cat(outs) if len(outs) > 1 else outs[0].contiguous()
@@ -286,8 +299,8 @@ VC._pipeline_device = _pipeline_device
 
 
 def _synth_class(version, if_f0):
-    if if_f0 != 1:
-        raise NotImplementedError("the *_nono (no-f0) synthesizers are out of scope of this build")
+    if if_f0 != 1:          # trained without f0: text encoder without pitch embedding + plain Generator (reference :209-218)
+        return SynthesizerTrnMs256NSFsid_nono if version == "v1" else SynthesizerTrnMs768NSFsid_nono
     return SynthesizerTrnMs256NSFsid if version == "v1" else SynthesizerTrnMs768NSFsid
 
 

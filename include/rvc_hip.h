@@ -102,6 +102,11 @@ int rvc_synth_set_tensor(rvc_synth* s, const char* name, const float* host_data,
 int rvc_synth_finalize(rvc_synth* s);
 int rvc_synth_destroy(rvc_synth* s);
 int rvc_synth_upp(rvc_synth* s);
+/* 1: SynthesizerTrnMs{256,768}NSFsid; 0: the no-f0 family SynthesizerTrnMs{256,768}NSFsid_nono (lib/infer_pack/models.py:812-1022),
+ * decided at finalize by the checkpoint (no enc_p.emb_pitch.*, dec.m_source.*, dec.noise_convs.*).  A no-f0 model takes NULL for
+ * pitch_dev, pitchf_dev and noise_src_dev in the calls below (infer(phone, phone_lengths, sid), one noise draw) and no protect blend
+ * (vc_infer_pipeline.py:84,:105-108). */
+int rvc_synth_has_f0(rvc_synth* s);
 /* phone_dev: [T][D] row-major (reference [1,T,D]) if phone_channel_major == 0, else [D][T].
  * pitch_dev int64 [T] (coarse 1..255), pitchf_dev [T] (Hz), noise_z_dev [inter][T], noise_src_dev [T*upp]
  * (the two torch.randn_like draws of the reference, models.py:801 and :409).  out_dev [T*upp]. */

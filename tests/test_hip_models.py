@@ -110,6 +110,35 @@ def test_synth_matches_reference_golden(name, config, version):
     assert rel_err(o.cpu(), g["wav"]) < TOL
 
 
+@pytest.mark.parametrize("name,config,version", [("synth_40k_v2_nono.npz", S.CONFIG_40K_V2, "v2"), ("synth_40k_v1_nono.npz", S.CONFIG_40K_V1, "v1")])
+def test_synth_nono_matches_reference_golden(name, config, version):
+    """The no-f0 family (reference models.py:812-1022): infer(phone, phone_lengths, sid), one noise draw, plain Generator."""
+    from comfy_rvc_amd.lib.infer_pack.models import SynthesizerTrnMs256NSFsid_nono, SynthesizerTrnMs768NSFsid_nono
+    g = golden(name)
+    cls = SynthesizerTrnMs768NSFsid_nono if version == "v2" else SynthesizerTrnMs256NSFsid_nono
+    net = cls(*config)                                                # reference call: the cpt["config"] list splatted, sr last
+    net.load_state_dict(S.synth_state_dict(config, version, 0, f0=False))
+    T = g["phone"].shape[1]
+    taps = {k: None for k in ("m_p", "logs_p", "z_p", "z")}
+    o, mask, _ = net.infer(torch.from_numpy(g["phone"]), torch.LongTensor([T]), torch.LongTensor([int(g["sid"])]), noise=g["noise_z"], taps=taps)
+    assert tuple(o.shape) == g["wav"].shape and tuple(mask.shape) == (1, 1, T)
+    for k in ("m_p", "logs_p", "z_p", "z"):
+        assert rel_err(cm(taps[k]), g[k]) < TOL, k
+    assert rel_err(o.cpu(), g["wav"]) < TOL
+    # the two families do not accept each other's checkpoints or arguments
+    with pytest.raises(ValueError, match="without f0"):
+        cls(*config).load_state_dict(S.synth_state_dict(config, version, 0))
+    f0net = make_synth(config, version)
+    from comfy_rvc_amd import _lib
+    out = torch.empty(T * net.upp, device="cuda")
+    ph, nz = torch.from_numpy(g["phone"]).cuda().contiguous(), torch.from_numpy(g["noise_z"]).cuda().contiguous()
+    with pytest.raises(RuntimeError, match="trained with f0"):        # C ABI: an f0 model without pitch arguments
+        _lib.check(_lib.lib.rvc_synth_infer(f0net._h, None, _lib.ptr(ph), 0, None, None, 0, _lib.ptr(nz), None, T, _lib.ptr(out), None))
+    with pytest.raises(RuntimeError, match="no-f0 model"):            # ... and a no-f0 model with them
+        pc = torch.ones(T, dtype=torch.int64, device="cuda"); pf = torch.ones(T, device="cuda"); ns = torch.zeros(T * net.upp, device="cuda")
+        _lib.check(_lib.lib.rvc_synth_infer(net._h, None, _lib.ptr(ph), 0, _lib.ptr(pc), _lib.ptr(pf), 0, _lib.ptr(nz), _lib.ptr(ns), T, _lib.ptr(out), None))
+
+
 def test_synth_matches_oracle_longer_sequence():
     from oracle import nets
     from oracle.pipeline import f0_postprocess

@@ -190,6 +190,45 @@ def test_pipeline_variants_match_oracle(variant):
     assert np.max(np.abs(out[0].astype(np.int32) - ref.astype(np.int32))) <= LSB
 
 
+@pytest.mark.parametrize("version,segmented", [("v2", False), ("v1", False), ("v2", True)])
+def test_pipeline_no_f0_model_matches_oracle(version, segmented):
+    """cpt["f0"] == 0: get_vc builds the *_nono synthesizer, VC.pipeline runs no pitch front-end and passes pitch None all the way
+    (reference vc_infer_pipeline.py:151-179,:209-218) - device pipeline and generic VC.vc path, against the CPU oracle."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.infer_pack.models import _SynthesizerNSFsid_nono
+    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+    from oracle import pipeline as opl
+    cfg_l = S.CONFIG_40K_V2 if version == "v2" else S.CONFIG_40K_V1
+    seg = dict(x_pad=1, x_query=1, x_center=2, x_max=3) if segmented else {}
+    audio = S.synth_audio(7.0 if segmented else 1.5, seed=33)
+    g = torch.Generator().manual_seed(14)
+    tape = []
+
+    def rec(shape):
+        t = torch.randn(shape, generator=g); tape.append(t); return t
+    ref = opl.pipeline(S.hubert_state_dict(0), None, S.synth_state_dict(cfg_l, version, 0, f0=False), cfg_l, version, audio,
+                       rms_mix_rate=0.25, protect=0.33, noise_fn=rec, if_f0=0, **seg)
+    cfg = Config(**seg)
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    vcd = get_vc(S.synth_checkpoint(cfg_l, version, 0, f0=0), config=cfg)
+    assert isinstance(vcd["net_g"], _SynthesizerNSFsid_nono)
+    vc = VC(40000, cfg)
+    for device_path in (True, False):
+        it = iter(tape)
+        vc.noise_fn = lambda shape: next(it)
+        model = hub
+        if not device_path:
+            class Wrap:               # hides the concrete type: VC.pipeline then takes the host path and VC.vc the generic callee protocol
+                def extract_features(self, **kw):
+                    return hub.extract_features(**kw)
+            model = Wrap()
+        out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=model, input_audio=(audio, 16000), sid=0, f0_up_key=0,
+                        f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, config=cfg)
+        assert out is not None and out[1] == 40000 and out[0].shape == ref.shape
+        assert np.max(np.abs(out[0].astype(np.int32) - ref.astype(np.int32))) <= LSB, device_path
+
+
 @pytest.mark.parametrize("case", ["short_0.4s", "short_0.12s", "silence", "loud", "stereo", "float64"])
 def test_pipeline_edge_inputs_match_oracle(models, case):
     """Clips shorter than the 1 s reflect pad (repeated reflection), all-zero input, peak > 1 (remix_audio rescales), stereo input
