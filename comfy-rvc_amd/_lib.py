@@ -100,6 +100,7 @@ SIGNATURES = {
     "rvc_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "rvc_op_attention_rel": (c_int, [c_void_p] * 8 + [c_int, c_int]),
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),
+    "rvc_resample": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),
     "rvc_set_conv_precision": (c_int, [c_int]),
     "rvc_prof_enable": (c_int, [c_int]),
     "rvc_prof_collect": (c_int, [P(C.c_double), P(C.c_double), P(c_int64)]),

@@ -15,6 +15,7 @@ void gemv(hipStream_t s, const float* W, const float* x, const float* b, float* 
 void zp_sample(hipStream_t s, const float* stats, const float* noise, float* zp, int C, int T);
 void flip_c(hipStream_t s, const float* x, float* y, int C, int T);
 void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitch, int C, int T);
+void resample(hipStream_t s, const float* x, long long n_in, const double* h, int half, int U, int D, float* y, long long n_out);
 void transpose(hipStream_t s, const float* in, float* out, int R, int C, long long ldin, long long ldout, int batch, long long bin,
                long long bout);
 void feats_prepare(hipStream_t s, const float* f, const float* f0, const float* pitchf, float* out, int D, int Th, int T, float protect,

@@ -239,6 +239,29 @@ void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitc
   hipLaunchKernelGGL(encp_embed_kernel, dim3(blocks), dim3(256), 0, s, x, emb, pitch, C, T, sqrtf((float)C));
 }
 
+// ---------------------------------------------------------------------------------------------- rational resampling
+// y[n] = sum_m x[m] h[m U - n D + half]: polyphase evaluation of a linear-phase low-pass designed on the U-times up-sampled grid
+// (host: lib/audio.py::design_resample_filter, float64).  One thread per output sample, float64 accumulation; the input is taken
+// as zero outside [0, n_in).  Stands in for librosa.resample(res_type="soxr_hq") at the two places the reference calls it
+// (lib/audio.py:150 input -> 16 kHz, vc_infer_pipeline.py:186 output -> resample_sr); 480 k outputs x 550 taps: well under 1 ms.
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long long n_in, const double* __restrict__ h, int half,
+                                                       int U, int D, float* __restrict__ y, long long n_out) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_out) return;
+  const long long c = n * D;                       // position of output n on the up-sampled grid
+  long long lo = c - half, hi = c + half;
+  long long m0 = lo <= 0 ? 0 : (lo + U - 1) / U;   // ceil(lo / U), clamped to the signal
+  long long m1 = hi / U;                           // floor (hi >= 0)
+  if (m1 > n_in - 1) m1 = n_in - 1;
+  double acc = 0.0;
+  for (long long m = m0; m <= m1; ++m) acc += (double)x[m] * h[m * U - c + half];
+  y[n] = (float)acc;
+}
+void resample(hipStream_t s, const float* x, long long n_in, const double* h, int half, int U, int D, float* y, long long n_out) {
+  if (n_out <= 0) return;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, x, n_in, h, half, U, D, y, n_out);
+}
+
 // ---------------------------------------------------------------------------------------------- transpose [R][C] -> [C][R]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C,
                                                         long long ldin, long long ldout, long long bin, long long bout) {

@@ -181,6 +181,14 @@ int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, cons
   RVC_CATCH
 }
 
+int rvc_resample(void* stream, const float* x, int64_t n_in, const double* taps, int half, int up, int down, float* y, int64_t n_out) {
+  RVC_TRY
+  RVC_REQUIRE(x && taps && y && n_in > 0 && half >= 0 && up > 0 && down > 0, "bad argument");
+  resample((hipStream_t)stream, x, n_in, taps, half, up, down, y, n_out);
+  check_launch();
+  RVC_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ feature retrieval
 struct rvc_index { FeatIndex* m; };
 int rvc_index_create(rvc_ctx* ctx, const float* big_npy, int64_t N, int D, rvc_index** out) {

@@ -1,4 +1,6 @@
 """Host-side audio helpers on the inference path (mirror of reference lib/audio.py:14,:115-124,:144-163,:274-304)."""
+import functools
+import math
 from collections.abc import Mapping
 
 import numpy as np
@@ -36,13 +38,64 @@ def get_audio(audio):
     return audio
 
 
+# ---------------------------------------------------------------------------------------------- resampling
+# The reference resamples with librosa.resample (default res_type "soxr_hq": linear phase, pass band up to 0.913 of the lower
+# Nyquist frequency, stop band from Nyquist, 20-bit precision).  librosa / soxr are not available to this build, so that exact
+# arithmetic cannot be reproduced ("parity unpinned"); what is restated is its specification: a linear-phase
+# Kaiser-windowed sinc with the same band edges and ~122 dB stop band, evaluated exactly (float64 taps, float64 accumulation) by the
+# polyphase kernel rvc_resample.  Output length = ceil(n * target / orig), as librosa computes it.
+RESAMPLE_PASSBAND, RESAMPLE_ATTEN_DB = 0.913, 122.0
+
+
+@functools.lru_cache(maxsize=16)
+def design_resample_filter(orig_sr, target_sr):
+    """(taps float64 [2*half+1], half, up, down): low-pass on the `up`-times up-sampled grid, DC gain `up`."""
+    g = math.gcd(int(orig_sr), int(target_sr))
+    up, down = int(target_sr) // g, int(orig_sr) // g
+    fs_up = float(orig_sr) * up
+    fn = min(orig_sr, target_sr) / 2.0
+    width = (1.0 - RESAMPLE_PASSBAND) * fn / fs_up                 # transition band, cycles / sample on the up-sampled grid
+    fc = 0.5 * (1.0 + RESAMPLE_PASSBAND) * fn / fs_up              # -6 dB point in the middle of it
+    beta = 0.1102 * (RESAMPLE_ATTEN_DB - 8.7)
+    half = int(math.ceil((RESAMPLE_ATTEN_DB - 7.95) / (14.36 * width) / 2.0))
+    k = np.arange(-half, half + 1, dtype=np.float64)
+    taps = 2.0 * fc * np.sinc(2.0 * fc * k) * np.kaiser(2 * half + 1, beta)
+    taps *= up / taps.sum()
+    return taps, half, up, down
+
+
+def resample_audio(audio, orig_sr, target_sr, device="cuda:0"):
+    """float32 [..., N] at orig_sr -> float32 [..., ceil(N * target / orig)] at target_sr on the GPU (rvc_resample)."""
+    import torch
+    from .. import _lib
+    audio = np.asarray(audio, dtype=np.float32)
+    if int(orig_sr) == int(target_sr):
+        return audio
+    taps, half, up, down = design_resample_filter(int(orig_sr), int(target_sr))
+    n_in = audio.shape[-1]
+    n_out = int(math.ceil(n_in * float(target_sr) / float(orig_sr)))
+    flat = np.ascontiguousarray(audio.reshape(-1, n_in))
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        h = torch.from_numpy(taps).to(dev)
+        x = torch.from_numpy(flat).to(dev)
+        y = torch.empty(flat.shape[0], n_out, dtype=torch.float32, device=dev)
+        for c in range(flat.shape[0]):
+            _lib.check(_lib.lib.rvc_resample(_lib.current_stream(), _lib.ptr(x[c]), n_in, _lib.ptr(h), half, up, down, _lib.ptr(y[c]), n_out))
+        out = y.cpu().numpy()
+    return out.reshape(audio.shape[:-1] + (n_out,))
+
+
+resample = resample_audio      # (remix_audio has a boolean parameter of that name)
+
+
 def remix_audio(input_audio, target_sr=None, norm=False, to_int16=False, resample=False, axis=0, merge_type=None, max_volume=.95, **kwargs):
     """float32 mono at target_sr, peak-limited to max_volume (reference lib/audio.py:144-163)."""
     audio = np.array(input_audio[0], dtype="float32")
     if target_sr is None:
         target_sr = input_audio[1]
     if resample or input_audio[1] != target_sr:
-        raise NotImplementedError("resampling needs librosa/soxr, absent here (parity-unpinned branch, SURVEY 8c); feed 16 kHz audio")
+        audio = resample_audio(audio, input_audio[1], target_sr, **{k: v for k, v in kwargs.items() if k == "device"})
     if audio.ndim > 1:
         audio = get_merge_func(merge_type)(audio, axis=axis)
     if norm:

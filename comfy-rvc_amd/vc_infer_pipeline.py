@@ -18,7 +18,7 @@ from scipy import signal
 
 from . import _lib
 from .config import config
-from .lib.audio import MAX_INT16, remix_audio
+from .lib.audio import MAX_INT16, remix_audio, resample
 from .lib.infer_pack.loaders import HubertModelWithFinalProj
 from .lib.infer_pack.models import (SynthesizerTrnMs256NSFsid, SynthesizerTrnMs256NSFsid_nono, SynthesizerTrnMs768NSFsid,
                                     SynthesizerTrnMs768NSFsid_nono, _SynthesizerNSFsid)
@@ -181,7 +181,7 @@ class VC(FeatureExtractor):
         if rms_mix_rate < 1:
             audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)
         if resample_sr >= 16000 and tgt_sr != resample_sr:
-            raise NotImplementedError("output resampling needs librosa/soxr (parity-unpinned branch, SURVEY 8c); use resample_sr=0")
+            audio_opt = resample(audio_opt, tgt_sr, resample_sr, device=str(self.device))     # reference :185-186 (librosa.resample)
         self.last_float = audio_opt          # float waveform before the int16 normalisation (parity tests compare this too)
         audio_max = np.abs(audio_opt).max() / 0.99
         audio_opt = (audio_opt * MAX_INT16 / audio_max).astype(np.int16)

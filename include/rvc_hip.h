@@ -192,6 +192,12 @@ int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, c
 int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev, float* har_dev, float* sine_dev, int T, int upp, float sr,
                        float lin_w, float lin_b, float* rad_dev, float* tmp_dev, float* phase_dev);
 
+/* Rational resampling by up/down (lowest terms): y_dev[n] = sum_m x_dev[m] * taps_dev[m*up - n*down + half], n < n_out, float64
+ * accumulation, zero extension outside the input.  taps_dev: 2*half+1 float64 coefficients of a linear-phase low-pass on the
+ * up-times up-sampled grid, DC gain `up`.  Replaces librosa.resample (soxr_hq) at lib/audio.py:150 (input -> 16 kHz) and
+ * vc_infer_pipeline.py:186 (output -> resample_sr); the coefficients are designed on the host (comfy-rvc_amd/lib/audio.py). */
+int rvc_resample(void* stream, const float* x_dev, int64_t n_in, const double* taps_dev, int half, int up, int down, float* y_dev, int64_t n_out);
+
 /* Matrix-core arithmetic of the Conv1d layers created AFTER the call (process-wide; models read it at *_finalize):
  *   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32; bitwise an fp32 FMA chain)
  *   1  default: the synthesizer's generator convolutions use the bf16x3 split (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on

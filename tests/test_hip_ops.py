@@ -415,3 +415,36 @@ def test_preprocess_filtfilt_pad_rms(L, n, dtype, t_pad):
     cols = 8000 * np.arange(n1)[None, :] + np.arange(16000)[:, None]
     ref_rms = np.sqrt(np.mean(np.abs(yp[cols]) ** 2, axis=0))
     assert np.allclose(rms1.cpu().numpy(), ref_rms, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("orig,target,n", [(44100, 16000, 30000), (48000, 16000, 4801), (40000, 48000, 20000), (16000, 44100, 7000), (44100, 16000, 37)])
+def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
+    """rvc_resample against the float64 definition y[n] = sum_m x[m] h[m U - n D + half] (zero extension), output length ceil(n t / o);
+    a pass-band sine keeps its amplitude and phase, a tone above the new Nyquist frequency is removed."""
+    from comfy_rvc_amd.lib.audio import design_resample_filter, resample_audio
+    h, half, up, down = design_resample_filter(orig, target)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = resample_audio(x, orig, target)
+    n_out = int(np.ceil(n * target / orig))
+    assert y.shape == (n_out,) and y.dtype == np.float32
+    ref = np.zeros(n_out)
+    for i in range(n_out):
+        c = i * down
+        m0, m1 = max(0, -((half - c) // up)), min(n - 1, (c + half) // up)
+        m = np.arange(m0, m1 + 1)
+        ref[i] = np.dot(x[m].astype(np.float64), h[m * up - c + half])
+    assert np.abs(y - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+    if n > 10000:
+        t_in, t_out = np.arange(n) / orig, np.arange(n_out) / target
+        f_pass, f_stop = 0.4 * min(orig, target) / 2, 0.5 * (min(orig, target) / 2 + max(orig, target) / 2)
+        yp = resample_audio(np.sin(2 * np.pi * f_pass * t_in).astype(np.float32), orig, target)
+        mid = slice(n_out // 4, 3 * n_out // 4)
+        assert np.abs(yp[mid] - np.sin(2 * np.pi * f_pass * t_out[mid])).max() < 2e-5
+        if target < orig:
+            ys = resample_audio(np.sin(2 * np.pi * f_stop * t_in).astype(np.float32), orig, target)
+            assert np.abs(ys[mid]).max() < 1e-5
+    # multi-channel input is resampled along the last axis, like librosa
+    x2 = np.stack([x, -0.5 * x])
+    y2 = resample_audio(x2, orig, target)
+    assert y2.shape == (2, n_out) and np.array_equal(y2[0], y) and np.allclose(y2[1], -0.5 * y, atol=1e-7)

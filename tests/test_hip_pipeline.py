@@ -292,3 +292,37 @@ def test_two_lanes_in_flight_equal_sequential_conversion(models):
     assert len(par) == len(seq)
     for a, b in zip(seq, par):
         assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_other_sample_rates_in_and_out(models):
+    """44.1 kHz stereo in (remix_audio resamples to 16 kHz, reference lib/audio.py:149-150) and resample_sr = 48000 out (reference
+    vc_infer_pipeline.py:185-186,:322).  librosa/soxr are absent, so these branches are checked against the same pipeline fed with
+    the resampled audio / resampled afterwards, not against the reference (parity unpinned)."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.audio import resample_audio
+    from comfy_rvc_amd.vc_infer_pipeline import VC, vc_single
+    hub, vcd, rm = models
+    t = np.arange(int(1.5 * 44100)) / 44100.0
+    a = (0.3 * np.sin(2 * np.pi * 220 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t))).astype(np.float32)
+    stereo = np.stack([a, 0.8 * a])                                     # [C, N] as get_audio delivers it
+    vc = VC(40000, Config())
+    vc.model_rmvpe = rm
+    args = dict(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0,
+                rms_mix_rate=0.25, protect=0.33)
+
+    def run(inp, **kw):
+        gen = torch.Generator().manual_seed(5)
+        vc.noise_fn = lambda shape: torch.randn(shape, generator=gen)
+        out = vc_single(input_audio=inp, **args, **kw)
+        assert out is not None
+        return out
+    wav, sr = run((stereo, 44100))
+    n16 = int(np.ceil(a.shape[0] * 16000 / 44100))
+    assert sr == 40000 and wav.dtype == np.int16 and abs(wav.shape[0] - (n16 // 160) * 400) <= 400
+    wav_ref, _ = run((resample_audio(stereo, 44100, 16000), 16000))      # same thing, resampled by the caller
+    assert np.array_equal(wav, wav_ref)
+    wav48, sr48 = run((stereo, 44100), resample_sr=48000)
+    assert sr48 == 48000 and wav48.shape[0] == int(np.ceil(wav.shape[0] * 48000 / 40000))
+    up = resample_audio(wav.astype(np.float32), 40000, 48000)
+    c = np.corrcoef(up, wav48.astype(np.float32))[0, 1]
+    assert c > 0.9999, c

@@ -111,3 +111,18 @@ def test_clip_lanes_fail_instead_of_hanging_when_a_lane_cannot_start(monkeypatch
     monkeypatch.setattr(P.torch.cuda, "set_device", lambda d: (_ for _ in ()).throw(RuntimeError("no such device")))
     with pytest.raises(RuntimeError, match="no such device"):
         pool.map([1, 2, 3])
+
+
+@pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (40000, 48000), (32000, 44100)])
+def test_resample_filter_meets_the_soxr_hq_specification(orig, target):
+    """The stand-in for librosa.resample(res_type="soxr_hq") (absent here: parity unpinned) restates its specification: linear phase,
+    flat up to 0.913 of the lower Nyquist frequency, > 120 dB down from Nyquist on, unit gain in every polyphase branch."""
+    from comfy_rvc_amd.lib.audio import design_resample_filter
+    h, half, up, down = design_resample_filter(orig, target)
+    assert h.shape[0] == 2 * half + 1 and np.array_equal(h, h[::-1]) and up * orig == down * target
+    assert max(abs(h[p::up].sum() - 1.0) for p in range(up)) < 1e-6
+    H = np.abs(np.fft.rfft(h, 1 << 21)) / up
+    f = np.fft.rfftfreq(1 << 21) * orig * up
+    fn = min(orig, target) / 2
+    assert 20 * np.log10(H[f >= fn].max()) < -120.0
+    assert np.abs(20 * np.log10(H[f <= 0.913 * fn])).max() < 1e-4
