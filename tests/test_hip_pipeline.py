@@ -318,7 +318,7 @@ def test_other_sample_rates_in_and_out(models):
         return out
     wav, sr = run((stereo, 44100))
     n16 = int(np.ceil(a.shape[0] * 16000 / 44100))
-    assert sr == 40000 and wav.dtype == np.int16 and abs(wav.shape[0] - (n16 // 160) * 400) <= 400
+    assert sr == 40000 and wav.dtype == np.int16 and abs(wav.shape[0] - (n16 // 160) * 400) <= 1200     # (T_h frames: a little shorter than n16 * 2.5)
     wav_ref, _ = run((resample_audio(stereo, 44100, 16000), 16000))      # same thing, resampled by the caller
     assert np.array_equal(wav, wav_ref)
     wav48, sr48 = run((stereo, 44100), resample_sr=48000)
