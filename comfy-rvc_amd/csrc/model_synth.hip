@@ -56,7 +56,7 @@ struct Synth {
   ConvLayer proj;
   FlowLayer flow[4];
   ConvLayer conv_pre, conv_post;
-  DevVec dec_cond_w, dec_cond_b;
+  DevVec dec_cond_w, dec_cond_b, conv_post_w;   // conv_post_w: raw [Ci][7] weights of the 1-channel output conv (ops.hip::conv_to1)
   std::vector<GenStage> stages;
   float lin_w = 1.f, lin_b = 0.f;
   bool f0 = true;        // false: the *_nono family (no pitch embedding, plain Generator: reference models.py:244-311,:812-1022)
@@ -69,7 +69,7 @@ static void synth_free(Synth& S) {
   S.enc.clear();
   fl(S.proj);
   for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); f.cond_w.free_(); f.cond_b.free_(); }
-  fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_();
+  fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_(); S.conv_post_w.free_();
   for (auto& st : S.stages) { fl(st.up); fl(st.noise); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
   S.stages.clear();
 }
@@ -159,6 +159,7 @@ void synth_finalize(Synth* S) {
   }
   S->conv_pre = make_conv1d(ts, "dec.conv_pre", 1, 3, 1, false);
   S->conv_post = make_conv1d(ts, "dec.conv_post", 1, 3, 1, false, false);
+  S->conv_post_w.upload(ts.get("dec.conv_post.weight").data);
   S->dec_cond_w.upload(ts.get("dec.cond.weight").data);
   S->dec_cond_b.upload(ts.get("dec.cond.bias").data);
   if (S->f0) {
@@ -358,8 +359,13 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     cur = xs; Tc = Tn;
   }
   if (!dry) {
-    ConvEpilogue Ep; Ep.pre_act = ACT_LRELU; Ep.pre_slope = 0.01f; Ep.act = ACT_TANH;
-    conv1d_run(S->conv_post, s, cur, Tc, Tc, out, Tc, Ep);
+    static const bool stream_post = [] { const char* e = getenv("RVC_CONVPOST_STREAM"); return !e || atoi(e) != 0; }();
+    if (stream_post) {
+      conv_to1(s, cur, Tc, S->conv_post_w.p, S->up_init >> nu, 7, 3, Tc, 0.01f, 1, out);
+    } else {
+      ConvEpilogue Ep; Ep.pre_act = ACT_LRELU; Ep.pre_slope = 0.01f; Ep.act = ACT_TANH;
+      conv1d_run(S->conv_post, s, cur, Tc, Tc, out, Tc, Ep);
+    }
   }
 }
 

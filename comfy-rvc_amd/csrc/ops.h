@@ -15,6 +15,8 @@ void gemv(hipStream_t s, const float* W, const float* x, const float* b, float* 
 void zp_sample(hipStream_t s, const float* stats, const float* noise, float* zp, int C, int T);
 void flip_c(hipStream_t s, const float* x, float* y, int C, int T);
 void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitch, int C, int T);
+void conv_to1(hipStream_t s, const float* x, long long ldx, const float* w /*[Ci][K]*/, int Ci, int K, int pad, int T, float pre_slope,
+              int act_tanh, float* y);
 void resample(hipStream_t s, const float* x, long long n_in, const double* h, int half, int U, int D, float* y, long long n_out);
 void transpose(hipStream_t s, const float* in, float* out, int R, int C, long long ldin, long long ldout, int batch, long long bin,
                long long bout);

@@ -239,6 +239,32 @@ void encp_embed(hipStream_t s, float* x, const float* emb, const long long* pitc
   hipLaunchKernelGGL(encp_embed_kernel, dim3(blocks), dim3(256), 0, s, x, emb, pitch, C, T, sqrtf((float)C));
 }
 
+// ---------------------------------------------------------------------------------------------- Conv1d to ONE output channel
+// y[t] = act(sum_c sum_j w[c][j] * pre(x[c][t + j - pad])): the generator's conv_post (Ci = 32 or 16, k = 7, no bias, leaky-ReLU 0.01
+// before, tanh after; reference models.py:561-563).  On the MFMA kernels a 1-row output wastes 31 of 32 tile rows and ran at
+// 0.65 TB/s; this is a plain streaming kernel: one thread per output sample, weights through scalar loads, the 7-fold reuse of x
+// served by L1 / L2.  HBM-bound: Ci * T * 4 bytes in, T * 4 out.
+__global__ __launch_bounds__(256) void conv_to1_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w, int Ci, int K,
+                                                       int pad, int T, float pre_slope, int act_tanh, float* __restrict__ y) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float acc = 0.f;
+  for (int c = 0; c < Ci; ++c) {
+    const float* xr = x + (long long)c * ldx;
+    for (int j = 0; j < K; ++j) {
+      const int q = t + j - pad;
+      float v = (q >= 0 && q < T) ? xr[q] : 0.f;
+      v = fmaxf(v, v * pre_slope);
+      acc = fmaf(w[c * K + j], v, acc);
+    }
+  }
+  y[t] = act_tanh ? tanhf(acc) : acc;
+}
+void conv_to1(hipStream_t s, const float* x, long long ldx, const float* w, int Ci, int K, int pad, int T, float pre_slope, int act_tanh,
+              float* y) {
+  hipLaunchKernelGGL(conv_to1_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, ldx, w, Ci, K, pad, T, pre_slope, act_tanh, y);
+}
+
 // ---------------------------------------------------------------------------------------------- rational resampling
 // y[n] = sum_m x[m] h[m U - n D + half]: polyphase evaluation of a linear-phase low-pass designed on the U-times up-sampled grid
 // (host: lib/audio.py::design_resample_filter, float64).  One thread per output sample, float64 accumulation; the input is taken
