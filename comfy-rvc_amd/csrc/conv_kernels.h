@@ -17,6 +17,9 @@ struct ConvArgsX : ConvArgs {
   int ni; unsigned magNI;  // 1-D: 64-wide column groups per staged row (ceil(span / 64)) and its division magic
   // bf16x3 kernel (conv_x3.hip): split weight image, its padded row count, X buffers in LDS (1 or 2)
   const unsigned char* Wx; int CoPx; int xbufs; int NC; int kreal; long long wxBatch;
+  // fused ResBlock pair (conv_x3_kernel<..., FUSE>): second conv's weight image, first conv's bias, halo (k - 1) / 2 of the
+  // second conv, slope of the leaky ReLU between the two
+  const unsigned char* Wx2; const float* bias1; int fuse_p2; float fuse_slope;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -124,5 +127,8 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s);
 // bf16x3 path: returns false when the layer / geometry is not eligible (caller falls back to the fp32 kernel)
 bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops);
 bool conv_x3_enabled();
+// y = (x + c2(lrelu(c1(lrelu(x))))) * scale [+ y] for a ResBlock1 pair of narrow layers in ONE launch; false when not eligible
+bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
+                      const ConvEpilogue& e2);
 
 }  // namespace rvc

@@ -39,7 +39,13 @@ __host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 7 : (BN 
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 
-template <int WM, int WN, int AM, int AN>
+// FUSE: ResBlock pair  y = (x + W2 * lrelu(W1 *_d lrelu(x) + b1) + b2) * scale [+ y]  in one launch (Ci = Co, all channels of the
+// tile resident in LDS): pass 1 is the ordinary stage loop of the dilated conv over BN columns; its accumulators (+ b1, leaky
+// ReLU, zero outside the sequence = the second conv's zero padding) are split and written over the input tile in LDS in the
+// same row format; pass 2 runs the stage loop of the second conv (dilation 1) on those rows and the ordinary epilogue stores the
+// BN - (k - 1) columns that have their full halo.  The intermediate tensor never goes to HBM: 2 reads + 1 write of [C][T]
+// instead of 5 + 1... (generator).
+template <int WM, int WN, int AM, int AN, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int li = lane0 & 31, lh = lane0 >> 5;
   const int z = blockIdx.z / p.ksplit, ks = blockIdx.z - z * p.ksplit;   // batch index, K-split index
   const int co0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  const int P2 = FUSE ? p.fuse_p2 : 0;                                    // halo of the fused second conv (each side)
+  const int n0 = blockIdx.x * (BN - 2 * P2);
   const float* __restrict__ X = p.X + (long long)z * p.xBatch;
   const unsigned char* __restrict__ Wg = p.Wx + (long long)z * p.wxBatch * 2;
 
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int gps = (ngroups + p.ksplit - 1) / p.ksplit;        // chunk groups per K split
   const int g0 = ks * gps, g1 = min(ngroups, g0 + gps);
   const int nstages = max(g1 - g0, 0) * ntb;
-  const int bx = n0 * st - p.pad;
+  const int bx = n0 * st - p.pad - P2;                 // (fused: column 0 of the tile is the first column of the intermediate)
   // 2-D 3x3 (p.Wd > 0): the tile is BH image rows x BWd columns; the staged "positions" are the (BH + 2) x PW halo patch in
   // row-major order, tap (dh, dw) is the position offset dh * PW + dw
   const bool two_d = p.Wd > 0;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     }
   };
   // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
-  auto issue_w = [&](int grp, int tb, int buf) {
+  auto issue_w = [&](const unsigned char* __restrict__ Wimg, int grp, int tb, int buf) {
 #ifdef RVC_X3_NOW
     return;
 #endif
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       const int j = pi / RB, rblk = pi - j * RB;            // j = ((chunk in group) * ut + tap in block) * 2 + (hi | lo)
       const int cc = j / (2 * ut), jr = j - cc * 2 * ut;
       const long long row = ((long long)((grp * NC + cc) * p.ktaps + tb * p.KT + (jr >> 1)) * 2 + (jr & 1)) * p.CoPx + co0 + rblk * 32;
-      const unsigned char* src = Wg + row * 32 + lane * 16;
+      const unsigned char* src = Wimg + row * 32 + lane * 16;
       unsigned char* dst = Ws + buf * wbuf + pi * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -180,31 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     bq[an] = two_d ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl;
   }
 
-  int chunk = g0, tb = 0;
-  const long long t_begin = X3TICK();
-  if (nstages > 0) { issue_w(g0, 0, 0); load_x(g0); }
-  X3TACC(1, X3TICK() - t_begin);
-  for (int it = 0; it < nstages; ++it) {
-    const long long ta = X3TICK();
-    const int buf = it & 1;
-    const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
-    if (tb == 0) {
-      if (p.xbufs == 1 && it > 0) __syncthreads();       // single X buffer: every wave is done with the previous chunk
-      store_x(xb);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stage's weight DMA has landed
-    __syncthreads();
-    const long long tb_ = X3TICK();
-    X3TACC(2, tb_ - ta);
-    int ntb_ = tb + 1, nchunk_ = chunk;
-    if (ntb_ == ntb) { ntb_ = 0; ++nchunk_; }
-    if (it + 1 < nstages) {
-      issue_w(nchunk_, ntb_, buf ^ 1);
-      if (ntb_ == 0) load_x(nchunk_);
-    }
-    const long long tc = X3TICK();
-    X3TACC(3, tc - tb_);
-    // ---- MFMAs of this stage
+  // ---- MFMAs of one stage: NC chunks x ut taps of weight buffer `buf` against input buffer `xb`
+  auto mfma_stage = [&](int buf, int xb, int tb, int dil_eff) {
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
     const unsigned char* wb = Ws + buf * wbuf;
 #ifdef RVC_X3_NOMFMA
@@ -215,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       const int cc = cu / ut, uu = cu - cc * ut;
       const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
       const int u = tb * p.KT + uu;
-      const int toff = two_d ? (u / 3) * p.PW + (u % 3) : (st == 1 ? u * p.dil : u / st);   // row offset inside the (phase) plane
+      const int toff = two_d ? (u / 3) * p.PW + (u % 3) : (st == 1 ? u * dil_eff : u / st);   // row offset inside the (phase) plane
       if (st > 1) xp += (u - toff * st) * Pm * 32;
       const unsigned char* wt = wb + cu * 2 * BM * 32;
       u32x4 ah[AM], al[AM], bh[AN], bl[AN];
@@ -247,8 +231,81 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
         for (int an = 0; an < AN; ++an)
           acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
     }
+  };
+
+  int chunk = g0, tb = 0;
+  const long long t_begin = X3TICK();
+  if (nstages > 0) { issue_w(Wg, g0, 0, 0); load_x(g0); }
+  X3TACC(1, X3TICK() - t_begin);
+  for (int it = 0; it < nstages; ++it) {
+    const long long ta = X3TICK();
+    const int buf = it & 1;
+    const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
+    if (tb == 0) {
+      if (p.xbufs == 1 && it > 0) __syncthreads();       // single X buffer: every wave is done with the previous chunk
+      store_x(xb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stage's weight DMA has landed
+    __syncthreads();
+    const long long tb_ = X3TICK();
+    X3TACC(2, tb_ - ta);
+    int ntb_ = tb + 1, nchunk_ = chunk;
+    if (ntb_ == ntb) { ntb_ = 0; ++nchunk_; }
+    if (it + 1 < nstages) {
+      issue_w(Wg, nchunk_, ntb_, buf ^ 1);
+      if (ntb_ == 0) load_x(nchunk_);
+    }
+    const long long tc = X3TICK();
+    X3TACC(3, tc - tb_);
+    mfma_stage(buf, xb, tb, p.dil);
     tb = ntb_; chunk = nchunk_;
     X3TACC(4, X3TICK() - tc);
+  }
+  if constexpr (FUSE) {
+    // ---- pass 1 -> LDS: h = lrelu(acc + b1) (0 outside the sequence), split, written over the input tile (row = tile column)
+    __syncthreads();                                        // every wave is done with the input tile and both weight buffers
+    const unsigned char* __restrict__ Wg2 = p.Wx2;
+    issue_w(Wg2, 0, 0, 0);                                  // first slab of the second conv lands while h is written
+    {
+      const float hs = p.fuse_slope;
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int nl = (wn * AN + an) * 32 + li;
+          const int gh = n0 - P2 + nl;
+          const bool inside = gh >= 0 && gh < p.Tin;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int mb = (wm * AM + am) * 32 + 8 * g;     // rows mb + 4 lh + {0..3}: one 8-byte quarter of an LDS row
+            u32x4 hl;                                       // {hi01, hi23, lo01, lo23}
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+              float a = acc[am][an][4 * g + 2 * e2] + p.bias1[mb + 4 * lh + 2 * e2];
+              float b = acc[am][an][4 * g + 2 * e2 + 1] + p.bias1[mb + 4 * lh + 2 * e2 + 1];
+              a = inside ? fmaxf(a, a * hs) : 0.f;
+              b = inside ? fmaxf(b, b * hs) : 0.f;
+              const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+              const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
+              hl[e2] = bf16_bits(ah) | (bf16_bits(bh) << 16);
+              hl[2 + e2] = bf16_bits(al) | (bf16_bits(bl) << 16);
+            }
+            const int cc = mb >> 4, hb = (mb >> 3) & 1;
+            unsigned char* row = Xs + cc * 2 * xplane + nl * 32 + ((hb ^ ((nl >> 3) & 1)) << 4) + lh * 8;
+            *reinterpret_cast<unsigned long long*>(row) = (unsigned long long)hl[0] | ((unsigned long long)hl[1] << 32);
+            *reinterpret_cast<unsigned long long*>(row + xplane) = (unsigned long long)hl[2] | ((unsigned long long)hl[3] << 32);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+        }
+    }
+    // ---- pass 2: the second conv (dilation 1) over the rows just written
+    for (int it = 0; it < ntb; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                      // (it = 0: also publishes h)
+      if (it + 1 < ntb) issue_w(Wg2, 0, it + 1, (it + 1) & 1);
+      mfma_stage(it & 1, 0, it, 1);
+    }
   }
   const long long t_epi = X3TICK();
 #ifdef RVC_X3_NOEPI
@@ -271,7 +328,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
         }
       }
   } else if (p.ostride == 1) {
-    dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(p, acc, z, co0, n0, wm, wn, li, lh);
+    if constexpr (FUSE) {
+      ConvArgsX pe = p;
+      pe.Tout = min(p.Tout, n0 + BN - 2 * P2);               // columns without their full halo belong to the neighbouring tiles
+      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(pe, acc, z, co0, n0, wm, wn, li, lh);
+    } else {
+      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(p, acc, z, co0, n0, wm, wn, li, lh);
+    }
   } else {
     // interleaved store of the ConvTranspose1d phases: row m = phase * orows + co goes to Y[co][n * ostride + phase]
     const float* __restrict__ bias = p.bias;
@@ -308,9 +371,9 @@ bool conv_x3_enabled() {
   return on;
 }
 
-template <int WM, int WN, int AM, int AN>
+template <int WM, int WN, int AM, int AN, bool FUSE = false>
 static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3_kernel<WM, WN, AM, AN>;
+  auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE>;
   static bool attr_set = false;
   if (!attr_set) {
     RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -418,6 +481,56 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   }
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
   conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch));
+  return true;
+}
+
+// ---------------------------------------------------------------------------- fused ResBlock pair (narrow generator stages)
+// The C = 32 stage of the generator is HBM-bound on the unfused kernels (each conv reads + writes [C][T] and the second one reads the
+// residual too: 5 tensor passes per pair); fused, a pair reads x (+ halo) twice (tile + residual, the second from L2) and writes y.
+bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
+                      const ConvEpilogue& e2) {
+  static const bool on = !(getenv("RVC_PAIR") && atoi(getenv("RVC_PAIR")) == 0);
+  if (!on || !conv_x3_enabled() || !c1.Wx_ || !c2.Wx_) return false;
+  const int C = c1.Co, k = c1.k;
+  if (c1.mode != 1 || c2.mode != 1 || c1.groups != 1 || c2.groups != 1 || c1.stride != 1 || c2.stride != 1 || c1.tconv_u || c2.tconv_u) return false;
+  if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != k || c2.dil != 1 || (k & 1) == 0 || C != 32) return false;
+  if (c1.pad != (k - 1) / 2 * c1.dil || c2.pad != (k - 1) / 2) return false;                      // "same" convolutions
+  if (e2.pre_act != ACT_LRELU || e2.act != ACT_NONE || e2.bias_override || e2.tout_limit || e2.R != X) return false;
+  if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
+  constexpr int BM = 32, BN = 256;
+  const int P2 = (k - 1) / 2, P1 = c1.pad;
+  const int NO = BN - 2 * P2;
+  if ((long long)(T + NO - 1) / NO < 512) return false;          // short sequences: the unfused path fills the chip better
+  ConvArgsX a{};
+  a.X = X; a.ldX = ldX; a.Y = Y; a.ldY = ldY; a.W = nullptr; a.bias = c2.bd_; a.bias1 = c1.bd_;
+  a.R = e2.R; a.ldR = e2.ldR; a.pre_act = ACT_LRELU; a.pre_slope = 0.1f; a.fuse_slope = e2.pre_slope;
+  a.act = ACT_NONE; a.act_slope = 0.f; a.act_before_res = 0; a.out_scale = e2.out_scale; a.accumulate = e2.accumulate;
+  a.Ci = C; a.Co = C; a.CoP = c1.CoP; a.Tin = T; a.Tout = T; a.Wd = 0; a.ktaps = k; a.kreal = k; a.dil = c1.dil; a.stride = 1; a.pad = P1;
+  a.ostride = 1; a.orows = C; a.up2 = 0;
+  a.xBatch = a.wBatch = a.yBatch = a.rBatch = 0; a.bBatch = 0; a.wxBatch = 0;
+  a.Wx = reinterpret_cast<const unsigned char*>(c1.Wx_); a.Wx2 = reinterpret_cast<const unsigned char*>(c2.Wx_); a.CoPx = c1.CoPx;
+  a.fuse_p2 = P2;
+  if (c1.CoPx != c2.CoPx) return false;
+  const int P = BN + 2 * P1;                                      // staged input columns
+  a.ni = (P + 63) / 64;
+  const int nchunk = C / 16, NC = nchunk;                         // every channel of the tile resident: one chunk group
+  if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  const int xbytes = (NC * 2 * P * 32 + 1023) & ~1023;
+  static const int budget_kb = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 76;   // two workgroups per CU
+  const int per_tap = 2 * NC * 2 * BM * 32;
+  int ktmax = (budget_kb * 1024 - xbytes) / per_tap;
+  if (ktmax < 1) return false;
+  if (ktmax > k) ktmax = k;
+  const int ntb = (k + ktmax - 1) / ktmax;
+  a.KT = (k + ntb - 1) / ntb;
+  a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = 1; a.ksplit = 1; a.partial = nullptr; a.ldP = 0;
+  const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
+  dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
+  ProfTicket tk = conv_prof_begin(s);
+  launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
+  // algorithmic traffic of the pair: x read, residual read, y write (+ previous y when accumulating) + both weight sets
+  const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
+  conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes);
   return true;
 }
 

@@ -4,6 +4,7 @@
 // Activations are channel-major [C][T]; weights arrive with the reference's state-dict names and are folded here.
 #include "model_common.h"
 #include "models.h"
+#include "conv_kernels.h"
 
 namespace rvc {
 
@@ -345,12 +346,15 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       for (int j = 0; j < 3; ++j) {
         const float* in = up;
         for (int m = 0; m < 3; ++m) {
-          ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f;
-          conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
           ConvEpilogue E2; E2.pre_act = ACT_LRELU; E2.pre_slope = 0.1f; E2.R = in; E2.ldR = Tn;
           float* dst = (m == 0) ? ya : (m == 1 ? yb : xs);
           if (m == 2) { E2.out_scale = 1.f / 3.f; E2.accumulate = (j > 0); }
-          conv1d_run(st.rb[j].c2[m], s, t1, Tn, Tn, dst, Tn, E2);
+          // narrow stages: both convs of the pair in one launch, the intermediate stays in LDS (conv_x3.hip, FUSE)
+          if (!conv_x3_pair_try(st.rb[j].c1[m], st.rb[j].c2[m], s, in, Tn, Tn, dst, Tn, E2)) {
+            ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f;
+            conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
+            conv1d_run(st.rb[j].c2[m], s, t1, Tn, Tn, dst, Tn, E2);
+          }
           in = dst;
         }
       }

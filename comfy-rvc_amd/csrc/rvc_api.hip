@@ -313,6 +313,16 @@ int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x, int Ti
   check_launch();
   RVC_CATCH
 }
+int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x, int T, float* y, float out_scale,
+                             int accumulate) {
+  RVC_TRY
+  RVC_REQUIRE(c1 && c2 && x && y, "null argument");
+  ConvEpilogue e; e.pre_act = ACT_LRELU; e.pre_slope = 0.1f; e.R = x; e.ldR = T; e.out_scale = out_scale; e.accumulate = accumulate;
+  RVC_REQUIRE(conv_x3_pair_try(c1->L, c2->L, (hipStream_t)stream, x, T, T, y, T, e),
+              "this pair of layers is not eligible for the fused ResBlock kernel (needs bf16x3 images, C = 32, equal odd k, long T)");
+  check_launch();
+  RVC_CATCH
+}
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
 int rvc_op_attention(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, float* out, int heads, int T) {
   RVC_TRY

@@ -176,6 +176,10 @@ int rvc_conv1d_plan_create(const float* w_host, const float* bias_host, int Ci, 
                            rvc_conv1d_plan** out);
 int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x_dev, int Tin, const float* res_dev, float* y_dev, int pre_act,
                         float pre_slope, int act, float act_slope);
+/* One ResBlock1 pair of the generator in a single launch (reference lib/infer_pack/modules.py:295-308):
+ * y = (x + conv2(lrelu(conv1(lrelu(x), dilated)))) * out_scale [+ y]; x_dev, y_dev [C][T].  Fails if the pair is not eligible. */
+int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x_dev, int T, float* y_dev, float out_scale,
+                             int accumulate);
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
 /* fused softmax(K^T Q) V + bias for head dimension 64: q_dev, k_dev channel-major [heads*64][T] (q pre-scaled), v_rm_dev row-major
  * [T][heads*64], bv_dev [heads*64] or NULL, out_dev channel-major [heads*64][T] */

@@ -448,3 +448,41 @@ def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
     x2 = np.stack([x, -0.5 * x])
     y2 = resample_audio(x2, orig, target)
     assert y2.shape == (2, n_out) and np.array_equal(y2[0], y) and np.allclose(y2[1], -0.5 * y, atol=1e-7)
+
+
+@pytest.mark.parametrize("k,d,T,scale,accum", [(11, 5, 140003, 1.0 / 3, True), (7, 3, 131072, 1.0, False), (3, 1, 200001, 1.0, False),
+                                               (3, 5, 126100, 1.0 / 3, True), (11, 1, 150000, 1.0, False)])
+def test_fused_resblock_pair(L, k, d, T, scale, accum):
+    """One ResBlock1 pair of the generator's 32-channel stage in a single launch (conv_x3_kernel FUSE: the intermediate stays in LDS,
+    zero outside the sequence like the second conv's padding) against fp64 torch: y = (x + c2(lrelu(c1_d(lrelu(x))))) * s [+ y]."""
+    Cc = 32
+    g = torch.Generator().manual_seed(1000 + 37 * k + d)
+    x = torch.randn(Cc, T, generator=g)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
+    xd = x.double()
+    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+    ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+    y0 = torch.randn(Cc, T, generator=g)
+    if accum:
+        ref = ref + y0
+    y, xg = dev(y0), dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs()
+    assert rel_err(y.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
+    # sequence ends and tile seams (tiles of 256 - (k - 1) columns) carry the same error as the interior
+    NO = 256 - (k - 1)
+    for c0 in (0, NO - 2, 7 * NO - 3, T - 40):
+        assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
