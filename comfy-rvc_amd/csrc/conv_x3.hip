@@ -43,8 +43,8 @@ __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__bui
 // tile resident in LDS): pass 1 is the ordinary stage loop of the dilated conv over BN columns; its accumulators (+ b1, leaky
 // ReLU, zero outside the sequence = the second conv's zero padding) are split and written over the input tile in LDS in the
 // same row format; pass 2 runs the stage loop of the second conv (dilation 1) on those rows and the ordinary epilogue stores the
-// BN - (k - 1) columns that have their full halo.  The intermediate tensor never goes to HBM: 2 reads + 1 write of [C][T]
-// instead of 5 + 1... (generator).
+// BN - (k - 1) columns that have their full halo.  The intermediate tensor never goes to HBM: x (tile + residual) and y instead of
+// x, t, t, x, y.  Used for the 32-channel generator stage (conv_x3_pair_try): k3 261 -> 196 us, k7 304 -> 233, k11 348 -> 308.
 template <int WM, int WN, int AM, int AN, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
@@ -497,7 +497,9 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   if (c1.pad != (k - 1) / 2 * c1.dil || c2.pad != (k - 1) / 2) return false;                      // "same" convolutions
   if (e2.pre_act != ACT_LRELU || e2.act != ACT_NONE || e2.bias_override || e2.tout_limit || e2.R != X) return false;
   if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
-  constexpr int BM = 32, BN = 256;
+  static const int bn_env = getenv("RVC_PAIR_BN") ? atoi(getenv("RVC_PAIR_BN")) : 256;
+  constexpr int BM = 32;
+  const int BN = bn_env == 128 ? 128 : 256;
   const int P2 = (k - 1) / 2, P1 = c1.pad;
   const int NO = BN - 2 * P2;
   if ((long long)(T + NO - 1) / NO < 512) return false;          // short sequences: the unfused path fills the chip better
@@ -516,7 +518,9 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int nchunk = C / 16, NC = nchunk;                         // every channel of the tile resident: one chunk group
   if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
   const int xbytes = (NC * 2 * P * 32 + 1023) & ~1023;
-  static const int budget_kb = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 76;   // two workgroups per CU
+  // three workgroups per CU with single-tap stages beat two with 4-tap stages (k3 233 -> 196 us, k7 279 -> 233, k11 352 -> 308):
+  // occupancy is what hides the per-stage latencies of this narrow tile
+  static const int budget_kb = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 53;
   const int per_tap = 2 * NC * 2 * BM * 32;
   int ktmax = (budget_kb * 1024 - xbytes) / per_tap;
   if (ktmax < 1) return false;
@@ -527,7 +531,8 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
-  launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
+  if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
+  else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
   // algorithmic traffic of the pair: x read, residual read, y write (+ previous y when accumulating) + both weight sets
   const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
   conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes);

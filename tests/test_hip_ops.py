@@ -451,7 +451,7 @@ def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
 
 
 @pytest.mark.parametrize("k,d,T,scale,accum", [(11, 5, 140003, 1.0 / 3, True), (7, 3, 131072, 1.0, False), (3, 1, 200001, 1.0, False),
-                                               (3, 5, 126100, 1.0 / 3, True), (11, 1, 150000, 1.0, False)])
+                                               (3, 5, 136100, 1.0 / 3, True), (11, 1, 150000, 1.0, False)])
 def test_fused_resblock_pair(L, k, d, T, scale, accum):
     """One ResBlock1 pair of the generator's 32-channel stage in a single launch (conv_x3_kernel FUSE: the intermediate stays in LDS,
     zero outside the sequence like the second conv's padding) against fp64 torch: y = (x + c2(lrelu(c1_d(lrelu(x))))) * s [+ y]."""
