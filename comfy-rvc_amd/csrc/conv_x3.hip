@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__bui
 // x, t, t, x, y.  Used for the 32-channel generator stage (conv_x3_pair_try): k3 261 -> 196 us, k7 304 -> 233, k11 348 -> 308.
 template <int WM, int WN, int AM, int AN, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
-  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = x3_slots(BN), RB = BM / 32;
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = (FUSE && BM == 64) ? 7 : x3_slots(BN), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
   const int NC = p.NC;                      // 16-channel chunks per stage
@@ -490,16 +490,17 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
                       const ConvEpilogue& e2) {
   static const bool on = !(getenv("RVC_PAIR") && atoi(getenv("RVC_PAIR")) == 0);
+  static const bool pair64 = getenv("RVC_PAIR64") && atoi(getenv("RVC_PAIR64")) != 0;      // experiment: 64-channel stage (2 WGs per CU)
   if (!on || !conv_x3_enabled() || !c1.Wx_ || !c2.Wx_) return false;
   const int C = c1.Co, k = c1.k;
   if (c1.mode != 1 || c2.mode != 1 || c1.groups != 1 || c2.groups != 1 || c1.stride != 1 || c2.stride != 1 || c1.tconv_u || c2.tconv_u) return false;
-  if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != k || c2.dil != 1 || (k & 1) == 0 || C != 32) return false;
+  if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != k || c2.dil != 1 || (k & 1) == 0 || !(C == 32 || (C == 64 && pair64))) return false;
   if (c1.pad != (k - 1) / 2 * c1.dil || c2.pad != (k - 1) / 2) return false;                      // "same" convolutions
   if (e2.pre_act != ACT_LRELU || e2.act != ACT_NONE || e2.bias_override || e2.tout_limit || e2.R != X) return false;
   if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
   static const int bn_env = getenv("RVC_PAIR_BN") ? atoi(getenv("RVC_PAIR_BN")) : 256;
-  constexpr int BM = 32;
-  const int BN = bn_env == 128 ? 128 : 256;
+  const int BM = C;
+  const int BN = (C == 64 || bn_env == 128) ? 128 : 256;
   const int P2 = (k - 1) / 2, P1 = c1.pad;
   const int NO = BN - 2 * P2;
   if ((long long)(T + NO - 1) / NO < 512) return false;          // short sequences: the unfused path fills the chip better
@@ -516,11 +517,12 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int P = BN + 2 * P1;                                      // staged input columns
   a.ni = (P + 63) / 64;
   const int nchunk = C / 16, NC = nchunk;                         // every channel of the tile resident: one chunk group
-  if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  if ((NC * 2 * a.ni + 3) / 4 > (C == 64 ? 7 : x3_slots(BN))) return false;
   const int xbytes = (NC * 2 * P * 32 + 1023) & ~1023;
   // three workgroups per CU with single-tap stages beat two with 4-tap stages (k3 233 -> 196 us, k7 279 -> 233, k11 352 -> 308):
   // occupancy is what hides the per-stage latencies of this narrow tile
-  static const int budget_kb = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 53;
+  static const int budget_kb_env = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 53;
+  const int budget_kb = C == 64 ? 80 : budget_kb_env;
   const int per_tap = 2 * NC * 2 * BM * 32;
   int ktmax = (budget_kb * 1024 - xbytes) / per_tap;
   if (ktmax < 1) return false;
@@ -531,7 +533,8 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
-  if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
+  if (C == 64) launch_x3<2, 2, 1, 2, true>(a, grid, lds, s);
+  else if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
   else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
   // algorithmic traffic of the pair: x read, residual read, y write (+ previous y when accumulating) + both weight sets
   const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);

@@ -5,9 +5,10 @@ import numpy as np, torch
 from comfy_rvc_amd import _lib as L
 L.get_ctx(0)
 L.check(L.lib.rvc_set_conv_precision(2))
-T = 1279200
+import os
+Cc = int(os.environ.get("PAIR_C", 32))
+T = 1279200 * 32 // Cc
 for k, d in ((3, 1), (3, 5), (7, 3), (11, 5)):
-    Cc = 32
     plans = []
     for dd in (d, 1):
         w = (np.random.randn(Cc, Cc, k) / np.sqrt(Cc * k)).astype(np.float32); b = np.zeros(Cc, np.float32)
@@ -25,4 +26,4 @@ for k, d in ((3, 1), (3, 5), (7, 3), (11, 5)):
         for _ in range(5): fn()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        print(f"C32 k{k} d{d} {name:8s} {ms*1e3:8.1f} us   {4.0*Cc*Cc*k*T/ms/1e9:6.1f} TFLOP/s  {3*4.0*Cc*T/ms/1e6:7.1f} GB/s (x, res, y)")
+        print(f"C{Cc} k{k} d{d} {name:8s} {ms*1e3:8.1f} us   {4.0*Cc*Cc*k*T/ms/1e9:6.1f} TFLOP/s  {3*4.0*Cc*T/ms/1e6:7.1f} GB/s (x, res, y)")
