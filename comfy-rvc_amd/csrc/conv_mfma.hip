@@ -634,9 +634,10 @@ TileCfg choose_tile(int M, long long N, int batch) {
     return TileCfg{1, 4, 1, 1};
   }
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-  if (Mp >= 128 && blocks(128, 128) >= 384) return TileCfg{2, 2, 2, 2};
-  if (Mp <= 64 && blocks(64, 256) >= 384) return TileCfg{2, 2, 1, 4};
-  if (blocks(64, 128) >= 384) return TileCfg{2, 2, 1, 2};
+  static const int fill = getenv("RVC_TILE_MINBLK") ? atoi(getenv("RVC_TILE_MINBLK")) : 384;    // workgroups a launch must have to take the larger tile
+  if (Mp >= 128 && blocks(128, 128) >= fill) return TileCfg{2, 2, 2, 2};
+  if (Mp <= 64 && blocks(64, 256) >= fill) return TileCfg{2, 2, 1, 4};
+  if (blocks(64, 128) >= fill) return TileCfg{2, 2, 1, 2};
   return best;   // 64 x 64
 }
 
