@@ -55,7 +55,7 @@ def cpu_baseline(seconds=3.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
