@@ -35,8 +35,21 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
   // single sweep: shifted sums (shift = first channel's value) keep the variance free of cancellation
   const float shift = ok ? (x[t] + (r ? r[t] : 0.f)) : 0.f;
   float sum = 0.f, sq = 0.f;
-  for (int c = sl; c < C; c += 16) {
-    if (ok) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; v -= shift; sum += v; sq += v * v; }
+  // four channels per iteration: their (independent) loads are in flight together - the kernel is latency-bound at ~100 workgroups
+  int c = sl;
+  if (ok) {
+    for (; c + 48 < C; c += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = x[(long long)(c + 16 * j) * ld + t];
+      if (r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[(long long)(c + 16 * j) * ld + t];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[j] - shift; sum += d; sq += d * d; }
+    }
+    for (; c < C; c += 16) { float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t]; v -= shift; sum += v; sq += v * v; }
   }
   s_a[sl][col] = sum; s_b[sl][col] = sq;
   __syncthreads();
@@ -46,8 +59,20 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(const float* __restric
   const float md = ts / (float)C;                       // mean - shift
   const float var = fmaxf(tq / (float)C - md * md, 0.f);
   const float mean = md + shift, rstd = rsqrtf(var + eps);
-  for (int c = sl; c < C; c += 16) {
-    if (ok) {
+  if (ok) {
+    c = sl;
+    for (; c + 48 < C; c += 64) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = x[(long long)(c + 16 * j) * ld + t];
+      if (r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[(long long)(c + 16 * j) * ld + t];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[(long long)(c + 16 * j) * ld + t] = (v[j] - mean) * rstd * gamma[c + 16 * j] + beta[c + 16 * j];
+    }
+    for (; c < C; c += 16) {
       float v = x[(long long)c * ld + t]; if (r) v += r[(long long)c * ld + t];
       y[(long long)c * ld + t] = (v - mean) * rstd * gamma[c] + beta[c];
     }
