@@ -185,10 +185,174 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ---- bf16x3 variant: Q, K, V and P are split into bf16 hi / lo while they are staged in LDS and both products run as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the arithmetic of conv_x3.hip): a 32 x 32 x 64 block
+// costs 12 MFMAs of 8 passes instead of 32 fp32 MFMAs of 16.
+constexpr int kXP = 72;        // LDS row pitch in bf16 elements (144 B)
+typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bf16_bits_a(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ void split_store(const f32x4& v, unsigned short* hi, unsigned short* lo) {
+  unsigned h[2], l[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+    const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
+    h[j] = bf16_bits_a(ah) | (bf16_bits_a(bh) << 16);
+    l[j] = bf16_bits_a(al) | (bf16_bits_a(bl) << 16);
+  }
+  *reinterpret_cast<unsigned long long*>(hi) = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
+  *reinterpret_cast<unsigned long long*>(lo) = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+}
+// acc0 / acc1 += A B^T over 64 reduction indices (4 steps of 16); two accumulation chains
+__device__ __forceinline__ void x3_block(const unsigned short* ah_, const unsigned short* al_, const unsigned short* bh_, const unsigned short* bl_,
+                                         f32x16& acc0, f32x16& acc1) {
+  u32x4a ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ah[c] = *reinterpret_cast<const u32x4a*>(ah_ + 16 * c); al[c] = *reinterpret_cast<const u32x4a*>(al_ + 16 * c);
+    bh[c] = *reinterpret_cast<const u32x4a*>(bh_ + 16 * c); bl[c] = *reinterpret_cast<const u32x4a*>(bl_ + 16 * c);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f32x16& acc = (c & 1) ? acc1 : acc0;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8a, al[c]), __builtin_bit_cast(bf16x8a, bh[c]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8a, ah[c]), __builtin_bit_cast(bf16x8a, bl[c]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8a, ah[c]), __builtin_bit_cast(bf16x8a, bh[c]), acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ Q, const float* __restrict__ K, long long ldqk,
+                                                        const float* __restrict__ V, long long ldv, const float* __restrict__ bv,
+                                                        float* __restrict__ out, long long ldo, int T) {
+  // bf16 hi / lo planes, rows of 64 reduction indices (128 B) + 16 B pad: ds_read_b128 of 32 consecutive rows is conflict-free
+  __shared__ __attribute__((aligned(16))) unsigned short Qs[2][64 * kXP], Ks[2][64 * kXP], Vs[2][kAD * kXP], Ps[2][64 * kXP];
+  __shared__ float red[2][2][64];          // [stat: max | sum][wm][query]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int h = blockIdx.y, q0 = blockIdx.x * 64;
+  const float* Qh = Q + (long long)h * kAD * ldqk;
+  const float* Kh = K + (long long)h * kAD * ldqk;
+  const float* Vh = V + h * kAD;
+
+  // Q tile -> Qs[query][d]: a thread takes 4 consecutive d of one query (4 coalesced loads) and writes them as one 16-byte store
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int e = tid + 256 * s, j = e & 63, d0 = (e >> 6) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (q0 + j < T) ? Qh[(long long)(d0 + i) * ldqk + q0 + j] : 0.f;
+    split_store(v, &Qs[0][j * kXP + d0], &Qs[1][j * kXP + d0]);
+  }
+  f32x4 kr[4], vr[4];
+  auto load_kv = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + 256 * s, j = e & 63, g4 = (e >> 6) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kr[s][i] = (k0 + j < T) ? Kh[(long long)(g4 + i) * ldqk + k0 + j] : 0.f;            // K[d = g4 + i][key = j]
+        vr[s][i] = (k0 + g4 + i < T) ? Vh[(long long)(k0 + g4 + i) * ldv + j] : 0.f;        // V[key = g4 + i][d = j]
+      }
+    }
+  };
+  auto store_kv = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int e = tid + 256 * s, j = e & 63, g4 = (e >> 6) * 4;
+      split_store(kr[s], &Ks[0][j * kXP + g4], &Ks[1][j * kXP + g4]);       // Ks[key j][d g4..]
+      split_store(vr[s], &Vs[0][j * kXP + g4], &Vs[1][j * kXP + g4]);       // Vs[d j][key g4..]
+    }
+  };
+
+  f32x16 o, o1;                             // two independent accumulation chains, summed at the end
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1.0e30f, l_run = 0.f;       // per query column wn*32 + li (identical in the lanes / waves that share a column)
+  const int ntiles = (T + 63) / 64;
+  // a v_mfma_f32_32x32x16_bf16 lane (i, half) holds reduction indices 16 c + 8 half .. + 7 of row i: one ds_read_b128 per plane
+  const int aoff_s = (wm * 32 + li) * kXP + lh * 8;              // A of S: key row
+  const int boff_s = (wn * 32 + li) * kXP + lh * 8;              // B of S: query row
+  const int aoff_o = (wm * 32 + li) * kXP + lh * 8;              // A of O: d row
+  const int boff_o = (wn * 32 + li) * kXP + lh * 8;              // B of O: query row
+  const unsigned long long t_begin = ATICK();
+  load_kv(0);
+  for (int it = 0; it < ntiles; ++it) {
+    const int k0 = it * 64;
+    const unsigned long long t0 = ATICK();
+    lds_barrier();                          // previous tile's Ks / Vs / Ps reads are done
+    store_kv();
+    lds_barrier();
+    if (it + 1 < ntiles) load_kv(k0 + 64);
+    const unsigned long long t1 = ATICK();
+    ATACC(1, t1 - t0);
+    // ---- S = K^T Q for this wave's 32 keys x 32 queries
+    f32x16 sacc, sacc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sacc1[r] = 0.f; }
+    x3_block(&Ks[0][aoff_s], &Ks[1][aoff_s], &Qs[0][boff_s], &Qs[1][boff_s], sacc, sacc1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r];
+    const unsigned long long t2 = ATICK();
+    ATACC(2, t2 - t1);
+    // rows of sacc: key = k0 + wm*32 + (r&3) + 8(r>>2) + 4 lh; column: query wn*32 + li
+    if (k0 + 64 > T) {                        // only the last key tile has a masked tail
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= T) sacc[r] = -1.0e30f;
+      }
+    }
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lh == 0) red[0][wm][wn * 32 + li] = mx;
+    lds_barrier();
+    const float m_tile = fmaxf(red[0][0][wn * 32 + li], red[0][1][wn * 32 + li]);
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pv[i] = expf(sacc[4 * g + i] - m_new); ps += pv[i]; }     // masked keys: exp(-1e30 - m) = 0
+      split_store(pv, &Ps[0][(wn * 32 + li) * kXP + wm * 32 + 8 * g + 4 * lh], &Ps[1][(wn * 32 + li) * kXP + wm * 32 + 8 * g + 4 * lh]);   // Ps[query][key .. key + 3]
+    }
+    ps += __shfl_xor(ps, 32);
+    if (lh == 0) red[1][wm][wn * 32 + li] = ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[r] *= alpha; o1[r] *= alpha; }
+    lds_barrier();
+    l_run = l_run * alpha + red[1][0][wn * 32 + li] + red[1][1][wn * 32 + li];
+    m_run = m_new;
+    const unsigned long long t3 = ATICK();
+    ATACC(3, t3 - t2);
+    // ---- O += V^T P : rows d = wm*32 + .., columns queries wn*32 + li
+    x3_block(&Vs[0][aoff_o], &Vs[1][aoff_o], &Ps[0][boff_o], &Ps[1][boff_o], o, o1);
+    ATACC(4, ATICK() - t3);
+  }
+  ATACC(6, ATICK() - t_begin); ATACC(0, 1);
+  const int q = q0 + wn * 32 + li;
+  if (q < T) {
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[(long long)(h * kAD + d) * ldo + q] = (o[r] + o1[r]) * inv + (bv ? bv[h * kAD + d] : 0.f);
+    }
+  }
+}
+
 // Q, K: channel-major [heads*64][T] (row pitch ldqk); V: row-major [T][heads*64] (row pitch ldv); out channel-major [heads*64][T].
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                      float* out, long long ldo, int heads, int dhead, int T) {
   RVC_REQUIRE(dhead == kAD, "fused attention is built for head dimension 64");
+  static const bool x3 = !(getenv("RVC_ATT_X3") && atoi(getenv("RVC_ATT_X3")) == 0);
+  if (x3) { hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T); return; }
   hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T);
 }
 
