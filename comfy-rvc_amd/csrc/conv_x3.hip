@@ -399,7 +399,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     static const int wide_blk = getenv("RVC_X3_WIDE") ? atoi(getenv("RVC_X3_WIDE")) : 600;
     auto blocks = [&](int bm, int bn) { return (long long)((a.Co + bm - 1) / bm) * ((a.Tout + bn - 1) / bn); };
     if (wide_blk > 0 && a.stride == 1 && a.Wd == 0) {
-      if (a.Co > 64 && blocks(128, 256) >= wide_blk) t = TileCfg{2, 2, 2, 4};
+      // (k <= 3 at 128+ channels is HBM-bound: three 128 x 128 workgroups per CU beat two wide ones, C128 k3 238 -> 219 us)
+      if (a.Co > 64 && blocks(128, 256) >= wide_blk && a.ktaps > 3) t = TileCfg{2, 2, 2, 4};
       else if (a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
   }
