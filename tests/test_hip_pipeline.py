@@ -351,3 +351,50 @@ def test_full_size_clip_is_deterministic_and_well_formed(models):
     assert 32300 <= int(np.abs(outs[0].astype(np.int32)).max()) <= 32440        # 0.99 * 32768 after the final normalisation
     frames = np.abs(outs[0].astype(np.float32)).reshape(-1, 400).mean(axis=1)   # 10 ms frames
     assert (frames < 1.0).mean() < 0.3                                           # (the synthetic clip has ~20 % silent gaps)
+
+
+def test_baseline_c4_slice_eight_48k_clips_through_three_lanes():
+    """BASELINE.json configs[3] per GPU: 8 clips of 30 s through the 48k_v2 synthesizer (upsample 12,10,2,2), here three at a time
+    through ClipLanes.  Size-independent properties: every clip has the documented length (2 * T_h * 480 - 2 * 48000 = 1 439 040),
+    the lane that converts a clip does not matter (clip-indexed noise; clips 0 and 5 re-converted alone are bit-identical)."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.rmvpe import RMVPE
+    from comfy_rvc_amd.parallel import ClipLanes
+    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+
+    def lane():
+        cfg = Config()
+        hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+        vcd = get_vc(S.synth_checkpoint(S.CONFIG_48K_V2, "v2", 0), config=cfg)
+        vc = VC(48000, cfg)
+        vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0))
+
+        def fn(clip, i):
+            gen = torch.Generator().manual_seed(500 + i)
+            vc.noise_fn = lambda shape: torch.randn(shape, generator=gen)
+            out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(clip, 16000), sid=0, f0_up_key=0,
+                            f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
+            assert out is not None and out[1] == 48000
+            return out[0]
+        return fn
+    lanes = [lane() for _ in range(3)]
+    clips = [S.synth_audio(30.0, seed=200 + i) for i in range(8)]
+    outs = ClipLanes(lanes, device="cuda").map(clips)
+    assert len(outs) == 8 and all(o.shape == (1439040,) and o.dtype == np.int16 for o in outs)
+    assert len({o.tobytes()[:4096] for o in outs}) == 8                          # eight different clips, eight different results
+    for i in (0, 5):
+        assert np.array_equal(lanes[2](clips[i], i), outs[i])
+
+
+def test_baseline_c2_rmvpe_60s_shape_and_determinism(models):
+    """BASELINE.json configs[1]: RMVPE alone on a 60 s clip (padded L = 992 000 -> n = 6201 frames, U-Net input [1,1,6208,128]):
+    frame count, voiced / unvoiced structure and bit-identical repeats (the GRU scan exchanges its state through polled
+    device memory).  The comparison with the CPU oracle at this size is tools/validate_rmvpe_long.py."""
+    _, _, rm = models
+    audio = np.pad(S.synth_audio(60.0, seed=9), (16000, 16000), mode="reflect")
+    f0a = rm.infer_from_audio(audio, thred=0.03)
+    f0b = rm.infer_from_audio(audio, thred=0.03)
+    assert f0a.shape == (6201,) and np.array_equal(f0a, f0b) and np.isfinite(f0a).all()
+    voiced = f0a > 0
+    assert 0.2 < voiced.mean() < 0.98 and f0a[voiced].min() > 30.0 and f0a[voiced].max() < 2100.0
