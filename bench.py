@@ -35,19 +35,20 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
 
 
-def cpu_baseline(seconds=3.0):
+def cpu_baseline(seconds=3.0, config=None):
     """The CPU oracle (validated restatement of the reference) timed on this box's host cores on a bounded sample."""
     from comfy_rvc_amd import synthetic as S
     from oracle import pipeline as opl
     threads = torch.get_num_threads()
     audio = S.synth_audio(seconds, seed=1)
-    sds = (S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0))
+    config = config or S.CONFIG_40K_V2
+    sds = (S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(config, "v2", 0))
     g = torch.Generator().manual_seed(0)
     t0 = time.perf_counter()
-    out = opl.pipeline(sds[0], sds[1], sds[2], S.CONFIG_40K_V2, "v2", audio, noise_fn=lambda shp: torch.randn(shp, generator=g),
+    out = opl.pipeline(sds[0], sds[1], sds[2], config, "v2", audio, noise_fn=lambda shp: torch.randn(shp, generator=g),
                        n_hubert_layers=12)   # the reference runs all 12 HuBERT layers (and discards the last)
     dt = time.perf_counter() - t0
-    return {"value": round(out.shape[0] / 40000.0 / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(threads), "kind": "port",
+    return {"value": round(out.shape[0] / float(config[-1]) / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(threads), "kind": "port",
             "sample": f"1 x {seconds:g} s clip, same procedural weights, oracle.pipeline (torch-CPU fp32 restatement of the "
                       f"reference, validated against reference goldens), {dt:.1f} s wall"}
 
@@ -59,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
+    ap.add_argument("--variant", choices=["40k_v2", "48k_v2"], default="40k_v2",
+                    help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,11 +96,12 @@ def main():
     audio = S.synth_audio(args.seconds, seed=100 + rank)
     params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
     n_lanes = max(1, args.lanes)
+    SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
 
     def make_lane():
         hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
-        vcd = get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0), config=cfg, device=dev)
-        vc = VC(40000, cfg)
+        vcd = get_vc(S.synth_checkpoint(SYN_CFG, "v2", 0), config=cfg, device=dev)
+        vc = VC(SYN_CFG[-1], cfg)
         vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
         vc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
 
@@ -139,7 +143,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    delivered = wav.shape[0] / 40000.0                       # audio seconds of one converted clip
+    delivered = wav.shape[0] / float(SYN_CFG[-1])                       # audio seconds of one converted clip
     value = delivered * n_lanes * world * args.steps / dt
 
     # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
@@ -214,15 +218,15 @@ def main():
         roofline["other_kernels"] = fams[1:]
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(config=SYN_CFG)
 
     if rank == 0:
         line = {
-            "metric": "audio-sec/wall-sec (xRT), 40k_v2 end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
+            "metric": f"audio-sec/wall-sec (xRT), {args.variant} end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
-            "config": {"workload": f"Full VC 40k_v2 (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_lanes} per GPU "
+            "config": {"workload": f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_lanes} per GPU "
                                    "per step (in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
                        "clips_per_step": world * n_lanes, "clips_in_flight_per_gpu": n_lanes, "audio_seconds_delivered_per_clip": round(delivered, 3),
                        "one_clip_alone_ms": round(alone_ms, 2), "one_clip_alone_xrt": round(delivered / alone_ms * 1e3, 1),
