@@ -15,6 +15,10 @@ struct FeatIndex {
   float* rows = nullptr;      // big_npy [N][D] (gather source for the blend)
   float* cols = nullptr;      // big_npy^T [D][N] (k-major GEMM operand)
   float* nhalf = nullptr;     // -|b_j|^2 / 2
+  // per 32768-row chunk: the rows as a k = 1 convolution layer (score = W f + bias) - on the bf16x3 kernel for large indices
+  // (3-term split, fp32 accumulation: scores to ~1e-5 relative, i.e. ties closer than that may resolve to the other neighbour;
+  // the reference's own IVF search with nprobe = 1 is far coarser), on the fp32 kernel for small ones
+  std::vector<ConvLayer> chunks;
 };
 
 __global__ void index_prep_kernel(const float* __restrict__ rows, float* __restrict__ cols, float* __restrict__ nhalf, long long N, int D) {
@@ -82,10 +86,26 @@ FeatIndex* index_create(Ctx* ctx, const float* big_npy, long long N, int D) {
     RVC_HIP_CHECK(hipMemcpy(I->rows, big_npy, (size_t)N * D * sizeof(float), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(index_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, I->rows, I->cols, I->nhalf, N, D);
     RVC_HIP_CHECK(hipDeviceSynchronize());
-  } catch (...) { dev_free(I->rows); dev_free(I->cols); dev_free(I->nhalf); delete I; throw; }
+    static const bool as_conv = !(getenv("RVC_INDEX_X3") && atoi(getenv("RVC_INDEX_X3")) == 0);
+    if (as_conv && D % 16 == 0 && N >= 4096) {
+      std::vector<float> nh((size_t)N);
+      RVC_HIP_CHECK(hipMemcpy(nh.data(), I->nhalf, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));   // the same bias values as the fp32 path
+      struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
+      const long long chunk = 32768;
+      I->chunks.resize((size_t)((N + chunk - 1) / chunk));
+      for (size_t c = 0; c < I->chunks.size(); ++c) {
+        const long long m0 = (long long)c * chunk;
+        const int M = (int)((N - m0) < chunk ? (N - m0) : chunk);
+        conv1d_layer_init(I->chunks[c], big_npy + m0 * D, nh.data() + m0, M, D, 1, 1, 0, 1, 1);
+      }
+      dev_free(I->cols); I->cols = nullptr;             // the k-major copy is only needed by the GEMM path
+    }
+  } catch (...) { for (auto& L : I->chunks) conv_layer_free(L); dev_free(I->rows); dev_free(I->cols); dev_free(I->nhalf); delete I; throw; }
   return I;
 }
-void index_destroy(FeatIndex* I) { if (I) { dev_free(I->rows); dev_free(I->cols); dev_free(I->nhalf); delete I; } }
+void index_destroy(FeatIndex* I) {
+  if (I) { for (auto& L : I->chunks) conv_layer_free(L); dev_free(I->rows); dev_free(I->cols); dev_free(I->nhalf); delete I; }
+}
 long long index_size(const FeatIndex* I) { return I->N; }
 int index_dim(const FeatIndex* I) { return I->D; }
 
@@ -99,7 +119,8 @@ void index_search(FeatIndex* I, hipStream_t s, const float* feats_cm, int T, lon
   ConvEpilogue E0;
   for (long long m0 = 0; m0 < I->N; m0 += chunk) {
     const int M = (int)((I->N - m0) < chunk ? (I->N - m0) : chunk);
-    gemm_tn_run(s, I->cols + m0, I->N, 0, feats_cm, T, 0, Y, T, 0, M, T, I->D, 1, I->nhalf + m0, 0, E0);
+    if (!I->chunks.empty()) conv1d_run(I->chunks[(size_t)(m0 / chunk)], s, feats_cm, T, T, Y, T, E0);
+    else gemm_tn_run(s, I->cols + m0, I->N, 0, feats_cm, T, 0, Y, T, 0, M, T, I->D, 1, I->nhalf + m0, 0, E0);
     hipLaunchKernelGGL(index_argmax_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, Y, M, T, (long long)T, m0, best, idx, m0 == 0 ? 1 : 0);
   }
   if (score) hipLaunchKernelGGL(index_score_kernel, dim3((T + 255) / 256), dim3(256), 0, s, feats_cm, best, score, I->D, T);
