@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: end-to-end 40k_v2 voice conversion throughput in audio-seconds per wall-second (xRT).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # N > 1 and no WORLD_SIZE in the environment: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = every rank converts LANES (default 3) synthetic 30 s / 16 kHz clips end to end through `vc_single` (host float32
-array in, int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT features, SynthesizerTrnMs768NSFsid at 40 kHz), the
-clips of a rank in flight concurrently on its GPU (parallel.ClipLanes: one host thread, stream set and model replica per lane -
-a batch-1 clip cannot fill 256 CUs in its narrow stages), and the int16 waveforms are gathered on rank 0 over RCCL (the path's
-only exchange step).  `--lanes 1` is the strictly sequential one-clip-at-a-time rate.  Clips are independent, so the work shards
-clip-per-GPU with no data-path collective besides that gather: weak scaling.  Weights are procedural
-(comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32 (fp32 MFMA, or the bf16x3 split with fp32 accumulation).
-Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
+One "step" = every rank converts CLIPS (default 12; 8 for --variant 48k_v2 = BASELINE.json configs[3]) synthetic 30 s / 16 kHz
+clips end to end through `vc_single` (host float32 array in, int16 host array out: zero-phase high-pass, RMVPE pitch, HuBERT
+features, SynthesizerTrnMs768NSFsid at 40 kHz), LANES (default 3) of them in flight concurrently on its GPU (parallel.ClipLanes:
+one host thread, stream set and model replica per lane - a batch-1 clip cannot fill 256 CUs in its narrow stages), and the int16
+waveforms of the step are gathered on rank 0 over RCCL (the path's only exchange step).  `--lanes 1` is the strictly sequential
+one-clip-at-a-time rate.  Clips are independent, so the work shards clip-per-GPU with no data-path collective besides that gather:
+weak scaling.  Weights are procedural (comfy-rvc_amd/synthetic.py) - no checkpoint is reachable offline - and compute is fp32
+(fp32 MFMA, or the bf16x3 split with fp32 accumulation).  Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).
+
+`--dry-run` replaces the conversion with a stub (no HIP call at all) and exists to exercise the launcher, the process group, the
+per-step gather and the timing protocol on a box without GPUs (tests/test_parallel_gloo.py); its line says so in `data`.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,111 +30,221 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per busy stream (see comfy-rvc_amd/__init__.py); before HIP initialises
-
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r2_pmc_traffic.json")
 
 
-def cpu_baseline(seconds=3.0, config=None):
-    """The CPU oracle (validated restatement of the reference) timed on this box's host cores on a bounded sample."""
+def launch_ranks(n):
+    """Parent of a self-launched N-rank run: starts one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and waits.
+    Runs before anything in this process has touched HIP (importing torch does not); the children are ordinary subprocesses, nothing
+    is exec'ed.  Rank 0's stdout is this process's stdout, so the JSON line appears exactly once."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    one_gpu = os.environ.get("RVC_BENCH_BACKEND", "nccl") != "nccl"      # gloo debugging of the control flow: every rank on device 0
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RVC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:      # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(config=None, seconds=10.0, budget_s=75.0):
+    """The CPU oracle (validated restatement of the reference) timed on this box's host cores as BASELINE.md section 4 describes:
+    BASELINE.json configs[0]'s 10 s clip, 1 warm-up + median of 3 timed runs, torch.set_num_threads(k) with k stated, per-stage
+    seconds.  Bounded: when a run takes longer than budget_s / 4 the remaining repeats are dropped (n_runs says how many were timed)."""
+    import numpy as np
+    import torch
     from comfy_rvc_amd import synthetic as S
-    from oracle import pipeline as opl
-    threads = torch.get_num_threads()
-    audio = S.synth_audio(seconds, seed=1)
+    from oracle import nets, pipeline as opl
+    ncpu = os.cpu_count() or 1
+    k = max(1, min(ncpu, 32))                  # torch-CPU conv/GEMM on these sizes stops scaling well before 32 threads
+    prev = torch.get_num_threads()
+    torch.set_num_threads(k)
     config = config or S.CONFIG_40K_V2
     sds = (S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(config, "v2", 0))
-    g = torch.Generator().manual_seed(0)
-    t0 = time.perf_counter()
-    out = opl.pipeline(sds[0], sds[1], sds[2], config, "v2", audio, noise_fn=lambda shp: torch.randn(shp, generator=g),
-                       n_hubert_layers=12)   # the reference runs all 12 HuBERT layers (and discards the last)
-    dt = time.perf_counter() - t0
-    return {"value": round(out.shape[0] / float(config[-1]) / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(threads), "kind": "port",
-            "sample": f"1 x {seconds:g} s clip, same procedural weights, oracle.pipeline (torch-CPU fp32 restatement of the "
-                      f"reference, validated against reference goldens), {dt:.1f} s wall"}
+    stage = {}
+
+    def timed(name, fn):
+        def w(*a, **kw):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                stage[name] = stage.get(name, 0.0) + time.perf_counter() - t
+        return w
+    orig = (nets.hubert_extract_features, nets.rmvpe_infer_from_audio, nets.synth_infer)
+    nets.hubert_extract_features, nets.rmvpe_infer_from_audio, nets.synth_infer = (timed("hubert", orig[0]), timed("rmvpe", orig[1]),
+                                                                                      timed("synthesizer", orig[2]))
+
+    def run(secs, seed):
+        g = torch.Generator().manual_seed(0)
+        audio = S.synth_audio(secs, seed=seed)
+        stage.clear()
+        t0 = time.perf_counter()
+        out = opl.pipeline(sds[0], sds[1], sds[2], config, "v2", audio, noise_fn=lambda shp: torch.randn(shp, generator=g),
+                           n_hubert_layers=12)   # the reference runs all 12 HuBERT layers (and discards the last)
+        dt = time.perf_counter() - t0
+        st = dict(stage)
+        st["host_dsp"] = max(dt - sum(st.values()), 0.0)
+        return out.shape[0] / float(config[-1]), dt, st
+    try:
+        run(1.0, 2)                               # warm-up: thread pool, lazy constants, allocator
+        runs = []
+        t_all = time.perf_counter()
+        for _ in range(3):
+            runs.append(run(seconds, 1))
+            if time.perf_counter() - t_all + runs[-1][1] > budget_s:
+                break
+    finally:
+        nets.hubert_extract_features, nets.rmvpe_infer_from_audio, nets.synth_infer = orig
+        torch.set_num_threads(prev)
+    runs.sort(key=lambda r: r[1])
+    delivered, dt, st = runs[len(runs) // 2]
+    return {"value": round(delivered / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(k), "kind": "port", "cpu": cpu_model(),
+            "host_logical_cpus": int(ncpu), "n_runs": len(runs), "wall_s_median": round(dt, 2),
+            "stage_seconds": {n: round(v, 2) for n, v in sorted(st.items())},
+            "sample": f"1 x {seconds:g} s clip (BASELINE.json configs[0] length), 1 s warm-up clip + median of {len(runs)} run(s), same procedural weights, "
+                      f"oracle.pipeline = torch-CPU fp32 restatement of the reference validated against reference goldens, "
+                      f"torch.set_num_threads({k})"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default 12; 8 for --variant 48k_v2 as BASELINE.json configs[3] states)")
     ap.add_argument("--variant", choices=["40k_v2", "48k_v2"], default="40k_v2",
                     help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # nothing in this process has initialised HIP
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dist = None
     backend = os.environ.get("RVC_BENCH_BACKEND", "nccl")
+    use_gpu = not args.dry_run
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:      # debugging the N > 1 control flow on a 1-GPU box: RVC_BENCH_BACKEND=gloo with LOCAL_RANK=0 on every rank
+        else:      # the N > 1 control flow on a 1-GPU (or no-GPU, with --dry-run) box: RVC_BENCH_BACKEND=gloo
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = f"cuda:{local_rank}"
     coll_dev = dev if backend == "nccl" else "cpu"      # where the collectives' tensors live
-    torch.cuda.set_device(local_rank)
 
-    from comfy_rvc_amd import _lib, synthetic as S
-    from comfy_rvc_amd.config import Config
-    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
-    from comfy_rvc_amd.lib.rmvpe import RMVPE
-    from comfy_rvc_amd.parallel import gather_waveforms
-    from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+    from comfy_rvc_amd import synthetic as S
+    from comfy_rvc_amd.parallel import ClipLanes, gather_waveforms
 
-    cfg = Config(device=dev)
-    from comfy_rvc_amd.parallel import ClipLanes
+    n_lanes = max(1, args.lanes)
+    n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else 12)
+    SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
     audio = S.synth_audio(args.seconds, seed=100 + rank)
     params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
-    n_lanes = max(1, args.lanes)
-    SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
+    vc = None
 
-    def make_lane():
-        hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
-        vcd = get_vc(S.synth_checkpoint(SYN_CFG, "v2", 0), config=cfg, device=dev)
-        vc = VC(SYN_CFG[-1], cfg)
-        vc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
-        vc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
+    if use_gpu:
+        from comfy_rvc_amd import _lib
+        from comfy_rvc_amd.config import Config
+        from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+        from comfy_rvc_amd.lib.rmvpe import RMVPE
+        from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
+        cfg = Config(device=dev)
 
-        def convert(clip, i=0):
-            out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(clip, 16000), config=cfg, **params)
-            assert out is not None, "vc_single failed"
-            return out[0]
-        return convert, vc
-    lanes = [make_lane() for _ in range(n_lanes)]
-    vc = lanes[0][1]
-    pool = ClipLanes([fn for fn, _ in lanes], device=dev)
+        def make_lane():
+            hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
+            vcd = get_vc(S.synth_checkpoint(SYN_CFG, "v2", 0), config=cfg, device=dev)
+            lvc = VC(SYN_CFG[-1], cfg)
+            lvc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
+            lvc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
+
+            def convert(clip, i=0):
+                out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=lvc, hubert_model=hub, input_audio=(clip, 16000), config=cfg, **params)
+                assert out is not None, "vc_single failed"
+                return out[0]
+            return convert, lvc
+        lanes = [make_lane() for _ in range(n_lanes)]
+        vc = lanes[0][1]
+        pool = ClipLanes([fn for fn, _ in lanes], device=dev)
+    else:
+        n_out = int((2 * ((int(args.seconds * 16000) + 32000 - 400) // 320 + 1)) * (SYN_CFG[-1] // 100) - 2 * SYN_CFG[-1])
+
+        def stub(clip, i=0):                    # --dry-run: the documented output length, no compute
+            time.sleep(0.002)
+            return np.zeros(n_out, dtype=np.int16)
+        lanes = [(stub, None) for _ in range(n_lanes)]
+        pool = ClipLanes([fn for fn, _ in lanes], device=None)
 
     def step():                            # single clip on lane 0, caller's thread and stream (warm-up, roofline pass)
         return lanes[0][0](audio)
 
     def run_steps(k):
-        """k steps = k * LANES clips of this rank through the lanes (a free lane pulls the next clip); the waveforms are handed to the
-        gather in clip order as they complete."""
-        wav = None
-        for wav in pool.imap([audio] * (k * n_lanes)):
-            if world > 1:
-                gather_waveforms(wav, coll_dev)
+        """k steps = k * CLIPS clips of this rank through the lanes (a free lane pulls the next clip while the previous step is gathered);
+        the waveforms of a step are handed to ONE gather (the path's only exchange) in clip order."""
+        wav, batch = None, []
+        for wav in pool.imap([audio] * (k * n_clips)):
+            batch.append(wav)
+            if len(batch) == n_clips:
+                if world > 1:
+                    gather_waveforms(np.concatenate(batch), coll_dev)
+                batch = []
         return wav
 
     def sync():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
     for fn, _ in lanes:                    # every lane sizes its workspaces once, sequentially
         fn(audio)
@@ -144,100 +259,118 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     delivered = wav.shape[0] / float(SYN_CFG[-1])                       # audio seconds of one converted clip
-    value = delivered * n_lanes * world * args.steps / dt
+    value = delivered * n_clips * world * args.steps / dt
 
     # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
     sync()
     t1 = time.perf_counter()
     for _ in range(3):
         step()
-    torch.cuda.synchronize()
+    if use_gpu:
+        torch.cuda.synchronize()
     alone_ms = (time.perf_counter() - t1) / 3 * 1e3
     sync()
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # one extra, untimed-for-the-headline pass with every conv-kernel launch bracketed by HIP events on its own stream
-        _lib.check(_lib.lib.rvc_prof_enable(1))
-        vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
-        step()
-        torch.cuda.synchronize()
-        NCFG = 24   # RVC_PROF_CFGS
-        ms = (C.c_double * NCFG)(); fl = (C.c_double * NCFG)(); ln = (C.c_int64 * NCFG)()
-        ex = (C.c_double * (NCFG * 8))()
-        ridge_f32 = FP32_MFMA_PEAK_TFLOPS * 1e12 / HBM_PEAK_BPS
-        ridge_x3 = BF16_MFMA_PEAK_TFLOPS / 3.0 * 1e12 / HBM_PEAK_BPS
-        _lib.check(_lib.lib.rvc_prof_collect_ex(ex, ridge_f32, ridge_x3))
-        _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
-        _lib.check(_lib.lib.rvc_prof_enable(0))
-        vc.overlap_streams = True
-        per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
-                                                            "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
-                   for i in range(NCFG) if ln[i]}
-        traffic = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"]
-        except (OSError, ValueError, KeyError):
-            pass
-
-        def family(idx, regime, kernel, desc, peak_tf, note):
-            """One roofline entry: the launches of a kernel family in one regime (0: MFMA-bound, 4: HBM-bound by arithmetic intensity)."""
-            t = sum(ex[i * 8 + regime] for i in idx); f_ = sum(ex[i * 8 + regime + 1] for i in idx)
-            by = sum(ex[i * 8 + regime + 2] for i in idx); l_ = sum(ex[i * 8 + regime + 3] for i in idx)
-            if l_ == 0:
-                return None
-            tr = traffic.get(kernel)
-            e = {"bound": "mfma" if regime == 0 else "hbm"}
-            if regime == 0:
-                ach = f_ / (t * 1e-3) / 1e12
-                e.update({"achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(ach / peak_tf, 4)})
-            else:
-                ach = by / (t * 1e-3) / 1e9
-                e.update({"achieved": round(ach, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(ach / (HBM_PEAK_BPS / 1e9), 4)})
-            e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                      "traffic_note": None if tr is None else "HBM bytes per launch averaged over ALL launches of this kernel: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
-                                                              "WRITE_SIZE, separate passes (profiles/r1_pmc_traffic.json, tools/pmc_traffic.py)",
-                      "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
-                      "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "algorithmic_mbytes_per_launch": round(by / l_ / 1e6, 2),
-                      "kernel_ms_per_clip": round(t, 2), "algorithmic_tflop_per_clip": round(f_ / 1e12, 3)})
-            return e
-        X3 = "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)"
-        F32 = "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)"
-        x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
-        split_note = ("launches are split by arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the ridge peak FLOP/s / 8 TB/s: "
-                      "this entry holds the %s-bound ones")
-        fams = [family(range(14, NCFG), 0, "rvc::conv_x3_kernel", X3, x3_peak, "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product; " + split_note % "MFMA"),
-                family(range(14, NCFG), 4, "rvc::conv_x3_kernel", X3, x3_peak, "HBM 8 TB/s; " + split_note % "HBM"),
-                family(range(0, 14), 0, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak; " + split_note % "MFMA"),
-                family(range(0, 14), 4, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "HBM 8 TB/s; " + split_note % "HBM")]
-        fams = [r for r in fams if r]
-        fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant entry = the one with the most kernel time per clip
-        roofline = fams[0]
-        roofline["per_tile_config"] = per_cfg
-        roofline["other_kernels"] = fams[1:]
+    if rank == 0 and use_gpu and not args.no_roofline:
+        roofline = roofline_pass(_lib, vc, step, torch)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
         cpu = cpu_baseline(config=SYN_CFG)
 
     if rank == 0:
+        cfg_idx = 2 if args.variant == "40k_v2" else 3
         line = {
             "metric": f"audio-sec/wall-sec (xRT), {args.variant} end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if use_gpu else "dry-run (stub conversion, NO GPU work: launcher / collective check only)",
             "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
-            "config": {"workload": f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_lanes} per GPU "
-                                   "per step (in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[2])",
-                       "clips_per_step": world * n_lanes, "clips_in_flight_per_gpu": n_lanes, "audio_seconds_delivered_per_clip": round(delivered, 3),
+            "ranks": world, "backend": (backend if world > 1 else None), "nccl_ranks": (world if (world > 1 and backend == "nccl") else None),
+            "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
+            "config": {"workload": f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_clips} per GPU "
+                                   f"per step ({n_lanes} in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
+                       "clips_per_step": world * n_clips, "clips_per_gpu_per_step": n_clips, "clips_in_flight_per_gpu": n_lanes,
+                       "audio_seconds_delivered_per_clip": round(delivered, 3),
                        "one_clip_alone_ms": round(alone_ms, 2), "one_clip_alone_xrt": round(delivered / alone_ms * 1e3, 1),
                        "weights": "procedural (comfy-rvc_amd/synthetic.py)", "noise": "device generator",
-                       "parallelism": f"clip-per-GPU x{world} ({n_lanes} lanes each), RCCL gather of int16 waveforms"},
+                       "parallelism": f"clip-per-GPU x{world} ({n_lanes} lanes each), one RCCL gather of the step's int16 waveforms"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_pass(_lib, vc, step, torch):
+    """One extra, untimed-for-the-headline clip with every conv-kernel launch bracketed by HIP events on the stream it is launched on
+    (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes."""
+    _lib.check(_lib.lib.rvc_prof_enable(1))
+    vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
+    step()
+    torch.cuda.synchronize()
+    NCFG = 24   # RVC_PROF_CFGS
+    ms = (C.c_double * NCFG)(); fl = (C.c_double * NCFG)(); ln = (C.c_int64 * NCFG)()
+    ex = (C.c_double * (NCFG * 8))()
+    ridge_f32 = FP32_MFMA_PEAK_TFLOPS * 1e12 / HBM_PEAK_BPS
+    ridge_x3 = BF16_MFMA_PEAK_TFLOPS / 3.0 * 1e12 / HBM_PEAK_BPS
+    _lib.check(_lib.lib.rvc_prof_collect_ex(ex, ridge_f32, ridge_x3))
+    _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
+    dump = os.environ.get("RVC_PROF_CSV")
+    if dump:                         # per-launch table (shape, tile, us, FLOPs, algorithmic bytes) for profiles/
+        _lib.check(_lib.lib.rvc_prof_dump_csv(dump.encode()))
+    _lib.check(_lib.lib.rvc_prof_enable(0))
+    vc.overlap_streams = True
+    per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
+                                                        "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
+               for i in range(NCFG) if ln[i]}
+    traffic, traffic_src = {}, None
+    try:
+        with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
+            doc = json.load(f)
+        traffic, traffic_src = doc["kernels"], f"from file {PMC_TRAFFIC_FILE} (commit {doc.get('commit', '?')}), not measured in this run"
+    except (OSError, ValueError, KeyError):
+        pass
+
+    def family(idx, regime, kernel, desc, peak_tf, note):
+        """One roofline entry: the launches of a kernel family in one regime (0: MFMA-bound, 4: HBM-bound by arithmetic intensity)."""
+        t = sum(ex[i * 8 + regime] for i in idx); f_ = sum(ex[i * 8 + regime + 1] for i in idx)
+        by = sum(ex[i * 8 + regime + 2] for i in idx); l_ = sum(ex[i * 8 + regime + 3] for i in idx)
+        if l_ == 0:
+            return None
+        tr = traffic.get(kernel)
+        e = {"bound": "mfma" if regime == 0 else "hbm"}
+        tf = f_ / (t * 1e-3) / 1e12
+        if regime == 0:
+            e.update({"achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4)})
+        else:
+            ach = by / (t * 1e-3) / 1e9
+            e.update({"achieved": round(ach, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(ach / (HBM_PEAK_BPS / 1e9), 4)})
+        e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                  "traffic_note": None if tr is None else "HBM bytes per launch averaged over ALL launches of this kernel: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                                                          "WRITE_SIZE, separate passes (tools/pmc_traffic.py); " + traffic_src,
+                  "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
+                  "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "algorithmic_mbytes_per_launch": round(by / l_ / 1e6, 2),
+                  "kernel_ms_per_clip": round(t, 2), "algorithmic_tflop_per_clip": round(f_ / 1e12, 3),
+                  "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
+                                    "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "algorithmic_tflops": round(tf, 2)}})
+        return e
+    X3 = "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)"
+    F32 = "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)"
+    x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+    split_note = ("launches are split by arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the ridge peak FLOP/s / 8 TB/s: "
+                  "this entry holds the %s-bound ones")
+    fams = [family(range(14, NCFG), 0, "rvc::conv_x3_kernel", X3, x3_peak, "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product; " + split_note % "MFMA"),
+            family(range(14, NCFG), 4, "rvc::conv_x3_kernel", X3, x3_peak, "HBM 8 TB/s; " + split_note % "HBM"),
+            family(range(0, 14), 0, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak; " + split_note % "MFMA"),
+            family(range(0, 14), 4, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "HBM 8 TB/s; " + split_note % "HBM")]
+    fams = [r for r in fams if r]
+    fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant entry = the one with the most kernel time per clip
+    roofline = fams[0]
+    roofline["per_tile_config"] = per_cfg
+    roofline["other_kernels"] = fams[1:]
+    return roofline
 
 
 if __name__ == "__main__":

@@ -12,3 +12,21 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __version__ = "0.1.0"
+
+
+# ComfyUI discovers a node pack through these two module attributes (reference __init__.py:12-31).  They resolve on first access
+# (PEP 562) so that `import comfy_rvc_amd.synthetic` and the like stay free of torch / the HIP library; accessing them without the
+# built library raises (there is no CPU path).
+WEB_DIRECTORY = None
+
+
+def __getattr__(name):
+    if name in ("NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"):
+        from .custom_nodes import rvc_nodes as _n
+        globals()["NODE_CLASS_MAPPINGS"] = dict(_n.NODE_CLASS_MAPPINGS)
+        globals()["NODE_DISPLAY_NAME_MAPPINGS"] = dict(_n.NODE_DISPLAY_NAME_MAPPINGS)
+        return globals()[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+__all__ = ["NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"]

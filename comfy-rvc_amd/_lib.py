@@ -56,6 +56,7 @@ SIGNATURES = {
     "rvc_ctx_create": (c_int, [c_int, P(c_void_p)]),
     "rvc_ctx_destroy": (c_int, [c_void_p]),
     "rvc_ctx_workspace_bytes": (c_int64, [c_void_p]),
+    "rvc_ctx_set_conv_precision": (c_int, [c_void_p, c_int]),
     "rvc_hubert_create": (c_int, [c_void_p, P(c_void_p)]),
     "rvc_hubert_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_hubert_finalize": (c_int, [c_void_p]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "rvc_rmvpe_destroy": (c_int, [c_void_p]),
     "rvc_rmvpe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, P(RmvpeTaps)]),
     "rvc_rmvpe_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "rvc_rmvpe_status": (c_int, [c_void_p, c_void_p]),
+    "rvc_rmvpe_debug_fault": (c_int, [c_void_p, c_int, C.c_uint]),
     "rvc_synth_create": (c_int, [c_void_p, P(SynthConfig), P(c_void_p)]),
     "rvc_synth_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_synth_finalize": (c_int, [c_void_p]),
@@ -103,6 +106,7 @@ SIGNATURES = {
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),
     "rvc_resample": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),
     "rvc_set_conv_precision": (c_int, [c_int]),
+    "rvc_prof_dump_csv": (c_int, [c_char_p]),
     "rvc_prof_enable": (c_int, [c_int]),
     "rvc_prof_collect": (c_int, [P(C.c_double), P(C.c_double), P(c_int64)]),
     "rvc_prof_collect_ex": (c_int, [P(C.c_double), C.c_double, C.c_double]),

@@ -117,7 +117,9 @@ int tile_cfg_id(const TileCfg& t);            // 0..6, -1 if not an instantiated
 constexpr int kProfCfgs = 24;
 struct ProfTicket { hipEvent_t a = nullptr, b = nullptr; bool on = false; };
 ProfTicket conv_prof_begin(hipStream_t s);
-void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes = 0.0);
+void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes = 0.0, const ConvArgsX* shape = nullptr, long long blocks = 0,
+                   int fused = 0);
+int conv_prof_dump_csv(const char* path);   // one row per recorded launch: shape, tile, grid, us, algorithmic FLOPs / bytes
 double conv_alg_bytes(const ConvArgsX& a, int batch);
 int conv_prof_collect_ex(double* out /* [kProfCfgs][8] */, double ridge_fp32, double ridge_x3);
 

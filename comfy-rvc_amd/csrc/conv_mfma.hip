@@ -14,6 +14,8 @@
 // both are single conflict-free ds_read_b32 per operand; fp32 accumulate, bitwise an fmaf chain.
 // Workgroup = 4 waves (WM x WN), each wave owns AM x AN accumulators of 32x32.
 #include "conv_kernels.h"
+#include <atomic>
+#include <tuple>
 
 #ifndef RVC_EPI_TWOPHASE
 #define RVC_EPI_TWOPHASE 0
@@ -394,19 +396,36 @@ void dev_free(void* p) { if (p) (void)hipFree(p); }
 
 // Per-stream scratch buffers (slot 0: split-K partials, slot 1/2: pipeline temporaries).  Work on one stream is ordered, so a
 // buffer can be reused by consecutive launches; growing (warm-up only) synchronises, steady state never allocates.
+// The key holds the device: the null / legacy stream handle is the same value on every device.  Only the registry is locked; a
+// buffer belongs to one stream, whose work is enqueued by one host thread at a time, so growing it synchronises that stream only and
+// does not stall the other lanes.
+namespace {
+struct ScratchBuf { void* p = nullptr; size_t cap = 0; };
+using ScratchKey = std::tuple<int, hipStream_t, int>;
+std::map<ScratchKey, ScratchBuf>& scratch_pool() { static std::map<ScratchKey, ScratchBuf> pool; return pool; }
+std::mutex& scratch_mu() { static std::mutex mu; return mu; }
+}  // namespace
 void* stream_scratch(hipStream_t s, int slot, size_t bytes) {
-  struct Buf { void* p = nullptr; size_t cap = 0; };
-  static std::map<std::pair<hipStream_t, int>, Buf> pool;
-  static std::mutex mu;                       // several host threads drive their own streams (one clip in flight per worker)
-  std::lock_guard<std::mutex> lk(mu);
-  Buf& b = pool[{s, slot}];
-  if (bytes > b.cap) {
-    RVC_HIP_CHECK(hipDeviceSynchronize());
-    if (b.p) (void)hipFree(b.p);
-    b.cap = bytes + bytes / 4 + (1 << 20);
-    RVC_HIP_CHECK(hipMalloc(&b.p, b.cap));
+  int dev = 0;
+  RVC_HIP_CHECK(hipGetDevice(&dev));
+  ScratchBuf* b;
+  { std::lock_guard<std::mutex> lk(scratch_mu()); b = &scratch_pool()[ScratchKey{dev, s, slot}]; }   // (std::map nodes are address-stable)
+  if (bytes > b->cap) {
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr; b->cap = 0;
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    RVC_HIP_CHECK(hipMalloc(&b->p, want));
+    b->cap = want;
   }
-  return b.p;
+  return b->p;
+}
+void stream_scratch_release(int device) {
+  std::lock_guard<std::mutex> lk(scratch_mu());
+  auto& pool = scratch_pool();
+  for (auto it = pool.begin(); it != pool.end();) {
+    if (std::get<0>(it->first) == device) { if (it->second.p) (void)hipFree(it->second.p); it = pool.erase(it); } else ++it;
+  }
 }
 
 void Arena::ensure(size_t bytes) {
@@ -442,10 +461,10 @@ static uint16_t bf16_rne(float f) {
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 static float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-static bool g_x3_default = false;
-static int g_precision = 1;      // 0: fp32 kernel only, 1: layers initialised under conv_x3_set_default(true), 2: every eligible layer
-void conv_x3_set_default(bool on) { g_x3_default = on; }
-void conv_set_precision(int mode) { g_precision = mode; }
+static thread_local bool g_x3_default = false;
+static thread_local int g_precision = 1;      // 0: fp32 kernel only, 1: layers initialised under conv_x3_set_default(true), 2: every eligible layer
+bool conv_x3_set_default(bool on) { const bool prev = g_x3_default; g_x3_default = on; return prev; }
+int conv_set_precision(int mode) { const int prev = g_precision; if (mode >= 0) g_precision = mode; return prev; }
 static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
   L.CoPx = (Co + 127) & ~127;
   const int nch = Ci / 16;
@@ -616,11 +635,8 @@ __global__ void interleave2x2_kernel(const float* __restrict__ ph, float* __rest
 template <int WM, int WN, int AM, int AN, int MODE>
 static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_mfma_kernel<WM, WN, AM, AN, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
@@ -642,8 +658,8 @@ TileCfg choose_tile(int M, long long N, int batch) {
 }
 
 // ---------------------------------------------------------------------------- optional per-launch profiling (HIP events)
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; };
-static bool g_prof_on = false;
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; int Ci, Co, k, dil, stride, Tout, Wd, ksplit, fused; long long blocks; };
+static std::atomic<bool> g_prof_on{false};
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
@@ -658,6 +674,7 @@ void conv_prof_enable(bool on) {
 }
 // Sums the event-timed conv launches recorded since conv_prof_enable(true).  Per tile configuration: ms, flops, launches.
 int conv_prof_collect(double* ms, double* flops, long long* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < kProfCfgs; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.b);
@@ -670,15 +687,34 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
 }
 const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < kProfCfgs) ? kCfgNames[i] : ""; }
 ProfTicket conv_prof_begin(hipStream_t s) {
-  ProfTicket t; t.on = g_prof_on;
+  ProfTicket t; t.on = g_prof_on.load(std::memory_order_relaxed);
   if (t.on) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); (void)hipEventRecord(t.a, s); }
   return t;
 }
-void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes) {
+void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes, const ConvArgsX* a, long long blocks, int fused) {
   if (!t.on) return;
   (void)hipEventRecord(t.b, s);
+  ProfRec r{t.a, t.b, flops, cfg, bytes, 0, 0, 0, 0, 0, 0, 0, 1, fused, blocks};
+  if (a) { r.Ci = a->Ci; r.Co = a->Co; r.k = a->kreal > 0 ? a->kreal : a->ktaps; r.dil = a->dil; r.stride = a->stride; r.Tout = a->Tout; r.Wd = a->Wd; r.ksplit = a->ksplit > 0 ? a->ksplit : 1; }
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back(ProfRec{t.a, t.b, flops, cfg, bytes});
+  g_prof.push_back(r);
+}
+int conv_prof_dump_csv(const char* path) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  FILE* f = fopen(path, "w");
+  if (!f) return -1;
+  fprintf(f, "launch,kernel,tile,Ci,Co,k,dil,stride,Tout,Wd,fused_pair,ksplit,workgroups,us,alg_gflop,alg_mbytes,tflops,alg_gbps\n");
+  int i = 0;
+  for (auto& r : g_prof) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? "conv_x3_kernel" : "conv_mfma_kernel", kCfgNames[r.cfg],
+            r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
+            t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0);
+  }
+  fclose(f);
+  return i;
 }
 // algorithmic HBM bytes of one launch: input + output (+ residual, + previous output when accumulating) + weights, fp32
 double conv_alg_bytes(const ConvArgsX& a, int batch) {
@@ -691,6 +727,7 @@ double conv_alg_bytes(const ConvArgsX& a, int batch) {
 // its kernel (peak FLOP/s / 8 TB/s): out[cfg][0..3] = {ms, flops, bytes, launches} of the MFMA-bound launches, [4..7] of the
 // HBM-bound ones.
 int conv_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < kProfCfgs * 8; ++i) out[i] = 0;
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.b);
@@ -787,7 +824,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
       (void)total;
       splitk_reduce_launch(a, S, batch, s);
     }
-    conv_prof_end(rec, s, flops, cfg_id, conv_alg_bytes(a, batch));
+    conv_prof_end(rec, s, flops, cfg_id, conv_alg_bytes(a, batch), &a, (long long)grid.x * grid.y * grid.z);
   };
 #define RVC_LAUNCH(ID_, WM_, WN_, AM_, AN_)                                                     \
   if (t.WM == WM_ && t.WN == WN_ && t.AM == AM_ && t.AN == AN_) {                               \

@@ -374,11 +374,8 @@ bool conv_x3_enabled() {
 template <int WM, int WN, int AM, int AN, bool FUSE = false>
 static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
@@ -481,7 +478,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
   }
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
-  conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch));
+  conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)grid.x * grid.y * grid.z);
   return true;
 }
 
@@ -539,7 +536,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
   // algorithmic traffic of the pair: x read, residual read, y write (+ previous y when accumulating) + both weight sets
   const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
-  conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes);
+  conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes, &a, (long long)grid.x, 1);
   return true;
 }
 

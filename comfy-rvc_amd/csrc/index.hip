@@ -37,7 +37,7 @@ __global__ __launch_bounds__(1024) void index_argmax_kernel(const float* __restr
   __shared__ long long s_i[16][64];
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + col;
-  float bv = -3.0e38f; long long bi = 0x7fffffffffffffffLL;
+  float bv = -3.0e38f; long long bi = m0;          // (a column of NaN scores compares false everywhere: it keeps a valid row)
   if (t < T)
     for (int m = sl; m < M; m += 16) {
       const float v = Y[(long long)m * ldY + t];
@@ -61,18 +61,21 @@ __global__ void index_score_kernel(const float* __restrict__ f, const float* __r
   if (t >= T) return;
   float s = 0.f;
   for (int c = 0; c < D; ++c) { const float v = f[(long long)c * T + t]; s = fmaf(v, v, s); }
-  score[t] = s - 2.f * best[t];
+  // cancellation can leave an exact member of the index at 0 or slightly below; the generic VC.vc path weighs by 1 / score^2
+  // (reference vc_infer_pipeline.py:66-68), so the distance is kept strictly positive
+  score[t] = fmaxf(s - 2.f * best[t], 1e-10f);
 }
 
 // out[c][t] = rate * rows[idx[t]][c] + (1 - rate) * f[c][t]      (reference :71-74; k = 1 makes the 1/score^2 weight exactly 1)
 __global__ void index_blend_kernel(const float* __restrict__ f, const float* __restrict__ rows, const long long* __restrict__ idx, float rate,
-                                   float* __restrict__ out, int D, int T) {
+                                   float* __restrict__ out, int D, int T, long long N) {
   const long long n = (long long)D * T;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long st = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += st) {
     const int c = (int)(i / T); const int t = (int)(i - (long long)c * T);
-    out[i] = rows[idx[t] * D + c] * rate + (1.f - rate) * f[i];
+    long long r = idx[t]; r = r < 0 ? 0 : (r >= N ? N - 1 : r);        // caller-supplied indices are clamped into the table
+    out[i] = rows[r * D + c] * rate + (1.f - rate) * f[i];
   }
 }
 
@@ -90,7 +93,7 @@ FeatIndex* index_create(Ctx* ctx, const float* big_npy, long long N, int D) {
     if (as_conv && D % 16 == 0 && N >= 4096) {
       std::vector<float> nh((size_t)N);
       RVC_HIP_CHECK(hipMemcpy(nh.data(), I->nhalf, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));   // the same bias values as the fp32 path
-      struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
+      ConvBuildScope x3scope(ctx->precision);
       const long long chunk = 32768;
       I->chunks.resize((size_t)((N + chunk - 1) / chunk));
       for (size_t c = 0; c < I->chunks.size(); ++c) {
@@ -128,7 +131,7 @@ void index_search(FeatIndex* I, hipStream_t s, const float* feats_cm, int T, lon
 
 void index_blend(FeatIndex* I, hipStream_t s, const float* feats_cm, const long long* idx, int T, float rate, float* out_cm) {
   const long long n = (long long)I->D * T; int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(index_blend_kernel, dim3(blocks), dim3(256), 0, s, feats_cm, I->rows, idx, rate, out_cm, I->D, T);
+  hipLaunchKernelGGL(index_blend_kernel, dim3(blocks), dim3(256), 0, s, feats_cm, I->rows, idx, rate, out_cm, I->D, T, I->N);
 }
 
 }  // namespace rvc

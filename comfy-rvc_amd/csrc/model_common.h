@@ -41,6 +41,8 @@ struct TensorStore {
 struct Ctx {
   int device = 0;
   size_t workspace_bytes = 0;   // sum of the model arenas (informational)
+  int precision = -1;           // conv arithmetic of the models built on this context: 0 fp32 MFMA only, 1 / 2 bf16x3 split where eligible,
+                                // -1 (default): the mode of the thread that finalizes the model (rvc_set_conv_precision, default 1)
 };
 
 // device vector owned by a model

@@ -54,7 +54,7 @@ void hubert_finalize(Hubert* H) {
   hubert_free(*H);
   // the k = 1 projections (feature projection, q/k, out, feed-forward, final_proj) also get a bf16x3 split weight image
   // (conv_x3.hip); strided / grouped convolutions and the activation x activation products of attention stay on the fp32 kernel
-  struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
+  ConvBuildScope x3scope(H->ctx->precision);
   // conv0: Conv1d(1, 512, 10, stride 5) == Linear(10 -> 512) over im2col frames
   conv1d_layer_init(H->conv[0], ts.get("feature_extractor.conv_layers.0.conv.weight", {512, 1, 10}).data.data(), nullptr, 512, 10, 1, 1, 0, 1, 1);
   for (int i = 1; i < 7; ++i)

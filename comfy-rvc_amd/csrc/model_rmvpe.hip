@@ -22,6 +22,7 @@ struct Rmvpe {
   DevVec wihT, b_ih, w_hh, b_hh;
   ConvLayer fc;
   unsigned long long* xbuf = nullptr; int* gru_err = nullptr;
+  int gru_fault = 0; unsigned gru_spin_limit = 0;          // test hooks (rmvpe_debug_fault)
 };
 
 Rmvpe* rmvpe_create(Ctx* ctx) { Rmvpe* R = new Rmvpe(); R->ctx = ctx; return R; }
@@ -72,7 +73,7 @@ static void make_cbr(CBR& B, const TensorStore& ts, const std::string& p, int ci
 
 void rmvpe_finalize(Rmvpe* R) {
   // 3x3 convolutions with Ci % 16 == 0 also get a bf16x3 split weight image (conv_x3.hip); Ci = 1 / transposed convs stay fp32
-  struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
+  ConvBuildScope x3scope(R->ctx->precision);
   const TensorStore& ts = R->ts;
   rmvpe_free(*R);
   conv1d_layer_init(R->stft, ts.get("stft.forward_basis", {1026, 1024}).data.data(), nullptr, 1026, 1024, 1, 1, 0, 1, 1);
@@ -123,6 +124,7 @@ void rmvpe_finalize(Rmvpe* R) {
   conv1d_layer_init(R->fc, ts.get("fc.1.weight", {360, 512}).data.data(), ts.get("fc.1.bias", {360}).data.data(), 360, 512, 1, 1, 0, 1, 1);
   RVC_HIP_CHECK(hipMalloc(&R->xbuf, sizeof(unsigned long long) * 2 * 2 * 256));
   RVC_HIP_CHECK(hipMalloc(&R->gru_err, sizeof(int)));
+  RVC_HIP_CHECK(hipMemset(R->gru_err, 0, sizeof(int)));
   R->ts.clear();
   R->ready = true;
 }
@@ -210,12 +212,12 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
     conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
     transpose(s, c3, feat, Tr, 128, 128, Tr, 3, (long long)Tr * 128, 128LL * Tr);           // [c][t][m] -> [c*128+m][t]
     gemm_tn_run(s, feat, Tr, 0, R->wihT.p, 1536, 0, gi, 1536, 0, Tr, 1536, 384, 1, nullptr, 0, E0);
-    gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr);
+    gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr, R->gru_spin_limit, R->gru_fault);
     if (taps && taps->gru) RVC_HIP_CHECK(hipMemcpyAsync(taps->gru, hid, (size_t)512 * Tr * sizeof(float), hipMemcpyDeviceToDevice, s));
     ConvEpilogue Es; Es.act = ACT_SIGMOID;
     conv1d_run(R->fc, s, hid, Tr, Tr, sal, Tr, Es);
     if (sal_out) transpose(s, sal, sal_out, 360, n, Tr, 360, 1, 0, 0);
-    if (f0_out) rmvpe_decode(s, sal, f0_out, n, Tr, thred);
+    if (f0_out) rmvpe_decode(s, sal, f0_out, n, Tr, thred, R->gru_err);
   }
 }
 
@@ -241,5 +243,14 @@ void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, 
 }
 
 size_t rmvpe_workspace(const Rmvpe* M) { return M->arena.cap; }
+
+int rmvpe_status(Rmvpe* R, hipStream_t s) {
+  int flag = 0;
+  if (!R->gru_err) return 0;
+  RVC_HIP_CHECK(hipMemcpyAsync(&flag, R->gru_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RVC_HIP_CHECK(hipStreamSynchronize(s));
+  return flag ? 1 : 0;
+}
+void rmvpe_debug_fault(Rmvpe* R, int fault, unsigned spin_limit) { R->gru_fault = fault; R->gru_spin_limit = spin_limit; }
 
 }  // namespace rvc

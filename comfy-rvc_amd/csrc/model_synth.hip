@@ -91,6 +91,7 @@ Synth* synth_create(Ctx* ctx, const SynthConfig& c) {
 void synth_destroy(Synth* S) { if (S) { synth_free(*S); S->arena.release(); delete S; } }
 void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim) { S->ts.set(name, d, shape, ndim); }
 int synth_upp(const Synth* S) { return S->upp; }
+int synth_feat_dim(const Synth* S) { return S->feat_dim; }
 bool synth_has_f0(const Synth* S) { return S->f0; }
 
 void synth_finalize(Synth* S) {
@@ -98,7 +99,7 @@ void synth_finalize(Synth* S) {
   synth_free(*S);
   // every eligible Conv1d (stride 1, groups 1, Ci % 16 == 0) also gets a bf16x3 split weight image: the generator ResBlocks
   // (70 % of a clip's FLOPs), flow WaveNet, enc_p projections; conv_x3.hip, ~1e-5 relative error per layer
-  struct X3Scope { X3Scope() { conv_x3_set_default(true); } ~X3Scope() { conv_x3_set_default(false); } } x3scope;
+  ConvBuildScope x3scope(S->ctx->precision);
   const int C = S->hidden, kc = C / S->n_heads;
   {
     const HostTensor& w = ts.get("enc_p.emb_phone.weight", {C, S->feat_dim});

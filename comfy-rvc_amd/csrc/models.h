@@ -16,6 +16,7 @@ void synth_destroy(Synth* S);
 void synth_set_tensor(Synth* S, const char* name, const float* d, const long long* shape, int ndim);
 void synth_finalize(Synth* S);
 int synth_upp(const Synth* S);
+int synth_feat_dim(const Synth* S);
 bool synth_has_f0(const Synth* S);      // false: *_nono family (decided by the checkpoint: no enc_p.emb_pitch)
 void synth_infer(Synth* S, hipStream_t s, const float* feat, int feat_channel_major, const long long* pitch, const float* pitchf, int sid,
                  const float* noise_z, const float* noise_src, int T, float* out, const SynthTaps* taps);
@@ -35,7 +36,8 @@ Rmvpe* rmvpe_create(Ctx* ctx);
 void rmvpe_destroy(Rmvpe* R);
 void rmvpe_set_tensor(Rmvpe* R, const char* name, const float* d, const long long* shape, int ndim);
 void rmvpe_finalize(Rmvpe* R);
-// mel_out [128][n], salience_out [n][360], f0_out [n] (float64); any may be null.  Returns through *gru_err a sticky flag.
+// mel_out [128][n], salience_out [n][360], f0_out [n] (float64); any may be null.  A failed GRU hand-off (the scan's workgroups poll each
+// other) sets a sticky device flag: f0_out is then NaN and rmvpe_status reports it.
 void rmvpe_forward(Rmvpe* R, hipStream_t s, const float* audio, long long L, float thred, float* mel_out, float* salience_out, double* f0_out,
                    const RmvpeTaps* taps);
 
@@ -49,6 +51,8 @@ void index_search(FeatIndex* I, hipStream_t s, const float* feats_cm, int T, lon
 void index_blend(FeatIndex* I, hipStream_t s, const float* feats_cm, const long long* idx, int T, float rate, float* out_cm);
 
 void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, float thred, double* f0);
+int rmvpe_status(Rmvpe* R, hipStream_t s);                 // waits for the stream; bit 0: the last forward's GRU scan timed out
+void rmvpe_debug_fault(Rmvpe* R, int fault, unsigned spin_limit);   // tests: make the next scans fail / shorten their spin limit
 size_t synth_workspace(const Synth* S);
 size_t hubert_workspace(const Hubert* H);
 size_t rmvpe_workspace(const Rmvpe* R);

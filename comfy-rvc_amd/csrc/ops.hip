@@ -435,7 +435,8 @@ void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long
 // gi: [T][1536] = W_ih x + (bias added here); out: channel-major [512][T].   nn.GRU gate order r, z, n.
 __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                        const float* __restrict__ w_hh, const float* __restrict__ b_hh,
-                                                       float* __restrict__ out, unsigned long long* xbuf, int* err, int T) {
+                                                       float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
+                                                       unsigned spin_limit, int fault) {
   constexpr int H = 256, HS = 32;
   constexpr int HP = 36;                                   // padded pitch of one 32-value segment of h in LDS (float4 reads of the
                                                            // eight segments then fall on disjoint banks)
@@ -444,7 +445,9 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
   const int xcd = blockIdx.x & 7;
   if (xcd != 0 && xcd != 4) return;
   const int dir = xcd >> 2, sl = blockIdx.x >> 3;
+  if (fault && dir == 1 && sl == 5) return;                 // fault injection (tests): one slice never publishes, its peers must time out
   const int tid = threadIdx.x;
+  bool failed = false;                                       // sticky per thread: after one timeout the stale value is used without polling
   const float* W = w_hh + (long long)dir * 3 * H * H;
   const float* BH = b_hh + dir * 3 * H;
   const float* BI = b_ih + dir * 3 * H;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
         for (;;) {
           v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == (unsigned)step) break;
-          if (++spins > (1u << 24)) { if (err) atomicExch(err, 1); break; }
+          if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         hs[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
@@ -527,19 +530,23 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
     __syncthreads();
   }
 }
+// *err is a sticky device flag: set when a workgroup gave up waiting for its peers (they need co-residency: 16 workgroups of 768
+// threads; a spin limit of 2^24 polls is ~10 s).  It is cleared here, consumed by rmvpe_decode (f0 becomes NaN) and reported by
+// rvc_rmvpe_status.
 void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* b_hh, float* out,
-              unsigned long long* xbuf, int* err, int T) {
+              unsigned long long* xbuf, int* err, int T, unsigned spin_limit, int fault) {
   (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
   (void)hipMemsetAsync(err, 0, sizeof(int), s);
-  hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T);
+  hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, spin_limit ? spin_limit : (1u << 24), fault);
 }
 
 // ---------------------------------------------------------------------------------------------- RMVPE decode
 // salience channel-major [360][ld]; f0[t] = 10 * 2^(cents/1200) with the 9-bin local weighted average around the argmax
 // (reference lib/rmvpe.py:607-612,:661-685); 0 where max <= thred.  Output float64 like the numpy reference.
-__global__ void rmvpe_decode_kernel(const float* __restrict__ sal, double* __restrict__ f0, int n, long long ld, float thred) {
+__global__ void rmvpe_decode_kernel(const float* __restrict__ sal, double* __restrict__ f0, int n, long long ld, float thred, const int* __restrict__ err) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
+  if (err && *err) { f0[t] = __longlong_as_double(0x7ff8000000000000LL); return; }     // the recurrence failed upstream: never hand out a plausible-looking pitch
   float mx = -1.f; int am = 0;
   for (int c = 0; c < 360; ++c) { const float v = sal[(long long)c * ld + t]; if (v > mx) { mx = v; am = c; } }
   double ps = 0.0, ws = 0.0;
@@ -556,8 +563,8 @@ __global__ void rmvpe_decode_kernel(const float* __restrict__ sal, double* __res
   if (f == 10.0) f = 0.0;
   f0[t] = f;
 }
-void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred) {
-  hipLaunchKernelGGL(rmvpe_decode_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sal, f0, n, ld, thred);
+void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred, const int* err) {
+  hipLaunchKernelGGL(rmvpe_decode_kernel, dim3((n + 127) / 128), dim3(128), 0, s, sal, f0, n, ld, thred, err);
 }
 
 // ---------------------------------------------------------------------------------------------- SineGen / SourceModuleHnNSF

@@ -11,6 +11,8 @@ void set_error(const std::string& msg) { g_err = msg; }
 using namespace rvc;
 
 struct rvc_ctx { Ctx c; };
+static std::mutex g_ctx_mu;
+static std::map<int, int> g_ctx_count;       // live contexts per device (the per-stream scratch is released with the last one)
 struct rvc_hubert { Hubert* m; rvc_ctx* ctx; };
 struct rvc_rmvpe { Rmvpe* m; rvc_ctx* ctx; };
 struct rvc_synth { Synth* m; rvc_ctx* ctx; };
@@ -45,10 +47,24 @@ int rvc_ctx_create(int device_id, rvc_ctx** out) {
               std::string("kernels are built for gfx950 only, found ") + prop.gcnArchName);
   rvc_ctx* c = new rvc_ctx();
   c->c.device = device_id;
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); ++g_ctx_count[device_id]; }
   *out = c;
   RVC_CATCH
 }
-int rvc_ctx_destroy(rvc_ctx* ctx) { delete ctx; return 0; }
+int rvc_ctx_destroy(rvc_ctx* ctx) {
+  if (!ctx) return 0;
+  bool last;
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); last = --g_ctx_count[ctx->c.device] <= 0; }
+  if (last) { (void)hipSetDevice(ctx->c.device); stream_scratch_release(ctx->c.device); }   // per-stream scratch goes with the last context of a device
+  delete ctx;
+  return 0;
+}
+int rvc_ctx_set_conv_precision(rvc_ctx* ctx, int mode) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && mode >= -1 && mode <= 2, "precision mode must be -1 (thread default), 0, 1 or 2");
+  ctx->c.precision = mode;
+  RVC_CATCH
+}
 int64_t rvc_ctx_workspace_bytes(rvc_ctx* ctx) { return ctx ? (int64_t)ctx->c.workspace_bytes : 0; }
 
 // ------------------------------------------------------------------------------------------------ hubert
@@ -102,6 +118,14 @@ int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio, int64_t L,
   check_launch();
   RVC_CATCH
 }
+int rvc_rmvpe_status(rvc_rmvpe* r, void* stream) {
+  RVC_TRY
+  RVC_REQUIRE(r, "null argument");
+  RVC_REQUIRE(rmvpe_status(r->m, (hipStream_t)stream) == 0,
+              "RMVPE: the GRU scan's workgroups timed out waiting for each other (they need to be co-resident); the f0 of the last forward is invalid (NaN)");
+  RVC_CATCH
+}
+int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit) { RVC_TRY RVC_REQUIRE(r, "null argument"); rmvpe_debug_fault(r->m, fault, spin_limit); RVC_CATCH }
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* sal, int64_t n, float thred, double* f0) {
   RVC_TRY
   RVC_REQUIRE(r && sal && f0 && n > 0, "bad argument");
@@ -156,6 +180,9 @@ int rvc_vc_segment(rvc_hubert* h, rvc_synth* s, void* stream, const float* audio
   hipStream_t st = (hipStream_t)stream;
   const long long Th = hubert_num_frames(L);
   const int D = version == 1 ? 256 : 768;
+  RVC_REQUIRE(version == 1 || version == 2, "version must be 1 (256-d) or 2 (768-d)");
+  RVC_REQUIRE(D == synth_feat_dim(s->m), "feature width of `version` does not match the synthesizer (v1 models take 256-d, v2 models 768-d features)");
+  RVC_REQUIRE(Th > 0 && 2 * Th < (1LL << 30), "segment length out of range");
   const int T = (int)(2 * Th);
   // scratch for the channel-major features lives in two small allocations owned by this call's stream order
   float* fcm = (float*)stream_scratch(st, 1, (size_t)D * Th * sizeof(float));
@@ -173,6 +200,8 @@ int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm, cons
   RVC_REQUIRE(s && feats_cm && noise_z && out, "null argument");
   check_pitch_args(s, pitch, pitchf, noise_src, do_protect);
   hipStream_t st = (hipStream_t)stream;
+  RVC_REQUIRE(feat_dim == synth_feat_dim(s->m), "feat_dim does not match the synthesizer (v1 models take 256-d, v2 models 768-d features)");
+  RVC_REQUIRE(Th > 0 && 2 * Th < (1LL << 30), "segment length out of range");
   const int T = (int)(2 * Th);
   float* fup = (float*)stream_scratch(st, 2, (size_t)feat_dim * T * sizeof(float));
   feats_prepare(st, feats_cm, feats0_cm, pitchf, fup, feat_dim, (int)Th, T, protect, do_protect);
@@ -348,16 +377,15 @@ int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float*
   RVC_TRY
   hipStream_t st = (hipStream_t)stream;
   const long long N = (long long)T * upp;
-  float* rad = nullptr; float* tmp = nullptr; double* bsum = nullptr;
-  RVC_HIP_CHECK(hipMalloc(&rad, T * sizeof(float)));
-  RVC_HIP_CHECK(hipMalloc(&tmp, T * sizeof(float)));
-  RVC_HIP_CHECK(hipMalloc(&bsum, ((N + 1023) / 1024) * sizeof(double)));
+  RVC_REQUIRE(T > 0 && upp > 0, "bad argument");
+  const size_t nb = (size_t)((N + 1023) / 1024);
+  const size_t tb = ((size_t)T * sizeof(float) + 255) & ~size_t(255);
+  char* scr = (char*)stream_scratch(st, 2, 2 * tb + nb * sizeof(double));        // temporaries from the stream's scratch: nothing to leak on failure
+  float* rad = (float*)scr; float* tmp = (float*)(scr + tb); double* bsum = (double*)(scr + 2 * tb);
   sine_source(st, f0, noise, har, sine, rad, tmp, bsum, T, upp, sr, lw, lb, phase_out);
-  if (rad_out) (void)hipMemcpyAsync(rad_out, rad, T * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (tmp_out) (void)hipMemcpyAsync(tmp_out, tmp, T * sizeof(float), hipMemcpyDeviceToDevice, st);
-  hipError_t e = hipStreamSynchronize(st);
-  (void)hipFree(rad); (void)hipFree(tmp); (void)hipFree(bsum);
-  RVC_HIP_CHECK(e);
+  if (rad_out) RVC_HIP_CHECK(hipMemcpyAsync(rad_out, rad, T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (tmp_out) RVC_HIP_CHECK(hipMemcpyAsync(tmp_out, tmp, T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  RVC_HIP_CHECK(hipStreamSynchronize(st));
   check_launch();
   RVC_CATCH
 }
@@ -379,6 +407,7 @@ int rvc_prof_collect(double* ms, double* flops, int64_t* launches) {
 }
 int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) { RVC_TRY conv_prof_collect_ex(out, ridge_fp32, ridge_x3); RVC_CATCH }
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
+int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 
 }  // extern "C"

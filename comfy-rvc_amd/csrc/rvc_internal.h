@@ -99,8 +99,18 @@ void tconv2d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][3][3]*/, const f
 void conv_layer_free(ConvLayer& L);
 // Layers initialised while this is on also get a bf16x3 split weight image and run on conv_x3_kernel when eligible
 // (stride 1, groups 1, Ci % 16 == 0): 3 bf16 MFMAs per fp32 product, fp32 accumulate, ~1e-5 relative error.
-void conv_x3_set_default(bool on);
-void conv_set_precision(int mode);   // 0: fp32 only, 1: model default (generator convolutions), 2: every eligible layer
+// Both switches are THREAD-LOCAL (a model is built by the thread that calls *_finalize; two threads building models at the same time
+// cannot see each other's scopes).  Models take their mode from their context (Ctx::precision) through ConvBuildScope.
+bool conv_x3_set_default(bool on);   // returns the previous value
+int conv_set_precision(int mode);    // 0: fp32 only, 1: layers initialised under conv_x3_set_default(true), 2: every eligible layer; returns the previous mode
+struct ConvBuildScope {              // RAII: layers initialised inside get bf16x3 images according to `precision`
+  int prev_mode; bool prev_default;
+  explicit ConvBuildScope(int precision) : prev_mode(conv_set_precision(-1)), prev_default(conv_x3_set_default(true)) {   // < 0: keep the thread's mode
+    if (precision >= 0) conv_set_precision(precision);
+  }
+  ~ConvBuildScope() { conv_x3_set_default(prev_default); conv_set_precision(prev_mode); }
+  ConvBuildScope(const ConvBuildScope&) = delete; ConvBuildScope& operator=(const ConvBuildScope&) = delete;
+};
 
 // launches.  1-D: X [Ci][Tin] with channel stride ldX, Y [Co][Tout] with channel stride ldY.
 int conv1d_out_len(const ConvLayer& L, int Tin);
@@ -129,7 +139,8 @@ void conv_timing_read(unsigned long long* out8, bool reset);   // debug builds (
 
 // ----------------------------------------------------------------------------- device memory
 float* dev_upload(const float* host, size_t n);
-void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // persistent per-stream scratch (grows on demand)
+void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // persistent per-(device, stream) scratch (grows on demand)
+void stream_scratch_release(int device);                        // frees the scratch of one device (last context of the device destroyed)
 void dev_free(void* p);
 
 struct Arena {

@@ -17,7 +17,7 @@ import torch
 
 from ..config import config
 from ..lib import BASE_MODELS_DIR
-from ..lib.audio import get_audio
+from ..lib.audio import audio_to_bytes, get_audio
 from ..lib.model_utils import load_hubert
 from ..vc_infer_pipeline import get_vc, vc_single
 
@@ -159,7 +159,10 @@ class RVCNode:
         wav, sr = output_audio
         audio_name = f"{widget_id}.{format}"
         ui = {"preview": [{"filename": audio_name, "type": "temp", "subfolder": "preview", "widgetId": widget_id}]}
-        return {"ui": ui, "result": (lambda: (wav, sr), to_audio_dict(wav, sr))}
+        # VHS_AUDIO = thunk returning the encoded stream (reference rvc_nodes.py:206: `lambda: audio_to_bytes(*output_audio)`, always WAV:
+        # PCM_16 for the int16 result).  `format` only names the preview / cache file upstream; no file is written here (file codecs are
+        # out of scope), so flac / mp3 previews are not produced.
+        return {"ui": ui, "result": (lambda: audio_to_bytes(wav, sr), to_audio_dict(wav, sr))}
 
 
 NODE_CLASS_MAPPINGS = {

@@ -33,9 +33,86 @@ def get_audio(audio):
         audio = audio()
     if isinstance(audio, Mapping):
         return audio["waveform"].squeeze(0).transpose(0, 1).numpy(), audio["sample_rate"]
-    if isinstance(audio, bytes):
-        raise NotImplementedError("encoded byte streams need soundfile/ffmpeg (file IO is out of scope of this build)")
+    if isinstance(audio, (bytes, bytearray, memoryview)):
+        return bytes_to_audio(bytes(audio))
     return audio
+
+
+# ---------------------------------------------------------------------------------------------- VHS_AUDIO byte streams
+# The reference moves audio between nodes as encoded bytes (VHS_AUDIO = thunk returning bytes): audio_to_bytes writes a WAV
+# through soundfile (lib/audio.py:188-204: PCM_16 when the samples exceed 1 in magnitude, i.e. int16-valued, IEEE float32
+# otherwise) and bytes_to_audio reads any libsndfile format back as float64 [C, N] (lib/audio.py:206-210).  soundfile is not
+# available to this build, so the RIFF/WAVE container is written and parsed here (PCM 8/16/24/32, IEEE float 32/64, plain and
+# WAVE_FORMAT_EXTENSIBLE headers); compressed containers (flac / mp3 / ogg) need an external codec and raise.
+def audio_to_bytes(audio, sr, target_sr=None, to_int16=False, to_stereo=False, format="WAV"):
+    """(samples [N] | [C, N] | [N, C], sr) -> WAV bytes, laid out as the reference's audio_to_bytes produces them."""
+    import struct
+    if str(format).upper() != "WAV":
+        raise NotImplementedError(f"audio_to_bytes: only the WAV container is built in (asked for {format!r}; flac/mp3 need libsndfile/ffmpeg)")
+    audio = np.array(audio, dtype="float32")
+    if to_int16:
+        audio_max = np.abs(audio).max() / .99
+        if audio_max > 1:
+            audio = audio / audio_max
+        audio = np.clip(audio * MAX_INT16, a_min=-MAX_INT16 + 1, a_max=MAX_INT16 - 1)
+    if to_stereo and audio.ndim < 2:
+        audio = np.stack([audio, audio], axis=-1)
+    if audio.ndim > 1 and audio.shape[0] < audio.shape[1]:
+        audio = audio.T                                             # frames x channels
+    rate = int(sr if target_sr is None else target_sr)
+    as_int = audio.size > 0 and np.abs(audio).max() > 1
+    data = np.ascontiguousarray(audio.astype("<i2" if as_int else "<f4"))
+    nch = 1 if data.ndim == 1 else data.shape[1]
+    bps = data.dtype.itemsize
+    payload = data.tobytes()
+    fmt = struct.pack("<HHIIHH", 1 if as_int else 3, nch, rate, rate * nch * bps, nch * bps, 8 * bps)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if not as_int:                                                  # non-PCM formats carry a fact chunk (frames per channel)
+        chunks += b"fact" + struct.pack("<II", 4, data.shape[0])
+    chunks += b"data" + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"")
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def bytes_to_audio(data, **kwargs):
+    """WAV bytes -> (float64 [N] or [C, N] scaled to [-1, 1), sr), as soundfile.read returns them (reference lib/audio.py:206-210)."""
+    import struct
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        kind = {b"fLaC": "flac", b"OggS": "ogg", b"ID3": "mp3"}.get(bytes(data[:4]), {b"ID3": "mp3"}.get(bytes(data[:3]), "unknown"))
+        raise NotImplementedError(f"bytes_to_audio: only RIFF/WAVE streams are built in (got a {kind} stream; flac/mp3 need libsndfile/ffmpeg)")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            payload = body
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None or len(fmt) < 16:
+        raise ValueError("bytes_to_audio: malformed WAV stream (fmt / data chunk missing)")
+    tag, nch, rate, _, align, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:                            # WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real tag
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    nframes = len(payload) // max(align, 1)
+    raw = payload[:nframes * align]
+    if tag == 3 and bits in (32, 64):
+        x = np.frombuffer(raw, dtype="<f4" if bits == 32 else "<f8").astype(np.float64)
+    elif tag == 1 and bits == 8:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    elif tag == 1 and bits in (16, 32):
+        x = np.frombuffer(raw, dtype="<i2" if bits == 16 else "<i4").astype(np.float64) / float(1 << (bits - 1))
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float64) / float(1 << 23)
+    else:
+        raise NotImplementedError(f"bytes_to_audio: WAV format tag {tag} with {bits} bits is not supported")
+    if nch > 1:
+        x = x.reshape(-1, nch)
+        if x.shape[1] < x.shape[0]:
+            x = x.T                                                 # channels x frames
+    return x, int(rate)
 
 
 # ---------------------------------------------------------------------------------------------- resampling

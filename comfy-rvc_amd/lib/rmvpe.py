@@ -90,7 +90,14 @@ class RMVPE:
 
     def infer_from_audio(self, audio, thred=0.03):
         """reference lib/rmvpe.py:614-623 -> numpy float64 [L // 160 + 1]"""
-        return self.infer(audio, thred)["f0"].cpu().numpy()   # audio may already be a device tensor
+        f0 = self.infer(audio, thred)["f0"].cpu().numpy()      # audio may already be a device tensor
+        self.check_status()
+        return f0
+
+    def check_status(self):
+        """Raises RvcHipError when the last forward's GRU scan failed (its workgroups poll each other; f0 is NaN then).  Synchronises."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.rvc_rmvpe_status(self._h, _lib.current_stream()))
 
     def infer_from_audio_with_pitch(self, audio, thred=0.03, f0_min=50, f0_max=1100):
         """reference lib/rmvpe.py:649-659 ("rmvpe+"): note the clip turns unvoiced zeros into f0_min, as upstream does."""

@@ -38,6 +38,10 @@ int rvc_ctx_create(int device_id, rvc_ctx** out);
 int rvc_ctx_destroy(rvc_ctx* ctx);
 /* bytes of activation workspace currently held by the context */
 int64_t rvc_ctx_workspace_bytes(rvc_ctx* ctx);
+/* Matrix-core arithmetic of the models FINALIZED on this context afterwards (state of the handle, not of the process):
+ *   0 fp32 MFMA everywhere, 1 / 2 bf16x3 split where a layer is eligible (see rvc_set_conv_precision), -1 (default) the mode of the
+ *   thread that calls *_finalize. */
+int rvc_ctx_set_conv_precision(rvc_ctx* ctx, int mode);
 
 /* ------------------------------------------------------------------ HuBERT / ContentVec (HF HubertModel + final_proj) */
 typedef struct rvc_hubert_taps {   /* optional device buffers for intermediate tensors (NULL = skip) */
@@ -73,6 +77,13 @@ int rvc_rmvpe_destroy(rvc_rmvpe* r);
 /* n = L / 160 + 1 frames.  mel_dev [128][n], salience_dev [n][360], f0_dev float64 [n]; any may be NULL. */
 int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio_dev, int64_t L, float thred, float* mel_dev,
                       float* salience_dev, double* f0_dev, const rvc_rmvpe_taps* taps);
+/* Waits for `stream` and reports the last forward of this handle: 0 = ok; non-zero (message via rvc_last_error) when the BiGRU scan's
+ * workgroups timed out waiting for each other - its 16 workgroups exchange h_t through polled device memory and need co-residency -
+ * in which case f0_dev of that forward holds NaN.  The reference has no counterpart (torch.nn.GRU, lib/rmvpe.py:420-428). */
+int rvc_rmvpe_status(rvc_rmvpe* r, void* stream);
+/* test hook: fault != 0 makes one workgroup of the following scans exit without publishing; spin_limit (0 = default 2^24 polls)
+ * bounds how long its peers wait before they raise the flag */
+int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit);
 /* decode alone: salience_dev [n][360] row-major -> f0 float64 [n] */
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* salience_dev, int64_t n, float thred, double* f0_dev);
 
@@ -202,7 +213,8 @@ int rvc_op_sine_source(void* stream, const float* f0_dev, const float* noise_dev
  * vc_infer_pipeline.py:186 (output -> resample_sr); the coefficients are designed on the host (comfy-rvc_amd/lib/audio.py). */
 int rvc_resample(void* stream, const float* x_dev, int64_t n_in, const double* taps_dev, int half, int up, int down, float* y_dev, int64_t n_out);
 
-/* Matrix-core arithmetic of the Conv1d layers created AFTER the call (process-wide; models read it at *_finalize):
+/* Matrix-core arithmetic of the Conv1d layers created AFTER the call BY THE CALLING THREAD (thread-local: free-standing ops / plans,
+ * and models whose context is left at mode -1; rvc_ctx_set_conv_precision is the per-handle form):
  *   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32; bitwise an fp32 FMA chain)
  *   1  default: the synthesizer's generator convolutions use the bf16x3 split (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; ~1e-5 relative error per layer), everything else fp32
@@ -221,6 +233,9 @@ int rvc_prof_collect(double* ms, double* flops, int64_t* launches);
  * given ridge (peak FLOP/s over peak HBM B/s of the kernel family), out[cfg][4..7] of those below it.  RVC_PROF_CFGS * 8 doubles. */
 int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_bf16x3);
 const char* rvc_prof_cfg_name(int i);
+/* writes one CSV row per launch recorded since rvc_prof_enable(1): kernel, tile, Ci, Co, k, dilation, stride, Tout, workgroups, us,
+ * algorithmic GFLOP / MB, TFLOP/s, GB/s (profiles/ per-launch-class tables) */
+int rvc_prof_dump_csv(const char* path);
 /* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
 int rvc_debug_conv_timing(uint64_t* out8, int reset);
 

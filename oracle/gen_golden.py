@@ -263,6 +263,60 @@ def gen_hostdsp(ns):
     print("hostdsp ok")
 
 
+def _audio_digest(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8).copy()
+
+
+def gen_fullsize(ns, which):
+    """BASELINE.json's full-size configurations through the REAL reference with the real segmentation constants (x_pad 1, x_query 6,
+    x_center 38, x_max 41).  The input clips are regenerated from comfy-rvc_amd/synthetic.py::synth_audio on both sides (a SHA-256 of the
+    samples is stored instead of 1.9-2.9 MB of audio); stored: int16 output, coarse pitch, f0.
+      pipeline_30s_40k_v2  configs[2] (C3): 30 s clip, 40k_v2, rmvpe f0
+      pipeline_30s_48k_v2  one clip of configs[3] (C4): 30 s, 48k_v2
+      pipeline_45s_40k_v2  > x_max = 41 s: the cut search of vc_infer_pipeline.py:123-135 runs with the real constants
+      rmvpe_60s            configs[1] (C2): RMVPE alone on the padded 60 s clip: f0, per-frame salience maximum / arg-max, salience sums"""
+    import time
+    if "full40" in which or "full45" in which:
+        hub, vcd = build_models(ns, S.CONFIG_40K_V2, "v2")
+        for tag, secs, aseed, nseed in (("pipeline_30s_40k_v2", 30.0, 100, 301), ("pipeline_45s_40k_v2", 45.0, 102, 303)):
+            if ("full40" if secs == 30.0 else "full45") not in which:
+                continue
+            audio = S.synth_audio(secs, seed=aseed)
+            t0 = time.time()
+            i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=nseed)
+            np.savez_compressed(os.path.join(OUT, tag + ".npz"), audio_seconds=np.float64(secs), audio_seed=np.int64(aseed), audio_sha256=_audio_digest(audio),
+                                out_i16=i16, sr=np.int64(sr), pitch=cap["pitch"].astype(np.int16), pitchf=cap["pitchf"], noise_seed=np.int64(nseed),
+                                n_segments=np.int64(len(shapes) // 2), seg_T=np.array([s[2] for s in shapes[0::2]], dtype=np.int64))
+            print(tag, i16.shape, sr, "segments", len(shapes) // 2, [s[2] for s in shapes[0::2]], "voiced", (cap["pitchf"] > 0).mean(), f"{time.time() - t0:.1f} s")
+    if "full48" in which:
+        hub, vcd = build_models(ns, S.CONFIG_48K_V2, "v2")
+        audio = S.synth_audio(30.0, seed=200)
+        t0 = time.time()
+        i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=302)
+        np.savez_compressed(os.path.join(OUT, "pipeline_30s_48k_v2.npz"), audio_seconds=np.float64(30.0), audio_seed=np.int64(200), audio_sha256=_audio_digest(audio),
+                            out_i16=i16, sr=np.int64(sr), pitch=cap["pitch"].astype(np.int16), pitchf=cap["pitchf"], noise_seed=np.int64(302),
+                            n_segments=np.int64(len(shapes) // 2))
+        print("pipeline_30s_48k_v2", i16.shape, sr, f"{time.time() - t0:.1f} s")
+    if "rmvpe60" in which:
+        mdir = os.path.join(ns.ws, "models")
+        torch.save(to_torch_sd(S.rmvpe_state_dict(0)), os.path.join(mdir, "rmvpe.pt"))
+        m = ns.rmvpe.RMVPE(os.path.join(mdir, "rmvpe.pt"), is_half=False, device="cpu")
+        clip = S.synth_audio(60.0, seed=9)
+        audio = np.pad(clip, (16000, 16000), mode="reflect")             # as VC.pipeline pads it (vc_infer_pipeline.py:141)
+        t0 = time.time()
+        with torch.no_grad():
+            mel = m.mel_extractor(torch.from_numpy(audio).float().unsqueeze(0), center=True)
+            hidden = m.mel2hidden(mel).squeeze(0).numpy()
+        f0 = m.decode(hidden.copy(), thred=0.03)
+        assert np.array_equal(f0, m.infer_from_audio(audio, thred=0.03))
+        np.savez_compressed(os.path.join(OUT, "rmvpe_60s.npz"), audio_seconds=np.float64(60.0), audio_seed=np.int64(9), audio_sha256=_audio_digest(audio),
+                            f0=f0, sal_max=hidden.max(axis=1), sal_argmax=hidden.argmax(axis=1).astype(np.int16),
+                            sal_rowsum=hidden.astype(np.float64).sum(axis=1), sal_colsum=hidden.astype(np.float64).sum(axis=0),
+                            sal_sub=hidden[::50].copy())
+        print("rmvpe_60s", hidden.shape, "voiced", (f0 > 0).mean(), f"{time.time() - t0:.1f} s")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load_reference()
@@ -287,6 +341,8 @@ def main():
         gen_synth_nono(ns, S.CONFIG_40K_V1, "v1", "40k_v1_nono")
     if "pipeline" in which:
         gen_pipeline(ns)
+    if {"full40", "full45", "full48", "rmvpe60"} & set(which):   # BASELINE.json's full-size configurations (minutes of CPU time)
+        gen_fullsize(ns, which)
 
 
 if __name__ == "__main__":

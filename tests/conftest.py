@@ -38,3 +38,41 @@ def noise_tape():
             return torch.randn(tuple(shape), generator=self.g)
 
     return Tape
+
+
+def golden_clip(g):
+    """The input clip of a full-size golden: regenerated from synthetic.synth_audio (seconds, seed) and checked against the stored SHA-256."""
+    import hashlib
+    from comfy_rvc_amd import synthetic as S
+    audio = S.synth_audio(float(g["audio_seconds"]), seed=int(g["audio_seed"]))
+    return audio
+
+
+def check_clip_digest(audio, g):
+    import hashlib
+    d = np.frombuffer(hashlib.sha256(np.ascontiguousarray(audio).tobytes()).digest(), dtype=np.uint8)
+    assert np.array_equal(d, g["audio_sha256"]), "synthetic.synth_audio no longer reproduces the clip this golden was generated from"
+
+
+def parity_stats(out_i16, ref_i16, lsb=33):
+    """int16 waveform vs the reference's: share of samples within `lsb`, the largest and the 99.99th-percentile deviation."""
+    d = np.abs(np.asarray(out_i16, dtype=np.int32) - np.asarray(ref_i16, dtype=np.int32))
+    return {"n": int(d.size), "within": float(np.mean(d <= lsb)), "max": int(d.max()), "p9999": float(np.percentile(d, 99.99)),
+            "mean": float(d.mean())}
+
+
+def record_parity(name, stats):
+    """Keeps the measured parity figures of the full-size cases (gpurun_out/ travels back from the GPU box; copied to profiles/)."""
+    import json
+    path = os.path.join(ROOT, "gpurun_out", "fullsize_parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = {}
+        if os.path.isfile(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = stats
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

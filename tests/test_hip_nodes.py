@@ -41,7 +41,12 @@ def test_node_graph_from_files(tmp_path, monkeypatch):
     torch.manual_seed(7)
     res = N.RVCNode().convert(audio_in, model_thunk, hub_thunk, params, f0_up_key=2, format="flac", use_cache=False)
     vhs, aud = res["result"]
-    wav, sr = vhs()
+    from comfy_rvc_amd.lib.audio import bytes_to_audio
+    blob = vhs()                                                   # VHS_AUDIO: thunk -> encoded WAV bytes (reference rvc_nodes.py:206)
+    assert isinstance(blob, bytes) and blob[:4] == b"RIFF"
+    wav_f, sr = bytes_to_audio(blob)
+    wav = aud["waveform"][0, :, 0].numpy()
+    assert np.array_equal(np.round(wav_f * 32768).astype(np.int16), wav)
     assert sr == 40000 and wav.dtype == np.int16 and aud["sample_rate"] == 40000 and tuple(aud["waveform"].shape) == (1, wav.shape[0], 1)
     assert res["ui"]["preview"][0]["filename"].endswith(".flac")
     # the thunks are memoised per (path, mtime): same objects on the second call, and the direct API gives the same audio
@@ -62,5 +67,47 @@ def test_node_graph_from_files(tmp_path, monkeypatch):
     params_i = dict(params, index_rate=0.8)
     torch.manual_seed(7)
     res_i = N.RVCNode().convert(audio_in, model_idx, hub_thunk, params_i, f0_up_key=2, use_cache=False)
-    wav_i, _ = res_i["result"][0]()
+    wav_i = res_i["result"][1]["waveform"][0, :, 0].numpy()
     assert wav_i.shape == wav.shape and np.abs(wav_i.astype(np.int32) - wav.astype(np.int32)).max() > 100     # the blend changes the audio
+
+
+def test_node_graph_bytes_in_bytes_out(tmp_path, monkeypatch):
+    """VHS_AUDIO on both sockets: a thunk returning WAV bytes goes in (reference lib/audio.py:115-124), a thunk returning WAV bytes
+    comes out, and feeding the output thunk into a second RVCNode works (chained conversion, resampled 40 k -> 16 k on the way in)."""
+    import comfy_rvc_amd.lib as lib
+    import comfy_rvc_amd.pitch_extraction as pe
+    from comfy_rvc_amd.custom_nodes import rvc_nodes as N
+    from comfy_rvc_amd.lib.audio import audio_to_bytes, bytes_to_audio
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.vc_infer_pipeline import get_vc
+    models = tmp_path / "models"
+    models.mkdir()
+    as_t = lambda sd: {k: torch.as_tensor(np.ascontiguousarray(v)).clone() for k, v in sd.items()}   # noqa: E731
+    torch.save(as_t(S.rmvpe_state_dict(0)), str(models / "rmvpe.pt"))
+    for mod in (lib, pe, N):
+        monkeypatch.setattr(mod, "BASE_MODELS_DIR", str(models), raising=False)
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    vcd = get_vc(S.synth_checkpoint(S.CONFIG_40K_V2, "v2", 0))
+    (params,) = N.LoadPitchExtractionParams().load_params(f0_method="rmvpe", f0_autotune=False, index_rate=0.0, resample_sr=0, rms_mix_rate=0.25,
+                                                          protect=0.25, crepe_hop_length=160)
+    audio = S.synth_audio(1.2, seed=42)
+    blob_in = audio_to_bytes(audio, 16000)                          # float32 WAV (|x| <= 1)
+    torch.manual_seed(3)
+    a = N.RVCNode().convert(lambda: blob_in, lambda: vcd, lambda: hub, params, f0_up_key=0, use_cache=False)
+    torch.manual_seed(3)
+    b = N.RVCNode().convert(N.to_audio_dict(audio, 16000), lambda: vcd, lambda: hub, params, f0_up_key=0, use_cache=False)
+    blob_a, blob_b = a["result"][0](), b["result"][0]()
+    assert isinstance(blob_a, bytes) and blob_a == blob_b           # bytes in == AUDIO dict in
+    wav, sr = bytes_to_audio(blob_a)
+    assert sr == 40000 and wav.ndim == 1 and np.abs(wav).max() > 0.5
+    c = N.RVCNode().convert(a["result"][0], lambda: vcd, lambda: hub, params, f0_up_key=-2, use_cache=False)   # chained through the thunk
+    wav2, sr2 = bytes_to_audio(c["result"][0]())
+    assert sr2 == 40000 and abs(wav2.shape[0] - wav.shape[0]) <= 1200
+
+
+def test_package_exports_node_mappings():
+    """ComfyUI imports the pack directory and reads NODE_CLASS_MAPPINGS / NODE_DISPLAY_NAME_MAPPINGS off the module (reference __init__.py:12-31)."""
+    import comfy_rvc_amd
+    from comfy_rvc_amd.custom_nodes import rvc_nodes as N
+    assert hasattr(comfy_rvc_amd, "NODE_CLASS_MAPPINGS") and comfy_rvc_amd.NODE_CLASS_MAPPINGS == N.NODE_CLASS_MAPPINGS
+    assert set(comfy_rvc_amd.NODE_DISPLAY_NAME_MAPPINGS) == {"LoadRVCModelNode", "RVCNode", "LoadHubertModel", "LoadPitchExtractionParams"}

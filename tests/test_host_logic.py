@@ -126,3 +126,47 @@ def test_resample_filter_meets_the_soxr_hq_specification(orig, target):
     fn = min(orig, target) / 2
     assert 20 * np.log10(H[f >= fn].max()) < -120.0
     assert np.abs(20 * np.log10(H[f <= 0.913 * fn])).max() < 1e-4
+
+
+def test_wav_bytes_round_trip_and_headers():
+    """audio_to_bytes / bytes_to_audio (reference lib/audio.py:188-210): PCM_16 when the samples are int16-valued, float32 otherwise,
+    [C, N] on the way back; checked against the stdlib wave reader and hand-built 8/24/32-bit and EXTENSIBLE streams."""
+    import io
+    import struct
+    import wave
+    from comfy_rvc_amd.lib.audio import audio_to_bytes, bytes_to_audio, get_audio
+    rng = np.random.default_rng(0)
+    x16 = (rng.standard_normal(1001) * 9000).astype(np.int16)      # odd length: payload padding
+    b = audio_to_bytes(x16, 40000)
+    w = wave.open(io.BytesIO(b))
+    assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 40000, 1001)
+    assert np.array_equal(np.frombuffer(w.readframes(1001), dtype="<i2"), x16)
+    y, sr = bytes_to_audio(b)
+    assert sr == 40000 and y.dtype == np.float64 and np.array_equal(y * 32768.0, x16.astype(np.float64))
+    st = np.stack([np.sin(np.arange(700) / 9.0), np.cos(np.arange(700) / 7.0)]).astype(np.float32) * 0.6    # [C, N] float
+    b2 = audio_to_bytes(st, 16000)
+    assert struct.unpack("<H", b2[20:22])[0] == 3                   # IEEE float
+    y2, sr2 = get_audio(lambda: b2)                                 # VHS_AUDIO thunk -> bytes -> (ndarray [C, N], sr)
+    assert sr2 == 16000 and y2.shape == (2, 700) and np.array_equal(y2.astype(np.float32), st)
+    b3 = audio_to_bytes(st[0], 16000, to_int16=True, to_stereo=True)
+    y3, _ = bytes_to_audio(b3)
+    assert y3.shape == (2, 700) and np.array_equal(y3[0], y3[1]) and np.abs(y3[0] - st[0]).max() < 1.0 / 32768 + 1e-9
+
+    def riff(tag, bits, payload, nch=1, ext=False):
+        align = nch * bits // 8
+        fmt = struct.pack("<HHIIHH", 0xFFFE if ext else tag, nch, 8000, 8000 * align, align, bits)
+        if ext:
+            fmt += struct.pack("<HHI", 22, bits, 0) + struct.pack("<H", tag) + b"\0" * 14
+        junk = b"LIST" + struct.pack("<I", 3) + b"abc\0"          # odd-sized chunk ahead of the data chunk
+        body = b"fmt " + struct.pack("<I", len(fmt)) + fmt + junk + b"data" + struct.pack("<I", len(payload)) + payload
+        return b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body
+    v = np.array([-8388608, -1, 0, 1, 8388607], dtype=np.int64)
+    p24 = b"".join(struct.pack("<i", int(t))[:3] for t in v)
+    assert np.array_equal(bytes_to_audio(riff(1, 24, p24))[0], v / 8388608.0)
+    assert np.array_equal(bytes_to_audio(riff(1, 8, bytes([0, 128, 255])))[0], np.array([-1.0, 0.0, 127 / 128.0]))
+    assert np.array_equal(bytes_to_audio(riff(1, 32, struct.pack("<2i", -2 ** 31, 2 ** 30), ext=True))[0], np.array([-1.0, 0.5]))
+    assert np.array_equal(bytes_to_audio(riff(3, 64, struct.pack("<2d", 0.25, -0.5)))[0], np.array([0.25, -0.5]))
+    with pytest.raises(NotImplementedError):
+        bytes_to_audio(b"fLaC" + b"\0" * 64)
+    with pytest.raises(NotImplementedError):
+        audio_to_bytes(x16, 40000, format="FLAC")

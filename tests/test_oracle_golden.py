@@ -116,3 +116,52 @@ def test_synth_nono_oracle_matches_reference():
         for k in ("m_p", "logs_p", "z_p", "z"):
             assert rel_err(taps[k], g[k]) < 2e-5, (name, k)
         assert rel_err(wav, g["wav"]) < 1e-4, name
+
+
+# ------------------------------------------------------------------ BASELINE.json's full-size configurations (oracle/gen_golden.py full40 full48 full45 rmvpe60)
+def _fullsize_oracle(gname, cfg):
+    from conftest import check_clip_digest, golden_clip, parity_stats
+    g = golden(gname)
+    audio = golden_clip(g)
+    check_clip_digest(audio, g)
+    gen = torch.Generator().manual_seed(int(g["noise_seed"]))
+    taps = {}
+    out = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(cfg, "v2", 0), cfg, "v2", audio,
+                       noise_fn=lambda shp: torch.randn(tuple(shp), generator=gen))
+    assert out.shape == g["out_i16"].shape and out.dtype == np.int16
+    st = parity_stats(out, g["out_i16"], 33)
+    assert st["within"] == 1.0 and st["max"] <= 33, st              # measured here: max 9 / 5 / 12 LSB at 30 s / 45 s / 30 s 48k
+    return g
+
+
+def test_pipeline_30s_40k_v2_oracle_matches_reference():
+    """BASELINE.json configs[2] (C3) at full size: every int16 sample within 33 LSB of the reference's own output."""
+    g = _fullsize_oracle("pipeline_30s_40k_v2.npz", S.CONFIG_40K_V2)
+    assert int(g["n_segments"]) == 1
+
+
+def test_pipeline_45s_cut_search_oracle_matches_reference():
+    """A clip longer than x_max = 41 s with the real constants (1, 6, 38, 41): the cut search (reference vc_infer_pipeline.py:123-135)
+    picks the reference's cut and both segments match."""
+    g = _fullsize_oracle("pipeline_45s_40k_v2.npz", S.CONFIG_40K_V2)
+    assert int(g["n_segments"]) == 2 and list(g["seg_T"]) == [3690, 1208]
+
+
+def test_pipeline_30s_48k_v2_oracle_matches_reference():
+    """One clip of BASELINE.json configs[3] (C4): 48k_v2 generator (upsample 12,10,2,2) at full size."""
+    _fullsize_oracle("pipeline_30s_48k_v2.npz", S.CONFIG_48K_V2)
+
+
+def test_rmvpe_60s_oracle_matches_reference():
+    """BASELINE.json configs[1] (C2): RMVPE alone on the padded 60 s clip: f0 on every frame, salience summaries."""
+    from conftest import check_clip_digest, golden_clip
+    g = golden("rmvpe_60s.npz")
+    audio = np.pad(golden_clip(g), (16000, 16000), mode="reflect")
+    check_clip_digest(audio, g)
+    taps = {}
+    f0 = nets.rmvpe_infer_from_audio(S.rmvpe_state_dict(0), audio, taps=taps)
+    sal = taps["salience"]
+    assert f0.shape == (6201,) and np.allclose(f0, g["f0"], rtol=1e-4)
+    assert np.max(np.abs(sal.max(axis=1) - g["sal_max"])) < 2e-5 and np.max(np.abs(sal[::50] - g["sal_sub"])) < 2e-5
+    assert np.mean(sal.argmax(axis=1) == g["sal_argmax"]) > 0.999
+    assert np.allclose(sal.astype(np.float64).sum(axis=1), g["sal_rowsum"], rtol=1e-4)

@@ -32,3 +32,36 @@ def test_shard_and_gather_world2(tmp_path):
     # feature dump: clip i was written by rank i mod 2, every file exactly once, [T_h, 768] each
     assert r["owners"] == [0, 1, 0, 1, 0]
     assert r["shapes"] == [[10 * (i + 1), 768] for i in range(5)]
+
+
+def _bench(*extra, env=None):
+    root = os.path.dirname(HERE)
+    e = dict(os.environ, RVC_BENCH_BACKEND="gloo", **(env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", "--seconds", "2", *extra],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                                 # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself (before anything touches HIP), the ranks
+    form a process group of two, every step ends in one gather, and rank 0 prints one line with n_gpus = 2.  --dry-run: stub conversion."""
+    r = _bench("--gpus", "2")
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["self_launched"] is True and r["backend"] == "gloo" and r["scaling"] == "weak"
+    assert r["steps"] == 3 and r["warmup"] == 1 and r["config"]["clips_per_step"] == 24 and r["config"]["clips_per_gpu_per_step"] == 12
+    assert r["data"].startswith("dry-run") and r["roofline"] is None and r["cpu_baseline"] is None
+    assert r["value"] > 0 and abs(r["ms_per_step"] * 3 - r["timed_region_s"] * 1e3) < 1.0
+    one = _bench("--gpus", "1", "--variant", "48k_v2")
+    assert one["n_gpus"] == 1 and one["self_launched"] is False and one["config"]["clips_per_gpu_per_step"] == 8     # BASELINE.json configs[3]: 8 clips per GPU
+    assert abs(one["config"]["audio_seconds_delivered_per_clip"] - 1.98) < 1e-6                   # 2 * T_h * 480 / 48000 - 2 for a 2 s clip
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    root = os.path.dirname(HERE)
+    e = dict(os.environ, RVC_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], env=e, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in p.stderr
