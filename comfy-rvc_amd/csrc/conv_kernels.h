@@ -20,6 +20,8 @@ struct ConvArgsX : ConvArgs {
   // fused ResBlock pair (conv_x3_kernel<..., FUSE>): second conv's weight image, first conv's bias, halo (k - 1) / 2 of the
   // second conv, slope of the leaky ReLU between the two
   const unsigned char* Wx2; const float* bias1; int fuse_p2; float fuse_slope;
+  int wbufs;       // weight slabs in the LDS ring (2 .. 4)
+  int xcd_remap;   // 1: tiles renumbered so that each XCD (L2) works on a contiguous run of them
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -22,8 +22,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef RVC_CONV_TIMING
 __device__ unsigned long long g_x3_timing[8];   // [0] blocks, [1] prologue, [2] X store + DMA wait + barrier, [3] prefetch issue, [4] MFMA loops, [5] epilogue, [6] total
-#define X3TICK() clock64()
-#define X3TACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_x3_timing[i], (unsigned long long)(v)); } while (0)
+// (accumulated in registers and published once per workgroup: an atomic per stage is a VMEM operation on the path the counted vmcnt waits watch)
+#define X3TICK() ((long long)__builtin_readcyclecounter())
+#define X3TACC(i, v) do { x3t[i] += (v); } while (0)
+#define X3TDECL() long long x3t[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define X3TFLUSH() do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_x3_timing[i_], (unsigned long long)x3t[i_]); } } while (0)
 void conv_x3_timing_read(unsigned long long* out8, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x3_timing), sizeof(unsigned long long) * 8);
@@ -32,12 +35,50 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset) {
 #else
 #define X3TICK() 0ll
 #define X3TACC(i, v) do {} while (0)
+#define X3TDECL() do {} while (0)
+#define X3TFLUSH() do {} while (0)
 #endif
 
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
 __host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 7 : (BN >= 128 ? 5 : 2); }
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
+// (a, b) -> packed bf16 pairs hi = {bf16(a), bf16(b)} and lo = {bf16(a - hi_a), bf16(b - hi_b)}, round-to-nearest-even: 2 + 2 + 2 VALU
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  const f32x2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: waits until at most n of this wave's VMEM operations (LDS-DMA pieces and register
+// loads alike, retired in issue order) are outstanding.  A smaller count than necessary only waits longer, so n is clamped to the table.
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define RVC_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 56 ? 56 : (n > 24 ? (n & ~7) : n))) {
+    RVC_VMC(0) RVC_VMC(1) RVC_VMC(2) RVC_VMC(3) RVC_VMC(4) RVC_VMC(5) RVC_VMC(6) RVC_VMC(7) RVC_VMC(8) RVC_VMC(9) RVC_VMC(10) RVC_VMC(11) RVC_VMC(12)
+    RVC_VMC(13) RVC_VMC(14) RVC_VMC(15) RVC_VMC(16) RVC_VMC(17) RVC_VMC(18) RVC_VMC(19) RVC_VMC(20) RVC_VMC(21) RVC_VMC(22) RVC_VMC(23) RVC_VMC(24)
+    RVC_VMC(32) RVC_VMC(40) RVC_VMC(48) RVC_VMC(56)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef RVC_VMC
+}
+// workgroup barrier that does NOT drain the VMEM queue (a __syncthreads() waits vmcnt(0) while LDS-DMA is in flight): LDS traffic of this
+// wave is complete (lgkmcnt(0)), DMA pieces of later stages stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// Consecutive hardware workgroup ids go round-robin to the 8 XCDs (each with its own L2).  Tiles are renumbered so that every XCD works
+// on one contiguous run of tiles (n fastest, same weight rows): neighbouring tiles share their halo columns and the weight image in
+// one L2 instead of fetching them eight times.  Bijective for any tile count; a wrong guess about the placement is only slower.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned total) {
+  const unsigned q = total >> 3, r = total & 7u, x = b & 7u, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
 
 // FUSE: ResBlock pair  y = (x + W2 * lrelu(W1 *_d lrelu(x) + b1) + b2) * scale [+ y]  in one launch (Ci = Co, all channels of the
 // tile resident in LDS): pass 1 is the ordinary stage loop of the dilated conv over BN columns; its accumulators (+ b1, leaky
@@ -47,7 +88,7 @@ __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__bui
 // x, t, t, x, y.  Used for the 32-channel generator stage (conv_x3_pair_try): k3 261 -> 196 us, k7 304 -> 233, k11 348 -> 308.
 template <int WM, int WN, int AM, int AN, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
-  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = (FUSE && BM == 64) ? 7 : x3_slots(BN), RB = BM / 32;
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = (FUSE && BM == 64) ? 7 : (FUSE ? 5 : x3_slots(BN)), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
   const int NC = p.NC;                      // 16-channel chunks per stage
@@ -58,18 +99,22 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int wbuf = NC * p.KT * 2 * BM * 32; // bytes of one weight buffer
   unsigned char* Xs = smem3;
   unsigned char* Ws = smem3 + ((p.xbufs * xbuf + 1023) & ~1023);
+  const int NS = p.wbufs;                   // weight slabs in the ring (2 .. 4): the DMA of stage s + NS - 1 is issued during stage s
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane0 & 31, lh = lane0 >> 5;
   const int z = blockIdx.z / p.ksplit, ks = blockIdx.z - z * p.ksplit;   // batch index, K-split index
-  const int co0 = blockIdx.y * BM;
+  const unsigned tile = p.xcd_remap ? xcd_tile(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y) : blockIdx.x + blockIdx.y * gridDim.x;
+  const int tile_y = (int)(tile / gridDim.x), tile_x = (int)(tile - (unsigned)tile_y * gridDim.x);
+  const int co0 = tile_y * BM;
   const int P2 = FUSE ? p.fuse_p2 : 0;                                    // halo of the fused second conv (each side)
-  const int n0 = blockIdx.x * (BN - 2 * P2);
+  const int n0 = tile_x * (BN - 2 * P2);
   const float* __restrict__ X = p.X + (long long)z * p.xBatch;
   const unsigned char* __restrict__ Wg = p.Wx + (long long)z * p.wxBatch * 2;
 
+  X3TDECL();
   f32x16 acc[AM][AN];
 #pragma unroll
   for (int am = 0; am < AM; ++am)
@@ -121,12 +166,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       const unsigned c0 = (unsigned)((grp * NC + cc) * 16 + hb * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
-        xr[s][j] = fmaxf(v, v * pre_slope);
+        xr[s][j] = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);   // raw: the activation is applied in store_x, so nothing here waits for the data
       }
     }
   };
-  // ---- input tile: registers -> hi/lo bf16 -> LDS
+  // ---- input tile: registers -> hi/lo bf16 -> LDS.  Two floats per v_cvt_pk_bf16_f32; the stride cases are separate straight-line
+  // bodies (a nested select over the stride compiled into ~100 instructions of divisions and branches per slot: 46 k of a 128 x 256
+  // tile's 340 k cycles went into this function)
   auto store_x = [&](int xb) {
 #ifdef RVC_X3_NOX
     return;
@@ -147,27 +193,43 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float a = xr[s][2 * j], b = xr[s][2 * j + 1];
-          const __bf16 ah = (__bf16)a, bh = (__bf16)b;
-          const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
-          hi[j] = bf16_bits(ah) | (bf16_bits(bh) << 16);
-          lo[j] = bf16_bits(al) | (bf16_bits(bl) << 16);
+          unsigned h_, l_;
+          split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);     // input activation: leaky ReLU (slope 1 = identity)
+          hi[j] = h_; lo[j] = l_;
         }
-        const int ph = st == 1 ? 0 : (st == 2 ? (q & 1) : q % st), m = st == 1 ? q : (st == 2 ? (q >> 1) : q / st);
-        const int off = (ph * Pm + m) * 32 + ((hb ^ ((m >> 3) & 1)) << 4);
+        int off;
+        if (st == 1) off = q * 32 + ((hb ^ ((q >> 3) & 1)) << 4);
+        else {
+          const int m = st == 2 ? (q >> 1) : q / st, ph = q - m * st;
+          off = (ph * Pm + m) * 32 + ((hb ^ ((m >> 3) & 1)) << 4);
+        }
         *reinterpret_cast<u32x4*>(xbase + off) = hi;
         *reinterpret_cast<u32x4*>(xbase + xplane + off) = lo;
       }
     }
   };
   // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
-  auto issue_w = [&](const unsigned char* __restrict__ Wimg, int grp, int tb, int buf) {
+  auto issue_w = [&](const unsigned char* __restrict__ Wimg, int grp, int tb, int buf) -> int {
 #ifdef RVC_X3_NOW
-    return;
+    return 0;
 #endif
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
     const int npieces = NC * ut * 2 * RB;
+    if (NC == 1 || ut == p.ktaps) {
+      // the (chunk, tap, hi | lo) rows of this stage are consecutive in the image: piece pi = wave + 4 i is row j0 + i * (4 / RB), 32-row
+      // block rblk - one multiply-add per piece instead of three integer divisions (the generic path below cost ~400 cycles per piece,
+      // a fifth of a stage of the 128 x 256 tile)
+      constexpr int JS = 4 / RB;
+      const int j0 = RB == 4 ? 0 : (RB == 2 ? (wave >> 1) : wave), rblk = RB == 4 ? wave : (RB == 2 ? (wave & 1) : 0);
+      const long long row0 = (long long)((grp * NC) * p.ktaps + tb * p.KT) * 2 + j0;
+      const unsigned char* src = Wimg + (row0 * p.CoPx + co0 + rblk * 32) * 32 + lane * 16;
+      const long long sstep = (long long)JS * p.CoPx * 32;
+      unsigned char* dst = Ws + buf * wbuf + wave * 1024;
+      for (int pi = wave; pi < npieces; pi += 4, src += sstep, dst += 4096)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    } else
     for (int pi = wave; pi < npieces; pi += 4) {
       const int j = pi / RB, rblk = pi - j * RB;            // j = ((chunk in group) * ut + tap in block) * 2 + (hi | lo)
       const int cc = j / (2 * ut), jr = j - cc * 2 * ut;
@@ -176,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       unsigned char* dst = Ws + buf * wbuf + pi * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
+    return wave < npieces ? (npieces - wave + 3) >> 2 : 0;
   };
 
   int aoff[AM], bq[AN];
@@ -233,32 +296,54 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     }
   };
 
+  // ---- stage loop.  VMEM operations of a wave retire in issue order, so "stage s's weights have landed" = at most (operations this
+  // wave issued after the last piece of stage s) outstanding: `issued` counts them, we0 .. we3 remember the count right after the
+  // weights of stages it .. it + 3.  The input rows of chunk c + 1 are requested as soon as chunk c's registers are free (first stage
+  // of chunk c), a whole chunk ahead of their use; nothing in the loop waits for vmcnt(0).
   int chunk = g0, tb = 0;
   const long long t_begin = X3TICK();
-  if (nstages > 0) { issue_w(Wg, g0, 0, 0); load_x(g0); }
+  int issued = 0, we0 = 0, we1 = 0, we2 = 0, we3 = 0;
+  int nchunk_i = g0, ntb_i = 0, issued_stages = 0;         // next (chunk, tap block) whose weights are to be requested
+  auto issue_next = [&]() {
+    const int pieces = issue_w(Wg, nchunk_i, ntb_i, issued_stages % NS);
+    issued += pieces;
+    ++issued_stages;
+    if (++ntb_i == ntb) { ntb_i = 0; ++nchunk_i; }
+    return issued;
+  };
+  if (nstages > 0) {
+    we0 = issue_next();
+    if (NS > 2 && nstages > 1) we1 = issue_next();
+    if (NS > 3 && nstages > 2) we2 = issue_next();
+    load_x(g0); issued += XS * 8;
+  }
   X3TACC(1, X3TICK() - t_begin);
   for (int it = 0; it < nstages; ++it) {
     const long long ta = X3TICK();
-    const int buf = it & 1;
+    const int buf = it % NS;
     const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
     if (tb == 0) {
-      if (p.xbufs == 1 && it > 0) __syncthreads();       // single X buffer: every wave is done with the previous chunk
+      if (p.xbufs == 1 && it > 0) lds_barrier();           // single X buffer: every wave is done with the previous chunk
       store_x(xb);
+      if (chunk + 1 < g1) { load_x(chunk + 1); issued += XS * 8; }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this stage's weight DMA has landed
-    __syncthreads();
+    const long long tw0 = X3TICK();
+    wait_vmcnt_le(issued - we0);                            // this stage's weight pieces (of this wave) have landed
+    const long long tw1 = X3TICK();
+    lds_barrier();                                          // ... and everybody else's; the slab of stage it - 1 is free again
     const long long tb_ = X3TICK();
-    X3TACC(2, tb_ - ta);
-    int ntb_ = tb + 1, nchunk_ = chunk;
-    if (ntb_ == ntb) { ntb_ = 0; ++nchunk_; }
-    if (it + 1 < nstages) {
-      issue_w(Wg, nchunk_, ntb_, buf ^ 1);
-      if (ntb_ == 0) load_x(nchunk_);
+    X3TACC(2, tw0 - ta); X3TACC(7, tw1 - tw0); X3TACC(1, tb_ - tw1);      // [2] input store, [7] DMA wait, [1] += barrier
+    we0 = we1; we1 = we2; we2 = we3;
+    if (issued_stages < nstages) {
+      const int e = issue_next();
+      // (bit selects: an if-chain here becomes an indexed store to scratch, and the scratch load that follows waits vmcnt(0))
+      const int m2 = -(int)(NS == 2), m3 = -(int)(NS == 3), m4 = -(int)(NS >= 4);
+      we0 = (e & m2) | (we0 & ~m2); we1 = (e & m3) | (we1 & ~m3); we2 = (e & m4) | (we2 & ~m4);
     }
     const long long tc = X3TICK();
     X3TACC(3, tc - tb_);
     mfma_stage(buf, xb, tb, p.dil);
-    tb = ntb_; chunk = nchunk_;
+    if (++tb == ntb) { tb = 0; ++chunk; }
     X3TACC(4, X3TICK() - tc);
   }
   if constexpr (FUSE) {
@@ -363,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     }
   }
   X3TACC(5, X3TICK() - t_epi); X3TACC(6, X3TICK() - t_begin); X3TACC(0, 1);
+  X3TFLUSH();
 }
 
 // ============================================================================ host side
@@ -433,13 +519,20 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   // +32 % time; three 128x128 workgroups instead of two: -12 %).  X double-buffered when that still leaves >= 2 taps per stage.
   static const int budget_kb = getenv("RVC_X3_LDS_KB") ? atoi(getenv("RVC_X3_LDS_KB")) : 53;
   const int budget = budget_kb * 1024;
+  // weight slabs: a ring of NS: the DMA of a slab is issued NS - 1 stages before its MFMAs, waited for with a counted vmcnt and published
+  // with a barrier that does not drain the queue.  Measured: NS = 3 / 4 lose to NS = 2 (C128 k11 490 vs 433 us): the LDS they take
+  // halves the taps per stage, and the per-stage costs (DMA issue, barrier) outweigh the ~400 cycles of DMA wait they would hide.
+  static const int wbufs_env = getenv("RVC_X3_WBUFS") ? atoi(getenv("RVC_X3_WBUFS")) : 2;
+  int NS = wbufs_env < 2 ? 2 : (wbufs_env > 4 ? 4 : wbufs_env);
   int xbufs = 2, xbytes = 0, ktmax = 0;
   for (;;) {
-    const int per_tap = 2 * NC * 2 * BM * 32;               // two buffers x NC chunks x {hi, lo} x BM rows x 32 B
+    const int per_tap = NS * NC * 2 * BM * 32;              // NS slabs x NC chunks x {hi, lo} x BM rows x 32 B
     xbufs = 2; xbytes = (xbufs * NC * 2 * a.stride * Pm * 32 + 1023) & ~1023;
     ktmax = (budget - xbytes) / per_tap;
     if (ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * a.stride * Pm * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
-    if (ktmax >= 1 || NC == 1) break;
+    if (ktmax >= 1) break;
+    if (NS > 2) { --NS; continue; }
+    if (NC == 1) break;
     NC >>= 1;
   }
   if (ktmax < 1) return false;
@@ -447,6 +540,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const int ntb = (a.ktaps + ktmax - 1) / ktmax;
   a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  a.wbufs = NS; a.xcd_remap = xcd_env;
   // split-K (k = 1 GEMMs on small grids): every stage of such a workgroup is a dependent global -> LDS round trip, so slicing the
   // reduction over S workgroups shortens the chain and puts more of them on a CU; partials are reduced in a fixed order
   int S = 1;
@@ -463,7 +558,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   }
   a.ksplit = S; a.ldP = (a.Tout + 31) & ~31;
   if (S > 1) a.partial = (float*)stream_scratch(s, 0, (size_t)S * a.Co * a.ldP * sizeof(float));
-  const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
+  const size_t lds = (size_t)xbytes + (size_t)NS * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
   ProfTicket tk = conv_prof_begin(s);
   switch (id) {
@@ -515,7 +610,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int P = BN + 2 * P1;                                      // staged input columns
   a.ni = (P + 63) / 64;
   const int nchunk = C / 16, NC = nchunk;                         // every channel of the tile resident: one chunk group
-  if ((NC * 2 * a.ni + 3) / 4 > (C == 64 ? 7 : x3_slots(BN))) return false;
+  if ((NC * 2 * a.ni + 3) / 4 > (C == 64 ? 7 : 5)) return false;
   const int xbytes = (NC * 2 * P * 32 + 1023) & ~1023;
   // three workgroups per CU with single-tap stages beat two with 4-tap stages (k3 233 -> 196 us, k7 279 -> 233, k11 352 -> 308):
   // occupancy is what hides the per-stage latencies of this narrow tile
@@ -528,6 +623,8 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int ntb = (k + ktmax - 1) / ktmax;
   a.KT = (k + ntb - 1) / ntb;
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = 1; a.ksplit = 1; a.partial = nullptr; a.ldP = 0;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  a.wbufs = 2; a.xcd_remap = xcd_env;
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   ProfTicket tk = conv_prof_begin(s);

@@ -37,5 +37,5 @@ for name, Ci, Co, Tin, k, s, d in CASES:
     print(f"{name:28s} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  ({fl/1e9:.1f} GFLOP)")
     tm = (C.c_uint64 * 8)(); L.lib.rvc_debug_conv_timing(tm, 1)
     if tm[0]:
-        nb = tm[0]; print("      per block cycles: " + "  ".join(f"{n} {tm[i]/nb:.0f}" for i, n in ((1,"prologue"),(2,"fill"),(3,"issue"),(4,"mfma"),(5,"epilogue"),(6,"total"))) + f"  blocks/launch {nb/(reps+1):.0f}")
+        nb = tm[0]; print("      per block cycles: " + "  ".join(f"{n} {tm[i]/nb:.0f}" for i, n in ((1,"prologue+barrier"),(2,"xstore"),(7,"dmawait"),(3,"issue"),(4,"mfma"),(5,"epilogue"),(6,"total"))) + f"  blocks/launch {nb/(reps+1):.0f}")
     L.lib.rvc_conv1d_plan_destroy(plan)
