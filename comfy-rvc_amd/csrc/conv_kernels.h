@@ -38,19 +38,20 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)):  v = acc + bias; act in {identity, ReLU, leaky ReLU} as max(v, slope v),
 // before or after the residual; * out_scale; (+ previous output).  Row r+1's residual / accumulate operands are requested
 // before row r is stored (vmcnt counts loads and stores alike).  32-bit element offsets through buffer descriptors.
-template <int WM, int WN, int AM, int AN, int G = 1>
-__device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)[AM][AN], int z, int co0, int n0, int wm, int wn, int li, int lh) {
+// HAS_R / HAS_ACC: whether the residual / the previous output are read at all.  (Reading them through a zero-extent descriptor costs
+// nothing in bandwidth but every dummy load is a VMEM instruction: half of the epilogue's memory instructions on a residual-only launch.)
+template <int WM, int WN, int AM, int AN, int G, bool HAS_R, bool HAS_ACC>
+__device__ __forceinline__ void dense_epilogue_t(const ConvArgsX& p, f32x16 (&acc)[AM][AN], int z, int co0, int n0, int wm, int wn, int li, int lh) {
   const float* __restrict__ bias = p.bias ? p.bias + (long long)z * p.bBatch : nullptr;
-  const float* R = p.R ? p.R + (long long)z * p.rBatch : nullptr;
+  const float* R = HAS_R ? p.R + (long long)z * p.rBatch : nullptr;
   float* Y = p.Y + (long long)z * p.yBatch;
   const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
   const float oscale = p.out_scale;
   const bool plain = p.orows == p.Co;
   const __amdgpu_buffer_rsrc_t yrs = make_rsrc(Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
-  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(R ? R : Y, R ? (unsigned)p.orows * (unsigned)p.ldR * 4u : 0u);   // no residual: all loads read 0
-  const __amdgpu_buffer_rsrc_t ars = make_rsrc(Y, p.accumulate ? (unsigned)p.orows * (unsigned)p.ldY * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rrs = make_rsrc(HAS_R ? R : Y, HAS_R ? (unsigned)p.orows * (unsigned)p.ldR * 4u : 0u);
   const bool abr = p.act_before_res != 0;
-  const bool need_loads = R != nullptr || p.accumulate;
+  constexpr bool need_loads = HAS_R || HAS_ACC;
   auto row_info = [&](int am, int r, bool& mok, float& bv, unsigned& yrow, unsigned& rrow) {
     const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
     mok = m < p.Co;
@@ -59,8 +60,7 @@ __device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)
     yrow = (unsigned)co * (unsigned)p.ldY; rrow = (unsigned)co * (unsigned)p.ldR;
   };
   // rows are processed in groups of G: the residual / accumulate operands of group g + 1 are requested before group g is
-  // stored, so G * AN (x2) loads per wave are in flight instead of AN (the epilogue of the HBM-bound launches is latency-bound;
-  // measured on the bf16x3 kernel: G = 8 -15 % on the 32-row tiles, G = 4 -6 % on the 8-accumulator tiles, where 8 spills)
+  // stored, so G * AN loads per operand and wave are in flight (the epilogue of the HBM-bound launches is latency-bound)
   static_assert(16 % G == 0, "group size");
 #pragma unroll
   for (int am = 0; am < AM; ++am) {
@@ -78,15 +78,15 @@ __device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)
         for (int an = 0; an < AN; ++an) {
           const int n = n0 + (wn * AN + an) * 32 + li;
           const bool ok = mok && n < p.Tout;
-          rr[j][an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
-          yy[j][an] = buf_load(ars, ok ? (yrow + (unsigned)n) * 4u : kOOB);
+          if constexpr (HAS_R) rr[j][an] = buf_load(rrs, ok ? (rrow + (unsigned)n) * 4u : kOOB);
+          if constexpr (HAS_ACC) yy[j][an] = buf_load(yrs, ok ? (yrow + (unsigned)n) * 4u : kOOB);
         }
       }
     };
-    if (need_loads) load_group(0, rv, yv);
+    if constexpr (need_loads) load_group(0, rv, yv);
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += G) {
-      if (need_loads && r0 + G < 16) load_group(r0 + G, rvn, yvn);
+      if constexpr (need_loads) { if (r0 + G < 16) load_group(r0 + G, rvn, yvn); }
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         bool mok; float bv; unsigned yrow, rrow;
@@ -108,6 +108,15 @@ __device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)
         for (int an = 0; an < AN; ++an) { rv[j][an] = rvn[j][an]; yv[j][an] = yvn[j][an]; }
     }
   }
+}
+// G = rows per load group when operands are read (bounded by registers: 2 x G x AN values per operand), GP for store-only launches
+template <int WM, int WN, int AM, int AN, int G = 1>
+__device__ __forceinline__ void dense_epilogue(const ConvArgsX& p, f32x16 (&acc)[AM][AN], int z, int co0, int n0, int wm, int wn, int li, int lh) {
+  const bool has_r = p.R != nullptr, has_acc = p.accumulate != 0;
+  if (has_r && has_acc) dense_epilogue_t<WM, WN, AM, AN, G, true, true>(p, acc, z, co0, n0, wm, wn, li, lh);
+  else if (has_r) dense_epilogue_t<WM, WN, AM, AN, (AM * AN >= 8 ? 2 * G : G) <= 16 ? (AM * AN >= 8 ? 2 * G : G) : 16, true, false>(p, acc, z, co0, n0, wm, wn, li, lh);
+  else if (has_acc) dense_epilogue_t<WM, WN, AM, AN, G, false, true>(p, acc, z, co0, n0, wm, wn, li, lh);
+  else dense_epilogue_t<WM, WN, AM, AN, G, false, false>(p, acc, z, co0, n0, wm, wn, li, lh);
 }
 
 // ---- host side

@@ -53,7 +53,7 @@ def main(argv):
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     tot = defaultdict(float)
     for key, c in sorted(classes.items(), key=lambda kv: -kv[1]["us"]):
-        us = c["us"] / c["n"]; tf = c["gf"] / c["us"] * 1e-3 if c["us"] else 0; gbs = c["mb"] / c["us"] * 1e3 if c["us"] else 0
+        us = c["us"] / c["n"]; tf = c["gf"] / c["us"] * 1e3 if c["us"] else 0; gbs = c["mb"] / c["us"] * 1e3 if c["us"] else 0
         hbm = c["hbm"] / c["hbm_n"] if c["hbm_n"] else None
         alg = c["mb"] / c["n"]
         print("| " + " | ".join(list(key[:11]) + [c["wg"], str(c["n"]), f"{us:.1f}", f"{c['us'] / 1e3:.2f}", f"{tf:.1f}", f"{tf / 157.3:.3f}", f"{tf / 833.3:.3f}",
