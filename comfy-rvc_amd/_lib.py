@@ -36,6 +36,10 @@ class RmvpeTaps(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("unet_out", "gru")]
 
 
+class CrepeTaps(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("conv1", "embed")]
+
+
 class SynthConfig(C.Structure):
     _fields_ = [("inter_channels", c_int), ("hidden_channels", c_int), ("filter_channels", c_int), ("n_heads", c_int),
                 ("n_layers", c_int), ("kernel_size", c_int), ("n_resblock_kernels", c_int),
@@ -71,6 +75,12 @@ SIGNATURES = {
     "rvc_rmvpe_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rvc_rmvpe_status": (c_int, [c_void_p, c_void_p]),
     "rvc_rmvpe_debug_fault": (c_int, [c_void_p, c_int, C.c_uint]),
+    "rvc_crepe_create": (c_int, [c_void_p, c_int, P(c_void_p)]),
+    "rvc_crepe_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
+    "rvc_crepe_finalize": (c_int, [c_void_p]),
+    "rvc_crepe_destroy": (c_int, [c_void_p]),
+    "rvc_crepe_num_frames": (c_int64, [c_int64, c_int, c_int]),
+    "rvc_crepe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, P(CrepeTaps)]),
     "rvc_synth_create": (c_int, [c_void_p, P(SynthConfig), P(c_void_p)]),
     "rvc_synth_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_synth_finalize": (c_int, [c_void_p]),

@@ -9,6 +9,7 @@ typedef rvc_synth_config SynthConfig;
 typedef rvc_synth_taps SynthTaps;
 typedef rvc_hubert_taps HubertTaps;
 typedef rvc_rmvpe_taps RmvpeTaps;
+typedef rvc_crepe_taps CrepeTaps;
 
 struct Synth;
 Synth* synth_create(Ctx* ctx, const SynthConfig& c);
@@ -56,5 +57,15 @@ void rmvpe_debug_fault(Rmvpe* R, int fault, unsigned spin_limit);   // tests: ma
 size_t synth_workspace(const Synth* S);
 size_t hubert_workspace(const Hubert* H);
 size_t rmvpe_workspace(const Rmvpe* R);
+
+// CREPE pitch network (model_crepe.hip): probabilities [360][n] for n = crepe_num_frames(L, hop, pad) frames
+struct Crepe;
+Crepe* crepe_create(Ctx* ctx, int tiny);
+void crepe_destroy(Crepe* M);
+void crepe_set_tensor(Crepe* M, const char* name, const float* d, const long long* shape, int ndim);
+void crepe_finalize(Crepe* M);
+long long crepe_num_frames(long long L, int hop, int pad);
+void crepe_forward(Crepe* M, hipStream_t s, const float* audio, long long L, int hop, int pad, float* probs, const CrepeTaps* taps);
+size_t crepe_workspace(const Crepe* M);
 
 }  // namespace rvc

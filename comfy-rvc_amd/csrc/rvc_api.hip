@@ -134,6 +134,32 @@ int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* sal, int64_t n, fl
   RVC_CATCH
 }
 
+// ------------------------------------------------------------------------------------------------ crepe
+struct rvc_crepe { Crepe* m; rvc_ctx* ctx; };
+int rvc_crepe_create(rvc_ctx* ctx, int tiny, rvc_crepe** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && out, "null argument");
+  rvc_crepe* c = new rvc_crepe(); c->ctx = ctx; c->m = crepe_create(&ctx->c, tiny); *out = c;
+  RVC_CATCH
+}
+int rvc_crepe_set_tensor(rvc_crepe* c, const char* name, const float* d, const int64_t* shape, int ndim) {
+  RVC_TRY
+  RVC_REQUIRE(c && name && d && ndim <= 8, "bad argument");
+  long long sh[8]; for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+  crepe_set_tensor(c->m, name, d, sh, ndim);
+  RVC_CATCH
+}
+int rvc_crepe_finalize(rvc_crepe* c) { RVC_TRY RVC_REQUIRE(c, "null argument"); RVC_HIP_CHECK(hipSetDevice(c->ctx->c.device)); crepe_finalize(c->m); RVC_CATCH }
+int rvc_crepe_destroy(rvc_crepe* c) { if (c) { crepe_destroy(c->m); delete c; } return 0; }
+int64_t rvc_crepe_num_frames(int64_t L, int hop, int pad) { return crepe_num_frames(L, hop, pad); }
+int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio, int64_t L, int hop, int pad, float* probs, const rvc_crepe_taps* taps) {
+  RVC_TRY
+  RVC_REQUIRE(c && audio && probs && hop > 0, "bad argument");
+  crepe_forward(c->m, (hipStream_t)stream, audio, L, hop, pad, probs, taps);
+  check_launch();
+  RVC_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ synth
 int rvc_synth_create(rvc_ctx* ctx, const rvc_synth_config* cfg, rvc_synth** out) {
   RVC_TRY

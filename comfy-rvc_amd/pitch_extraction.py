@@ -1,10 +1,12 @@
 """FeatureExtractor: f0 front-end dispatch and coarse-pitch quantisation (mirror of reference pitch_extraction.py:13-303).
 
-Only the RMVPE front-ends ("rmvpe", "rmvpe+") run on this build's HIP path; pm / harvest / dio / crepe are third-party
-CPU libraries in the reference (parselmouth, pyworld, torchcrepe) and stay out of scope - their dictionary slots exist
-so that a caller can plug a replacement in, exactly as with the reference's `f0_method_dict`.
+The RMVPE front-ends ("rmvpe", "rmvpe+") and the CREPE front-ends ("crepe", "mangio-crepe" and their -tiny forms: the network of
+third-party torchcrepe re-implemented as HIP kernels, lib/crepe.py) run on this build's HIP path; pm / harvest / dio are third-party
+CPU libraries in the reference (parselmouth, pyworld) and stay out of scope - their dictionary slots exist so that a caller can
+plug a replacement in, exactly as with the reference's `f0_method_dict`.
 """
 import os
+from functools import partial
 
 import numpy as np
 
@@ -39,9 +41,13 @@ class FeatureExtractor:
         self.f0_method_dict = {
             "pm": _unsupported("pm"), "harvest": _unsupported("harvest"), "dio": _unsupported("dio"),
             "rmvpe": self.get_rmvpe, "rmvpe_onnx": self.get_rmvpe, "rmvpe+": self.get_pitch_dependant_rmvpe,
-            "crepe": _unsupported("crepe"), "crepe-tiny": _unsupported("crepe-tiny"),
-            "mangio-crepe": _unsupported("mangio-crepe"), "mangio-crepe-tiny": _unsupported("mangio-crepe-tiny"),
+            "crepe": self.get_f0_official_crepe_computation,
+            # (the reference binds model='model' for the -tiny slots, pitch_extraction.py:42,:44, which torchcrepe rejects; 'tiny' is what is meant)
+            "crepe-tiny": partial(self.get_f0_official_crepe_computation, model="tiny"),
+            "mangio-crepe": self.get_f0_crepe_computation,
+            "mangio-crepe-tiny": partial(self.get_f0_crepe_computation, model="tiny"),
         }
+        self.model_crepe = {}        # capacity ("full" / "tiny") -> lib.crepe.Crepe; filled lazily from models/torchcrepe/<capacity>.pth
 
     def __del__(self):
         if hasattr(self, "model_rmvpe"):
@@ -92,6 +98,42 @@ class FeatureExtractor:
 
     def get_pitch_dependant_rmvpe(self, x, f0_min=0, f0_max=40000, *args, **kwargs):
         return self._rmvpe().infer_from_audio_with_pitch(x, thred=0.03, f0_min=f0_min, f0_max=f0_max)
+
+    def _crepe(self, model):
+        if model not in self.model_crepe:
+            from .lib.crepe import Crepe   # noqa: PLC0415
+            dev = self.device if str(self.device).startswith("cuda") else "cuda:0"
+            self.model_crepe[model] = Crepe(None, model, dev)
+        return self.model_crepe[model]
+
+    def get_f0_crepe_computation(self, x, f0_min, f0_max, *args, **kwargs):
+        """"mangio-crepe" (reference pitch_extraction.py:76-120): quantile-normalised audio, torchcrepe.predict at crepe_hop_length,
+        frames below 1 mHz dropped, linear interpolation onto x.shape[0] // hop frames."""
+        from .lib import crepe as tc   # noqa: PLC0415
+        x = np.asarray(x.cpu() if hasattr(x, "cpu") else x).astype(np.float32)
+        x /= np.quantile(np.abs(x), 0.999)
+        hop_length = kwargs.get("crepe_hop_length", 160)
+        model = kwargs.get("model", "full")
+        pitch = tc.predict(x[None], self.sr, hop_length, f0_min, f0_max, model, batch_size=hop_length * 2, device=self.device, pad=True,
+                           crepe=self._crepe(model))
+        p_len = x.shape[0] // hop_length
+        source = np.array(pitch.squeeze(0).cpu().float().numpy())
+        source[source < 0.001] = np.nan
+        target = np.interp(np.arange(0, len(source) * p_len, len(source)) / p_len, np.arange(0, len(source)), source)
+        return np.nan_to_num(target)
+
+    def get_f0_official_crepe_computation(self, x, f0_min, f0_max, *args, **kwargs):
+        """"crepe" (reference pitch_extraction.py:122-150): torchcrepe.predict at the 10 ms hop with periodicity, median-3 on the
+        periodicity, mean-3 on the pitch, frames with periodicity < 0.1 unvoiced."""
+        from .lib import crepe as tc   # noqa: PLC0415
+        x = np.asarray(x.cpu() if hasattr(x, "cpu") else x)
+        model = kwargs.get("model", "full")
+        f0, pd = tc.predict(np.copy(x).astype(np.float32)[None], self.sr, self.window, f0_min, f0_max, model, batch_size=512, device=self.device,
+                            return_periodicity=True, crepe=self._crepe(model))
+        pd = tc.filter_median(pd[0].numpy(), 3)
+        f0 = tc.filter_mean(f0[0].numpy(), 3)
+        f0[pd < 0.1] = 0
+        return f0
 
     def get_f0_hybrid_computation(self, methods_list, merge_type, x, f0_min, f0_max, filter_radius, crepe_hop_length, time_step, **kwargs):
         """Median/mean/... merge of several f0 tracks (reference pitch_extraction.py:205-248), run sequentially."""

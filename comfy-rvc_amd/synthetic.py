@@ -374,3 +374,30 @@ def designed_f0(n_frames, seed=0):
     uv = ((t % 0.9) > 0.7)
     f0 = np.where(uv, 0.0, f0)
     return f0.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------- CREPE (torchcrepe state-dict names)
+CREPE_CHANNELS = {"full": [1024, 128, 128, 128, 256, 512], "tiny": [128, 16, 16, 16, 32, 64]}
+
+
+def crepe_state_dict(model="full", seed=0):
+    """Procedural weights in torchcrepe's layout (conv{i}.weight [Co, Ci, k, 1], conv{i}_BN.*, classifier.*): unit-gain convolutions,
+    BatchNorm statistics near the identity, a classifier whose logits spread over a few units (pitch salience with clear maxima)."""
+    ch = CREPE_CHANNELS[model]
+    sd, cin = {}, 1
+    for i, co in enumerate(ch, 1):
+        k = 512 if i == 1 else 64
+        sd[f"conv{i}.weight"] = _normal(seed, f"crepe.{model}.conv{i}.w", (co, cin, k, 1), np.sqrt(2.0 / (cin * k)))
+        sd[f"conv{i}.bias"] = _normal(seed, f"crepe.{model}.conv{i}.b", (co,), 0.05)
+        sd[f"conv{i}_BN.weight"] = _uniform(seed, f"crepe.{model}.bn{i}.g", (co,), 0.8, 1.2)
+        sd[f"conv{i}_BN.bias"] = _normal(seed, f"crepe.{model}.bn{i}.b", (co,), 0.1)
+        sd[f"conv{i}_BN.running_mean"] = _uniform(seed, f"crepe.{model}.bn{i}.m", (co,), 0.2, 0.6)
+        sd[f"conv{i}_BN.running_var"] = _uniform(seed, f"crepe.{model}.bn{i}.v", (co,), 0.3, 0.7)
+        cin = co
+    F = 4 * ch[-1]
+    sd["classifier.weight"] = _normal(seed, f"crepe.{model}.fc.w", (PITCH_BINS_CREPE, F), 2.0 / np.sqrt(F))
+    sd["classifier.bias"] = _normal(seed, f"crepe.{model}.fc.b", (PITCH_BINS_CREPE,), 0.5) - 1.0
+    return sd
+
+
+PITCH_BINS_CREPE = 360

@@ -87,6 +87,27 @@ int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit);
 /* decode alone: salience_dev [n][360] row-major -> f0 float64 [n] */
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* salience_dev, int64_t n, float thred, double* f0_dev);
 
+/* ------------------------------------------------------------------ CREPE (torchcrepe.Crepe "full" / "tiny") */
+/* Replaces the network inside torchcrepe.predict, which the reference calls for f0_method "crepe" / "mangio-crepe"
+ * (pitch_extraction.py:76-150; torchcrepe is a third-party package, not vendored upstream: its published architecture is restated).
+ * Tensors by their torchcrepe state-dict names: conv{1..6}.weight / .bias, conv{1..6}_BN.{weight,bias,running_mean,running_var},
+ * classifier.weight / .bias. */
+typedef struct rvc_crepe rvc_crepe;
+typedef struct rvc_crepe_taps {
+  float* conv1;        /* [C1][256]  ReLU(conv1) of frame 0 (before BatchNorm / pooling) */
+  float* embed;        /* [4*C6][B]  flattened last feature map of the first batch of frames (B = min(n, 512)), row = position * C6 + channel */
+} rvc_crepe_taps;
+int rvc_crepe_create(rvc_ctx* ctx, int tiny, rvc_crepe** out);
+int rvc_crepe_set_tensor(rvc_crepe* c, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int rvc_crepe_finalize(rvc_crepe* c);
+int rvc_crepe_destroy(rvc_crepe* c);
+/* frames of 1024 samples every `hop`: pad != 0 (torchcrepe's default) zero-pads the audio by 512 on both sides, n = 1 + L / hop;
+ * pad == 0: n = 1 + (L - 1024) / hop */
+int64_t rvc_crepe_num_frames(int64_t L, int hop, int pad);
+/* audio_dev float32 [L] at 16 kHz -> probs_dev [360][n] channel-major: per-frame sigmoid outputs over the 360 pitch bins
+ * (the mean / std normalisation of every frame, the six conv blocks and the classifier); decoding stays with the caller */
+int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio_dev, int64_t L, int hop, int pad, float* probs_dev, const rvc_crepe_taps* taps);
+
 /* ------------------------------------------------------------------ synthesizer */
 typedef struct rvc_synth_config {   /* the fields of cpt["config"] that the inference graph needs */
   int inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;

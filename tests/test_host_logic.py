@@ -170,3 +170,28 @@ def test_wav_bytes_round_trip_and_headers():
         bytes_to_audio(b"fLaC" + b"\0" * 64)
     with pytest.raises(NotImplementedError):
         audio_to_bytes(x16, 40000, format="FLAC")
+
+
+def test_crepe_host_decoding_matches_oracle():
+    """lib/crepe.py's host-side decoding (bin masking, softmax, banded Viterbi, cents + dither, periodicity, NaN-aware median / mean
+    filters) against the oracle's literal restatement of torchcrepe, on flat (procedural network) and peaked (moving ridge) salience."""
+    import torch
+    from comfy_rvc_amd import synthetic as S
+    from comfy_rvc_amd.lib import crepe as pc
+    from oracle import crepe as oc
+    x = S.synth_audio(2.0, seed=3)
+    with torch.no_grad():
+        flat = oc.infer(S.crepe_state_dict("tiny", 0), oc.preprocess(torch.from_numpy(x)[None], 160), "tiny").numpy()
+    n = flat.shape[0]
+    centre = (180 + 120 * np.sin(np.arange(n) / 9.0)).astype(int)
+    ridge = np.stack([0.02 + 0.9 * np.exp(-0.5 * ((np.arange(360) - c) / 2.0) ** 2) for c in centre]).astype(np.float32)
+    assert (pc.frequency_to_bins(50.0), pc.frequency_to_bins(1600.0, ceil=True)) == (oc.frequency_to_bins(50.0), oc.frequency_to_bins(1600.0, torch.ceil)) == (39, 340)
+    for P in (flat, ridge):
+        np.random.seed(5)
+        a, pa = oc.postprocess(torch.from_numpy(P), 50, 1100, True)
+        np.random.seed(5)
+        b, pb = pc.postprocess(P.T, 50, 1100, True)
+        assert np.allclose(a[0].numpy(), b, rtol=1e-6) and np.array_equal(pa[0].numpy(), pb)
+        assert np.array_equal(oc.filter_median(pa, 3)[0].numpy(), pc.filter_median(pb, 3))
+        assert np.allclose(oc.filter_mean(a, 3)[0].numpy(), pc.filter_mean(b, 3), rtol=1e-6, equal_nan=True)
+    assert len(set(np.round(b))) > 100                              # the ridge case really moves across bins
