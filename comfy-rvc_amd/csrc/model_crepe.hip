@@ -159,7 +159,8 @@ static void crepe_graph(Crepe* M, hipStream_t s, Arena& A, const float* audio, l
     ConvEpilogue Er; Er.act = ACT_RELU;
     const long long N1 = (long long)B * 256;
     conv1d_run(M->conv[0], s, col, N1, (int)N1, bufA, N1, Er);                       // [C1][B * 256], ReLU'd
-    if (taps && taps->conv1 && f0 == 0) RVC_HIP_CHECK(hipMemcpyAsync(taps->conv1, bufA, (size_t)M->ch[0] * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (taps && taps->conv1 && f0 == 0)
+      RVC_HIP_CHECK(hipMemcpy2DAsync(taps->conv1, 256 * sizeof(float), bufA, (size_t)N1 * sizeof(float), 256 * sizeof(float), (size_t)M->ch[0], hipMemcpyDeviceToDevice, s));
     float* cur = bufA; float* nxt = bufB;
     long long ldin = N1; int Sin = 256, Lin = 256;
     for (int i = 1; i < 6; ++i) {

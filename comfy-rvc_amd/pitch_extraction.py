@@ -42,7 +42,8 @@ class FeatureExtractor:
             "pm": _unsupported("pm"), "harvest": _unsupported("harvest"), "dio": _unsupported("dio"),
             "rmvpe": self.get_rmvpe, "rmvpe_onnx": self.get_rmvpe, "rmvpe+": self.get_pitch_dependant_rmvpe,
             "crepe": self.get_f0_official_crepe_computation,
-            # (the reference binds model='model' for the -tiny slots, pitch_extraction.py:42,:44, which torchcrepe rejects; 'tiny' is what is meant)
+            # (the reference binds model='model' for the -tiny slots, pitch_extraction.py:42,:44 - a name torchcrepe rejects; 'tiny' is what is
+            # meant.  Through get_f0 the bound keyword never applies: its parameter dict carries model="full", as upstream, :268-271)
             "crepe-tiny": partial(self.get_f0_official_crepe_computation, model="tiny"),
             "mangio-crepe": self.get_f0_crepe_computation,
             "mangio-crepe-tiny": partial(self.get_f0_crepe_computation, model="tiny"),

@@ -194,4 +194,4 @@ def test_crepe_host_decoding_matches_oracle():
         assert np.allclose(a[0].numpy(), b, rtol=1e-6) and np.array_equal(pa[0].numpy(), pb)
         assert np.array_equal(oc.filter_median(pa, 3)[0].numpy(), pc.filter_median(pb, 3))
         assert np.allclose(oc.filter_mean(a, 3)[0].numpy(), pc.filter_mean(b, 3), rtol=1e-6, equal_nan=True)
-    assert len(set(np.round(b))) > 100                              # the ridge case really moves across bins
+    assert len(set(np.round(b))) > 50                               # the ridge case really moves across bins
