@@ -22,9 +22,9 @@ WEB_DIRECTORY = None
 
 def __getattr__(name):
     if name in ("NODE_CLASS_MAPPINGS", "NODE_DISPLAY_NAME_MAPPINGS"):
-        from .custom_nodes import rvc_nodes as _n
-        globals()["NODE_CLASS_MAPPINGS"] = dict(_n.NODE_CLASS_MAPPINGS)
-        globals()["NODE_DISPLAY_NAME_MAPPINGS"] = dict(_n.NODE_DISPLAY_NAME_MAPPINGS)
+        from .custom_nodes import rvc_nodes as _n, uvr as _u
+        globals()["NODE_CLASS_MAPPINGS"] = {**_u.NODE_CLASS_MAPPINGS, **_n.NODE_CLASS_MAPPINGS}
+        globals()["NODE_DISPLAY_NAME_MAPPINGS"] = {**_u.NODE_DISPLAY_NAME_MAPPINGS, **_n.NODE_DISPLAY_NAME_MAPPINGS}
         return globals()[name]
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 

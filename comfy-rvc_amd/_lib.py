@@ -40,6 +40,11 @@ class CrepeTaps(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("conv1", "embed")]
 
 
+class Mdx23Config(C.Structure):
+    _fields_ = [(n, c_int) for n in ("n_fft", "hop", "dim_f", "dim_t", "num_channels", "growth", "num_scales", "num_subbands", "blocks_per_scale",
+                                     "bottleneck", "num_targets", "audio_channels")]
+
+
 class SynthConfig(C.Structure):
     _fields_ = [("inter_channels", c_int), ("hidden_channels", c_int), ("filter_channels", c_int), ("n_heads", c_int),
                 ("n_layers", c_int), ("kernel_size", c_int), ("n_resblock_kernels", c_int),
@@ -81,6 +86,11 @@ SIGNATURES = {
     "rvc_crepe_destroy": (c_int, [c_void_p]),
     "rvc_crepe_num_frames": (c_int64, [c_int64, c_int, c_int]),
     "rvc_crepe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, P(CrepeTaps)]),
+    "rvc_mdx23_create": (c_int, [c_void_p, P(Mdx23Config), P(c_void_p)]),
+    "rvc_mdx23_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
+    "rvc_mdx23_finalize": (c_int, [c_void_p]),
+    "rvc_mdx23_destroy": (c_int, [c_void_p]),
+    "rvc_mdx23_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rvc_synth_create": (c_int, [c_void_p, P(SynthConfig), P(c_void_p)]),
     "rvc_synth_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_synth_finalize": (c_int, [c_void_p]),

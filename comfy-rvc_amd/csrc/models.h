@@ -58,6 +58,15 @@ size_t synth_workspace(const Synth* S);
 size_t hubert_workspace(const Hubert* H);
 size_t rmvpe_workspace(const Rmvpe* R);
 
+// MDX23C separation network (model_mdx23.hip): one chunk [2][hop * (dim_t - 1)] -> [S][2][chunk]
+struct Mdx23;
+Mdx23* mdx23_create(Ctx* ctx, const rvc_mdx23_config& c);
+void mdx23_destroy(Mdx23* M);
+void mdx23_set_tensor(Mdx23* M, const char* name, const float* d, const long long* shape, int ndim);
+void mdx23_finalize(Mdx23* M);
+void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out);
+size_t mdx23_workspace(const Mdx23* M);
+
 // CREPE pitch network (model_crepe.hip): probabilities [360][n] for n = crepe_num_frames(L, hop, pad) frames
 struct Crepe;
 Crepe* crepe_create(Ctx* ctx, int tiny);

@@ -160,6 +160,33 @@ int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio, int64_t L,
   RVC_CATCH
 }
 
+// ------------------------------------------------------------------------------------------------ mdx23c
+struct rvc_mdx23 { Mdx23* m; rvc_ctx* ctx; };
+int rvc_mdx23_create(rvc_ctx* ctx, const rvc_mdx23_config* cfg, rvc_mdx23** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && cfg && out, "null argument");
+  rvc_mdx23* h = new rvc_mdx23(); h->ctx = ctx; h->m = nullptr;
+  try { h->m = mdx23_create(&ctx->c, *cfg); } catch (...) { delete h; throw; }
+  *out = h;
+  RVC_CATCH
+}
+int rvc_mdx23_set_tensor(rvc_mdx23* m, const char* name, const float* d, const int64_t* shape, int ndim) {
+  RVC_TRY
+  RVC_REQUIRE(m && name && d && ndim <= 8, "bad argument");
+  long long sh[8]; for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+  mdx23_set_tensor(m->m, name, d, sh, ndim);
+  RVC_CATCH
+}
+int rvc_mdx23_finalize(rvc_mdx23* m) { RVC_TRY RVC_REQUIRE(m, "null argument"); RVC_HIP_CHECK(hipSetDevice(m->ctx->c.device)); mdx23_finalize(m->m); RVC_CATCH }
+int rvc_mdx23_destroy(rvc_mdx23* m) { if (m) { mdx23_destroy(m->m); delete m; } return 0; }
+int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk, int64_t L, float* out) {
+  RVC_TRY
+  RVC_REQUIRE(m && chunk && out, "null argument");
+  mdx23_forward(m->m, (hipStream_t)stream, chunk, L, out);
+  check_launch();
+  RVC_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ synth
 int rvc_synth_create(rvc_ctx* ctx, const rvc_synth_config* cfg, rvc_synth** out) {
   RVC_TRY

@@ -401,3 +401,66 @@ def crepe_state_dict(model="full", seed=0):
 
 
 PITCH_BINS_CREPE = 360
+
+
+# ----------------------------------------------------------------------------------- MDX23C (karafan TFC_TDF_net state-dict names)
+def mdx23c_config(n_fft=8192, hop=1024, dim_f=4096, dim_t=256, num_channels=128, growth=128, num_scales=5, num_subbands=4, blocks=2, bottleneck=4,
+                  overlap=8):
+    """The fields of reference lib/karafan/Data/model_2_stem_full_band_8k.yaml that the network and demix_mdxv3 read (defaults = that file)."""
+    return {"audio": {"chunk_size": hop * (dim_t - 1), "dim_f": dim_f, "dim_t": dim_t, "hop_length": hop, "n_fft": n_fft, "num_channels": 2,
+                      "sample_rate": 44100},
+            "model": {"act": "gelu", "bottleneck_factor": bottleneck, "growth": growth, "norm": "InstanceNorm", "num_blocks_per_scale": blocks,
+                      "num_channels": num_channels, "num_scales": num_scales, "num_subbands": num_subbands, "scale": [2, 2]},
+            "training": {"instruments": ["Vocals", "Instrumental"], "target_instrument": None},
+            "inference": {"batch_size": 1, "dim_t": dim_t, "num_overlap": overlap}}
+
+
+MDX23C_SMALL = dict(n_fft=512, hop=64, dim_f=256, dim_t=16, num_channels=32, growth=16, num_scales=2, num_subbands=4)
+
+
+def mdx23c_spec(cfg):
+    """(name, shape, kind) for every tensor of TFC_TDF_net(cfg).state_dict(), in the reference's construction order (tfc_tdf.py:147-195)."""
+    m, a = cfg["model"], cfg["audio"]
+    k, n, l, g, bn = m["num_subbands"], m["num_scales"], m["num_blocks_per_scale"], m["growth"], m["bottleneck_factor"]
+    dim_c = k * a["num_channels"] * 2
+    S = len(cfg["training"]["instruments"])
+    c, f = m["num_channels"], a["dim_f"] // k
+    out = [("first_conv.weight", (c, dim_c, 1, 1), "conv")]
+
+    def norm(p, ch):
+        out.append((p + ".weight", (ch,), "gamma")); out.append((p + ".bias", (ch,), "beta"))
+
+    def tfc(prefix, in_c, ch, ff):
+        for i in range(l):
+            p = f"{prefix}.blocks.{i}."
+            norm(p + "tfc1.0", in_c); out.append((p + "tfc1.2.weight", (ch, in_c, 3, 3), "conv"))
+            norm(p + "tdf.0", ch); out.append((p + "tdf.2.weight", (ff // bn, ff), "conv"))
+            norm(p + "tdf.3", ch); out.append((p + "tdf.5.weight", (ff, ff // bn), "conv"))
+            norm(p + "tfc2.0", ch); out.append((p + "tfc2.2.weight", (ch, ch, 3, 3), "conv"))
+            out.append((p + "shortcut.weight", (ch, in_c, 1, 1), "conv"))
+            in_c = ch
+    for i in range(n):
+        tfc(f"encoder_blocks.{i}.tfc_tdf", c, c, f)
+        norm(f"encoder_blocks.{i}.downscale.conv.0", c); out.append((f"encoder_blocks.{i}.downscale.conv.2.weight", (c + g, c, 2, 2), "conv"))
+        f //= 2; c += g
+    tfc("bottleneck_block", c, c, f)
+    for i in range(n):
+        norm(f"decoder_blocks.{i}.upscale.conv.0", c); out.append((f"decoder_blocks.{i}.upscale.conv.2.weight", (c, c - g, 2, 2), "tconv"))
+        f *= 2; c -= g
+        tfc(f"decoder_blocks.{i}.tfc_tdf", 2 * c, c, f)
+    out.append(("final_conv.0.weight", (c, c + dim_c, 1, 1), "conv"))
+    out.append(("final_conv.2.weight", (S * dim_c, c, 1, 1), "conv"))
+    return out
+
+
+def mdx23c_state_dict(cfg, seed=0):
+    sd = {}
+    for name, shape, kind in mdx23c_spec(cfg):
+        if kind == "gamma":
+            sd[name] = _uniform(seed, "mdx." + name, shape, 0.8, 1.2)
+        elif kind == "beta":
+            sd[name] = _normal(seed, "mdx." + name, shape, 0.1)
+        else:
+            fan = int(np.prod(shape[1:])) if kind == "conv" else int(shape[0] * shape[2] * shape[3])
+            sd[name] = _normal(seed, "mdx." + name, shape, 1.0 / np.sqrt(fan))
+    return sd

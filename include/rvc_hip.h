@@ -108,6 +108,25 @@ int64_t rvc_crepe_num_frames(int64_t L, int hop, int pad);
  * (the mean / std normalisation of every frame, the six conv blocks and the classifier); decoding stays with the caller */
 int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio_dev, int64_t L, int hop, int pad, float* probs_dev, const rvc_crepe_taps* taps);
 
+/* ------------------------------------------------------------------ MDX23C vocal / instrumental separation (UVR chain) */
+/* Replaces TFC_TDF_net.forward of reference lib/karafan/tfc_tdf.py:147-235 (with its STFT / inverse, :47-77); demix_mdxv3's chunking
+ * (lib/karafan/inference.py:32-74) calls it once per chunk.  Fields = the entries of the model's yaml that the network reads
+ * (lib/karafan/Data/model_2_stem_full_band_8k.yaml).  Tensors by their state-dict names plus three host-built constants:
+ * "stft.basis" [2 dim_f][n_fft], "istft.basis" [n_fft][2 dim_f] (windowed DFT matrices) and "window" [n_fft] (periodic hann). */
+typedef struct rvc_mdx23 rvc_mdx23;
+typedef struct rvc_mdx23_config {
+  int n_fft, hop, dim_f, dim_t;
+  int num_channels, growth, num_scales, num_subbands, blocks_per_scale, bottleneck;
+  int num_targets;       /* instruments the mask head separates (2: vocals, instrumental) */
+  int audio_channels;    /* 2 */
+} rvc_mdx23_config;
+int rvc_mdx23_create(rvc_ctx* ctx, const rvc_mdx23_config* cfg, rvc_mdx23** out);
+int rvc_mdx23_set_tensor(rvc_mdx23* m, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int rvc_mdx23_finalize(rvc_mdx23* m);
+int rvc_mdx23_destroy(rvc_mdx23* m);
+/* chunk_dev float32 [2][L] with L = hop * (dim_t - 1) -> out_dev [num_targets][2][L] */
+int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk_dev, int64_t L, float* out_dev);
+
 /* ------------------------------------------------------------------ synthesizer */
 typedef struct rvc_synth_config {   /* the fields of cpt["config"] that the inference graph needs */
   int inter_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size;

@@ -317,6 +317,56 @@ def gen_fullsize(ns, which):
         print("rmvpe_60s", hidden.shape, "voiced", (f0 > 0).mean(), f"{time.time() - t0:.1f} s")
 
 
+def gen_mdx23c():
+    """The reference's own TFC_TDF_net (lib/karafan/tfc_tdf.py is pure torch and imports stand-alone) and demix_mdxv3's arithmetic on a
+    reduced configuration with procedural weights: spectrogram, first conv, first encoder scale, bottleneck, mask-head output, separated
+    chunk, and a 3-chunk overlap-add of a longer clip."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_tfc_tdf", os.path.join(ref_shim.REF_ROOT, "lib", "karafan", "tfc_tdf.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    def ns(d):
+        return NS({k: ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    cfg = S.mdx23c_config(**S.MDX23C_SMALL)
+    net = m.TFC_TDF_net(ns(cfg)).eval()
+    sd = S.mdx23c_state_dict(cfg, 0)
+    assert [k for k in net.state_dict()] == [n for n, _, _ in S.mdx23c_spec(cfg)], "state-dict layout differs from the reference module"
+    net.load_state_dict(to_torch_sd(sd), strict=True)
+    rng = np.random.default_rng(31)
+    C = cfg["audio"]["chunk_size"]
+    x = (rng.standard_normal((2, C)) * 0.3).astype(np.float32)
+    taps = {}
+    hooks = [net.first_conv.register_forward_hook(lambda mod, i, o: taps.__setitem__("first_conv", o[0])),
+             net.encoder_blocks[0].tfc_tdf.register_forward_hook(lambda mod, i, o: taps.__setitem__("enc0", o[0])),
+             net.bottleneck_block.register_forward_hook(lambda mod, i, o: taps.__setitem__("bottleneck", o[0])),
+             net.final_conv.register_forward_hook(lambda mod, i, o: taps.__setitem__("mask_out", o[0]))]
+    with torch.no_grad():
+        specg = net.stft(torch.from_numpy(x)[None])[0]
+        y = net(torch.from_numpy(x)[None])[0]
+    for h in hooks:
+        h.remove()
+    # demix_mdxv3's arithmetic (inference.py:32-74) around the reference module, overlap 4, on a clip of 2.6 chunks
+    overlap = 4
+    clip = (rng.standard_normal((2, int(2.6 * C))) * 0.3).astype(np.float32)
+    H = C // overlap
+    L = clip.shape[1]
+    pad_size = H - (L - C) % H
+    mix = torch.cat([torch.zeros(2, C - H), torch.from_numpy(clip), torch.zeros(2, pad_size + C - H)], 1)
+    chunks = mix.unfold(1, C, H).transpose(0, 1)
+    X = torch.zeros(2, *mix.shape)
+    with torch.no_grad():
+        for cnt, ch in enumerate(chunks):
+            X[..., cnt * H: cnt * H + C] += net(ch[None])[0]
+    est = (X[..., C - H: -(pad_size + C - H)] / overlap).numpy()
+    np.savez_compressed(os.path.join(OUT, "mdx23c_small.npz"), x=x, spec=np_(specg), out=np_(y), clip=clip, demix=est, overlap=np.int64(overlap),
+                        **{k: np_(v) for k, v in taps.items()})
+    print("mdx23c_small", y.shape, "rms", float(y.pow(2).mean().sqrt()), "demix", est.shape, {k: tuple(v.shape) for k, v in taps.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load_reference()
@@ -341,6 +391,8 @@ def main():
         gen_synth_nono(ns, S.CONFIG_40K_V1, "v1", "40k_v1_nono")
     if "pipeline" in which:
         gen_pipeline(ns)
+    if "mdx23c" in which:
+        gen_mdx23c()
     if {"full40", "full45", "full48", "rmvpe60"} & set(which):   # BASELINE.json's full-size configurations (minutes of CPU time)
         gen_fullsize(ns, which)
 

@@ -1,0 +1,111 @@
+"""GPU: the MDX23C separation network and the UVR -> VC chain (BASELINE config C5) on the HIP path against golden vectors of
+the reference's own TFC_TDF_net (oracle/gen_golden.py mdx23c) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from comfy_rvc_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+    cfg = S.mdx23c_config(**S.MDX23C_SMALL)
+    net = TFC_TDF_net(cfg)
+    net.load_state_dict(S.mdx23c_state_dict(cfg, 0))
+    return cfg, net
+
+
+def test_mdx23c_chunk_matches_reference_golden(small):
+    """One chunk through STFT -> TFC/TDF U-Net -> mask head -> inverse STFT against the reference module's output (1e-3 of the peak)."""
+    cfg, net = small
+    g = golden("mdx23c_small.npz")
+    y = net(g["x"][None])[0].cpu().numpy()
+    assert y.shape == g["out"].shape == (2, 2, cfg["audio"]["chunk_size"])
+    assert rel_err(y, g["out"]) < 1e-3
+    # two chunks in one batch: each equals its own single call (no state between chunks)
+    x2 = np.stack([g["x"], g["x"][::-1].copy() * 0.5])
+    y2 = net(x2).cpu().numpy()
+    assert np.array_equal(y2[0], y) and rel_err(y2[1], net(x2[1:2])[0].cpu().numpy()) < 1e-6
+
+
+def test_demix_mdxv3_matches_reference_golden(small):
+    """demix_mdxv3: zero padding, chunks every C / overlap samples, overlap-add, 1 / overlap - on a clip of 2.6 chunks, overlap 4."""
+    from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
+    cfg, net = small
+    g = golden("mdx23c_small.npz")
+    est = demix_mdxv3(g["clip"], net, net.device, cfg, int(g["overlap"]))
+    assert list(est) == ["Vocals", "Instrumental"]
+    got = np.stack([est["Vocals"], est["Instrumental"]])
+    assert got.shape == g["demix"].shape and rel_err(got, g["demix"]) < 1e-3
+
+
+def test_mdx23c_other_geometry_matches_oracle():
+    """A second geometry (3 scales, 2 sub-bands, one block per scale, wider bottleneck factor) against the CPU oracle."""
+    from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+    from oracle import mdx23c as om
+    cfg = S.mdx23c_config(n_fft=1024, hop=128, dim_f=512, dim_t=32, num_channels=48, growth=16, num_scales=3, num_subbands=2, blocks=1, bottleneck=8)
+    sd = S.mdx23c_state_dict(cfg, 1)
+    net = TFC_TDF_net(cfg)
+    net.load_state_dict(sd)
+    x = (np.random.default_rng(4).standard_normal((2, cfg["audio"]["chunk_size"])) * 0.2).astype(np.float32)
+    with torch.no_grad():
+        ref = om.forward(sd, cfg, x).numpy()
+    assert rel_err(net(x[None])[0].cpu().numpy(), ref) < 1e-3
+
+
+def test_full_mdx23c_recipe_runs_at_size():
+    """The shipped recipe (n_fft 8192, dim_f 4096, dim_t 256, 128 channels + 128 per scale, 5 scales: 112 M parameters) on one 5.9 s
+    chunk - too large for the CPU oracle inside the suite, so size-independent properties: shape, finiteness, bit-identical repeats,
+    and the silent-input fixed point (every convolution is bias-free and the mask multiplies the first conv's output: zeros in, zeros out)."""
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG
+    from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+    cfg = MDX23C_CONFIG
+    net = TFC_TDF_net(cfg)
+    net.load_state_dict(S.mdx23c_state_dict(cfg, 0))
+    x = (np.random.default_rng(5).standard_normal((1, 2, 261120)) * 0.1).astype(np.float32)
+    a = net(x).cpu().numpy()
+    b = net(x).cpu().numpy()
+    assert a.shape == (1, 2, 2, 261120) and np.isfinite(a).all() and np.array_equal(a, b) and np.abs(a).max() > 1e-4
+    z = net(np.zeros_like(x)).cpu().numpy()
+    assert np.abs(z).max() < 1e-6            # all-zero input: the mask multiplies a zero spectrogram branch and every conv is bias-free
+
+
+def test_uvr_then_vc_chain(small, tmp_path, monkeypatch):
+    """BASELINE config C5 in miniature: UVR5Node (karafan MDX23C, reduced recipe with a yaml next to the checkpoint) splits a stereo
+    44.1 kHz clip, the vocal stem thunk goes into RVCNode (48k_v2 synthesizer) and comes out as WAV bytes at 48 kHz."""
+    import yaml
+    import comfy_rvc_amd.lib as lib
+    import comfy_rvc_amd.pitch_extraction as pe
+    from comfy_rvc_amd.custom_nodes import rvc_nodes as N, uvr as U
+    from comfy_rvc_amd.lib.audio import bytes_to_audio
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.vc_infer_pipeline import get_vc
+    models = tmp_path / "models"
+    (models / "karafan").mkdir(parents=True)
+    cfg, _ = small
+    as_t = lambda sd: {k: torch.as_tensor(np.ascontiguousarray(v)).clone() for k, v in sd.items()}   # noqa: E731
+    torch.save(as_t(S.mdx23c_state_dict(cfg, 0)), str(models / "karafan" / "MDX23C-8KFFT-InstVoc_HQ.ckpt"))
+    yaml.safe_dump(cfg, open(models / "karafan" / "MDX23C-8KFFT-InstVoc_HQ.yaml", "w"))
+    torch.save(as_t(S.rmvpe_state_dict(0)), str(models / "rmvpe.pt"))
+    for mod in (lib, pe, N, U):
+        monkeypatch.setattr(mod, "BASE_MODELS_DIR", str(models), raising=False)
+    t = np.arange(int(0.8 * 44100)) / 44100.0
+    stereo = np.stack([0.3 * np.sin(2 * np.pi * 220 * t), 0.2 * np.sin(2 * np.pi * 330 * t)]).astype(np.float32)
+    assert "karafan/MDX23C-8KFFT-InstVoc_HQ.ckpt" in U.UVR5Node.INPUT_TYPES()["required"]["model"][0]
+    vocals, music = U.UVR5Node().split(N.to_audio_dict(stereo, 44100), "karafan/MDX23C-8KFFT-InstVoc_HQ.ckpt", overlap=2)
+    v, sr = bytes_to_audio(vocals())
+    m, _ = bytes_to_audio(music())
+    assert sr == 44100 and v.shape == m.shape == stereo.shape and np.isfinite(v).all()
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    vcd = get_vc(S.synth_checkpoint(S.CONFIG_48K_V2, "v2", 0))
+    (params,) = N.LoadPitchExtractionParams().load_params(f0_method="rmvpe", f0_autotune=False, index_rate=0.0, resample_sr=0, rms_mix_rate=0.25,
+                                                          protect=0.25, crepe_hop_length=160)
+    out = N.RVCNode().convert(vocals, lambda: vcd, lambda: hub, params, f0_up_key=0, use_cache=False)
+    wav, sr2 = bytes_to_audio(out["result"][0]())
+    assert sr2 == 48000 and wav.ndim == 1 and wav.shape[0] > 0.5 * 48000 and np.isfinite(wav).all()
+    with pytest.raises(NotImplementedError):
+        U.UVR5Node().split(N.to_audio_dict(stereo, 44100), "UVR/HP5-vocals+instrumentals.pth")

@@ -109,5 +109,5 @@ def test_package_exports_node_mappings():
     """ComfyUI imports the pack directory and reads NODE_CLASS_MAPPINGS / NODE_DISPLAY_NAME_MAPPINGS off the module (reference __init__.py:12-31)."""
     import comfy_rvc_amd
     from comfy_rvc_amd.custom_nodes import rvc_nodes as N
-    assert hasattr(comfy_rvc_amd, "NODE_CLASS_MAPPINGS") and comfy_rvc_amd.NODE_CLASS_MAPPINGS == N.NODE_CLASS_MAPPINGS
-    assert set(comfy_rvc_amd.NODE_DISPLAY_NAME_MAPPINGS) == {"LoadRVCModelNode", "RVCNode", "LoadHubertModel", "LoadPitchExtractionParams"}
+    assert hasattr(comfy_rvc_amd, "NODE_CLASS_MAPPINGS") and all(comfy_rvc_amd.NODE_CLASS_MAPPINGS[k] is v for k, v in N.NODE_CLASS_MAPPINGS.items())
+    assert set(comfy_rvc_amd.NODE_DISPLAY_NAME_MAPPINGS) == {"LoadRVCModelNode", "RVCNode", "LoadHubertModel", "LoadPitchExtractionParams", "UVR5Node"}

@@ -165,3 +165,20 @@ def test_rmvpe_60s_oracle_matches_reference():
     assert np.max(np.abs(sal.max(axis=1) - g["sal_max"])) < 2e-5 and np.max(np.abs(sal[::50] - g["sal_sub"])) < 2e-5
     assert np.mean(sal.argmax(axis=1) == g["sal_argmax"]) > 0.999
     assert np.allclose(sal.astype(np.float64).sum(axis=1), g["sal_rowsum"], rtol=1e-4)
+
+
+def test_mdx23c_oracle_matches_reference_module():
+    """oracle/mdx23c.py (explicit DFT matrices instead of torch.stft / istft, functional TFC_TDF blocks, demix_mdxv3's chunking) against
+    taps and outputs of the reference's own TFC_TDF_net on the reduced configuration (oracle/gen_golden.py mdx23c)."""
+    from oracle import mdx23c as om
+    g = golden("mdx23c_small.npz")
+    cfg = S.mdx23c_config(**S.MDX23C_SMALL)
+    sd = S.mdx23c_state_dict(cfg, 0)
+    taps = {}
+    with torch.no_grad():
+        y = om.forward(sd, cfg, g["x"], taps).numpy()
+    for k in ("spec", "first_conv", "enc0", "bottleneck", "mask_out"):
+        assert rel_err(taps[k], g[k]) < 1e-5, k
+    assert rel_err(y, g["out"]) < 1e-5
+    d = om.demix_mdxv3(sd, cfg, g["clip"], int(g["overlap"]))
+    assert rel_err(np.stack([d["Vocals"], d["Instrumental"]]), g["demix"]) < 1e-5
