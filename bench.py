@@ -151,8 +151,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default 12; 8 for --variant 48k_v2 as BASELINE.json configs[3] states)")
-    ap.add_argument("--variant", choices=["40k_v2", "48k_v2"], default="40k_v2",
-                    help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model")
+    ap.add_argument("--variant", choices=["40k_v2", "48k_v2", "uvr_48k_v2"], default="40k_v2",
+                    help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model; uvr_48k_v2 = "
+                         "configs[4]'s chain: MDX23C vocal split of a stereo 44.1 kHz clip (overlap 8) -> VC of the vocal stem with the 48k_v2 model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
@@ -187,9 +188,13 @@ def main():
     from comfy_rvc_amd.parallel import ClipLanes, gather_waveforms
 
     n_lanes = max(1, args.lanes)
-    n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else 12)
+    chain = args.variant == "uvr_48k_v2"
+    n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else (3 if chain else 12))
     SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
-    audio = S.synth_audio(args.seconds, seed=100 + rank)
+    if chain:      # stereo 44.1 kHz "song": the voice-like synthetic signal on both channels plus different noise beds
+        audio = np.stack([S.synth_audio(args.seconds, seed=100 + rank, sr=44100), S.synth_audio(args.seconds, seed=300 + rank, sr=44100)])
+    else:
+        audio = S.synth_audio(args.seconds, seed=100 + rank)
     params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
     vc = None
 
@@ -208,8 +213,19 @@ def main():
             lvc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
             lvc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
 
+            mdx = None
+            if chain:
+                from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG
+                from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
+                from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+                mdx = TFC_TDF_net(MDX23C_CONFIG, device=dev)
+                mdx.load_state_dict(S.mdx23c_state_dict(MDX23C_CONFIG, 0))
+
             def convert(clip, i=0):
-                out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=lvc, hubert_model=hub, input_audio=(clip, 16000), config=cfg, **params)
+                sr_in = 16000
+                if chain:      # UVR5Node.split -> vocal stem -> RVCNode.convert (reference custom_nodes/uvr.py:56-100, rvc_nodes.py:186-206)
+                    clip, sr_in = demix_mdxv3(clip, mdx, dev, MDX23C_CONFIG, MDX23C_CONFIG["inference"]["num_overlap"])["Vocals"], 44100
+                out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=lvc, hubert_model=hub, input_audio=(clip, sr_in), config=cfg, **params)
                 assert out is not None, "vc_single failed"
                 return out[0]
             return convert, lvc
@@ -276,10 +292,10 @@ def main():
         roofline = roofline_pass(_lib, vc, step, torch)
     cpu = None
     if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
-        cpu = cpu_baseline(config=SYN_CFG)
+        cpu = cpu_baseline(config=SYN_CFG) if not chain else None      # (the CPU oracle of the separation net at full size takes minutes per chunk)
 
     if rank == 0:
-        cfg_idx = 2 if args.variant == "40k_v2" else 3
+        cfg_idx = {"40k_v2": 2, "48k_v2": 3, "uvr_48k_v2": 4}[args.variant]
         line = {
             "metric": f"audio-sec/wall-sec (xRT), {args.variant} end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -288,7 +304,8 @@ def main():
             "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
             "ranks": world, "backend": (backend if world > 1 else None), "nccl_ranks": (world if (world > 1 and backend == "nccl") else None),
             "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
-            "config": {"workload": f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s 16 kHz clips, {n_clips} per GPU "
+            "config": {"workload": ("MDX23C vocal split (stereo 44.1 kHz, overlap 8) -> " if chain else "") +
+                                   f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s {'44.1 kHz stereo' if chain else '16 kHz'} clips, {n_clips} per GPU "
                                    f"per step ({n_lanes} in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
                        "clips_per_step": world * n_clips, "clips_per_gpu_per_step": n_clips, "clips_in_flight_per_gpu": n_lanes,
                        "audio_seconds_delivered_per_clip": round(delivered, 3),

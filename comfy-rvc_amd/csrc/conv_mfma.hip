@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) {
         const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= p.Co) continue;
-        const int co = m % p.orows, ph = m / p.orows;
+        const int co = MODE == 2 ? m % p.orows : m / p.ostride, ph = MODE == 2 ? m / p.orows : m - co * p.ostride;
         const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
@@ -512,6 +512,10 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
 }
 
+// ConvTranspose1d as u polyphase stride-1 convolutions: GEMM row co * u + r = output channel co, phase r, i.e. the PHASE is the fastest
+// row index.  One tile then holds every phase of its channels, so the interleaved stores of a workgroup fill whole cache lines between
+// them (with phase-major rows the u partial writes of a line came from u different workgroups / L2s: 9x the algorithmic HBM traffic
+// on the 10x up-sampler, rocprofv3 FETCH / WRITE_SIZE).
 void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci, int Co, int k, int u, int pad) {
   const int E2 = (k - 1 - pad) / u, E1 = (u - 1 + pad) / u;
   L.mode = 1; L.groups = 1; L.Ci = Ci; L.co_real = Co; L.Co = u * Co; L.CoP = (L.Co + 31) & ~31;
@@ -529,17 +533,17 @@ void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci,
           const int kk = e * u + r + pad;
           if (kk < 0 || kk >= k) continue;
           const int chunk = ci / L.CK, vcc = ci % L.CK;
-          P[(((size_t)chunk * L.ktaps + j) * L.CK + vcc) * L.CoP + (size_t)r * Co + co] = w[((size_t)ci * Co + co) * k + kk];
+          P[(((size_t)chunk * L.ktaps + j) * L.CK + vcc) * L.CoP + (size_t)co * u + r] = w[((size_t)ci * Co + co) * k + kk];
         }
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && Ci % 16 == 0 && L.Co >= 32) {
-    // bf16x3 image of the equivalent stride-1 convolution: Weq[r * Co + co][ci][j]
+    // bf16x3 image of the equivalent stride-1 convolution: Weq[co * u + r][ci][j]
     std::vector<float> Weq((size_t)L.Co * Ci * L.ktaps, 0.f);
     for (int r = 0; r < u; ++r)
       for (int co = 0; co < Co; ++co)
         for (int ci = 0; ci < Ci; ++ci)
           for (int j = 0; j < L.ktaps; ++j) {
             const int kk = (E2 - j) * u + r + pad;
-            if (kk >= 0 && kk < k) Weq[(((size_t)r * Co + co) * Ci + ci) * L.ktaps + j] = w[((size_t)ci * Co + co) * k + kk];
+            if (kk >= 0 && kk < k) Weq[(((size_t)co * u + r) * Ci + ci) * L.ktaps + j] = w[((size_t)ci * Co + co) * k + kk];
           }
     pack_x3(L, Weq.data(), L.Co, Ci, L.ktaps);
   }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(p, acc, z, co0, n0, wm, wn, li, lh);
     }
   } else {
-    // interleaved store of the ConvTranspose1d phases: row m = phase * orows + co goes to Y[co][n * ostride + phase]
+    // interleaved store of the ConvTranspose1d phases: row m = co * ostride + phase goes to Y[co][n * ostride + phase]
     const float* __restrict__ bias = p.bias;
     float* Y = p.Y;
     const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       for (int r = 0; r < 16; ++r) {
         const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= p.Co) continue;
-        const int ph = m / p.orows, co = m - ph * p.orows;
+        const int co = m / p.ostride, ph = m - co * p.ostride;      // phase-fastest rows (tconv1d_layer_init)
         const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
