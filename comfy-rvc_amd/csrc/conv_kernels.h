@@ -20,6 +20,8 @@ struct ConvArgsX : ConvArgs {
   // fused ResBlock pair (conv_x3_kernel<..., FUSE>): second conv's weight image, first conv's bias, halo (k - 1) / 2 of the
   // second conv, slope of the leaky ReLU between the two
   const unsigned char* Wx2; const float* bias1; int fuse_p2; float fuse_slope;
+  const unsigned char* Xs; long long xsTp;      // split-resident input image (replaces X; see ConvEpilogue) and its rows per plane
+  unsigned char* Ys; long long ysTp; float ys_slope;   // split-resident output image (replaces Y), activation slope applied before the split
   int wbufs;       // weight slabs in the LDS ring (2 .. 4)
   int xcd_remap;   // 1: tiles renumbered so that each XCD (L2) works on a contiguous run of them
 };
@@ -138,7 +140,7 @@ int conv_prof_collect_ex(double* out /* [kProfCfgs][8] */, double ridge_fp32, do
 void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s);
 
 // bf16x3 path: returns false when the layer / geometry is not eligible (caller falls back to the fp32 kernel)
-bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops);
+bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops, bool dry = false);
 bool conv_x3_enabled();
 // y = (x + c2(lrelu(c1(lrelu(x))))) * scale [+ y] for a ResBlock1 pair of narrow layers in ONE launch; false when not eligible
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,

@@ -864,6 +864,7 @@ static ConvEpilogue split_epilogue(const ConvEpilogue& e, bool& post) {
 static void fill_epilogue(ConvArgsX& a, const ConvEpilogue& e) {
   a.R = e.R; a.ldR = e.ldR; a.pre_act = e.pre_act; a.pre_slope = e.pre_slope; a.act = e.act; a.act_slope = e.act_slope;
   a.act_before_res = e.act_before_res; a.out_scale = e.out_scale; a.accumulate = e.accumulate;
+  a.Xs = e.xs_in; a.xsTp = e.xs_tp; a.Ys = e.ys_out; a.ysTp = e.ys_tp; a.ys_slope = e.ys_slope;
 }
 
 int conv1d_out_len(const ConvLayer& L, int Tin) {
@@ -899,11 +900,24 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.tconv_u > 0 ? L.ktaps : L.k;
-  if (!(L.Wx_ && conv_x3_try(a, L.groups, s, flops))) run_conv(a, 1, L.groups, s, flops);
+  if (!(L.Wx_ && conv_x3_try(a, L.groups, s, flops))) {
+    RVC_REQUIRE(!e.xs_in && !e.ys_out, "split-resident tensors need the bf16x3 kernel (check conv1d_split_eligible first)");
+    run_conv(a, 1, L.groups, s, flops);
+  }
   if (post) {
     RVC_REQUIRE(L.tconv_u == 0, "post-activation on a transposed conv");
     act_res_inplace(s, Y, e0.R, L.groups * L.Co, Tout, ldY, e0.ldR, e0.act, e0.act_slope, e0.act_before_res);
   }
+}
+
+bool conv1d_split_eligible(const ConvLayer& L, int Tin) {
+  if (L.mode != 1 || !L.Wx_ || L.tconv_u || L.stride != 1 || L.groups != 1 || (L.Co & 31) || (L.Ci & 15)) return false;
+  ConvArgsX a{};
+  a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = Tin; a.Wd = 0; a.ktaps = L.ktaps; a.dil = L.dil; a.stride = 1; a.pad = L.pad;
+  a.Tout = conv1d_out_len(L, Tin); a.ostride = 1; a.orows = L.Co; a.ldX = Tin; a.ldY = a.Tout; a.ldR = a.Tout;
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.kreal = L.k;
+  a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_);          // any non-null value: ask for the split-input geometry
+  return conv_x3_try(a, 1, nullptr, 0.0, true);
 }
 
 void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch, const float* B, long long ldB, long long bBatch,

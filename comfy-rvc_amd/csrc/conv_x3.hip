@@ -86,14 +86,17 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned total) {
 // same row format; pass 2 runs the stage loop of the second conv (dilation 1) on those rows and the ordinary epilogue stores the
 // BN - (k - 1) columns that have their full halo.  The intermediate tensor never goes to HBM: x (tile + residual) and y instead of
 // x, t, t, x, y.  Used for the 32-channel generator stage (conv_x3_pair_try): k3 261 -> 196 us, k7 304 -> 233, k11 348 -> 308.
-template <int WM, int WN, int AM, int AN, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
-  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = (FUSE && BM == 64) ? 7 : (FUSE ? 5 : x3_slots(BN)), RB = BM / 32;
+// XSPLIT: the input arrives as a split-resident image (ConvEpilogue::xs_in) and is copied into LDS by DMA; no staging registers.
+// YSPLIT: the output is written as a split-resident image (ConvEpilogue::ys_out) - separate instantiations, so that the plain kernels keep
+// their register budgets (the 128 x 128 tile its three workgroups per CU).
+template <int WM, int WN, int AM, int AN, bool FUSE = false, bool XSPLIT = false, bool YSPLIT = false>
+__global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !FUSE) ? 3 : 2) void conv_x3_kernel(const ConvArgsX p) {   // (128 x 128 tile: three workgroups per CU = 168 VGPRs)
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = XSPLIT ? 1 : ((FUSE && BM == 64) ? 7 : (FUSE ? 5 : x3_slots(BN))), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
   const int NC = p.NC;                      // 16-channel chunks per stage
   const int st = p.stride;                  // strided convs keep one sub-plane per input phase (position mod stride): unit-stride reads
-  const int Pm = (P + st - 1) / st;         // rows per phase sub-plane
+  const int Pm = XSPLIT ? ((P + 31) & ~31) : (P + st - 1) / st;   // rows per phase sub-plane (split-resident input: whole 1-KiB pieces)
   const int xplane = st * Pm * 32;          // bytes of one hi / lo plane
   const int xbuf = NC * 2 * xplane;         // bytes of one X buffer
   const int wbuf = NC * p.KT * 2 * BM * 32; // bytes of one weight buffer
@@ -129,6 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   const int g0 = ks * gps, g1 = min(ngroups, g0 + gps);
   const int nstages = max(g1 - g0, 0) * ntb;
   const int bx = n0 * st - p.pad - P2;                 // (fused: column 0 of the tile is the first column of the intermediate)
+  // split-resident input: LDS row q holds image row bx + q + margin, whose 16-B halves are swapped by bit 3 of THAT index
+  const int sw0 = XSPLIT ? ((bx + kSplitMargin) & 15) : 0;
   // 2-D 3x3 (p.Wd > 0): the tile is BH image rows x BWd columns; the staged "positions" are the (BH + 2) x PW halo patch in
   // row-major order, tap (dh, dw) is the position offset dh * PW + dw
   const bool two_d = p.Wd > 0;
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
 
   // ---- input tile: global -> registers.  Slot s of wave w covers 64 positions x 8 channels (one 16-B half of the LDS rows).
   auto load_x = [&](int grp) {
+    if constexpr (XSPLIT) return;
 #ifdef RVC_X3_NOX
     return;
 #endif
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   // bodies (a nested select over the stride compiled into ~100 instructions of divisions and branches per slot: 46 k of a 128 x 256
   // tile's 340 k cycles went into this function)
   auto store_x = [&](int xb) {
+    if constexpr (XSPLIT) return;
 #ifdef RVC_X3_NOX
     return;
 #endif
@@ -208,6 +215,36 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
       }
     }
   };
+  // ---- split-resident input: the (chunk, hi | lo) planes of the tile are contiguous runs of the image: 1 KiB (32 positions) per
+  // wave-instruction straight into LDS.  Returns the number of pieces this wave issued.
+  auto issue_x = [&](int grp, int xb) -> int {
+    if constexpr (!XSPLIT) return 0;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int ppp = xplane >> 10;                                   // pieces per plane (xplane is a multiple of 1 KiB)
+    const int npieces = NC * 2 * ppp;
+    for (int pi = wave; pi < npieces; pi += 4) {
+      const int pl = pi / ppp, j = pi - pl * ppp;                   // plane = (chunk in group) * 2 + (hi | lo)
+      const long long row = (long long)((grp * NC) * 2 + pl) * p.xsTp + (bx + kSplitMargin) + (long long)j * 32;
+      const unsigned char* src = p.Xs + row * 32 + lane * 16;
+      unsigned char* dst = Xs + xb * xbuf + pl * xplane + j * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    return wave < npieces ? (npieces - wave + 3) >> 2 : 0;
+  };
+  // rows of the staged tile that lie outside the sequence are the convolution's zero padding: the image holds no defined data there
+  const bool x_edge = XSPLIT && (bx < 0 || bx + P > p.Tin);
+  auto zero_edges = [&](int xb) {
+    for (int q = tid0; q < P; q += 256) {
+      const int t = bx + q;
+      if (t >= 0 && t < p.Tin) continue;
+      for (int pl = 0; pl < NC * 2; ++pl) {
+        u32x4* r = reinterpret_cast<u32x4*>(Xs + xb * xbuf + pl * xplane + q * 32);
+        r[0] = u32x4{0u, 0u, 0u, 0u}; r[1] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+
   // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
   auto issue_w = [&](const unsigned char* __restrict__ Wimg, int grp, int tb, int buf) -> int {
 #ifdef RVC_X3_NOW
@@ -274,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
 #pragma unroll
       for (int an = 0; an < AN; ++an) {
         const int q = bq[an] + toff;
-        const int off = q * 32 + ((lh ^ ((q >> 3) & 1)) << 4);
+        const int off = q * 32 + ((lh ^ (((q + sw0) >> 3) & 1)) << 4);
         bh[an] = *reinterpret_cast<const u32x4*>(xp + off);
         bl[an] = *reinterpret_cast<const u32x4*>(xp + xplane + off);
       }
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
   // of chunk c), a whole chunk ahead of their use; nothing in the loop waits for vmcnt(0).
   int chunk = g0, tb = 0;
   const long long t_begin = X3TICK();
-  int issued = 0, we0 = 0, we1 = 0, we2 = 0, we3 = 0;
+  int issued = 0, we0 = 0, we1 = 0, we2 = 0, we3 = 0, xe = 0;   // xe: `issued` right after the input pieces of the current chunk
   int nchunk_i = g0, ntb_i = 0, issued_stages = 0;         // next (chunk, tap block) whose weights are to be requested
   auto issue_next = [&]() {
     const int pieces = issue_w(Wg, nchunk_i, ntb_i, issued_stages % NS);
@@ -315,24 +352,31 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
     we0 = issue_next();
     if (NS > 2 && nstages > 1) we1 = issue_next();
     if (NS > 3 && nstages > 2) we2 = issue_next();
-    load_x(g0); issued += XS * 8;
+    if constexpr (XSPLIT) { issued += issue_x(g0, p.xbufs == 2 ? (g0 & 1) : 0); xe = issued; }
+    else { load_x(g0); issued += XS * 8; }
   }
   X3TACC(1, X3TICK() - t_begin);
   for (int it = 0; it < nstages; ++it) {
     const long long ta = X3TICK();
     const int buf = it % NS;
     const int xb = p.xbufs == 2 ? (chunk & 1) : 0;
-    if (tb == 0) {
+    if (!XSPLIT && tb == 0) {
       if (p.xbufs == 1 && it > 0) lds_barrier();           // single X buffer: every wave is done with the previous chunk
       store_x(xb);
       if (chunk + 1 < g1) { load_x(chunk + 1); issued += XS * 8; }
     }
     const long long tw0 = X3TICK();
-    wait_vmcnt_le(issued - we0);                            // this stage's weight pieces (of this wave) have landed
+    // this stage's weight pieces (of this wave) have landed - and, at the start of a chunk, its split-resident input pieces
+    wait_vmcnt_le((XSPLIT && tb == 0) ? min(issued - we0, issued - xe) : issued - we0);
     const long long tw1 = X3TICK();
     lds_barrier();                                          // ... and everybody else's; the slab of stage it - 1 is free again
     const long long tb_ = X3TICK();
     X3TACC(2, tw0 - ta); X3TACC(7, tw1 - tw0); X3TACC(1, tb_ - tw1);      // [2] input store, [7] DMA wait, [1] += barrier
+    if (XSPLIT && tb == 0) {
+      if (x_edge) { zero_edges(xb); lds_barrier(); }        // (first / last tiles only) zero padding rows, published before the MFMAs
+      // the other input buffer was read during the previous chunk; every wave is past it now (barrier above): request the next chunk
+      if (chunk + 1 < g1) { issued += issue_x(chunk + 1, xb ^ 1); xe = issued; }
+    }
     we0 = we1; we1 = we2; we2 = we3;
     if (issued_stages < nstages) {
       const int e = issue_next();
@@ -412,13 +456,54 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgsX p) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), prs, (int)(ok ? ((unsigned)m * (unsigned)p.ldP + (unsigned)n) * 4u : kOOB), 0, 0);
         }
       }
+  } else if (YSPLIT) {
+    // ---- split-resident output: v = act(acc + bias) -> bf16 hi / lo rows [chunk][hi | lo][margin + n][16 ch].  A lane holds 4 + 4
+    // channels of each 16-channel chunk of its column; v_permlane32_swap trades quads with the lane 32 away so that every lane owns
+    // one 16-B half of a row: 4 b128 stores per accumulator instead of 16 dword stores, each wave instruction a contiguous KiB.
+    const float sl = p.ys_slope;
+    const float* __restrict__ bias = p.bias;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        const int mb = co0 + (wm * AM + am) * 32;
+        const long long pos = (long long)n + kSplitMargin;
+        const int hsel = (lh ^ (int)((pos >> 3) & 1)) << 4;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          unsigned hA[2], lA[2], hB[2], lB[2];
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            const int ma = mb + 16 * g2 + 4 * lh + 2 * e2;
+            float a0 = acc[am][an][8 * g2 + 2 * e2] + (bias ? bias[ma] : 0.f), a1 = acc[am][an][8 * g2 + 2 * e2 + 1] + (bias ? bias[ma + 1] : 0.f);
+            float b0 = acc[am][an][8 * g2 + 4 + 2 * e2] + (bias ? bias[ma + 8] : 0.f), b1 = acc[am][an][8 * g2 + 5 + 2 * e2] + (bias ? bias[ma + 9] : 0.f);
+            split2(fmaxf(a0, a0 * sl), fmaxf(a1, a1 * sl), hA[e2], lA[e2]);
+            split2(fmaxf(b0, b0 * sl), fmaxf(b1, b1 * sl), hB[e2], lB[e2]);
+          }
+          u32x4 hi, lo;
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t sh = __builtin_amdgcn_permlane32_swap(hA[e2], hB[e2], false, false);
+            const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
+            hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
+          }
+          if (n < p.Tout && mb + 16 * g2 < p.Co) {
+            const long long chunk = (mb >> 4) + g2;
+            unsigned char* row = p.Ys + ((chunk * 2) * p.ysTp + pos) * 32 + hsel;
+            *reinterpret_cast<u32x4*>(row) = hi;
+            *reinterpret_cast<u32x4*>(row + p.ysTp * 32) = lo;
+          }
+        }
+      }
   } else if (p.ostride == 1) {
     if constexpr (FUSE) {
       ConvArgsX pe = p;
       pe.Tout = min(p.Tout, n0 + BN - 2 * P2);               // columns without their full halo belong to the neighbouring tiles
       dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(pe, acc, z, co0, n0, wm, wn, li, lh);
     } else {
-      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(p, acc, z, co0, n0, wm, wn, li, lh);
+      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : (XSPLIT ? 4 : 8))>(p, acc, z, co0, n0, wm, wn, li, lh);
     }
   } else {
     // interleaved store of the ConvTranspose1d phases: row m = co * ostride + phase goes to Y[co][n * ostride + phase]
@@ -457,16 +542,19 @@ bool conv_x3_enabled() {
   return on;
 }
 
-template <int WM, int WN, int AM, int AN, bool FUSE = false>
+template <int WM, int WN, int AM, int AN, bool FUSE = false, bool XSPLIT = false, bool YSPLIT = false>
 static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE>;
+  auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE, XSPLIT, YSPLIT>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
-bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
+bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry) {
   if (!conv_x3_enabled() || !a0.Wx) return false;
+  const bool xs = a0.Xs != nullptr;
+  if ((xs || a0.Ys) && (a0.Wd > 0 || a0.stride != 1 || a0.ostride != 1 || (a0.Co & 31) || batch != 1)) return false;
+  if (xs && a0.pre_act != ACT_NONE) return false;                     // the producer applied the activation
   if (a0.Wd > 0 && (a0.ktaps != 9 || a0.stride != 1)) return false;
   if ((a0.stride != 1 && a0.dil != 1) || a0.up2 || (a0.ostride != 1 && a0.R) || (a0.Ci & 15) || batch != 1) return false;
   if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
@@ -494,6 +582,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (t.WM == 2 && t.WN == 2 && t.AM == 2 && t.AN == 4) id = 7;
   if (t.WM == 1 && t.WN == 4 && t.AM == 2 && t.AN == 4) id = 8;
   if (id < 0) return false;
+  if ((xs || a0.Ys) && !(id == 3 || id == 4 || id == 7 || id == 8)) return false;   // tiles instantiated with the split-resident paths
+  if (xs && a0.Ys) return false;                                                    // (one side at a time so far)
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
@@ -507,13 +597,13 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     P = (a.BH + 2) * a.PW;
     a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
   }
-  const int Pm = (P + a.stride - 1) / a.stride;
+  const int Pm = xs ? ((P + 31) & ~31) : (P + a.stride - 1) / a.stride;
   a.ni = (P + 63) / 64;
   const int nchunk = a.Ci / 16;
   // chunks per stage: short reductions per chunk (k <= 3) take several chunks per stage so that a stage outlasts its DMA
   int NC = a.ktaps == 1 ? 4 : (a.ktaps <= 3 ? 2 : 1);
-  while (NC > 1 && (nchunk % NC != 0 || (NC * 2 * a.ni + 3) / 4 > x3_slots(BN))) NC >>= 1;
-  if ((NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  while (NC > 1 && (nchunk % NC != 0 || (!xs && (NC * 2 * a.ni + 3) / 4 > x3_slots(BN)))) NC >>= 1;
+  if (!xs && (NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
   // LDS budget per workgroup: 53 KiB = three workgroups per CU for the tiles whose registers allow it (<= 170 VGPRs), two for the
   // 8-accumulator tiles.  Measured: occupancy matters more than stage length (one 156 KiB workgroup per CU with 3x longer stages:
   // +32 % time; three 128x128 workgroups instead of two: -12 %).  X double-buffered when that still leaves >= 2 taps per stage.
@@ -529,7 +619,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
     const int per_tap = NS * NC * 2 * BM * 32;              // NS slabs x NC chunks x {hi, lo} x BM rows x 32 B
     xbufs = 2; xbytes = (xbufs * NC * 2 * a.stride * Pm * 32 + 1023) & ~1023;
     ktmax = (budget - xbytes) / per_tap;
-    if (ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * a.stride * Pm * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
+    if (!xs && ktmax < 2 && a.ktaps > ktmax && a.ktaps > 1) { xbufs = 1; xbytes = (NC * 2 * a.stride * Pm * 32 + 1023) & ~1023; ktmax = (budget - xbytes) / per_tap; }
     if (ktmax >= 1) break;
     if (NS > 2) { --NS; continue; }
     if (NC == 1) break;
@@ -539,6 +629,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   if (ktmax > a.ktaps) ktmax = a.ktaps;
   const int ntb = (a.ktaps + ktmax - 1) / ktmax;
   a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
+  if (dry) return true;
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.wbufs = NS; a.xcd_remap = xcd_env;
@@ -561,6 +652,21 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops) {
   const size_t lds = (size_t)xbytes + (size_t)NS * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
   ProfTicket tk = conv_prof_begin(s);
+  if (xs) {
+    switch (id) {
+      case 3: launch_x3<2, 2, 2, 2, false, true>(a, grid, lds, s); break;
+      case 4: launch_x3<2, 2, 1, 4, false, true>(a, grid, lds, s); break;
+      case 7: launch_x3<2, 2, 2, 4, false, true>(a, grid, lds, s); break;
+      default: launch_x3<1, 4, 2, 4, false, true>(a, grid, lds, s); break;
+    }
+  } else if (a.Ys) {
+    switch (id) {
+      case 3: launch_x3<2, 2, 2, 2, false, false, true>(a, grid, lds, s); break;
+      case 4: launch_x3<2, 2, 1, 4, false, false, true>(a, grid, lds, s); break;
+      case 7: launch_x3<2, 2, 2, 4, false, false, true>(a, grid, lds, s); break;
+      default: launch_x3<1, 4, 2, 4, false, false, true>(a, grid, lds, s); break;
+    }
+  } else
   switch (id) {
     case 0: launch_x3<1, 4, 1, 4>(a, grid, lds, s); break;
     case 1: launch_x3<1, 4, 1, 2>(a, grid, lds, s); break;

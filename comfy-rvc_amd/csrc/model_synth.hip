@@ -331,6 +331,17 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     float* yb = A.alloc<float>((size_t)Cc * Tn);
     float* xs = A.alloc<float>((size_t)Cc * Tn);
     float* fr = (S->f0 && st.noise_k > 1) ? A.alloc<float>((size_t)st.noise_k * Tn) : nullptr;
+    // split-resident intermediate of a ResBlock pair: c1's epilogue writes t = lrelu(c1(..) + b1) as the bf16 hi / lo image c2 stages in
+    // LDS (DMA, no conversion, no staging registers; 4 b128 stores per accumulator instead of 16 dword stores on c1's side)
+    static const bool split_on = !(getenv("RVC_SPLIT") && atoi(getenv("RVC_SPLIT")) == 0);
+    bool split_pair[3][3];
+    bool any_split = false;
+    for (int j = 0; j < 3; ++j)
+      for (int m = 0; m < 3; ++m) {
+        split_pair[j][m] = split_on && conv1d_split_eligible(st.rb[j].c1[m], Tn) && conv1d_split_eligible(st.rb[j].c2[m], Tn);
+        any_split = any_split || split_pair[j][m];
+      }
+    unsigned char* t1s = any_split ? A.alloc<unsigned char>(split_image_bytes(Cc, Tn)) : nullptr;
     if (!dry) {
       RVC_REQUIRE(conv1d_out_len(st.up, Tc) == Tn, "ConvTranspose1d geometry must give T_out = u * T_in");
       if (!S->f0) {
@@ -353,8 +364,15 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
           // narrow stages: both convs of the pair in one launch, the intermediate stays in LDS (conv_x3.hip, FUSE)
           if (!conv_x3_pair_try(st.rb[j].c1[m], st.rb[j].c2[m], s, in, Tn, Tn, dst, Tn, E2)) {
             ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f;
-            conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
-            conv1d_run(st.rb[j].c2[m], s, t1, Tn, Tn, dst, Tn, E2);
+            if (split_pair[j][m]) {
+              E1.ys_out = t1s; E1.ys_tp = split_image_tp(Tn); E1.ys_slope = E2.pre_slope;       // c2's input activation, applied once by the producer
+              conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, nullptr, Tn, E1);
+              ConvEpilogue E2s = E2; E2s.pre_act = ACT_NONE; E2s.xs_in = t1s; E2s.xs_tp = E1.ys_tp;
+              conv1d_run(st.rb[j].c2[m], s, nullptr, Tn, Tn, dst, Tn, E2s);
+            } else {
+              conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
+              conv1d_run(st.rb[j].c2[m], s, t1, Tn, Tn, dst, Tn, E2);
+            }
           }
           in = dst;
         }

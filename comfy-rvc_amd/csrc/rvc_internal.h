@@ -87,7 +87,17 @@ struct ConvEpilogue {
   float out_scale = 1.f; int accumulate = 0;
   const float* bias_override = nullptr;   // per-call bias vector replacing the layer's own (speaker conditioning)
   int tout_limit = 0;                     // >0: compute only the first tout_limit output positions
+  // split-resident activations (bf16x3 kernel only, conv_x3.hip): the tensor lives as the bf16 hi / lo image the kernel stages in LDS,
+  // [16-channel chunk][hi | lo][kSplitMargin + t][16 ch], written by the producer's epilogue (activation `ys_slope` already applied)
+  // and copied straight into LDS by the consumer (no conversion, no registers).  xs_in replaces X, ys_out replaces Y.
+  const unsigned char* xs_in = nullptr; long long xs_tp = 0;
+  unsigned char* ys_out = nullptr; long long ys_tp = 0; float ys_slope = 1.f;
 };
+constexpr int kSplitMargin = 64;                                                   // positions in front of t = 0 (covers every left halo)
+inline long long split_image_tp(long long T) { return (T + kSplitMargin + 640 + 31) & ~31LL; }   // rows per plane: margin + T + the last tile's overhang
+inline size_t split_image_bytes(int C, long long T) { return (size_t)(C / 16) * 2 * (size_t)split_image_tp(T) * 32; }
+// true when this layer at this length runs on the bf16x3 kernel with a tile that has the split-input / split-output paths
+bool conv1d_split_eligible(const ConvLayer& L, int Tin);
 
 // host-side packing + upload (weights in PyTorch layouts)
 void conv1d_layer_init(ConvLayer& L, const float* w /*[Co][Ci/groups][k]*/, const float* bias, int Co, int Ci, int k,
