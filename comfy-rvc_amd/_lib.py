@@ -86,6 +86,7 @@ SIGNATURES = {
     "rvc_crepe_destroy": (c_int, [c_void_p]),
     "rvc_crepe_num_frames": (c_int64, [c_int64, c_int, c_int]),
     "rvc_crepe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, P(CrepeTaps)]),
+    "rvc_crepe_viterbi": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "rvc_mdx23_create": (c_int, [c_void_p, P(Mdx23Config), P(c_void_p)]),
     "rvc_mdx23_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_mdx23_finalize": (c_int, [c_void_p]),

@@ -135,6 +135,92 @@ __global__ void crepe_pool_kernel(const float* __restrict__ in, long long ldin, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- Viterbi decoding (torchcrepe.decode.viterbi)
+// Masked softmax over the bins [lo, hi) of every frame (float32, like the torch original), log with the float32 "tiny" floor
+// (librosa.sequence.viterbi) - all frames in parallel - then one workgroup walks the frames: value[j] = logp[t][j] + max_k (value[k] + log A[k][j]) in float64 with the
+// triangular transition matrix A[i][j] = max(12 - |i - j|, 0) / row sum, whose band |i - j| <= 11 is all that can win (out-of-band
+// entries are log(2.2e-308) = -708 in librosa's dense form).  First maximum wins in ascending k, as np.argmax.  Back-pointers (int8
+// offsets) go to global memory; the backtrack re-reads them 32 frames at a time through LDS.
+// pass 1 (one wave per frame, all frames in parallel): logp[t][j] = log(softmax_j(masked probs)[j] + tiny32)
+__global__ __launch_bounds__(64) void crepe_logsoftmax_kernel(const float* __restrict__ probs, int n, int lo, int hi, float* __restrict__ logp) {
+  const int t = blockIdx.x, l = threadIdx.x;
+  float p[6]; float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const int j = l + 64 * i; p[i] = (j < 360 && j >= lo && j < hi) ? probs[(long long)j * n + t] : -INFINITY; mx = fmaxf(mx, p[i]); }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float e[6], sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { e[i] = p[i] == -INFINITY ? 0.f : expf(p[i] - mx); sm += e[i]; }
+  for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const int j = l + 64 * i; if (j < 360) logp[(long long)t * 360 + j] = logf(e[i] / sm + 1.17549435e-38f); }
+}
+// pass 2 (one workgroup): the recurrence, one barrier per frame
+__global__ __launch_bounds__(384) void crepe_viterbi_kernel(const float* __restrict__ probs, const float* __restrict__ logp, int n, signed char* __restrict__ ptr,
+                                                           int* __restrict__ bins, float* __restrict__ per) {
+  constexpr int NB = 360;
+  __shared__ double val[2][NB + 22];
+  __shared__ signed char pblk[32][NB];
+  __shared__ int cur;
+  const int j = threadIdx.x;
+  double lt[23];
+  if (j < NB) {
+    for (int d = -11; d <= 11; ++d) {
+      const int i = j + d;                      // source state
+      if (i < 0 || i >= NB) { lt[d + 11] = -1e300; continue; }
+      int rs = 0;
+      for (int k = max(0, i - 11); k <= min(NB - 1, i + 11); ++k) rs += 12 - abs(i - k);
+      lt[d + 11] = log((double)(12 - abs(d)) / (double)rs + 2.2250738585072014e-308);
+    }
+  }
+  for (int q = j; q < 2 * (NB + 22); q += blockDim.x) (&val[0][0])[q] = -1e300;
+  __syncthreads();
+  float lp_next = j < NB ? logp[j] : 0.f;
+  for (int t = 0; t < n; ++t) {
+    const double lp = (double)lp_next;
+    if (j < NB && t + 1 < n) lp_next = logp[(long long)(t + 1) * NB + j];          // next frame's row is in flight during this step
+    if (j < NB) {
+      double* vo = val[t & 1] + 11;
+      if (t == 0) vo[j] = lp + log(1.0 / NB + 2.2250738585072014e-308);
+      else {
+        const double* vi = val[(t - 1) & 1] + 11;
+        double best = -1e308; int bd = 0;
+#pragma unroll
+        for (int d = -11; d <= 11; ++d) { const double c = vi[j + d] + lt[d + 11]; if (c > best) { best = c; bd = d; } }
+        vo[j] = lp + best;
+        ptr[(long long)t * NB + j] = (signed char)bd;
+      }
+    }
+    __syncthreads();
+  }
+  // arg-max of the last frame (first maximum), then the backtrack
+  if (j == 0) {
+    const double* v = val[(n - 1) & 1] + 11;
+    int b = 0;
+    for (int k = 1; k < NB; ++k) if (v[k] > v[b]) b = k;
+    cur = b; bins[n - 1] = b; per[n - 1] = probs[(long long)b * n + (n - 1)];
+  }
+  __syncthreads();
+  for (int t1 = n - 1; t1 >= 1; t1 -= 32) {
+    const int cnt = min(32, t1);                               // frames t1, t1 - 1, ..., t1 - cnt + 1 hold the pointers into t - 1
+    for (int q = j; q < cnt * NB; q += blockDim.x) { const int r = q / NB, c = q - r * NB; pblk[r][c] = ptr[(long long)(t1 - r) * NB + c]; }
+    __syncthreads();
+    if (j == 0) {
+      int b = cur;
+      for (int r = 0; r < cnt; ++r) { b += pblk[r][b]; const int t = t1 - r - 1; bins[t] = b; per[t] = probs[(long long)b * n + t]; }
+      cur = b;
+    }
+    __syncthreads();
+  }
+}
+void crepe_viterbi(hipStream_t s, const float* probs, int n, int lo, int hi, int* bins, float* per) {
+  char* scr = (char*)stream_scratch(s, 3, (size_t)n * 360 * 5 + 256);
+  float* logp = (float*)scr;
+  signed char* ptr = (signed char*)(scr + (size_t)n * 360 * 4);
+  hipLaunchKernelGGL(crepe_logsoftmax_kernel, dim3((unsigned)n), dim3(64), 0, s, probs, n, lo, hi, logp);
+  hipLaunchKernelGGL(crepe_viterbi_kernel, dim3(1), dim3(384), 0, s, probs, logp, n, ptr, bins, per);
+}
+
 static int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
 
 // probabilities [360][n] (channel-major), frames in batches of at most `FB`

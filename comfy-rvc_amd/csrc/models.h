@@ -76,5 +76,6 @@ void crepe_finalize(Crepe* M);
 long long crepe_num_frames(long long L, int hop, int pad);
 void crepe_forward(Crepe* M, hipStream_t s, const float* audio, long long L, int hop, int pad, float* probs, const CrepeTaps* taps);
 size_t crepe_workspace(const Crepe* M);
+void crepe_viterbi(hipStream_t s, const float* probs, int n, int lo, int hi, int* bins, float* per);   // torchcrepe.decode.viterbi + periodicity
 
 }  // namespace rvc

@@ -160,6 +160,14 @@ int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio, int64_t L,
   RVC_CATCH
 }
 
+int rvc_crepe_viterbi(void* stream, const float* probs, int64_t n, int min_bin, int max_bin, int32_t* bins, float* periodicity) {
+  RVC_TRY
+  RVC_REQUIRE(probs && bins && periodicity && n > 0 && n < (1 << 24) && min_bin >= 0 && max_bin <= 360 && min_bin < max_bin, "bad argument");
+  crepe_viterbi((hipStream_t)stream, probs, (int)n, min_bin, max_bin, bins, periodicity);
+  check_launch();
+  RVC_CATCH
+}
+
 // ------------------------------------------------------------------------------------------------ mdx23c
 struct rvc_mdx23 { Mdx23* m; rvc_ctx* ctx; };
 int rvc_mdx23_create(rvc_ctx* ctx, const rvc_mdx23_config* cfg, rvc_mdx23** out) {

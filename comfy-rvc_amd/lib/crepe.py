@@ -1,11 +1,12 @@
 """CREPE pitch tracking on the HIP path: the part of `torchcrepe.predict` that the reference's f0 methods "crepe" / "mangio-crepe" /
 "crepe-tiny" / "mangio-crepe-tiny" rely on (reference pitch_extraction.py:76-150; torchcrepe is a third-party package, requirements.txt:24).
 
-The network (frame normalisation, six convolution blocks, classifier, sigmoid) runs as HIP kernels behind rvc_crepe_forward
-(csrc/model_crepe.hip); decoding happens at 100 fps on the host, where torchcrepe has it too (its Viterbi decoder is librosa's, on the
-CPU): bins outside [fmin, fmax) masked, softmax over bins, Viterbi with the triangular transition matrix, cents + triangular dither
-(scipy.stats.triang on numpy's global RNG, exactly the call torchcrepe makes), periodicity = probability at the decoded bin, and the
-NaN-aware median / mean filters.  torchcrepe's exact arithmetic cannot be checked offline: parity-unpinned; the restatement
+The network (frame normalisation, six convolution blocks, classifier, sigmoid) runs as HIP kernels behind rvc_crepe_forward and the
+decoder (bins outside [fmin, fmax) masked, softmax over bins, Viterbi with the triangular transition matrix, periodicity = probability
+at the decoded bin) behind rvc_crepe_viterbi (csrc/model_crepe.hip); torchcrepe decodes on the CPU with librosa's Viterbi.  What stays
+on the host is what depends on numpy's global RNG - cents + triangular dither (scipy.stats.triang, exactly the call torchcrepe makes) -
+and the NaN-aware median / mean filters over the 100 fps tracks.  `viterbi_bins` / `postprocess` below are the same decoder in numpy:
+they pin the device kernel in tests/test_hip_crepe.py and are themselves pinned to the oracle in tests/test_host_logic.py.  torchcrepe's exact arithmetic cannot be checked offline: parity-unpinned; the restatement
 follows torchcrepe 0.0.23.
 
 Weights: torchcrepe ships `full.pth` / `tiny.pth` inside its package; put them under `models/torchcrepe/` (or pass a state dict).
@@ -187,8 +188,18 @@ def predict(audio, sample_rate, hop_length=None, fmin=50., fmax=2006., model="fu
     a = a.reshape(1, -1) if a.dim() == 1 else a
     assert a.shape[0] == 1, "one clip per call"
     net = crepe if crepe is not None else _model_for(model, device)
-    probs = net.probabilities(a[0], hop_length, pad).cpu().numpy()
-    out = postprocess(probs, fmin, fmax, return_periodicity)
-    if return_periodicity:
-        return torch.from_numpy(out[0])[None], torch.from_numpy(np.ascontiguousarray(out[1]))[None]
-    return torch.from_numpy(out)[None]
+    probs = net.probabilities(a[0], hop_length, pad)
+    bins, per = viterbi_device(probs, frequency_to_bins(fmin), frequency_to_bins(fmax, ceil=True))
+    pitch = torch.from_numpy(bins_to_frequency(bins))[None]
+    return (pitch, torch.from_numpy(per)[None]) if return_periodicity else pitch
+
+
+def viterbi_device(probs, min_bin, max_bin):
+    """Masked softmax + Viterbi path + periodicity gather on the GPU (rvc_crepe_viterbi): probs device tensor [360, n] ->
+    (bins int64 [n], periodicity float32 [n]) numpy.  `viterbi_bins` / `postprocess` above are the same algorithm on the host."""
+    n = int(probs.shape[1])
+    bins = torch.empty(n, dtype=torch.int32, device=probs.device)
+    per = torch.empty(n, dtype=torch.float32, device=probs.device)
+    with torch.cuda.device(probs.device):
+        _lib.check(_lib.lib.rvc_crepe_viterbi(_lib.current_stream(), _lib.ptr(probs), n, int(min_bin), int(max_bin), _lib.ptr(bins), _lib.ptr(per)))
+    return bins.cpu().numpy().astype(np.int64), per.cpu().numpy()

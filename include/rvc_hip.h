@@ -108,6 +108,11 @@ int64_t rvc_crepe_num_frames(int64_t L, int hop, int pad);
  * (the mean / std normalisation of every frame, the six conv blocks and the classifier); decoding stays with the caller */
 int rvc_crepe_forward(rvc_crepe* c, void* stream, const float* audio_dev, int64_t L, int hop, int pad, float* probs_dev, const rvc_crepe_taps* taps);
 
+/* torchcrepe.decode.viterbi (its librosa.sequence.viterbi call included) and the periodicity gather of core.postprocess on the device:
+ * bins outside [min_bin, max_bin) are masked, softmax over bins, most likely path under the triangular (width 12) transition matrix with a
+ * uniform prior; bins_dev int32 [n], periodicity_dev [n] = probs[bin][frame].  Cents / dither / Hz stay on the host (numpy's RNG). */
+int rvc_crepe_viterbi(void* stream, const float* probs_dev, int64_t n, int min_bin, int max_bin, int32_t* bins_dev, float* periodicity_dev);
+
 /* ------------------------------------------------------------------ MDX23C vocal / instrumental separation (UVR chain) */
 /* Replaces TFC_TDF_net.forward of reference lib/karafan/tfc_tdf.py:147-235 (with its STFT / inverse, :47-77); demix_mdxv3's chunking
  * (lib/karafan/inference.py:32-74) calls it once per chunk.  Fields = the entries of the model's yaml that the network reads

@@ -39,6 +39,28 @@ def test_crepe_probabilities_match_oracle(nets, model, hop, pad, seconds):
     assert np.max(np.abs(p.T - ref)) < 1e-3                         # sigmoid outputs in [0, 1]; measured ~1e-5
 
 
+def test_device_viterbi_matches_host_decoding(nets):
+    """rvc_crepe_viterbi (masked softmax, banded Viterbi in float64, back-pointer walk, periodicity gather) against lib/crepe.py's host
+    implementation (itself pinned to the oracle's literal librosa restatement in tests/test_host_logic.py), on flat network output
+    and on a ridge that crosses most of the bin range, for two frequency windows."""
+    from comfy_rvc_amd.lib import crepe as pc
+    _, net = nets["tiny"]
+    flat = net.probabilities(S.synth_audio(9.0, seed=21), 160)                    # 901 frames
+    n = flat.shape[1]
+    centre = (180 + 150 * np.sin(np.arange(n) / 17.0)).astype(int)
+    ridge = torch.from_numpy(np.stack([0.02 + 0.9 * np.exp(-0.5 * ((np.arange(360) - c) / 2.0) ** 2) for c in centre]).astype(np.float32).T.copy()).cuda()
+    for P in (flat, ridge):
+        for fmin, fmax in ((50.0, 1600.0), (80.0, 700.0)):
+            lo, hi = pc.frequency_to_bins(fmin), pc.frequency_to_bins(fmax, ceil=True)
+            bins, per = pc.viterbi_device(P, lo, hi)
+            Ph = P.cpu().numpy()
+            pm = Ph.copy(); pm[:lo] = -np.inf; pm[hi:] = -np.inf
+            e = np.exp(pm - pm.max(axis=0, keepdims=True))
+            ref = pc.viterbi_bins((e / e.sum(axis=0, keepdims=True)).astype(np.float32))
+            assert bins.shape == ref.shape and (bins == ref).mean() >= 0.995, (bins != ref).sum()
+            assert np.array_equal(per, Ph[bins, np.arange(n)]) and bins.min() >= lo and bins.max() < hi
+
+
 def _fe(nets):
     from comfy_rvc_amd.config import Config
     from comfy_rvc_amd.lib.rmvpe import RMVPE
