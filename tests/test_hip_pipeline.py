@@ -330,10 +330,12 @@ def test_other_sample_rates_in_and_out(models):
 
 # ------------------------------------------------------------------ BASELINE.json's full-size configurations against the reference
 # Goldens: oracle/gen_golden.py full40 full48 full45 rmvpe60 (the REAL reference, real segmentation constants 1 / 6 / 38 / 41).
-# Gates: >= 99.5 % of the int16 samples within 33 LSB (1e-3 of full scale; the f0 passes through an arg-max, so single frames may
-# legitimately differ) AND the excluded samples are bounded: none further than FS_BOUND from the reference, 99.99 % within P9999_BOUND.
-FS_BOUND = 1640       # 5e-2 of full scale
-P9999_BOUND = 330     # 1e-2 of full scale
+# Gates: >= 99.99 % of the int16 samples within 33 LSB (1e-3 of full scale; the f0 passes through an arg-max, so a frame may legitimately
+# differ) AND the excluded samples are bounded: none further than FS_BOUND from the reference, the 99.99th percentile within 33 LSB.
+# Measured on MI355X (profiles/r2_fullsize_parity.json): every sample within 12 LSB, every f0 frame equal.
+FS_BOUND = 164        # 5e-3 of full scale
+P9999_BOUND = 33      # 1e-3 of full scale
+WITHIN = 0.9999
 
 
 def _fullsize(gname, syn_cfg, noise_tape, repeats=1):
@@ -379,7 +381,7 @@ def _fullsize(gname, syn_cfg, noise_tape, repeats=1):
                "voicing_equal": float(((cap["pitchf"][:n] > 0) == (g["pitchf"][:n] > 0)).mean())})
     record_parity(gname, st)
     assert st["f0_within_1e-3"] >= 0.995 and st["voicing_equal"] >= 0.999 and st["coarse_max_diff"] <= 1, st
-    assert st["within"] >= 0.995 and st["max"] <= FS_BOUND and st["p9999"] <= P9999_BOUND, st
+    assert st["within"] >= WITHIN and st["max"] <= FS_BOUND and st["p9999"] <= P9999_BOUND, st
     return g, wav, st
 
 
@@ -437,7 +439,7 @@ def test_c4_slice_eight_48k_clips_through_three_lanes(noise_tape):
     assert len({o.tobytes()[:4096] for o in outs}) == 8                          # eight different clips, eight different results
     st = parity_stats(outs[0], g["out_i16"], LSB)
     record_parity("c4_slice_clip0_through_lanes", st)
-    assert st["within"] >= 0.995 and st["max"] <= FS_BOUND and st["p9999"] <= P9999_BOUND, st
+    assert st["within"] >= WITHIN and st["max"] <= FS_BOUND and st["p9999"] <= P9999_BOUND, st
     for i in (0, 5):
         assert np.array_equal(lanes[2](clips[i], i), outs[i])
 
