@@ -22,6 +22,7 @@ struct Crepe {
   bool ready = false, tiny = false;
   int ch[6] = {1024, 128, 128, 128, 256, 512};
   ConvLayer conv[6], fc;
+  ConvLayer gemm[6];             // layers 5 and 6 (L = 16, 8 positions per frame) as GEMMs over an explicit im2col (K = 64 C_in)
   DevVec bn_a[6], bn_b[6];       // BatchNorm folded to y = a * x + b (applied after the ReLU, before the max-pool)
 };
 
@@ -35,7 +36,7 @@ Crepe* crepe_create(Ctx* ctx, int tiny) {
 }
 void crepe_set_tensor(Crepe* M, const char* name, const float* d, const long long* shape, int ndim) { M->ts.set(name, d, shape, ndim); }
 static void crepe_free(Crepe& M) {
-  for (int i = 0; i < 6; ++i) { conv_layer_free(M.conv[i]); M.bn_a[i].free_(); M.bn_b[i].free_(); }
+  for (int i = 0; i < 6; ++i) { conv_layer_free(M.conv[i]); conv_layer_free(M.gemm[i]); M.bn_a[i].free_(); M.bn_b[i].free_(); }
   conv_layer_free(M.fc);
 }
 void crepe_destroy(Crepe* M) { if (M) { crepe_free(*M); M->arena.release(); delete M; } }
@@ -51,6 +52,7 @@ void crepe_finalize(Crepe* M) {
     const HostTensor& w = ts.get(n + ".weight", {co, cin, k, 1});
     const HostTensor& b = ts.get(n + ".bias", {co});
     if (i == 0) conv1d_layer_init(M->conv[0], w.data.data(), b.data.data(), co, 512, 1, 1, 0, 1, 1);   // Linear(512 taps -> C1) over im2col columns
+    else if (i >= 4) conv1d_layer_init(M->gemm[i], w.data.data(), b.data.data(), co, cin * 64, 1, 1, 0, 1, 1);   // [Co][Ci][64] is already [Co][K]
     else conv1d_layer_init(M->conv[i], w.data.data(), b.data.data(), co, cin, 64, 1, 0, 1, 1);
     const HostTensor& g = ts.get(n + "_BN.weight", {co}); const HostTensor& be = ts.get(n + "_BN.bias", {co});
     const HostTensor& mu = ts.get(n + "_BN.running_mean", {co}); const HostTensor& var = ts.get(n + "_BN.running_var", {co});
@@ -221,6 +223,18 @@ void crepe_viterbi(hipStream_t s, const float* probs, int n, int lo, int hi, int
   hipLaunchKernelGGL(crepe_viterbi_kernel, dim3(1), dim3(384), 0, s, probs, logp, n, ptr, bins, per);
 }
 
+// im2col of a slot-layout tensor for the short late layers: col[(ci * 64 + t)][b * L + p] = x[ci][b * S + p + t]  (S = L + 63: the slots
+// already hold the zero padding).  With L = 16 / 8 positions per frame the dense 1-D convolution over the slots would spend (L + 63) / L =
+// 4.9x / 8.9x the MFMA work on columns that straddle two frames; the GEMM over K = 64 C_in does exactly the algorithmic work.
+__global__ void crepe_slot_im2col_kernel(const float* __restrict__ x, long long ldx, int S, int L, int C, int B, float* __restrict__ col) {
+  const long long N = (long long)B * L, tot = (long long)C * 64 * N, st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += st) {
+    const long long r = i / N, c = i - r * N;
+    const int ci = (int)(r >> 6), t = (int)(r & 63), b = (int)(c / L), pp = (int)(c - (long long)b * L);
+    col[i] = x[(long long)ci * ldx + (long long)b * S + pp + t];
+  }
+}
+
 static int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); }
 
 // probabilities [360][n] (channel-major), frames in batches of at most `FB`
@@ -231,7 +245,8 @@ static void crepe_graph(Crepe* M, hipStream_t s, Arena& A, const float* audio, l
   float* mean = A.alloc<float>((size_t)n);
   float* rstd = A.alloc<float>((size_t)n);
   if (!dry) hipLaunchKernelGGL(crepe_stats_kernel, dim3((unsigned)n), dim3(64), 0, s, audio, L, hop, off, (int)n, mean, rstd);
-  float* col = A.alloc<float>((size_t)512 * FB * 256);
+  const size_t colsz = std::max((size_t)512 * FB * 256, std::max((size_t)M->ch[3] * 64 * FB * 16, (size_t)M->ch[4] * 64 * FB * 8));
+  float* col = A.alloc<float>(colsz);
   size_t bufsz = (size_t)M->ch[0] * FB * 256;                      // largest activation: the dense first-layer output
   for (int i = 1; i < 6; ++i) bufsz = std::max(bufsz, (size_t)std::max(M->ch[i - 1], M->ch[i]) * FB * ((256 >> i) + 63));
   float* bufA = A.alloc<float>(bufsz + 64);
@@ -254,9 +269,17 @@ static void crepe_graph(Crepe* M, hipStream_t s, Arena& A, const float* audio, l
       const long long Tin = (long long)B * S, Tout = Tin - 63;
       hipLaunchKernelGGL(crepe_pool_kernel, dim3(grid_for((long long)M->ch[i - 1] * Tin)), dim3(256), 0, s, cur, ldin, Sin, Lin, M->bn_a[i - 1].p, M->bn_b[i - 1].p,
                          nxt, M->ch[i - 1], B, 0);                                    // [C_{i-1}][B * S] slots
-      conv1d_run(M->conv[i], s, nxt, Tin, (int)Tin, cur, Tin, Er);                   // [C_i][B * S - 63], frame b position p at b * S + p
+      if (i >= 4) {
+        // L = 16 / 8: GEMM over the explicit im2col; output dense [C_i][B * L] (frame b position p at b * L + p)
+        const long long N = (long long)B * Lo;
+        hipLaunchKernelGGL(crepe_slot_im2col_kernel, dim3(grid_for((long long)M->ch[i - 1] * 64 * N)), dim3(256), 0, s, nxt, Tin, S, Lo, M->ch[i - 1], B, col);
+        conv1d_run(M->gemm[i], s, col, N, (int)N, cur, N, Er);
+        ldin = N; Sin = Lo; Lin = Lo;
+      } else {
+        conv1d_run(M->conv[i], s, nxt, Tin, (int)Tin, cur, Tin, Er);                 // [C_i][B * S - 63], frame b position p at b * S + p
+        ldin = Tin; Sin = S; Lin = Lo;
+      }
       (void)Tout;
-      ldin = Tin; Sin = S; Lin = Lo;
     }
     hipLaunchKernelGGL(crepe_pool_kernel, dim3(grid_for((long long)M->ch[5] * B * 4)), dim3(256), 0, s, cur, ldin, Sin, Lin, M->bn_a[5].p, M->bn_b[5].p, flat,
                        M->ch[5], B, 1);                                               // [4 * C6][B], row = pos * C6 + c
