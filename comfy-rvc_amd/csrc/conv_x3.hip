@@ -302,34 +302,40 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
       const int toff = two_d ? (u / 3) * p.PW + (u % 3) : (st == 1 ? u * dil_eff : u / st);   // row offset inside the (phase) plane
       if (st > 1) xp += (u - toff * st) * Pm * 32;
       const unsigned char* wt = wb + cu * 2 * BM * 32;
-      u32x4 ah[AM], al[AM], bh[AN], bl[AN];
+      u32x4 ah[AM], al[AM];
 #pragma unroll
       for (int am = 0; am < AM; ++am) {
         ah[am] = *reinterpret_cast<const u32x4*>(wt + aoff[am]);
         al[am] = *reinterpret_cast<const u32x4*>(wt + BM * 32 + aoff[am]);
       }
+      // B operands in groups of at most four column blocks (eight-block tiles: 32 instead of 64 operand registers live at once)
+      constexpr int ANG = AN > 4 ? 4 : AN;
 #pragma unroll
-      for (int an = 0; an < AN; ++an) {
-        const int q = bq[an] + toff;
-        const int off = q * 32 + ((lh ^ (((q + sw0) >> 3) & 1)) << 4);
-        bh[an] = *reinterpret_cast<const u32x4*>(xp + off);
-        bl[an] = *reinterpret_cast<const u32x4*>(xp + xplane + off);
+      for (int a0 = 0; a0 < AN; a0 += ANG) {
+        u32x4 bh[ANG], bl[ANG];
+#pragma unroll
+        for (int an = 0; an < ANG; ++an) {
+          const int q = bq[a0 + an] + toff;
+          const int off = q * 32 + ((lh ^ (((q + sw0) >> 3) & 1)) << 4);
+          bh[an] = *reinterpret_cast<const u32x4*>(xp + off);
+          bl[an] = *reinterpret_cast<const u32x4*>(xp + xplane + off);
+        }
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+          for (int an = 0; an < ANG; ++an)
+            acc[am][a0 + an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][a0 + an], 0, 0, 0);
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+          for (int an = 0; an < ANG; ++an)
+            acc[am][a0 + an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][a0 + an], 0, 0, 0);
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+          for (int an = 0; an < ANG; ++an)
+            acc[am][a0 + an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][a0 + an], 0, 0, 0);
       }
-#pragma unroll
-      for (int am = 0; am < AM; ++am)
-#pragma unroll
-        for (int an = 0; an < AN; ++an)
-          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
-#pragma unroll
-      for (int am = 0; am < AM; ++am)
-#pragma unroll
-        for (int an = 0; an < AN; ++an)
-          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
-#pragma unroll
-      for (int am = 0; am < AM; ++am)
-#pragma unroll
-        for (int an = 0; an < AN; ++an)
-          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
     }
   };
 
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
       pe.Tout = min(p.Tout, n0 + BN - 2 * P2);               // columns without their full halo belong to the neighbouring tiles
       dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : 8)>(pe, acc, z, co0, n0, wm, wn, li, lh);
     } else {
-      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? 4 : (XSPLIT ? 4 : 8))>(p, acc, z, co0, n0, wm, wn, li, lh);
+      dense_epilogue<WM, WN, AM, AN, (AM * AN >= 8 ? (AN >= 8 ? 2 : 4) : (XSPLIT ? 4 : 8))>(p, acc, z, co0, n0, wm, wn, li, lh);
     }
   } else {
     // interleaved store of the ConvTranspose1d phases: row m = co * ostride + phase goes to Y[co][n * ostride + phase]
@@ -571,8 +577,11 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
     auto blocks = [&](int bm, int bn) { return (long long)((a.Co + bm - 1) / bm) * ((a.Tout + bn - 1) / bn); };
     if (wide_blk > 0 && a.stride == 1 && a.Wd == 0) {
       // (k <= 3 at 128+ channels is HBM-bound: three 128 x 128 workgroups per CU beat two wide ones, C128 k3 238 -> 219 us)
-      if (a.Co > 64 && blocks(128, 256) >= wide_blk && a.ktaps > 3) t = TileCfg{2, 2, 2, 4};
-      else if (a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
+      // (round 2, after the staging / epilogue changes and with split-resident inputs: the 64 x 256 tile at three workgroups per CU now
+      // beats 64 x 512 at two - C64 k7 205 -> 187 us - and a split-input consumer with k <= 7 prefers 128 x 128: 333 -> 317 us)
+      static const int wide64 = getenv("RVC_X3_WIDE64") ? atoi(getenv("RVC_X3_WIDE64")) : 0;
+      if (a.Co > 64 && blocks(128, 256) >= wide_blk && a.ktaps > 3 && !(xs && a.ktaps <= 7)) t = TileCfg{2, 2, 2, 4};
+      else if (wide64 && a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
   }
   if (const char* f = getenv("RVC_FORCE_TILE")) {
