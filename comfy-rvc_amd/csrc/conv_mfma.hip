@@ -453,8 +453,8 @@ static void upload_layer(ConvLayer& L, const std::vector<float>& packed, const f
 void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); dev_free(L.bd4_); L.Wd_ = L.bd_ = L.bd4_ = nullptr; L.Wx_ = nullptr; }
 
 // bf16x3 weight image (conv_x3.hip): every fp32 weight is split w = hi + lo (both bf16, round-to-nearest-even) and stored
-// [16-channel chunk][tap][hi|lo][CoPx rows][16 channels] with the two 8-channel halves of a row swapped when bit 3 of the row
-// is set, so that the LDS copy (a linear global_load_lds image) is conflict-free for ds_read_b128.
+// [16-channel chunk][tap][hi|lo][8-channel half][CoPx rows][8 channels]: 16-B rows per half-plane, which is the layout the kernel
+// keeps in LDS (conflict-free ds_read_b128 at any row offset without a swizzle).
 static uint16_t bf16_rne(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
@@ -476,10 +476,9 @@ static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
         const float v = w[((size_t)co * Ci + ci) * k + u];
         const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
         const int chunk = ci >> 4, c16 = ci & 15;
-        const size_t col = (size_t)((((c16 >> 3) ^ ((co >> 3) & 1)) << 3) + (c16 & 7));
-        const size_t base = ((size_t)chunk * k + u) * 2;
-        P[((base + 0) * L.CoPx + co) * 16 + col] = hi;
-        P[((base + 1) * L.CoPx + co) * 16 + col] = lo;
+        const size_t base = (((size_t)chunk * k + u) * 2 * 2 + (size_t)(c16 >> 3)) * L.CoPx + co;   // (chunk, tap, hi, half) plane, row co
+        P[base * 8 + (c16 & 7)] = hi;
+        P[(base + 2 * (size_t)L.CoPx) * 8 + (c16 & 7)] = lo;
       }
   RVC_HIP_CHECK(hipMalloc(&L.Wx_, P.size() * sizeof(uint16_t)));
   RVC_HIP_CHECK(hipMemcpy(L.Wx_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -554,6 +553,15 @@ void tconv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Ci,
   upload_layer(L, P, bias, Co);
 }
 
+void conv2d_kx_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci, int KH, int KW, int PH, int PWL) {
+  RVC_REQUIRE(Ci % 16 == 0 && KH >= 1 && KW >= 1 && PH >= 0 && PH < KH && PWL >= 0 && PWL < KW, "conv2d_kx: Ci must be a multiple of 16, padding inside the window");
+  L.mode = 2; L.groups = 1; L.Ci = Ci; L.Co = Co; L.co_real = Co; L.CoP = (Co + 31) & ~31;
+  L.k = KH * KW; L.stride = 1; L.dil = 1; L.pad = 0; L.tconv_u = 0; L.up2 = 0; L.ktaps = KH * KW;
+  L.kh = KH; L.kw = KW; L.ph = PH; L.pwl = PWL;
+  L.CK = 16; L.nchunk = Ci / 16; L.wBatch = 0;
+  pack_x3(L, w, Co, Ci, KH * KW);                          // [Co][Ci][KH * KW] is the tap order dh * KW + dw the kernel walks
+  L.bd_ = bias ? dev_upload(bias, Co) : nullptr;
+}
 void conv2d3x3_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci) {
   L.mode = 2; L.groups = 1; L.Ci = Ci; L.Co = Co; L.co_real = Co; L.CoP = (Co + 31) & ~31;
   L.k = 3; L.stride = 1; L.dil = 1; L.pad = 1; L.tconv_u = 0; L.up2 = 0; L.ktaps = 9;
@@ -669,7 +677,7 @@ static std::mutex g_prof_mu;
 static const char* kCfgNames[kProfCfgs] = {"1x4x1x4/1d", "1x4x1x2/1d", "1x4x1x1/1d", "2x2x2x2/1d", "2x2x1x4/1d", "2x2x1x2/1d", "2x2x1x1/1d",
                                            "1x4x1x4/2d", "1x4x1x2/2d", "1x4x1x1/2d", "2x2x2x2/2d", "2x2x1x4/2d", "2x2x1x2/2d", "2x2x1x1/2d",
                                            "1x4x1x4/x3", "1x4x1x2/x3", "1x4x1x1/x3", "2x2x2x2/x3", "2x2x1x4/x3", "2x2x1x2/x3", "2x2x1x1/x3",
-                                           "2x2x2x4/x3", "1x4x2x4/x3", ""};
+                                           "2x2x2x4/x3", "1x4x2x4/x3", "2x4x2x4/x3"};
 void conv_prof_enable(bool on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -963,6 +971,21 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
     }
   }
   if (!(L.Wx_ && !L.up2 && conv_x3_try(a, 1, s, flops))) run_conv(a, 2, 1, s, flops);
+}
+
+bool conv2d_kx_try(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY, const ConvEpilogue& e, bool dry) {
+  RVC_REQUIRE(L.mode == 2 && L.Wx_, "conv2d_kx_try on a layer without a bf16x3 image");
+  if ((Wd & (Wd - 1)) != 0 || Wd < 2 || !simple_act(e.act)) return false;
+  ConvArgsX a{};
+  a.X = X; a.W = nullptr; a.bias = L.bd_; a.Y = Y;
+  fill_epilogue(a, e);
+  a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = H; a.Tout = H * Wd; a.Wd = Wd; a.ktaps = L.ktaps; a.dil = 1; a.stride = 1; a.pad = 0;
+  a.KH = L.kh; a.KW = L.kw; a.PH = L.ph; a.PWL = L.pwl;
+  a.CK = 16; a.nchunk = L.nchunk;
+  a.ldX = ldX; a.ldY = ldY; a.up2 = 0; a.ostride = 1; a.orows = L.Co;
+  a.xBatch = a.wBatch = a.yBatch = a.rBatch = 0; a.bBatch = L.Co;
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.ktaps;
+  return conv_x3_try(a, 1, s, 2.0 * H * (double)Wd * L.ktaps * L.Ci * L.Co, dry);
 }
 
 }  // namespace rvc

@@ -8,10 +8,12 @@
 // Same GEMM view, tiles and epilogue as conv_mfma.hip (stride-1 1-D convolutions only):
 //   Y[m][n] = sum_{chunk, tap, c16} W[m][chunk*16 + c16][tap] * X[chunk*16 + c16][n - pad + tap*dil]
 // One MFMA consumes 16 channels of one tap: lane (i, half) holds channels half*8 .. half*8+7 of row / position i.
-// LDS images (16 channels = 32 B per row, the two 16-B halves swapped when bit 3 of the row index is set, which makes every
-// ds_read_b128 lane group hit 16 distinct slots for any tap offset):
-//   X: [chunk][hi|lo][position q][16 ch] bf16, converted from the fp32 [C][T] activation while staging (registers -> ds_write_b128)
-//   W: [chunk][tap][hi|lo][row m][16 ch] bf16, a linear copy of the host-packed image by global_load_lds_dwordx4 (no registers),
+// LDS images: the 16 channels of a row are kept as two half-planes of 8 channels = 16 B per row ([half][row][8 ch]).  Lane (i, half)
+// reads one 16-B row of its half-plane: the 16 lanes a ds_read_b128 services per LDS cycle ({0-3,12-15,20-27}, ...) touch 16 rows that
+// are distinct mod 16 = all 64 banks once, for ANY tap offset, and an operand address is base + row * 16 (one add per tap; round 1-2
+// kept 32-B rows with the halves swapped by bit 3 of the row index, which cost ~7 VALU per operand read to undo).
+//   X: [chunk][hi|lo][half][position q][8 ch] bf16, converted from the fp32 [C][T] activation while staging (registers -> ds_write_b128)
+//   W: [chunk][tap][hi|lo][half][row m][8 ch] bf16, copied from the host-packed image by global_load_lds_dwordx4 (no registers),
 //      double-buffered so that the DMA of stage s+1 runs under the MFMAs of stage s; one barrier per stage.
 // A stage is NC 16-channel chunks x KT taps: NC = 1 for the wide dilated kernels of the generator, up to 4 for k = 1 (GEMM).
 #include "conv_kernels.h"
@@ -40,7 +42,7 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset) {
 #endif
 
 // 8-float register slots for the prefetched input tile per tile width (checked against the launch geometry on the host)
-__host__ __device__ constexpr int x3_slots(int BN) { return BN >= 512 ? 7 : (BN >= 128 ? 5 : 2); }
+__host__ __device__ constexpr int x3_slots(int BN, int NW = 4) { return NW == 8 ? 3 : (BN >= 512 ? 7 : (BN >= 128 ? 5 : 2)); }
 
 __device__ __forceinline__ unsigned bf16_bits(__bf16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); }
 // (a, b) -> packed bf16 pairs hi = {bf16(a), bf16(b)} and lo = {bf16(a - hi_a), bf16(b - hi_b)}, round-to-nearest-even: 2 + 2 + 2 VALU
@@ -89,15 +91,20 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned total) {
 // XSPLIT: the input arrives as a split-resident image (ConvEpilogue::xs_in) and is copied into LDS by DMA; no staging registers.
 // YSPLIT: the output is written as a split-resident image (ConvEpilogue::ys_out) - separate instantiations, so that the plain kernels keep
 // their register budgets (the 128 x 128 tile its three workgroups per CU).
+// WM x WN = 4 waves (256 threads, two or three workgroups per CU) or 8 waves (512 threads, ONE workgroup per CU, two waves per SIMD: the
+// eight waves share one weight stream, so the L2 -> LDS traffic and the DMA issue per output halve against two 4-wave workgroups, and the
+// whole LDS of the CU is one workgroup's: 4-5 taps per stage instead of 1)
 template <int WM, int WN, int AM, int AN, bool FUSE = false, bool XSPLIT = false, bool YSPLIT = false>
-__global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !FUSE) ? 3 : 2) void conv_x3_kernel(const ConvArgsX p) {   // (128 x 128 tile: three workgroups per CU = 168 VGPRs)
-  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = XSPLIT ? 1 : ((FUSE && BM == 64) ? 7 : (FUSE ? 5 : x3_slots(BN))), RB = BM / 32;
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : ((WM == 2 && WN == 2 && AM == 2 && AN == 2 && !FUSE) ? 3 : 2)) void conv_x3_kernel(const ConvArgsX p) {   // (128 x 128 tile: three workgroups per CU = 168 VGPRs)
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, XS = XSPLIT ? 1 : ((FUSE && BM == 64) ? 7 : (FUSE ? 5 : x3_slots(BN, NW))), RB = BM / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
   const int P = p.WROW;                     // staged input positions: (BN - 1) * stride + (ktaps - 1) * dil + 1
   const int NC = p.NC;                      // 16-channel chunks per stage
   const int st = p.stride;                  // strided convs keep one sub-plane per input phase (position mod stride): unit-stride reads
-  const int Pm = XSPLIT ? ((P + 31) & ~31) : (P + st - 1) / st;   // rows per phase sub-plane (split-resident input: whole 1-KiB pieces)
+  const int Pm = XSPLIT ? ((P + 63) & ~63) : (P + st - 1) / st;   // rows per phase sub-plane (split-resident input: whole 1-KiB pieces of a half-plane)
   const int xplane = st * Pm * 32;          // bytes of one hi / lo plane
+  const int xhalf = xplane >> 1;            // ... of one of its two 8-channel half-planes
   const int xbuf = NC * 2 * xplane;         // bytes of one X buffer
   const int wbuf = NC * p.KT * 2 * BM * 32; // bytes of one weight buffer
   unsigned char* Xs = smem3;
@@ -132,11 +139,10 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
   const int g0 = ks * gps, g1 = min(ngroups, g0 + gps);
   const int nstages = max(g1 - g0, 0) * ntb;
   const int bx = n0 * st - p.pad - P2;                 // (fused: column 0 of the tile is the first column of the intermediate)
-  // split-resident input: LDS row q holds image row bx + q + margin, whose 16-B halves are swapped by bit 3 of THAT index
-  const int sw0 = XSPLIT ? ((bx + kSplitMargin) & 15) : 0;
   // 2-D 3x3 (p.Wd > 0): the tile is BH image rows x BWd columns; the staged "positions" are the (BH + 2) x PW halo patch in
   // row-major order, tap (dh, dw) is the position offset dh * PW + dw
   const bool two_d = p.Wd > 0;
+  const int kKW = p.KW > 0 ? p.KW : 3, kPH = p.KW > 0 ? p.PH : 1, kPWL = p.KW > 0 ? p.PWL : 1;   // 2-D window (default 3 x 3, pad 1)
   int h0 = 0, w0 = 0;
   if (two_d) { h0 = n0 / p.Wd; w0 = n0 - h0 * p.Wd; }
   const int ni = p.ni;                                                      // 64-position groups per plane row set
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
-      const int t = wave + 4 * s;
+      const int t = wave + NW * s;
       const int cc = (t >= 2 * ni) + (t >= 4 * ni) + (t >= 6 * ni);       // NC <= 4
       const int g = t - cc * 2 * ni;
       const int hb = g >= ni ? 1 : 0;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
       bool ok = cc < NC && q < P && x >= 0 && x < p.Tin;
       if (two_d) {
         const int rr = (int)__umulhi((unsigned)q, p.magPW), cw = q - rr * p.PW;
-        const int hh = h0 - 1 + rr, ww = w0 - 1 + cw;
+        const int hh = h0 - kPH + rr, ww = w0 - kPWL + cw;
         ok = cc < NC && q < P && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
         x = hh * p.Wd + ww;
       }
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
     unsigned char* xbase0 = Xs + xb * xbuf;
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
-      const int t = wave + 4 * s;
+      const int t = wave + NW * s;
       const int cc = (t >= 2 * ni) + (t >= 4 * ni) + (t >= 6 * ni);
       const int g = t - cc * 2 * ni;
       const int hb = g >= ni ? 1 : 0;
@@ -205,47 +211,48 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
           hi[j] = h_; lo[j] = l_;
         }
         int off;
-        if (st == 1) off = q * 32 + ((hb ^ ((q >> 3) & 1)) << 4);
+        if (st == 1) off = hb * xhalf + q * 16;
         else {
           const int m = st == 2 ? (q >> 1) : q / st, ph = q - m * st;
-          off = (ph * Pm + m) * 32 + ((hb ^ ((m >> 3) & 1)) << 4);
+          off = hb * xhalf + (ph * Pm + m) * 16;
         }
         *reinterpret_cast<u32x4*>(xbase + off) = hi;
         *reinterpret_cast<u32x4*>(xbase + xplane + off) = lo;
       }
     }
   };
-  // ---- split-resident input: the (chunk, hi | lo) planes of the tile are contiguous runs of the image: 1 KiB (32 positions) per
-  // wave-instruction straight into LDS.  Returns the number of pieces this wave issued.
+  // ---- split-resident input: every (chunk, hi | lo, half) half-plane of the tile is a contiguous run of the image: 1 KiB (64 positions)
+  // per wave-instruction straight into LDS.  Returns the number of pieces this wave issued.
   auto issue_x = [&](int grp, int xb) -> int {
     if constexpr (!XSPLIT) return 0;
     int lane = lane0;
     asm volatile("" : "+v"(lane));
-    const int ppp = xplane >> 10;                                   // pieces per plane (xplane is a multiple of 1 KiB)
-    const int npieces = NC * 2 * ppp;
-    for (int pi = wave; pi < npieces; pi += 4) {
-      const int pl = pi / ppp, j = pi - pl * ppp;                   // plane = (chunk in group) * 2 + (hi | lo)
-      const long long row = (long long)((grp * NC) * 2 + pl) * p.xsTp + (bx + kSplitMargin) + (long long)j * 32;
-      const unsigned char* src = p.Xs + row * 32 + lane * 16;
-      unsigned char* dst = Xs + xb * xbuf + pl * xplane + j * 1024;
+    const int pph = xhalf >> 10;                                    // pieces per half-plane (xhalf is a multiple of 1 KiB)
+    const int npieces = NC * 4 * pph;
+    for (int pi = wave; pi < npieces; pi += NW) {
+      const int hp = pi / pph, j = pi - hp * pph;                   // half-plane = ((chunk in group) * 2 + (hi | lo)) * 2 + half
+      const long long row = (long long)((grp * NC) * 4 + hp) * p.xsTp + (bx + kSplitMargin) + (long long)j * 64;
+      const unsigned char* src = p.Xs + row * 16 + lane * 16;
+      unsigned char* dst = Xs + xb * xbuf + hp * xhalf + j * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    return wave < npieces ? (npieces - wave + 3) >> 2 : 0;
+    return wave < npieces ? (npieces - wave + NW - 1) / NW : 0;
   };
   // rows of the staged tile that lie outside the sequence are the convolution's zero padding: the image holds no defined data there
   const bool x_edge = XSPLIT && (bx < 0 || bx + P > p.Tin);
   auto zero_edges = [&](int xb) {
-    for (int q = tid0; q < P; q += 256) {
+    for (int q = tid0; q < P; q += NT) {
       const int t = bx + q;
       if (t >= 0 && t < p.Tin) continue;
       for (int pl = 0; pl < NC * 2; ++pl) {
-        u32x4* r = reinterpret_cast<u32x4*>(Xs + xb * xbuf + pl * xplane + q * 32);
-        r[0] = u32x4{0u, 0u, 0u, 0u}; r[1] = u32x4{0u, 0u, 0u, 0u};
+        unsigned char* r = Xs + xb * xbuf + pl * xplane + q * 16;
+        *reinterpret_cast<u32x4*>(r) = u32x4{0u, 0u, 0u, 0u}; *reinterpret_cast<u32x4*>(r + xhalf) = u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
 
-  // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (32 rows) per wave-instruction
+  // ---- weight slab of (chunk, tap block): global -> LDS by DMA, 1 KiB (64 rows of one half-plane; BM = 32: both halves) per
+  // wave-instruction.  LDS 16-B row r of a (chunk, tap, hi | lo) plane is (half, m) = (r / BM, r % BM); the image keeps [half][CoPx rows].
   auto issue_w = [&](const unsigned char* __restrict__ Wimg, int grp, int tb, int buf) -> int {
 #ifdef RVC_X3_NOW
     return 0;
@@ -254,37 +261,42 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
     asm volatile("" : "+v"(lane));
     const int ut = min(p.KT, p.ktaps - tb * p.KT);
     const int npieces = NC * ut * 2 * RB;
+    auto lane_src = [&](int rblk) -> long long {                   // byte offset of this lane's row inside a plane of the image
+      const int r = rblk * 64 + lane;
+      return ((long long)(r / BM) * p.CoPx + co0 + (r % BM)) * 16;
+    };
     if (NC == 1 || ut == p.ktaps) {
       // the (chunk, tap, hi | lo) rows of this stage are consecutive in the image: piece pi = wave + 4 i is row j0 + i * (4 / RB), 32-row
       // block rblk - one multiply-add per piece instead of three integer divisions (the generic path below cost ~400 cycles per piece,
       // a fifth of a stage of the 128 x 256 tile)
-      constexpr int JS = 4 / RB;
-      const int j0 = RB == 4 ? 0 : (RB == 2 ? (wave >> 1) : wave), rblk = RB == 4 ? wave : (RB == 2 ? (wave & 1) : 0);
+      static_assert(NW % RB == 0, "row blocks per wave round");
+      constexpr int JS = NW / RB;
+      const int j0 = wave / RB, rblk = wave % RB;
       const long long row0 = (long long)((grp * NC) * p.ktaps + tb * p.KT) * 2 + j0;
-      const unsigned char* src = Wimg + (row0 * p.CoPx + co0 + rblk * 32) * 32 + lane * 16;
+      const unsigned char* src = Wimg + row0 * p.CoPx * 32 + lane_src(rblk);
       const long long sstep = (long long)JS * p.CoPx * 32;
       unsigned char* dst = Ws + buf * wbuf + wave * 1024;
-      for (int pi = wave; pi < npieces; pi += 4, src += sstep, dst += 4096)
+      for (int pi = wave; pi < npieces; pi += NW, src += sstep, dst += NW * 1024)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     } else
-    for (int pi = wave; pi < npieces; pi += 4) {
+    for (int pi = wave; pi < npieces; pi += NW) {
       const int j = pi / RB, rblk = pi - j * RB;            // j = ((chunk in group) * ut + tap in block) * 2 + (hi | lo)
       const int cc = j / (2 * ut), jr = j - cc * 2 * ut;
-      const long long row = ((long long)((grp * NC + cc) * p.ktaps + tb * p.KT + (jr >> 1)) * 2 + (jr & 1)) * p.CoPx + co0 + rblk * 32;
-      const unsigned char* src = Wimg + row * 32 + lane * 16;
+      const long long row = (long long)((grp * NC + cc) * p.ktaps + tb * p.KT + (jr >> 1)) * 2 + (jr & 1);
+      const unsigned char* src = Wimg + row * p.CoPx * 32 + lane_src(rblk);
       unsigned char* dst = Ws + buf * wbuf + pi * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    return wave < npieces ? (npieces - wave + 3) >> 2 : 0;
+    return wave < npieces ? (npieces - wave + NW - 1) / NW : 0;
   };
 
   int aoff[AM], bq[AN];
 #pragma unroll
-  for (int am = 0; am < AM; ++am) { const int m = (wm * AM + am) * 32 + li; aoff[am] = m * 32 + ((lh ^ ((m >> 3) & 1)) << 4); }
+  for (int am = 0; am < AM; ++am) { const int m = (wm * AM + am) * 32 + li; aoff[am] = lh * (BM * 16) + m * 16; }
 #pragma unroll
   for (int an = 0; an < AN; ++an) {
     const int nl = (wn * AN + an) * 32 + li;
-    bq[an] = two_d ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl;
+    bq[an] = (two_d ? (nl / p.BWd) * p.PW + (nl % p.BWd) : nl) * 16 + lh * xhalf;      // byte offset of this lane's row in its half-plane
   }
 
   // ---- MFMAs of one stage: NC chunks x ut taps of weight buffer `buf` against input buffer `xb`
@@ -294,13 +306,13 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
 #ifdef RVC_X3_NOMFMA
     for (int cu = 0; cu < 0; ++cu) {
 #else
-    for (int cu = 0; cu < NC * ut; ++cu) {
+    for (int cu = 0, cc = 0, uu = 0; cu < NC * ut; ++cu, cc += (uu + 1 == ut), uu = (uu + 1 == ut) ? 0 : uu + 1) {
 #endif
-      const int cc = cu / ut, uu = cu - cc * ut;
       const unsigned char* xp = Xs + xb * xbuf + cc * 2 * xplane;
       const int u = tb * p.KT + uu;
-      const int toff = two_d ? (u / 3) * p.PW + (u % 3) : (st == 1 ? u * dil_eff : u / st);   // row offset inside the (phase) plane
-      if (st > 1) xp += (u - toff * st) * Pm * 32;
+      const int toff = two_d ? (u / kKW) * p.PW + (u % kKW) : (st == 1 ? u * dil_eff : u / st);   // row offset inside the (phase) plane
+      if (st > 1) xp += (u - toff * st) * Pm * 16;
+      xp += toff * 16;
       const unsigned char* wt = wb + cu * 2 * BM * 32;
       u32x4 ah[AM], al[AM];
 #pragma unroll
@@ -315,8 +327,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
         u32x4 bh[ANG], bl[ANG];
 #pragma unroll
         for (int an = 0; an < ANG; ++an) {
-          const int q = bq[a0 + an] + toff;
-          const int off = q * 32 + ((lh ^ (((q + sw0) >> 3) & 1)) << 4);
+          const int off = bq[a0 + an];
           bh[an] = *reinterpret_cast<const u32x4*>(xp + off);
           bl[an] = *reinterpret_cast<const u32x4*>(xp + xplane + off);
         }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
               hl[2 + e2] = bf16_bits(al) | (bf16_bits(bl) << 16);
             }
             const int cc = mb >> 4, hb = (mb >> 3) & 1;
-            unsigned char* row = Xs + cc * 2 * xplane + nl * 32 + ((hb ^ ((nl >> 3) & 1)) << 4) + lh * 8;
+            unsigned char* row = Xs + cc * 2 * xplane + hb * xhalf + nl * 16 + lh * 8;
             *reinterpret_cast<unsigned long long*>(row) = (unsigned long long)hl[0] | ((unsigned long long)hl[1] << 32);
             *reinterpret_cast<unsigned long long*>(row + xplane) = (unsigned long long)hl[2] | ((unsigned long long)hl[3] << 32);
           }
@@ -475,7 +486,6 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
         const int n = n0 + (wn * AN + an) * 32 + li;
         const int mb = co0 + (wm * AM + am) * 32;
         const long long pos = (long long)n + kSplitMargin;
-        const int hsel = (lh ^ (int)((pos >> 3) & 1)) << 4;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
           unsigned hA[2], lA[2], hB[2], lB[2];
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(256, (WM == 2 && WN == 2 && AM == 2 && AN == 2 && !
           }
           if (n < p.Tout && mb + 16 * g2 < p.Co) {
             const long long chunk = (mb >> 4) + g2;
-            unsigned char* row = p.Ys + ((chunk * 2) * p.ysTp + pos) * 32 + hsel;
+            unsigned char* row = p.Ys + ((chunk * 4 + lh) * p.ysTp + pos) * 16;     // [chunk][hi | lo][half][position][8 ch]
             *reinterpret_cast<u32x4*>(row) = hi;
             *reinterpret_cast<u32x4*>(row + p.ysTp * 32) = lo;
           }
@@ -553,7 +563,7 @@ static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) 
   auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE, XSPLIT, YSPLIT>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
 }
 
 bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry) {
@@ -561,7 +571,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   const bool xs = a0.Xs != nullptr;
   if ((xs || a0.Ys) && (a0.Wd > 0 || a0.stride != 1 || a0.ostride != 1 || (a0.Co & 31) || batch != 1)) return false;
   if (xs && a0.pre_act != ACT_NONE) return false;                     // the producer applied the activation
-  if (a0.Wd > 0 && (a0.ktaps != 9 || a0.stride != 1)) return false;
+  const int KH2 = a0.KW > 0 ? a0.KH : 3, KW2 = a0.KW > 0 ? a0.KW : 3;
+  if (a0.Wd > 0 && (a0.ktaps != KH2 * KW2 || a0.stride != 1)) return false;
   if ((a0.stride != 1 && a0.dil != 1) || a0.up2 || (a0.ostride != 1 && a0.R) || (a0.Ci & 15) || batch != 1) return false;
   if (!(a0.act == ACT_NONE || a0.act == ACT_LRELU || a0.act == ACT_RELU) || !(a0.pre_act == ACT_NONE || a0.pre_act == ACT_LRELU)) return false;
   if ((double)a0.orows * (double)a0.ldY * 4.0 >= 2147483648.0 || (double)a0.orows * (double)a0.ldR * 4.0 >= 2147483648.0 ||
@@ -580,6 +591,11 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       // (round 2, after the staging / epilogue changes and with split-resident inputs: the 64 x 256 tile at three workgroups per CU now
       // beats 64 x 512 at two - C64 k7 205 -> 187 us - and a split-input consumer with k <= 7 prefers 128 x 128: 333 -> 317 us)
       static const int wide64 = getenv("RVC_X3_WIDE64") ? atoi(getenv("RVC_X3_WIDE64")) : 0;
+      // 8-wave workgroups (128 x 512 tile, one per CU): RVC_X3_W8 = minimum tap count that takes them (0 = never)
+      static const int w8_taps = getenv("RVC_X3_W8") ? atoi(getenv("RVC_X3_W8")) : 0;
+      static const int w8_blk = getenv("RVC_X3_W8_BLK") ? atoi(getenv("RVC_X3_W8_BLK")) : 400;
+      if (w8_taps > 0 && a.Co > 64 && a.ktaps >= w8_taps && blocks(128, 512) >= w8_blk) t = TileCfg{2, 4, 2, 4};
+      else
       if (a.Co > 64 && blocks(128, 256) >= wide_blk && a.ktaps > 3 && !(xs && a.ktaps <= 7)) t = TileCfg{2, 2, 2, 4};
       else if (wide64 && a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
@@ -590,8 +606,10 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   int id = tile_cfg_id(t);
   if (t.WM == 2 && t.WN == 2 && t.AM == 2 && t.AN == 4) id = 7;
   if (t.WM == 1 && t.WN == 4 && t.AM == 2 && t.AN == 4) id = 8;
+  if (t.WM == 2 && t.WN == 4 && t.AM == 2 && t.AN == 4) id = 9;
+  const int NW = t.WM * t.WN;
   if (id < 0) return false;
-  if ((xs || a0.Ys) && !(id == 3 || id == 4 || id == 7 || id == 8)) return false;   // tiles instantiated with the split-resident paths
+  if ((xs || a0.Ys) && !(id == 3 || id == 4 || id == 7 || id == 8 || id == 9)) return false;   // tiles instantiated with the split-resident paths
   if (xs && a0.Ys) return false;                                                    // (one side at a time so far)
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
@@ -602,22 +620,23 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1;
   if (a.Wd > 0) {
     // tile = whole image rows or a power-of-two fraction of one row (Wd is a power of two)
-    a.BWd = BN < a.Wd ? BN : a.Wd; a.BH = BN < a.Wd ? 1 : BN / a.Wd; a.PW = a.BWd + 2;
-    P = (a.BH + 2) * a.PW;
+    a.BWd = BN < a.Wd ? BN : a.Wd; a.BH = BN < a.Wd ? 1 : BN / a.Wd; a.PW = a.BWd + KW2 - 1;
+    P = (a.BH + KH2 - 1) * a.PW;
     a.magPW = (unsigned)((0x100000000ULL + a.PW - 1) / a.PW);
   }
-  const int Pm = xs ? ((P + 31) & ~31) : (P + a.stride - 1) / a.stride;
+  const int Pm = xs ? ((P + 63) & ~63) : (P + a.stride - 1) / a.stride;
   a.ni = (P + 63) / 64;
   const int nchunk = a.Ci / 16;
   // chunks per stage: short reductions per chunk (k <= 3) take several chunks per stage so that a stage outlasts its DMA
   int NC = a.ktaps == 1 ? 4 : (a.ktaps <= 3 ? 2 : 1);
-  while (NC > 1 && (nchunk % NC != 0 || (!xs && (NC * 2 * a.ni + 3) / 4 > x3_slots(BN)))) NC >>= 1;
-  if (!xs && (NC * 2 * a.ni + 3) / 4 > x3_slots(BN)) return false;
+  while (NC > 1 && (nchunk % NC != 0 || (!xs && (NC * 2 * a.ni + NW - 1) / NW > x3_slots(BN, NW)))) NC >>= 1;
+  if (!xs && (NC * 2 * a.ni + NW - 1) / NW > x3_slots(BN, NW)) return false;
   // LDS budget per workgroup: 53 KiB = three workgroups per CU for the tiles whose registers allow it (<= 170 VGPRs), two for the
   // 8-accumulator tiles.  Measured: occupancy matters more than stage length (one 156 KiB workgroup per CU with 3x longer stages:
   // +32 % time; three 128x128 workgroups instead of two: -12 %).  X double-buffered when that still leaves >= 2 taps per stage.
   static const int budget_kb = getenv("RVC_X3_LDS_KB") ? atoi(getenv("RVC_X3_LDS_KB")) : 53;
-  const int budget = budget_kb * 1024;
+  static const int budget8_kb = getenv("RVC_X3_LDS8_KB") ? atoi(getenv("RVC_X3_LDS8_KB")) : 156;   // 8-wave workgroups own the CU's LDS
+  const int budget = (NW == 8 ? budget8_kb : budget_kb) * 1024;
   // weight slabs: a ring of NS: the DMA of a slab is issued NS - 1 stages before its MFMAs, waited for with a counted vmcnt and published
   // with a barrier that does not drain the queue.  Measured: NS = 3 / 4 lose to NS = 2 (C128 k11 490 vs 433 us): the LDS they take
   // halves the taps per stage, and the per-stage costs (DMA issue, barrier) outweigh the ~400 cycles of DMA wait they would hide.
@@ -666,6 +685,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       case 3: launch_x3<2, 2, 2, 2, false, true>(a, grid, lds, s); break;
       case 4: launch_x3<2, 2, 1, 4, false, true>(a, grid, lds, s); break;
       case 7: launch_x3<2, 2, 2, 4, false, true>(a, grid, lds, s); break;
+      case 9: launch_x3<2, 4, 2, 4, false, true>(a, grid, lds, s); break;
       default: launch_x3<1, 4, 2, 4, false, true>(a, grid, lds, s); break;
     }
   } else if (a.Ys) {
@@ -673,6 +693,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       case 3: launch_x3<2, 2, 2, 2, false, false, true>(a, grid, lds, s); break;
       case 4: launch_x3<2, 2, 1, 4, false, false, true>(a, grid, lds, s); break;
       case 7: launch_x3<2, 2, 2, 4, false, false, true>(a, grid, lds, s); break;
+      case 9: launch_x3<2, 4, 2, 4, false, false, true>(a, grid, lds, s); break;
       default: launch_x3<1, 4, 2, 4, false, false, true>(a, grid, lds, s); break;
     }
   } else
@@ -685,6 +706,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
     case 5: launch_x3<2, 2, 1, 2>(a, grid, lds, s); break;
     case 7: launch_x3<2, 2, 2, 4>(a, grid, lds, s); break;
     case 8: launch_x3<1, 4, 2, 4>(a, grid, lds, s); break;
+    case 9: launch_x3<2, 4, 2, 4>(a, grid, lds, s); break;
     default: launch_x3<2, 2, 1, 1>(a, grid, lds, s); break;
   }
   if (S > 1) splitk_reduce_launch(a, S, 1, s);

@@ -59,6 +59,7 @@ struct ConvArgs {
   float out_scale; int accumulate;                       // y = [y +] out_scale * v
   int ostride, orows;                                    // 1-D interleaved store: m -> (co = m % orows, r = m / orows); addr = co*ldY + n*ostride + r
   int up2;                                               // 2-D: ConvTranspose 2x2 phase interleave
+  int KH, KW, PH, PWL;                                   // 2-D window (0 = 3 x 3, pad 1): taps KH x KW, zero padding PH rows above / PWL columns left
 };
 
 // A convolution layer with its weights packed for the kernel and resident on the device.
@@ -75,6 +76,7 @@ struct ConvLayer {
   int up2 = 0;             // 2-D ConvTranspose (k3 s2 p1 op1) as 4 phase convs
   int conv_pad = 0;        // ConvTranspose1d: left pad of the equivalent stride-1 conv
   long long wBatch = 0;    // packed elements per group
+  int kh = 3, kw = 3, ph = 1, pwl = 1;   // 2-D window (conv2d_kx_layer_init; the 3 x 3 layers keep the defaults)
   uint16_t* Wx_ = nullptr; // bf16x3 split image (conv_x3.hip), null when the layer only runs on the fp32 kernel
   int CoPx = 0; long long wxBatch = 0;
 };
@@ -88,13 +90,13 @@ struct ConvEpilogue {
   const float* bias_override = nullptr;   // per-call bias vector replacing the layer's own (speaker conditioning)
   int tout_limit = 0;                     // >0: compute only the first tout_limit output positions
   // split-resident activations (bf16x3 kernel only, conv_x3.hip): the tensor lives as the bf16 hi / lo image the kernel stages in LDS,
-  // [16-channel chunk][hi | lo][kSplitMargin + t][16 ch], written by the producer's epilogue (activation `ys_slope` already applied)
+  // [16-channel chunk][hi | lo][8-channel half][kSplitMargin + t][8 ch], written by the producer's epilogue (activation `ys_slope` already applied)
   // and copied straight into LDS by the consumer (no conversion, no registers).  xs_in replaces X, ys_out replaces Y.
   const unsigned char* xs_in = nullptr; long long xs_tp = 0;
   unsigned char* ys_out = nullptr; long long ys_tp = 0; float ys_slope = 1.f;
 };
 constexpr int kSplitMargin = 64;                                                   // positions in front of t = 0 (covers every left halo)
-inline long long split_image_tp(long long T) { return (T + kSplitMargin + 640 + 31) & ~31LL; }   // rows per plane: margin + T + the last tile's overhang
+inline long long split_image_tp(long long T) { return (T + kSplitMargin + 704 + 63) & ~63LL; }   // rows per plane: margin + T + the last tile's overhang
 inline size_t split_image_bytes(int C, long long T) { return (size_t)(C / 16) * 2 * (size_t)split_image_tp(T) * 32; }
 // true when this layer at this length runs on the bf16x3 kernel with a tile that has the split-input / split-output paths
 bool conv1d_split_eligible(const ConvLayer& L, int Tin);
@@ -106,6 +108,9 @@ void tconv1d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][k]*/, const floa
 void conv2d3x3_layer_init(ConvLayer& L, const float* w /*[Co][Ci][3][3]*/, const float* bias, int Co, int Ci);
 void conv2d1x1_layer_init(ConvLayer& L, const float* w /*[Co][Ci]*/, const float* bias, int Co, int Ci);
 void tconv2d_layer_init(ConvLayer& L, const float* w /*[Ci][Co][3][3]*/, const float* bias, int Ci, int Co);
+// general KH x KW window with asymmetric zero padding, bf16x3 kernel only (no fp32 twin): conv2d_kx_try returns false when the
+// geometry does not fit the kernel's tile / LDS limits (callers keep another formulation for that case); dry = eligibility only
+void conv2d_kx_layer_init(ConvLayer& L, const float* w /*[Co][Ci][KH][KW]*/, const float* bias, int Co, int Ci, int KH, int KW, int PH, int PWL);
 void conv_layer_free(ConvLayer& L);
 // Layers initialised while this is on also get a bf16x3 split weight image and run on conv_x3_kernel when eligible
 // (stride 1, groups 1, Ci % 16 == 0): 3 bf16 MFMAs per fp32 product, fp32 accumulate, ~1e-5 relative error.
@@ -133,6 +138,9 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
 // 2-D: X [Ci][H][Wd], Y [Co][H][Wd] (or [Co][2H][2Wd] for up2).
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
                 const ConvEpilogue& e);
+
+bool conv2d_kx_try(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY, const ConvEpilogue& e,
+                   bool dry = false);
 
 // fused multi-head attention (attention.hip): Q, K channel-major [heads*64][T], V row-major [T][heads*64], out channel-major
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,

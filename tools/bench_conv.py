@@ -28,6 +28,17 @@ for name, Ci, Co, Tin, k, s, d in CASES:
     y = torch.empty(Co, Tout, device="cuda"); r = torch.randn(Co, Tout, device="cuda")
     run = lambda: L.check(L.lib.rvc_conv1d_plan_run(plan, None, L.ptr(x), Tin, None if NORES else L.ptr(r), L.ptr(y), 1, 0.1, 0, 0.0))
     run(); torch.cuda.synchronize()
+    if os.environ.get('BENCH_CHECK') == '1' and s == 1:
+        # value check of the first / last 3000 output columns against a float64 CPU convolution of the matching input slices
+        import torch.nn.functional as F
+        W = 3000; halo = pad + 8
+        xc = x.double().cpu(); wc = torch.from_numpy(w).double(); rc = r.double().cpu(); yc = y.double().cpu()
+        for lo, hi in ((0, W), (Tout - W, Tout)):
+            a0, a1 = max(lo - halo, 0), min(hi + halo, Tin)
+            ref = F.conv1d(F.leaky_relu(xc[None, :, a0:a1], 0.1), wc, padding=pad, dilation=d)[0]   # plan_run: pre-activation leaky ReLU 0.1
+            ref = ref[:, lo - a0: lo - a0 + (hi - lo)] + (0 if NORES else rc[:, lo:hi])
+            err = (yc[:, lo:hi] - ref).abs().max().item() / ref.abs().max().item()
+            print(f"      check cols {lo}:{hi}  rel err {err:.2e}")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): run()

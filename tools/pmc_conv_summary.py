@@ -1,0 +1,14 @@
+"""Averages the counters of tools/pmc_conv.sh over the dispatches of the convolution kernel (the longest-running kernel family of the run)."""
+import csv, glob, sys
+from collections import defaultdict
+pre = sys.argv[1]
+tot = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for f in sorted(glob.glob(pre + "*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "conv_x3_kernel" not in k and "conv_mfma_kernel" not in k: continue
+        a = tot[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+for k, cs in tot.items():
+    print(k)
+    for c, (n, v) in cs.items():
+        print(f"  {c:42s} {v / n:16.1f}   (n={n})")
