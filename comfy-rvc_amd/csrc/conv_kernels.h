@@ -142,6 +142,9 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s);
 // bf16x3 path: returns false when the layer / geometry is not eligible (caller falls back to the fp32 kernel)
 bool conv_x3_try(ConvArgsX& a, int batch, hipStream_t s, double flops, bool dry = false);
 bool conv_x3_enabled();
+// software-pipelined kernel for stride-1 1-D convolutions on 2 x 2-wave tiles (conv_x3p.hip); `a` as conv_x3_try prepared it
+bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry);
+int conv_x3p_check_read();
 // y = (x + c2(lrelu(c1(lrelu(x))))) * scale [+ y] for a ResBlock1 pair of narrow layers in ONE launch; false when not eligible
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
                       const ConvEpilogue& e2);

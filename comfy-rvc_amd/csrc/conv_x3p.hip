@@ -1,0 +1,400 @@
+// Software-pipelined bf16x3 split-MFMA Conv1d for the stride-1 convolutions of the generator (gfx950 only).
+//
+// Same arithmetic, LDS / image layouts and epilogues as conv_x3.hip (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, half-plane
+// rows); what differs is the order in which ONE WAVE does its work.  Measured on the staged kernel (C128 k11, 128 x 256 tiles): a
+// workgroup alone on a CU needs 241 k cycles for 67.6 k cycles of MFMA issue - a wave issues in order, and every (chunk, tap) unit was
+// DMA issue -> wait -> barrier -> address arithmetic -> operand reads -> wait -> 24 MFMAs, with the tile's input conversion, its first
+// loads and its residual reads in bursts in between; a second workgroup on the CU hides part of that (338 k for two tiles), a third
+// does not fit the registers.  Here the unit is the pipeline stage and nothing waits for what it has just asked for:
+//   * the three MFMA groups of a unit run in the order (hi_w * lo_x), (lo_w * hi_x), (hi_w * hi_x); the operands of the second group
+//     are requested before the first is issued, those of the NEXT unit's first group before the third (one spare register set for the
+//     hi weights): every ds_read_b128 has a group of 8 MFMAs (256 cycles) to land;
+//   * weights go through a ring of 3 - 4 single-unit slots, requested 2 - 3 units ahead by LDS-DMA; one barrier per unit, between the
+//     second and the third group, publishes the next unit's slot while MFMAs are still queued;
+//   * the fp32 input of chunk c + 1 is converted and stored one 8-channel x 64-position slot at a time, spread over the units of chunk
+//     c, and the slot's registers are refilled at once with chunk c + 2 (a whole chunk of latency); split-resident inputs are DMA'd
+//     a chunk ahead;
+//   * residual + bias are loaded straight into the accumulators at the start of the tile (when no activation sits between them and
+//     the sum), so the epilogue is a burst of stores with no load in front of it.
+#include "conv_x3_dev.h"
+
+namespace rvc {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int T, int N, class F> __device__ __forceinline__ void static_for(F& f) {
+  if constexpr (T < N) { f(std::integral_constant<int, T>{}); static_for<T + 1, N>(f); }
+}
+#ifdef RVC_X3P_CHECK
+__device__ int g_x3p_bad;       // waits whose compile-time count exceeded the exact run-time one (must stay 0)
+int conv_x3p_check_read() { int v = 0, z = 0; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_x3p_bad), sizeof(int)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3p_bad), &z, sizeof(int)); return v; }
+#define X3P_CHECK(N, exact) do { if ((N) > (exact) && (threadIdx.x & 63) == 0) atomicAdd(&g_x3p_bad, 1); } while (0)
+#else
+int conv_x3p_check_read() { return -1; }
+#define X3P_CHECK(N, exact) do {} while (0)
+#endif
+
+// KT = taps (compile-time: the units of a chunk are unrolled, so every vmcnt wait is an immediate - see the counting rules at the waits).
+template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
+__global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(const ConvArgsX p) {
+  constexpr int WM = 2, WN = 2, NW = 4;
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
+  constexpr int R = (AM == 2 && AN == 4) ? 4 : 3;           // weight slots in the ring (LDS of two / three workgroups per CU)
+  constexpr int XS = 3;                                     // fp32 staging slots per wave (8 channels x 64 positions each): P <= 384
+  constexpr int NPW = 2 * RB / NW;                          // weight pieces per unit and wave (BM = 64: 1, BM = 128: 2)
+  constexpr int NPX = (BN + 64) / 64;                       // split-resident input: pieces per chunk and wave (Pm = BN + 64)
+  constexpr int wslot = 2 * BM * 32;                        // bytes of one weight slot: [hi | lo][half][BM rows][16 B]
+  static_assert(RB == 2 || RB == 4, "64- or 128-row tiles");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3p[];
+  const int P = p.WROW;                                     // staged input positions: BN + (KT - 1) * dil
+  const int Pm = XSPLIT ? BN + 64 : P;
+  const int xplane = Pm * 32, xhalf = xplane >> 1, xbuf = 2 * xplane;
+  unsigned char* Xs = smem3p;
+  unsigned char* Ws = smem3p + ((2 * xbuf + 1023) & ~1023);
+
+  const int tid0 = threadIdx.x;
+  int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned tile = p.xcd_remap ? xcd_tile(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y) : blockIdx.x + blockIdx.y * gridDim.x;
+  const int tile_y = (int)(tile / gridDim.x), tile_x = (int)(tile - (unsigned)tile_y * gridDim.x);
+  const int co0 = tile_y * BM, n0 = tile_x * BN;
+  const int nck = p.nchunk;                                  // >= 3 (host)
+  const int bx = n0 - p.pad;
+  const int ni = p.ni;                                       // 64-position groups of the staged row
+  const int dil16 = p.dil * 16;
+  const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, XSPLIT ? 0u : (unsigned)p.Ci * (unsigned)p.ldX * 4u);
+
+  // ---- accumulators: zero, or residual + bias when nothing but the scale follows the sum (the loads are the oldest VMEM operations of
+  // the wave; their latency lies under the prologue's input loads and first weight slots)
+  const bool r_init = !YSPLIT && p.R != nullptr && p.act == ACT_NONE;
+  f32x16 acc[AM][AN];
+  if (r_init) {
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.R, (unsigned)p.orows * (unsigned)p.ldR * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (p.bias && m < p.Co) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          acc[am][an][r] = buf_load(rrs, (m < p.Co && n < p.Tout) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB) + bv;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+  }
+
+#ifdef RVC_X3P_CHECK
+  int issued = 0, mk_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mk_x[XS] = {0, 0, 0}, mk_xs = 0;   // exact bookkeeping (debug build only)
+#define X3P_ISSUED(n) (issued += (n))
+#else
+#define X3P_ISSUED(n) do {} while (0)
+#endif
+
+  // ---- weights: unit u = (chunk, tap) is 2 * RB pieces of 1 KiB; consecutive units are consecutive planes of the image
+  const unsigned char* wsrc;
+  {
+    const int hl0 = wave / RB, r0 = (wave % RB) * 64 + lane;
+    wsrc = p.Wx + (long long)hl0 * p.CoPx * 32 + ((long long)(r0 / BM) * p.CoPx + co0 + (r0 % BM)) * 16;
+  }
+  const long long wstep = (long long)p.CoPx * 64;            // one unit = hi + lo planes
+  int slw = 0;                                               // slot of the next unit to request
+#ifdef RVC_X3P_CHECK
+  int uw = 0;
+#endif
+  auto issue_w = [&]() {
+    unsigned char* dst = Ws + slw * wslot + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if constexpr (RB == 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)p.CoPx * 32),
+                                       (__attribute__((address_space(3))) void*)(dst + NW * 1024), 16, 0, 0);
+    wsrc += wstep; slw = slw + 1 == R ? 0 : slw + 1;
+    X3P_ISSUED(NPW);
+#ifdef RVC_X3P_CHECK
+    mk_w[uw & 7] = issued; ++uw;
+#endif
+  };
+
+  // ---- fp32 input: slot s of this wave = 8 channels (one half-plane) x 64 positions of the staged tile.  Slots beyond the tile are
+  // loaded through out-of-range offsets (no memory traffic) so that every wave issues the same number of operations.
+  float xr[XS][8];
+  auto slot_geom = [&](int s, int& hb, int& q) -> bool {
+    const int t = wave + NW * s;
+    hb = t >= ni ? 1 : 0;
+    q = (t - hb * ni) * 64 + lane;
+    return t < 2 * ni && q < P;
+  };
+  auto load_slot = [&](int s, int chunk) {
+    int hb, q;
+    const bool ok = slot_geom(s, hb, q);
+    const int x = bx + q;
+    const unsigned voff = (ok && x >= 0 && x < p.Tin) ? (unsigned)x * 4u : kOOB;
+    const unsigned c0 = (unsigned)(chunk * 16 + hb * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xr[s][j] = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
+    X3P_ISSUED(8);
+#ifdef RVC_X3P_CHECK
+    mk_x[s] = issued;
+#endif
+  };
+  auto store_slot = [&](int s, int xb) {
+    int hb, q;
+    if (slot_geom(s, hb, q)) {
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = xr[s][2 * j], b = xr[s][2 * j + 1];
+        unsigned h_, l_;
+        split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);       // input activation: leaky ReLU (slope 1 = identity)
+        hi[j] = h_; lo[j] = l_;
+      }
+      unsigned char* d = Xs + xb * xbuf + hb * xhalf + q * 16;
+      *reinterpret_cast<u32x4*>(d) = hi;
+      *reinterpret_cast<u32x4*>(d + xplane) = lo;
+    }
+  };
+  // ---- split-resident input: chunk -> X buffer by DMA, 1 KiB (64 positions of one half-plane) per wave-instruction, NPX per wave
+  auto issue_x = [&](int chunk, int xb) {
+    constexpr int pph = (BN + 64) / 64;                          // pieces per half-plane
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int pi = wave + NW * i;
+      const int hp = pi / pph, j = pi - hp * pph;               // half-plane = (hi | lo) * 2 + half
+      const long long row = (long long)(chunk * 4 + hp) * p.xsTp + (bx + kSplitMargin) + (long long)j * 64;
+      const unsigned char* src = p.Xs + row * 16 + lane * 16;
+      unsigned char* dst = Xs + xb * xbuf + hp * xhalf + j * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    X3P_ISSUED(NPX);
+#ifdef RVC_X3P_CHECK
+    mk_xs = issued;
+#endif
+  };
+  const bool x_edge = XSPLIT && (bx < 0 || bx + P > p.Tin);
+  auto zero_edges = [&](int xb) {                                // rows outside the sequence are the convolution's zero padding
+    for (int q = tid0; q < P; q += NW * 64) {
+      const int t = bx + q;
+      if (t >= 0 && t < p.Tin) continue;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        unsigned char* r = Xs + xb * xbuf + pl * xplane + q * 16;
+        *reinterpret_cast<u32x4*>(r) = u32x4{0u, 0u, 0u, 0u}; *reinterpret_cast<u32x4*>(r + xhalf) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+
+  // ---- operand addresses: lane (i, half) reads the 16-B row i of its half-plane; column / row blocks are 512 B apart
+  const int aoff = lh * (BM * 16) + ((wm * AM) * 32 + li) * 16;
+  const int boff = lh * xhalf + ((wn * AN) * 32 + li) * 16;
+
+  // ---- prologue.  Issue order (the waits below count on it): [residual] input of chunk 0 | weight units 0 .. R - 2 | input of chunk 1
+  if constexpr (XSPLIT) {
+    issue_x(0, 0);
+  } else {
+#pragma unroll
+    for (int s = 0; s < XS; ++s) load_slot(s, 0);
+  }
+  issue_w(); issue_w();
+  if constexpr (R > 3) issue_w();
+  if constexpr (XSPLIT) {
+    issue_x(1, 1);
+    wait_vmcnt<(R - 2) * NPW + NPX>();                           // chunk 0 and unit 0 have landed (younger: units 1 .. R - 2, chunk 1)
+  } else {
+    wait_vmcnt<(R - 1) * NPW>();                                 // chunk 0's loads (younger: the weight units)
+#pragma unroll
+    for (int s = 0; s < XS; ++s) store_slot(s, 0);
+#pragma unroll
+    for (int s = 0; s < XS; ++s) load_slot(s, 1);
+    wait_vmcnt<(R - 2) * NPW + 8 * XS>();                        // unit 0 (younger: units 1 .. R - 2, chunk 1's loads)
+  }
+#pragma unroll
+  for (int am = 0; am < AM; ++am)
+#pragma unroll
+    for (int an = 0; an < AN; ++an) asm volatile("" : "+v"(acc[am][an]));     // (the residual loads are complete from here on: no wait for them inside the loop)
+  lds_barrier();
+  if (x_edge) { zero_edges(0); lds_barrier(); }
+
+  u32x4 ah[AM], ahn[AM], al[AM], bh[AN], bl[AN];
+  {
+    const unsigned char* wa = Ws + aoff;
+    const unsigned char* xa = Xs + boff;
+#pragma unroll
+    for (int am = 0; am < AM; ++am) ah[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+    for (int an = 0; an < AN; ++an) bl[an] = *reinterpret_cast<const u32x4*>(xa + xplane + an * 512);
+  }
+
+  int sl = 0;                                                    // weight slot of the current unit
+  for (int c = 0; c < nck; ++c) {
+    const int xb = c & 1;
+    const bool tail2 = c + 2 >= nck, tail1 = c + 1 >= nck;       // no chunk c + 2 / c + 1
+    auto unit = [&](auto tc) {
+      constexpr int T = decltype(tc)::value;
+      // ---- operands of the second group
+      {
+        const unsigned char* wa = Ws + sl * wslot + BM * 32 + aoff;
+        const unsigned char* xa = Xs + xb * xbuf + T * dil16 + boff;
+#pragma unroll
+        for (int am = 0; am < AM; ++am) al[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) bh[an] = *reinterpret_cast<const u32x4*>(xa + an * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 1: hi_w * lo_x
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
+      // ---- input of chunk c + 1: slot s is converted and stored during tap (s * KT) / XS, its registers refilled with chunk c + 2
+      if constexpr (!XSPLIT) {
+        auto stage = [&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if constexpr ((s * KT) / XS == T) {
+            if (!tail1) {
+              // operations issued after this slot's loads: chunk 0 - the later slots of the prologue's batch, one unit of weights per tap so
+              // far, the refills of the earlier slots; otherwise KT units of weights and the refills of the other slots (of the later
+              // ones only when chunk c + 1 is the last)
+              constexpr int T0 = 8 * (XS - 1) + NPW * T, TS = NPW * KT + 8 * (XS - 1), TL = NPW * KT + 8 * (XS - 1 - s);
+              if (c == 0) { X3P_CHECK(T0, issued - mk_x[s]); wait_vmcnt<T0>(); }
+              else if (tail2) { X3P_CHECK(TL, issued - mk_x[s]); wait_vmcnt<TL>(); }
+              else { X3P_CHECK(TS, issued - mk_x[s]); wait_vmcnt<TS>(); }
+              store_slot(s, xb ^ 1);
+              if (!tail2) load_slot(s, c + 2);
+            }
+          }
+        };
+        static_for<0, XS>(stage);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 2: lo_w * hi_x
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- next unit: its weight slot (and, at a chunk boundary, its input buffer) published; the slot of unit u - 1 refilled
+      constexpr bool last_tap = T + 1 == KT;
+      if (!(last_tap && tail1)) {
+        // operations issued after the pieces of unit u + 1 (requested R - 2 units ago): unit u + 2 (R = 4) and the input traffic of the
+        // window - fp32: a slot refill (8 loads) in every unit that converts one; split: the chunk pieces issued after a last tap
+        constexpr bool cvT = ((0 * KT) / XS == T) || ((1 * KT) / XS == T) || ((2 * KT) / XS == T);
+        constexpr int Tp = T == 0 ? KT - 1 : T - 1;
+        constexpr bool cvP = ((0 * KT) / XS == Tp) || ((1 * KT) / XS == Tp) || ((2 * KT) / XS == Tp);
+        constexpr int SX = XSPLIT ? ((R > 3 ? NPW : 0) + ((T == 0 || (R > 3 && T == 1)) ? NPX : 0))
+                                  : ((R > 3 ? NPW + (cvP ? 8 : 0) : 0) + (cvT ? 8 : 0));
+        // chunk 0: the prologue requested chunk 1's input in one batch after the weight units
+        constexpr int S0 = XSPLIT ? SX : (T == 0 ? (R > 3 ? NPW : 0) + 8 * XS + (cvT ? 8 : 0)
+                                                 : ((R > 3 && T == 1) ? 8 * XS + 8 + NPW + (cvT ? 8 : 0) : SX));
+        // last two chunks (fp32) / last chunk (split): no input traffic any more; the last units request no weights either
+        constexpr int SL = (R > 3 && T + 2 < KT) ? NPW : 0, SL2 = R > 3 ? NPW : 0;
+#ifdef RVC_X3P_CHECK
+        const int exact = issued - mk_w[(c * KT + T + 1) & 7];
+#endif
+        if (tail1) { X3P_CHECK(SL, exact); wait_vmcnt<SL>(); }
+        else if (XSPLIT ? false : tail2) { X3P_CHECK(SL2, exact); wait_vmcnt<SL2>(); }
+        else if (c == 0) { X3P_CHECK(S0, exact); wait_vmcnt<S0>(); }
+        else { X3P_CHECK(SX, exact); wait_vmcnt<SX>(); }
+        lds_barrier();
+        const int sn = sl + 1 == R ? 0 : sl + 1;
+        if (XSPLIT && last_tap && x_edge) { zero_edges(xb ^ 1); lds_barrier(); }
+        if (!(tail1 && T + R - 1 >= KT)) issue_w();               // unit u + R - 1 into the slot unit u - 1 was read from
+        if constexpr (XSPLIT && last_tap) { if (!tail2) issue_x(c + 2, xb); }   // this chunk's buffer is free: every wave is past its last read
+        const unsigned char* wa = Ws + sn * wslot + aoff;
+        const unsigned char* xa = Xs + (last_tap ? xb ^ 1 : xb) * xbuf + xplane + (last_tap ? 0 : (T + 1) * dil16) + boff;
+#pragma unroll
+        for (int am = 0; am < AM; ++am) ahn[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) bl[an] = *reinterpret_cast<const u32x4*>(xa + an * 512);
+        sl = sn;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 3: hi_w * hi_x
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am) ah[am] = ahn[am];
+    };
+    static_for<0, KT>(unit);
+  }
+
+  // ---- epilogue
+  if constexpr (YSPLIT) {
+    ysplit_epilogue<WM, WN, AM, AN>(p, acc, co0, n0, wm, wn, li, lh);
+  } else if (r_init) {
+    ConvArgsX pe = p;
+    pe.R = nullptr; pe.bias = nullptr;                            // already inside the accumulators
+    dense_epilogue<WM, WN, AM, AN, 4>(pe, acc, 0, co0, n0, wm, wn, li, lh);
+  } else {
+    dense_epilogue<WM, WN, AM, AN, 4>(p, acc, 0, co0, n0, wm, wn, li, lh);
+  }
+}
+
+// ============================================================================ host side
+template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
+static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_x3p_kernel<AM, AN, KT, XSPLIT, YSPLIT>;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
+template <int AM, int AN, int KT>
+static void launch_x3p_io(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (a.Xs) launch_x3p<AM, AN, KT, true, false>(a, grid, lds, s);
+  else if (a.Ys) launch_x3p<AM, AN, KT, false, true>(a, grid, lds, s);
+  else launch_x3p<AM, AN, KT, false, false>(a, grid, lds, s);
+}
+template <int AM, int AN>
+static void launch_x3p_k(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (a.ktaps == 3) launch_x3p_io<AM, AN, 3>(a, grid, lds, s);
+  else if (a.ktaps == 7) launch_x3p_io<AM, AN, 7>(a, grid, lds, s);
+  else launch_x3p_io<AM, AN, 11>(a, grid, lds, s);
+}
+
+// a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the geometry is not the
+// pipelined kernel's (the staged kernel takes it): kernel sizes 3 / 7 / 11 (the generator's), at least three 16-channel chunks.
+bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry) {
+  static const int on = getenv("RVC_X3P") ? atoi(getenv("RVC_X3P")) : 1;
+  if (!on) return false;
+  const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
+  if (a.Wd > 0 || a.stride != 1 || a.ostride != 1 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
+  if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
+  if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
+  const int BM = 64 * AM, BN = 64 * AN;
+  const int P = BN + (a.ktaps - 1) * a.dil;
+  if (P > 384 || P > BN + 64) return false;                       // three staging slots per wave; split input: BN + 64 rows per half-plane
+  const int Pm = xs ? BN + 64 : P;
+  const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
+  const int wslot = 2 * BM * 32;
+  const int R = (AM == 2 && AN == 4) ? 4 : 3;
+  const size_t lds = (size_t)xbytes + (size_t)R * wslot;
+  if (lds > (size_t)(AM * AN >= 8 ? 80 : 53) * 1024) return false;   // two / three workgroups per CU
+  if (dry) return true;
+  a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  a.xcd_remap = xcd_env;
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1);
+  grid_out = grid;
+  if (AM == 2 && AN == 4) launch_x3p_k<2, 4>(a, grid, lds, s);
+  else if (AM == 1 && AN == 4) launch_x3p_k<1, 4>(a, grid, lds, s);
+  else launch_x3p_k<2, 2>(a, grid, lds, s);
+  return true;
+}
+
+}  // namespace rvc

@@ -470,5 +470,6 @@ int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) { RVC_T
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
+int rvc_debug_x3p_check(void) { return conv_x3p_check_read(); }
 
 }  // extern "C"

@@ -283,6 +283,9 @@ const char* rvc_prof_cfg_name(int i);
 int rvc_prof_dump_csv(const char* path);
 /* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
 int rvc_debug_conv_timing(uint64_t* out8, int reset);
+/* debug builds only (-DRVC_X3P_CHECK): number of waits of the pipelined bf16x3 kernel whose compile-time vmcnt exceeded the exact
+ * run-time count since the last call (must be 0); -1 in ordinary builds */
+int rvc_debug_x3p_check(void);
 
 #ifdef __cplusplus
 }
