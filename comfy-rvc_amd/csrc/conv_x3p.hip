@@ -18,7 +18,19 @@
 //     the sum), so the epilogue is a burst of stores with no load in front of it.
 #include "conv_x3_dev.h"
 
+#ifndef RVC_X3P_R24
+#define RVC_X3P_R24 4          // weight ring slots of the 128 x 256 tile (two workgroups per CU: 80 KB each)
+#endif
+
 namespace rvc {
+
+// conversion schedule: slot s (of XS) of the next chunk is converted during tap (s * KT) / XS
+constexpr int x3p_cv(int t, int KT, int XS) {
+  t = ((t % KT) + KT) % KT;
+  for (int s = 0; s < XS; ++s) if ((s * KT) / XS == t) return 1;
+  return 0;
+}
+constexpr int x3p_cvsum(int t0, int t1, int KT, int XS) { int n = 0; for (int t = t0; t <= t1; ++t) n += x3p_cv(t, KT, XS); return n; }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
@@ -36,12 +48,27 @@ int conv_x3p_check_read() { return -1; }
 #define X3P_CHECK(N, exact) do {} while (0)
 #endif
 
+#ifdef RVC_CONV_TIMING
+__device__ unsigned long long g_x3p_timing[8];   // [0] tiles, [1] prologue, [2] compute between barriers, [3] weight wait, [4] barrier, [5] epilogue, [6] total
+void conv_x3p_timing_read(unsigned long long* out8, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x3p_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3p_timing), z, sizeof(z)); }
+}
+#define XPTICK() ((long long)__builtin_readcyclecounter())
+#define XPACC(i, v) do { xpt[i] += (v); } while (0)
+#else
+void conv_x3p_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 8; ++i) out8[i] = 0; }
+#define XPTICK() 0ll
+#define XPACC(i, v) do {} while (0)
+#endif
+
 // KT = taps (compile-time: the units of a chunk are unrolled, so every vmcnt wait is an immediate - see the counting rules at the waits).
 template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
 __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(const ConvArgsX p) {
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
-  constexpr int R = (AM == 2 && AN == 4) ? 4 : 3;           // weight slots in the ring (LDS of two / three workgroups per CU)
+  constexpr int R = (AM == 2 && AN == 4) ? RVC_X3P_R24 : 3;  // weight slots in the ring (LDS of two / three workgroups per CU)
   constexpr int XS = 3;                                     // fp32 staging slots per wave (8 channels x 64 positions each): P <= 384
   constexpr int NPW = 2 * RB / NW;                          // weight pieces per unit and wave (BM = 64: 1, BM = 128: 2)
   constexpr int NPX = (BN + 64) / 64;                       // split-resident input: pieces per chunk and wave (Pm = BN + 64)
@@ -69,6 +96,11 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, XSPLIT ? 0u : (unsigned)p.Ci * (unsigned)p.ldX * 4u);
 
+#ifdef RVC_CONV_TIMING
+  long long xpt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const long long t_begin = XPTICK();
+  long long t_last = t_begin;
   // ---- accumulators: zero, or residual + bias when nothing but the scale follows the sum (the loads are the oldest VMEM operations of
   // the wave; their latency lies under the prologue's input loads and first weight slots)
   const bool r_init = !YSPLIT && p.R != nullptr && p.act == ACT_NONE;
@@ -206,8 +238,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
 #pragma unroll
     for (int s = 0; s < XS; ++s) load_slot(s, 0);
   }
-  issue_w(); issue_w();
-  if constexpr (R > 3) issue_w();
+#pragma unroll
+  for (int i = 0; i < R - 1; ++i) issue_w();
   if constexpr (XSPLIT) {
     issue_x(1, 1);
     wait_vmcnt<(R - 2) * NPW + NPX>();                           // chunk 0 and unit 0 have landed (younger: units 1 .. R - 2, chunk 1)
@@ -237,6 +269,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   }
 
   int sl = 0;                                                    // weight slot of the current unit
+  t_last = XPTICK(); XPACC(1, t_last - t_begin);
   for (int c = 0; c < nck; ++c) {
     const int xb = c & 1;
     const bool tail2 = c + 2 >= nck, tail1 = c + 1 >= nck;       // no chunk c + 2 / c + 1
@@ -291,24 +324,27 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
       if (!(last_tap && tail1)) {
         // operations issued after the pieces of unit u + 1 (requested R - 2 units ago): unit u + 2 (R = 4) and the input traffic of the
         // window - fp32: a slot refill (8 loads) in every unit that converts one; split: the chunk pieces issued after a last tap
-        constexpr bool cvT = ((0 * KT) / XS == T) || ((1 * KT) / XS == T) || ((2 * KT) / XS == T);
-        constexpr int Tp = T == 0 ? KT - 1 : T - 1;
-        constexpr bool cvP = ((0 * KT) / XS == Tp) || ((1 * KT) / XS == Tp) || ((2 * KT) / XS == Tp);
-        constexpr int SX = XSPLIT ? ((R > 3 ? NPW : 0) + ((T == 0 || (R > 3 && T == 1)) ? NPX : 0))
-                                  : ((R > 3 ? NPW + (cvP ? 8 : 0) : 0) + (cvT ? 8 : 0));
-        // chunk 0: the prologue requested chunk 1's input in one batch after the weight units
-        constexpr int S0 = XSPLIT ? SX : (T == 0 ? (R > 3 ? NPW : 0) + 8 * XS + (cvT ? 8 : 0)
-                                                 : ((R > 3 && T == 1) ? 8 * XS + 8 + NPW + (cvT ? 8 : 0) : SX));
+        // General R: the pieces of unit u + 1 were requested R - 2 units ago; younger are units u + 2 .. u + R - 2 and the input traffic
+        // issued since: fp32 - the refill (8 loads) of every converting unit u - (R - 3) .. u; split - the chunk pieces that follow the
+        // weight request of a last tap, i.e. when this tap is one of 0 .. R - 3.
+        constexpr int SX = (R - 3) * NPW + (XSPLIT ? (T <= R - 3 ? NPX : 0) : 8 * x3p_cvsum(T - (R - 3), T, KT, XS));
+        // chunk 0, units 0 .. R - 3: their weights were requested in the prologue, before chunk 1's input batch
+        constexpr int S0 = (XSPLIT || T > R - 3) ? SX : (R - 3) * NPW + 8 * XS + 8 * x3p_cvsum(0, T, KT, XS);
         // last two chunks (fp32) / last chunk (split): no input traffic any more; the last units request no weights either
-        constexpr int SL = (R > 3 && T + 2 < KT) ? NPW : 0, SL2 = R > 3 ? NPW : 0;
+        constexpr int nyw = KT - 2 - T < 0 ? 0 : (KT - 2 - T > R - 3 ? R - 3 : KT - 2 - T);
+        constexpr int SL = nyw * NPW, SL2 = (R - 3) * NPW;
 #ifdef RVC_X3P_CHECK
         const int exact = issued - mk_w[(c * KT + T + 1) & 7];
 #endif
+        const long long ta = XPTICK();
         if (tail1) { X3P_CHECK(SL, exact); wait_vmcnt<SL>(); }
         else if (XSPLIT ? false : tail2) { X3P_CHECK(SL2, exact); wait_vmcnt<SL2>(); }
         else if (c == 0) { X3P_CHECK(S0, exact); wait_vmcnt<S0>(); }
         else { X3P_CHECK(SX, exact); wait_vmcnt<SX>(); }
+        const long long tb = XPTICK();
         lds_barrier();
+        const long long tcc = XPTICK();
+        XPACC(2, ta - t_last); XPACC(3, tb - ta); XPACC(4, tcc - tb); t_last = tcc;
         const int sn = sl + 1 == R ? 0 : sl + 1;
         if (XSPLIT && last_tap && x_edge) { zero_edges(xb ^ 1); lds_barrier(); }
         if (!(tail1 && T + R - 1 >= KT)) issue_w();               // unit u + R - 1 into the slot unit u - 1 was read from
@@ -335,6 +371,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   }
 
   // ---- epilogue
+  const long long t_epi = XPTICK();
+  XPACC(2, t_epi - t_last);
   if constexpr (YSPLIT) {
     ysplit_epilogue<WM, WN, AM, AN>(p, acc, co0, n0, wm, wn, li, lh);
   } else if (r_init) {
@@ -344,6 +382,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   } else {
     dense_epilogue<WM, WN, AM, AN, 4>(p, acc, 0, co0, n0, wm, wn, li, lh);
   }
+#ifdef RVC_CONV_TIMING
+  { const long long te = XPTICK(); XPACC(5, te - t_epi); XPACC(6, te - t_begin); XPACC(0, 1);
+    if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_x3p_timing[i], (unsigned long long)xpt[i]); }
+#endif
 }
 
 // ============================================================================ host side
@@ -382,7 +424,7 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   const int Pm = xs ? BN + 64 : P;
   const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
   const int wslot = 2 * BM * 32;
-  const int R = (AM == 2 && AN == 4) ? 4 : 3;
+  const int R = (AM == 2 && AN == 4) ? RVC_X3P_R24 : 3;
   const size_t lds = (size_t)xbytes + (size_t)R * wslot;
   if (lds > (size_t)(AM * AN >= 8 ? 80 : 53) * 1024) return false;   // two / three workgroups per CU
   if (dry) return true;

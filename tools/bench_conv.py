@@ -49,6 +49,8 @@ for name, Ci, Co, Tin, k, s, d in CASES:
     tm = (C.c_uint64 * 8)(); L.lib.rvc_debug_conv_timing(tm, 1)
     if tm[0]:
         nb = tm[0]; print("      per block cycles: " + "  ".join(f"{n} {tm[i]/nb:.0f}" for i, n in ((1,"prologue+barrier"),(2,"xstore"),(7,"dmawait"),(3,"issue"),(4,"mfma"),(5,"epilogue"),(6,"total"))) + f"  blocks/launch {nb/(reps+1):.0f}")
+    if tm[0] and os.environ.get('BENCH_X3P_TIMING') == '1':
+        nb = tm[0]; print("      x3p per tile cycles: " + "  ".join(f"{n} {tm[i]/nb:.0f}" for i, n in ((1,"prologue"),(2,"compute"),(3,"wwait"),(4,"barrier"),(5,"epilogue"),(6,"total"))))
     bad = L.lib.rvc_debug_x3p_check()
     if bad > 0: print(f"      !!! x3p wait check: {bad} waits with a too large compile-time count")
     elif bad == 0: print("      x3p wait check ok")

@@ -1,4 +1,4 @@
-# SQ / TA / TCP counters of ONE convolution shape under tools/bench_conv.py (separate rocprofv3 passes of 8 counters each):
+# SQ / L2 counters (the TA / TCP derived sums take minutes per pass on this pool: left out) of ONE convolution shape under tools/bench_conv.py (separate rocprofv3 passes of 8 counters each):
 #   bash tools/pmc_conv.sh "C128 k11" tag [ENV=VAL ...]     -> gpurun_out/pmcconv_<tag>.txt
 sel="$1"; tag="$2"; shift 2
 export TMPDIR=/tmp
@@ -12,8 +12,6 @@ for grp in \
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
  "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT" \
  "SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL" \
- "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum" \
- "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" \
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" ; do
   i=$((i+1)); d=gpurun_out/pmcconv_${tag}_$i; rm -rf $d
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d $d -o p -- python3 tools/bench_conv.py "$sel" > $d.out 2>&1

@@ -6,7 +6,7 @@ tot = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for f in sorted(glob.glob(pre + "*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "conv_x3_kernel" not in k and "conv_mfma_kernel" not in k: continue
+        if "conv_x3" not in k and "conv_mfma_kernel" not in k: continue
         a = tot[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, cs in tot.items():
     print(k)
