@@ -388,6 +388,223 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
 #endif
 }
 
+// ============================================================================ k = 1 (GEMM): the projections of HuBERT / the text encoder / the flow
+// Y[m][n] = sum_k W[m][k] X[k][n] with the fp32 activation X = [K][N] (time contiguous).  The same pipeline with one 16-channel chunk
+// as the unit: every unit brings its own input slot (BN = 128 columns x 16 channels = one 8-channel x 64-column piece per wave) and its
+// own weight slot; both go through rings of three.  A wave keeps four input slots in flight in registers (loaded four units ahead,
+// converted two units ahead of their use), the unit loop is unrolled by four so that the register slot is a compile-time index and every
+// wait an immediate.  Loads and weight requests run past the end of the reduction with out-of-range / repeated addresses instead of
+// stopping (nobody reads what they deliver), so the counts of the steady state hold to the last unit.  blockIdx.z = K split.
+template <int AM, int AN>
+__global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
+  constexpr int WM = 2, WN = 2, NW = 4;
+  constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
+  static_assert(BN == 128 && (RB == 2 || RB == 4), "128 columns: one staging piece per wave and unit");
+  constexpr int NPW = 2 * RB / NW;                          // weight pieces per unit and wave
+  constexpr int RW = 3, RX = 3, LX = 4;                     // weight / input slots in LDS, input slots in flight in registers
+  constexpr int wslot = 2 * BM * 32, xslot = 2 * BN * 32;   // [hi | lo][half][rows][16 B]
+  constexpr int xplane = BN * 32, xhalf = xplane / 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3g[];
+  unsigned char* Xs = smem3g;
+  unsigned char* Ws = smem3g + RX * xslot;
+
+  const int tid0 = threadIdx.x;
+  int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned tile = p.xcd_remap ? xcd_tile(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y) : blockIdx.x + blockIdx.y * gridDim.x;
+  const int tile_y = (int)(tile / gridDim.x), tile_x = (int)(tile - (unsigned)tile_y * gridDim.x);
+  const int co0 = tile_y * BM, n0 = tile_x * BN;
+  const int ks = blockIdx.z;
+  const int upk = p.nchunk / p.ksplit;                       // units per K split (a multiple of 4, >= 8: host)
+  const int u0 = ks * upk, U = upk;
+  const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
+
+  const bool r_init = p.ksplit == 1 && p.R != nullptr && p.act == ACT_NONE;
+  f32x16 acc[AM][AN];
+  if (r_init) {
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.R, (unsigned)p.orows * (unsigned)p.ldR * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (p.bias && m < p.Co) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          acc[am][an][r] = buf_load(rrs, (m < p.Co && n < p.Tout) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB) + bv;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+  }
+
+  // ---- weights: unit u = chunk u0 + u, 2 * RB pieces of 1 KiB; the request for a unit past the end repeats the last one
+  const unsigned char* wsrc;
+  {
+    const int hl0 = wave / RB, r0 = (wave % RB) * 64 + lane;
+    wsrc = p.Wx + ((long long)u0 * 2 + hl0) * p.CoPx * 32 + ((long long)(r0 / BM) * p.CoPx + co0 + (r0 % BM)) * 16;
+  }
+  const long long wstep = (long long)p.CoPx * 64;
+  int slw = 0, uw = 0;
+  auto issue_w = [&]() {
+    unsigned char* dst = Ws + slw * wslot + wave * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if constexpr (RB == 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)p.CoPx * 32),
+                                       (__attribute__((address_space(3))) void*)(dst + NW * 1024), 16, 0, 0);
+    ++uw;
+    wsrc += uw < U ? wstep : 0;
+    slw = slw + 1 == RW ? 0 : slw + 1;
+  };
+  // ---- input: this wave's piece of a unit = 8 channels (half hb) x 64 columns
+  const int hb = wave >> 1, xq = (wave & 1) * 64 + lane;
+  const unsigned xvoff = (n0 + xq < p.Tin) ? (unsigned)(n0 + xq) * 4u : kOOB;
+  float xr[LX][8];
+  auto load_unit = [&](int j, int u) {                        // register slot j <- unit u (out of range past the end: zeros, no traffic)
+    const unsigned c0 = (unsigned)((u0 + u) * 16 + hb * 8);
+    const unsigned vo = u < U ? xvoff : kOOB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xr[j][i] = buf_load(xrs, vo, (c0 + i) * (unsigned)p.ldX * 4u);
+  };
+  auto store_unit = [&](int j, int xl) {                      // register slot j -> input slot xl of the ring
+    u32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = xr[j][2 * i], b = xr[j][2 * i + 1];
+      unsigned h_, l_;
+      split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);
+      hi[i] = h_; lo[i] = l_;
+    }
+    unsigned char* d = Xs + xl * xslot + hb * xhalf + xq * 16;
+    *reinterpret_cast<u32x4*>(d) = hi;
+    *reinterpret_cast<u32x4*>(d + xplane) = lo;
+  };
+
+  const int aoff = lh * (BM * 16) + ((wm * AM) * 32 + li) * 16;
+  const int boff = lh * xhalf + ((wn * AN) * 32 + li) * 16;
+
+  // ---- prologue.  Issue order: [residual] input units 0 .. 3 | weight units 0, 1 | (units 0, 1 converted) input units 4, 5
+#pragma unroll
+  for (int j = 0; j < LX; ++j) load_unit(j, j);
+  issue_w(); issue_w();
+  wait_vmcnt<16 + 2 * NPW>();                                  // units 0, 1 (younger: units 2, 3, the weights)
+  store_unit(0, 0); store_unit(1, 1);
+  load_unit(0, 4); load_unit(1, 5);
+  wait_vmcnt<NPW + 16>();                                      // weight unit 0 (younger: weight unit 1, input units 4, 5)
+#pragma unroll
+  for (int am = 0; am < AM; ++am)
+#pragma unroll
+    for (int an = 0; an < AN; ++an) asm volatile("" : "+v"(acc[am][an]));
+  lds_barrier();
+
+  u32x4 ah[AM], ahn[AM], al[AM], bh[AN], bl[AN];
+  {
+    const unsigned char* wa = Ws + aoff;
+    const unsigned char* xa = Xs + boff;
+#pragma unroll
+    for (int am = 0; am < AM; ++am) ah[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+    for (int an = 0; an < AN; ++an) bl[an] = *reinterpret_cast<const u32x4*>(xa + xplane + an * 512);
+  }
+
+  int sl = 0, xl = 0;                                          // weight / input slot of the current unit
+  for (int ug = 0; ug < U; ug += 4) {
+    const bool first = ug == 0;
+    auto unit = [&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int u = ug + J;
+      {
+        const unsigned char* wa = Ws + sl * wslot + BM * 32 + aoff;
+        const unsigned char* xa = Xs + xl * xslot + boff;
+#pragma unroll
+        for (int am = 0; am < AM; ++am) al[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) bh[an] = *reinterpret_cast<const u32x4*>(xa + an * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
+      {
+        // unit u + 2's input: loaded four units ago into register slot (J + 2) % 4; operations issued since - steady state: that unit's
+        // weight request and three units of (8 loads + weights); first group: see the prologue's issue order
+        constexpr int JS = (J + 2) % LX;
+        constexpr int NS = 24 + 4 * NPW;
+        constexpr int NF = J == 0 ? 24 + 2 * NPW : (J == 1 ? 24 + 3 * NPW : (J == 2 ? 24 + 2 * NPW : 24 + 3 * NPW));
+        if (first) wait_vmcnt<NF>(); else wait_vmcnt<NS>();
+        const int xs2 = xl + 2 >= RX ? xl + 2 - RX : xl + 2;
+        store_unit(JS, xs2);
+        load_unit(JS, u + 6);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // weight unit u + 1 (requested one unit ago; younger: this unit's 8 loads - first unit: the prologue's units 4, 5 as well)
+        if (first && J == 0) wait_vmcnt<24>(); else wait_vmcnt<8>();
+        lds_barrier();
+        issue_w();                                             // unit u + 2 into the slot unit u - 1 was read from
+        const int sn = sl + 1 == RW ? 0 : sl + 1, xn = xl + 1 == RX ? 0 : xl + 1;
+        const unsigned char* wa = Ws + sn * wslot + aoff;
+        const unsigned char* xa = Xs + xn * xslot + xplane + boff;
+#pragma unroll
+        for (int am = 0; am < AM; ++am) ahn[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
+#pragma unroll
+        for (int an = 0; an < AN; ++an) bl[an] = *reinterpret_cast<const u32x4*>(xa + an * 512);
+        sl = sn; xl = xn;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am) ah[am] = ahn[am];
+    };
+    static_for<0, 4>(unit);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the requests past the end: nothing may land in LDS after the workgroup has gone)
+
+  if (p.ksplit > 1) {
+    float* Pp = p.partial + ((long long)blockIdx.z * p.Co) * p.ldP;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(Pp, (unsigned)p.Co * (unsigned)p.ldP * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          const bool ok = m < p.Co && n < p.Tout;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), prs, (int)(ok ? ((unsigned)m * (unsigned)p.ldP + (unsigned)n) * 4u : kOOB), 0, 0);
+        }
+      }
+  } else if (r_init) {
+    ConvArgsX pe = p;
+    pe.R = nullptr; pe.bias = nullptr;
+    dense_epilogue<WM, WN, AM, AN, 4>(pe, acc, 0, co0, n0, wm, wn, li, lh);
+  } else {
+    dense_epilogue<WM, WN, AM, AN, 4>(p, acc, 0, co0, n0, wm, wn, li, lh);
+  }
+}
+
 // ============================================================================ host side
 template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
 static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -436,6 +653,45 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   if (AM == 2 && AN == 4) launch_x3p_k<2, 4>(a, grid, lds, s);
   else if (AM == 1 && AN == 4) launch_x3p_k<1, 4>(a, grid, lds, s);
   else launch_x3p_k<2, 2>(a, grid, lds, s);
+  return true;
+}
+
+template <int AM, int AN>
+static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_x3g_kernel<AM, AN>;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
+
+// k = 1 convolutions (GEMMs) on the pipelined kernel: fp32 [K][N] input, K a multiple of 64 and >= 128.  Small grids are split over K
+// (deterministic second pass: splitk_reduce_launch).  Returns false when the geometry is not this kernel's.
+bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, bool dry) {
+  static const int on = getenv("RVC_X3G") ? atoi(getenv("RVC_X3G")) : 1;
+  if (!on) return false;
+  if (a.Wd > 0 || a.ktaps != 1 || a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 63) || a.Ci < 128) return false;
+  if (a.Tin != a.Tout) return false;
+  const int AM = a.Co > 64 ? 2 : 1, BM = 64 * AM, BN = 128;
+  const int U = a.Ci / 16;
+  const long long nblk = (long long)((a.Co + BM - 1) / BM) * ((a.Tout + BN - 1) / BN);
+  static const int min_blk = getenv("RVC_X3G_MINBLK") ? atoi(getenv("RVC_X3G_MINBLK")) : 24;
+  if (nblk < min_blk) return false;
+  // K split: enough workgroups for the chip (a 128 x 128 tile of a K = 768 GEMM is 9 us of MFMAs), at least 8 units per split, groups of 4
+  static const int target = getenv("RVC_X3G_BLK") ? atoi(getenv("RVC_X3G_BLK")) : 256;
+  int S = 1;
+  for (int c : {2, 3, 4, 6, 8}) {
+    if (nblk * S >= target) break;
+    if (U % (4 * c) == 0 && U / c >= 8) S = c;
+  }
+  if (dry) return true;
+  a.nchunk = U; a.NC = 1; a.KT = 1; a.ksplit = S; a.xcd_remap = 0; a.wbufs = 3; a.xbufs = 3;
+  a.ldP = (a.Tout + 31) & ~31; a.partial = nullptr;
+  if (S > 1) a.partial = (float*)stream_scratch(s, 0, (size_t)S * a.Co * a.ldP * sizeof(float));
+  const size_t lds = (size_t)3 * (2 * BN * 32) + (size_t)3 * (2 * BM * 32);
+  dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
+  grid_out = grid; ksplit_out = S;
+  if (AM == 2) launch_x3g<2, 2>(a, grid, lds, s); else launch_x3g<1, 2>(a, grid, lds, s);
+  if (S > 1) splitk_reduce_launch(a, S, 1, s);
   return true;
 }
 

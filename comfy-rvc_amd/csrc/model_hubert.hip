@@ -8,7 +8,7 @@ namespace rvc {
 
 struct HubLayer {
   ConvLayer qk;        // fused q (pre-scaled by head_dim^-0.5) and k projections: 768 -> 1536
-  DevVec wvT, bv;      // v projection as [in][out]; bias added after P.V (softmax rows sum to 1)
+  DevVec bv;           // v projection bias, added after P.V (softmax rows sum to 1); the v rows are part of the qk layer (768 -> 2304)
   ConvLayer o, ff1, ff2;
   DevVec g1, b1, g2, b2;
 };
@@ -40,7 +40,7 @@ static void hubert_free(Hubert& H) {
   for (auto& c : H.conv) conv_layer_free(c);
   H.gn_g.free_(); H.gn_b.free_(); H.fp_g.free_(); H.fp_b.free_(); H.enc_g.free_(); H.enc_b.free_();
   conv_layer_free(H.proj); conv_layer_free(H.pos); conv_layer_free(H.final_proj);
-  for (auto& l : H.layers) { conv_layer_free(l.qk); l.wvT.free_(); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
+  for (auto& l : H.layers) { conv_layer_free(l.qk); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
   H.layers.clear();
 }
 void hubert_destroy(Hubert* H) { if (H) { hubert_free(*H); H->arena.release(); delete H; } }
@@ -93,11 +93,12 @@ void hubert_finalize(Hubert* H) {
     const HostTensor& wk = ts.get(p + "attention.k_proj.weight", {768, 768});
     const HostTensor& bq = ts.get(p + "attention.q_proj.bias", {768});
     const HostTensor& bk = ts.get(p + "attention.k_proj.bias", {768});
-    std::vector<float> w(2 * (size_t)768 * 768), b(2 * 768);
-    for (size_t i = 0; i < (size_t)768 * 768; ++i) { w[i] = wq.data[i] * qs; w[(size_t)768 * 768 + i] = wk.data[i]; }
+    // one 768 -> 2304 projection: q (scaled), k, v rows; v's bias is added after the attention (softmax rows sum to 1)
+    const HostTensor& wv = ts.get(p + "attention.v_proj.weight", {768, 768});
+    std::vector<float> w(3 * (size_t)768 * 768), b(3 * 768, 0.f);
+    for (size_t i = 0; i < (size_t)768 * 768; ++i) { w[i] = wq.data[i] * qs; w[(size_t)768 * 768 + i] = wk.data[i]; w[2 * (size_t)768 * 768 + i] = wv.data[i]; }
     for (int i = 0; i < 768; ++i) { b[i] = bq.data[i] * qs; b[768 + i] = bk.data[i]; }
-    conv1d_layer_init(Y.qk, w.data(), b.data(), 1536, 768, 1, 1, 0, 1, 1);
-    Y.wvT.upload(transpose2d(ts.get(p + "attention.v_proj.weight", {768, 768}).data.data(), 768, 768));
+    conv1d_layer_init(Y.qk, w.data(), b.data(), 2304, 768, 1, 1, 0, 1, 1);
     Y.bv.upload(ts.get(p + "attention.v_proj.bias", {768}).data);
     linear_layer(Y.o, ts, p + "attention.out_proj", 768, 768);
     linear_layer(Y.ff1, ts, p + "feed_forward.intermediate_dense", 3072, 768);
@@ -152,7 +153,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   RVC_REQUIRE(need <= (int)H->layers.size(), "not enough encoder layers loaded");
   {
     const size_t mark = A.off;
-    float* qk = A.alloc<float>((size_t)1536 * T);
+    float* qk = A.alloc<float>((size_t)2304 * T);
     float* vr = A.alloc<float>((size_t)T * 768);
     float* attn = A.alloc<float>((size_t)768 * T);
     float* ff = A.alloc<float>((size_t)3072 * T);
@@ -162,7 +163,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
         if (taps && l == 0) tap(taps->hidden_0, h, (size_t)768 * T);
         if (taps && l == 8) tap(taps->hidden_8, h, (size_t)768 * T);
         conv1d_run(Y.qk, s, h, T, T, qk, T, E0);
-        gemm_tn_run(s, h, T, 0, Y.wvT.p, 768, 0, vr, 768, 0, T, 768, 768, 1, nullptr, 0, E0);
+        transpose(s, qk + (size_t)1536 * T, vr, 768, T, T, 768, 1, 0, 0);      // V row-major [T][768] for the fused attention
         // softmax(K^T Q) V + bv without materialising the [12][T][T] scores (attention.hip)
         attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, attn, T, 12, 64, T);
         ConvEpilogue Er; Er.R = h; Er.ldR = T;

@@ -30,7 +30,7 @@ static ConvLayer make_conv1d(const TensorStore& ts, const std::string& p, int st
 
 struct EncLayer {
   ConvLayer qk;            // fused conv_q (pre-scaled by 1/sqrt(kc)) and conv_k: C -> 2C
-  DevVec wvT, bv;          // conv_v as [Ci][Co] for the row-major V product; its bias is added after P.V
+  DevVec bv;               // conv_v's bias, added after P.V; its rows are part of the qk layer (C -> 3 C)
   ConvLayer relk, relv;    // emb_rel_k as a 21-row projection of Q; emb_rel_v as a 21 -> kc projection of banded P
   ConvLayer o, ffn1, ffn2;
   DevVec g1, b1, g2, b2;
@@ -66,7 +66,7 @@ struct Synth {
 static void synth_free(Synth& S) {
   auto fl = [](ConvLayer& L) { conv_layer_free(L); };
   S.emb_phone_wT.free_(); S.emb_phone_b.free_(); S.emb_pitch.free_(); S.emb_g.free_();
-  for (auto& e : S.enc) { fl(e.qk); e.wvT.free_(); e.bv.free_(); fl(e.relk); fl(e.relv); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
+  for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
   S.enc.clear();
   fl(S.proj);
   for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); f.cond_w.free_(); f.cond_b.free_(); }
@@ -118,12 +118,13 @@ void synth_finalize(Synth* S) {
     const std::string p = "enc_p.encoder.attn_layers." + std::to_string(l) + ".";
     const HostTensor& wq = ts.get(p + "conv_q.weight", {C, C, 1});
     const HostTensor& wk = ts.get(p + "conv_k.weight", {C, C, 1});
-    std::vector<float> w(2 * (size_t)C * C), b(2 * (size_t)C);
-    for (size_t i = 0; i < (size_t)C * C; ++i) { w[i] = wq.data[i] * qscale; w[(size_t)C * C + i] = wk.data[i]; }
+    // one C -> 3 C projection: q (scaled), k, v rows; v's bias is added after the attention
+    const HostTensor& wv = ts.get(p + "conv_v.weight", {C, C, 1});
+    std::vector<float> w(3 * (size_t)C * C), b(3 * (size_t)C, 0.f);
+    for (size_t i = 0; i < (size_t)C * C; ++i) { w[i] = wq.data[i] * qscale; w[(size_t)C * C + i] = wk.data[i]; w[2 * (size_t)C * C + i] = wv.data[i]; }
     const HostTensor& bq = ts.get(p + "conv_q.bias", {C}); const HostTensor& bk = ts.get(p + "conv_k.bias", {C});
     for (int i = 0; i < C; ++i) { b[i] = bq.data[i] * qscale; b[C + i] = bk.data[i]; }
-    conv1d_layer_init(e.qk, w.data(), b.data(), 2 * C, C, 1, 1, 0, 1, 1);
-    e.wvT.upload(transpose2d(ts.get(p + "conv_v.weight", {C, C, 1}).data.data(), C, C));
+    conv1d_layer_init(e.qk, w.data(), b.data(), 3 * C, C, 1, 1, 0, 1, 1);
     e.bv.upload(ts.get(p + "conv_v.bias", {C}).data);
     const HostTensor& rk = ts.get(p + "emb_rel_k", {1, 21, kc});
     conv1d_layer_init(e.relk, rk.data.data(), nullptr, 21, kc, 1, 1, 0, 1, 1);            // [r][d]: out[r][q] = sum_d E_k[r][d] Q[d][q]
@@ -228,7 +229,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   }
   {
     const size_t mark = A.off;
-    float* qk = A.alloc<float>((size_t)2 * C * T);
+    float* qk = A.alloc<float>((size_t)3 * C * T);
     float* vr = A.alloc<float>((size_t)T * C);
     static const bool fused_env = [] { const char* e = getenv("RVC_ENCP_FUSED"); return !e || atoi(e) != 0; }();
     const bool fused_att = fused_env && kc == 96;
@@ -241,7 +242,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       for (int l = 0; l < S->n_layers; ++l) {
         EncLayer& e = S->enc[l];
         conv1d_run(e.qk, s, x, T, T, qk, T, E0);
-        gemm_tn_run(s, x, T, 0, e.wvT.p, C, 0, vr, C, 0, T, C, C, 1, nullptr, 0, E0);                       // V row-major [T][C] (bias later)
+        transpose(s, qk + (size_t)2 * C * T, vr, C, T, T, C, 1, 0, 0);                                       // V row-major [T][C] (bias later)
         for (int h = 0; h < H; ++h) conv1d_run(e.relk, s, qk + (size_t)h * kc * T, T, T, relk + (size_t)h * 21 * T, T, E0);
         if (fused_att) {
           // softmax(K^T Q + banded rel-k bias) V + bv in one kernel; the band of probabilities comes back in pb for the rel-v projection
