@@ -413,6 +413,20 @@ int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* str
   check_launch();
   RVC_CATCH
 }
+int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x, int T, float* y, float out_scale,
+                                   int accumulate) {
+  RVC_TRY
+  RVC_REQUIRE(c1 && c2 && x && y, "null argument");
+  RVC_REQUIRE(conv1d_split_eligible(c1->L, T) && conv1d_split_eligible(c2->L, T), "layers not eligible for split-resident tensors at this length");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* img = (unsigned char*)stream_scratch(s, 5, split_image_bytes(c1->L.Co, T));
+  ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f; E1.ys_out = img; E1.ys_tp = split_image_tp(T); E1.ys_slope = 0.1f;
+  conv1d_run(c1->L, s, x, T, T, nullptr, T, E1);
+  ConvEpilogue E2; E2.R = x; E2.ldR = T; E2.out_scale = out_scale; E2.accumulate = accumulate; E2.xs_in = img; E2.xs_tp = E1.ys_tp;
+  conv1d_run(c2->L, s, nullptr, T, T, y, T, E2);
+  check_launch();
+  RVC_CATCH
+}
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
 int rvc_op_attention(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, float* out, int heads, int T) {
   RVC_TRY

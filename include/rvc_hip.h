@@ -234,6 +234,11 @@ int rvc_conv1d_plan_run(rvc_conv1d_plan* p, void* stream, const float* x_dev, in
                         float pre_slope, int act, float act_slope);
 /* One ResBlock1 pair of the generator in a single launch (reference lib/infer_pack/modules.py:295-308):
  * y = (x + conv2(lrelu(conv1(lrelu(x), dilated)))) * out_scale [+ y]; x_dev, y_dev [C][T].  Fails if the pair is not eligible. */
+/* The same pair as two launches with a split-resident intermediate, the way the wide generator stages run it (reference
+ * lib/infer_pack/modules.py:295-308): conv1 writes lrelu(conv1(lrelu(x)) + b1) as the bf16 hi / lo image conv2 stages by DMA.
+ * Fails if the layers are not eligible for the split-resident paths at this length. */
+int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x_dev, int T, float* y_dev,
+                                   float out_scale, int accumulate);
 int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x_dev, int T, float* y_dev, float out_scale,
                              int accumulate);
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);

@@ -450,6 +450,50 @@ def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
     assert y2.shape == (2, n_out) and np.array_equal(y2[0], y) and np.allclose(y2[1], -0.5 * y, atol=1e-7)
 
 
+@pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(128, 11, 5, 70003, 1.0 / 3, True), (128, 7, 3, 66001, 1.0, False), (128, 3, 1, 80000, 1.0, False),
+                                                  (64, 11, 1, 131000, 1.0, False), (64, 7, 5, 140001, 1.0 / 3, True), (64, 3, 3, 140000, 1.0, False),
+                                                  (192, 7, 1, 60000, 1.0, False), (256, 11, 3, 32000, 1.0, True), (256, 3, 5, 30001, 1.0, False)])
+def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
+    """One ResBlock1 pair as the wide generator stages run it: conv1 writes its output as the bf16 hi / lo image (split-resident), conv2
+    stages that image by DMA - both on the software-pipelined kernel (conv_x3p.hip; channel counts from three chunks up, every kernel size
+    of the generator, sequence ends inside / at tile borders) - against fp64 torch."""
+    g = torch.Generator().manual_seed(2000 + 37 * k + d + Cc)
+    x = torch.randn(Cc, T, generator=g)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
+    xd = x.double()
+    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+    ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+    y0 = torch.randn(Cc, T, generator=g)
+    if accum:
+        ref = ref + y0
+    y, xg = dev(y0), dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    try:
+        L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
+    except L.RvcHipError as e:
+        if "not eligible" in str(e):
+            pytest.skip("the tile heuristics keep this shape off the split-resident paths")
+        raise
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs()
+    assert rel_err(y.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
+    for c0 in (0, 126, 254, T // 2, T - 40):                      # sequence ends and tile seams carry the same error as the interior
+        assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    bad = L.lib.rvc_debug_x3p_check()                             # (a -DRVC_X3P_CHECK build counts waits whose compile-time vmcnt was too large)
+    assert bad <= 0, f"{bad} waits of the pipelined kernel with a too large compile-time count"
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
 @pytest.mark.parametrize("k,d,T,scale,accum", [(11, 5, 140003, 1.0 / 3, True), (7, 3, 131072, 1.0, False), (3, 1, 200001, 1.0, False),
                                                (3, 5, 136100, 1.0 / 3, True), (11, 1, 150000, 1.0, False)])
 def test_fused_resblock_pair(L, k, d, T, scale, accum):
