@@ -713,6 +713,9 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
+  dim3 gpf;
+  if (C == 32 && BN == 256 && conv_x3pf_try(a, T, s, gpf)) grid = gpf;     // software-pipelined fused pair (conv_x3p.hip)
+  else
   if (C == 64) launch_x3<2, 2, 1, 2, true>(a, grid, lds, s);
   else if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
   else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);

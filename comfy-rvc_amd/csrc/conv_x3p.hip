@@ -605,6 +605,223 @@ __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
   }
 }
 
+// ============================================================================ fused ResBlock pair of the 32-channel generator stage
+// y = (x + c2(lrelu(c1_d(lrelu(x)) + b1)) + b2) * scale [+ y] in one launch, the intermediate in LDS (what conv_x3_kernel<FUSE> did with
+// one barrier, one weight wait and one round of operand reads per 6 MFMAs: 86 k cycles per tile for 8.4 k cycles of MFMA issue).  Here:
+// both 16-channel chunks of the input tile are converted once (they are the two input buffers of the pipeline), the weights of BOTH
+// convolutions are one stream of 4 KT single-tap units through a ring of four 2-KiB slots (a unit requested three units ahead; requests
+// past the end repeat the last unit so that one immediate wait count holds throughout), every unit's six operand reads are issued a whole
+// unit ahead of its MFMAs, and the residual tile is read at the very start into registers of its own (32: the tile is narrow) and becomes
+// the initial value of the second pass's accumulators.
+// Tile: 32 rows x 256 intermediate columns = 256 - (KT - 1) output columns; 4 waves side by side (2 column blocks each).
+template <int KT>
+__global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
+  constexpr int NW = 4, AN = 2, BM = 32, BN = 256, R = 4, P2 = (KT - 1) / 2;
+  constexpr int wslot = 2 * BM * 32;                         // [hi | lo][half][32 rows][16 B] = 2 KiB
+  constexpr int XS = 5;                                      // staging slots per wave: 2 chunks x 2 halves x 5 column groups / 4 waves
+  constexpr int NU = 2 * KT;                                 // units per pass
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3f[];
+  const int P = p.WROW;                                      // staged input columns: 256 + (KT - 1) * dil  (<= 320)
+  const int xplane = P * 32, xhalf = xplane >> 1, xbuf = 2 * xplane;
+  unsigned char* Xs = smem3f;                                // two chunk buffers: x, later the intermediate
+  unsigned char* Ws = smem3f + ((2 * xbuf + 1023) & ~1023);
+
+  const int tid0 = threadIdx.x;
+  int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile_x = (int)(p.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
+  const int n0 = tile_x * (BN - 2 * P2);                     // first output column; intermediate column nl <-> position n0 - P2 + nl
+  const int bx = n0 - P2 - p.pad;                            // first staged input column
+  const int ni = p.ni;                                       // 64-column groups of the staged tile (<= 5)
+  const int dil16 = p.dil * 16;
+  const float pre_slope = p.pre_slope, hs = p.fuse_slope;
+  const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
+
+  // ---- weights: units 0 .. 2 KT - 1 of conv1, then of conv2; every wave requests one piece per unit (waves 2, 3 repeat the pieces of
+  // waves 0, 1: one count for all)
+  const long long lane_w = (long long)(wave & 1) * p.CoPx * 32 + ((long long)lh * p.CoPx + li) * 16;
+  const long long wstep = (long long)p.CoPx * 64;
+  const unsigned char* wsrc = p.Wx + lane_w;
+  int slw = 0, uw = 0;
+  auto issue_w = [&]() {
+    unsigned char* dst = Ws + slw * wslot + (wave & 1) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    ++uw;
+    if (uw == NU) wsrc = p.Wx2 + lane_w;                     // conv2's image
+    else if (uw < 2 * NU) wsrc += wstep;                     // (past the end: the last unit again)
+    slw = slw + 1 == R ? 0 : slw + 1;
+  };
+
+  // ---- prologue: the residual tile (oldest loads; needed only at the second pass), the whole input tile (both chunks), three weight units
+  float rr[AN][16];
+  {
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(p.R, (unsigned)p.Co * (unsigned)p.ldR * 4u);
+    const int nend = min(p.Tout, n0 + BN - 2 * P2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wave * AN + an) * 32 + li;
+        rr[an][r] = buf_load(rrs, n < nend ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB);
+      }
+    }
+  }
+  {
+    float xr[XS][8];
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const int t = wave + NW * s;                            // 0 .. 19: chunk, half, column group
+      const int cc = t / (2 * ni), g = t - cc * 2 * ni, hb = g >= ni ? 1 : 0, q = (g - hb * ni) * 64 + lane;
+      const int x = bx + q;
+      const unsigned voff = (t < 4 * ni && q < P && x >= 0 && x < p.Tin) ? (unsigned)x * 4u : kOOB;
+      const unsigned c0 = (unsigned)(cc * 16 + hb * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xr[s][j] = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
+    }
+    issue_w(); issue_w(); issue_w();
+    wait_vmcnt<3>();                                          // the input (younger: three weight pieces)
+#pragma unroll
+    for (int s = 0; s < XS; ++s) {
+      const int t = wave + NW * s;
+      const int cc = t / (2 * ni), g = t - cc * 2 * ni, hb = g >= ni ? 1 : 0, q = (g - hb * ni) * 64 + lane;
+      if (t < 4 * ni && q < P) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = xr[s][2 * j], b = xr[s][2 * j + 1];
+          unsigned h_, l_;
+          split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);
+          hi[j] = h_; lo[j] = l_;
+        }
+        unsigned char* d = Xs + cc * xbuf + hb * xhalf + q * 16;
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + xplane) = lo;
+      }
+    }
+  }
+  wait_vmcnt<2>();                                            // weight unit 0
+  lds_barrier();
+
+  f32x16 acc[AN];
+#pragma unroll
+  for (int an = 0; an < AN; ++an)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[an][r] = 0.f;
+
+  const int aoff = lh * (BM * 16) + li * 16;
+  const int boff = lh * xhalf + (wave * AN * 32 + li) * 16;
+  u32x4 ah, al, bh[AN], bl[AN], ahn, aln, bhn[AN], bln[AN];
+  auto read_ops = [&](u32x4& a_h, u32x4& a_l, u32x4 (&b_h)[AN], u32x4 (&b_l)[AN], int slot, int xoff) {
+    const unsigned char* wa = Ws + slot * wslot + aoff;
+    const unsigned char* xa = Xs + xoff + boff;
+    a_h = *reinterpret_cast<const u32x4*>(wa); a_l = *reinterpret_cast<const u32x4*>(wa + BM * 32);
+#pragma unroll
+    for (int an = 0; an < AN; ++an) { b_h[an] = *reinterpret_cast<const u32x4*>(xa + an * 512); b_l[an] = *reinterpret_cast<const u32x4*>(xa + xplane + an * 512); }
+  };
+  read_ops(ah, al, bh, bl, 0, 0);
+
+  int sl = 0;
+  // one pass = 2 chunks x KT taps over the two chunk buffers; D16 = tap distance in bytes
+  auto pass = [&](int D16, bool last_pass) {
+    auto unit = [&](auto uc) {
+      constexpr int Uu = decltype(uc)::value;                 // unit inside the pass
+      constexpr int T = Uu % KT, Cc = Uu / KT;
+      constexpr bool last = Uu + 1 == NU;
+      // next unit's weights are published; its operands are requested now, a whole unit ahead (at the end of the first pass only the
+      // weights: the intermediate is not written yet)
+      wait_vmcnt<1>();                                        // unit u + 1 (younger: unit u + 2)
+      lds_barrier();
+      issue_w();                                              // unit u + 3 into the slot unit u - 1 was read from
+      const int sn = sl + 1 == R ? 0 : sl + 1;
+      if constexpr (!last) {
+        constexpr int Tn = (Uu + 1) % KT, Cn = (Uu + 1) / KT;
+        read_ops(ahn, aln, bhn, bln, sn, Cn * xbuf + Tn * D16);
+      } else {
+        const unsigned char* wa = Ws + sn * wslot + aoff;
+        ahn = *reinterpret_cast<const u32x4*>(wa); aln = *reinterpret_cast<const u32x4*>(wa + BM * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[an]), acc[an], 0, 0, 0);
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[an]), acc[an], 0, 0, 0);
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[an]), acc[an], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ah = ahn; al = aln;
+      if constexpr (!last) {
+#pragma unroll
+        for (int an = 0; an < AN; ++an) { bh[an] = bhn[an]; bl[an] = bln[an]; }
+      }
+      sl = sn;
+      (void)T; (void)Cc;
+    };
+    static_for<0, NU>(unit);
+    (void)last_pass;
+  };
+
+  // ---- pass 1: the dilated conv over the 256 columns
+  pass(dil16, false);
+  // ---- the intermediate h = lrelu(acc + b1) (0 outside the sequence: the second conv's zero padding), split, over the input tile
+  lds_barrier();                                              // every wave is done with the input tile
+  {
+#pragma unroll
+    for (int an = 0; an < AN; ++an) {
+      const int nl = (wave * AN + an) * 32 + li;
+      const int gh = n0 - P2 + nl;
+      const bool inside = gh >= 0 && gh < p.Tin;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int mb = 8 * g;                                 // rows mb + 4 lh + {0..3}: one 8-byte quarter of a 16-B row
+        u32x4 hl;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          float a = acc[an][4 * g + 2 * e2] + p.bias1[mb + 4 * lh + 2 * e2];
+          float b = acc[an][4 * g + 2 * e2 + 1] + p.bias1[mb + 4 * lh + 2 * e2 + 1];
+          a = inside ? fmaxf(a, a * hs) : 0.f;
+          b = inside ? fmaxf(b, b * hs) : 0.f;
+          unsigned h_, l_;
+          split2(a, b, h_, l_);
+          hl[e2] = h_; hl[2 + e2] = l_;
+        }
+        const int cc = mb >> 4, hb = (mb >> 3) & 1;
+        unsigned char* row = Xs + cc * xbuf + hb * xhalf + nl * 16 + lh * 8;
+        *reinterpret_cast<unsigned long long*>(row) = (unsigned long long)hl[0] | ((unsigned long long)hl[1] << 32);
+        *reinterpret_cast<unsigned long long*>(row + xplane) = (unsigned long long)hl[2] | ((unsigned long long)hl[3] << 32);
+      }
+    }
+  }
+  lds_barrier();                                              // h published
+  // ---- pass 2 accumulators: residual + bias2 (nothing but the scale follows the sum)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float bv = p.bias ? p.bias[(r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
+#pragma unroll
+    for (int an = 0; an < AN; ++an) acc[an][r] = rr[an][r] + bv;
+  }
+  {
+    const unsigned char* xa = Xs + boff;
+#pragma unroll
+    for (int an = 0; an < AN; ++an) { bh[an] = *reinterpret_cast<const u32x4*>(xa + an * 512); bl[an] = *reinterpret_cast<const u32x4*>(xa + xplane + an * 512); }
+  }
+  pass(16, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the requests past the end
+  {
+    ConvArgsX pe = p;
+    pe.R = nullptr; pe.bias = nullptr;                         // inside the accumulators
+    pe.Tout = min(p.Tout, n0 + BN - 2 * P2);                   // columns without their full halo belong to the neighbouring tiles
+    f32x16 a2[1][AN];
+#pragma unroll
+    for (int an = 0; an < AN; ++an) a2[0][an] = acc[an];
+    dense_epilogue<1, 4, 1, AN, 4>(pe, a2, 0, 0, n0, 0, wave, li, lh);
+  }
+}
+
 // ============================================================================ host side
 template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
 static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -692,6 +909,28 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   grid_out = grid; ksplit_out = S;
   if (AM == 2) launch_x3g<2, 2>(a, grid, lds, s); else launch_x3g<1, 2>(a, grid, lds, s);
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
+  return true;
+}
+
+template <int KT>
+static void launch_x3pf(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = conv_x3pf_kernel<KT>;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
+// a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32, BN = 256).  false: the staged fused kernel takes the pair.
+bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out) {
+  static const int on = getenv("RVC_X3PF") ? atoi(getenv("RVC_X3PF")) : 1;
+  if (!on || a.Ci != 32 || a.Co != 32 || !(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
+  const int P = 256 + (a.ktaps - 1) * a.dil;
+  if (P > 320) return false;
+  a.WROW = P; a.ni = (P + 63) / 64;
+  const size_t lds = (size_t)((2 * 2 * P * 32 + 1023) & ~1023) + 4 * 2048;
+  const int NO = 256 - (a.ktaps - 1);
+  dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
+  grid_out = grid;
+  if (a.ktaps == 3) launch_x3pf<3>(a, grid, lds, s); else if (a.ktaps == 7) launch_x3pf<7>(a, grid, lds, s); else launch_x3pf<11>(a, grid, lds, s);
   return true;
 }
 
