@@ -672,7 +672,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   if (!on || !conv_x3_enabled() || !c1.Wx_ || !c2.Wx_) return false;
   const int C = c1.Co, k = c1.k;
   if (c1.mode != 1 || c2.mode != 1 || c1.groups != 1 || c2.groups != 1 || c1.stride != 1 || c2.stride != 1 || c1.tconv_u || c2.tconv_u) return false;
-  if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != k || c2.dil != 1 || (k & 1) == 0 || !(C == 32 || (C == 64 && pair64))) return false;
+  if (c1.Ci != C || c2.Ci != C || c2.Co != C || c2.k != k || c2.dil != 1 || (k & 1) == 0 || !(C == 32 || C == 64)) return false;
   if (c1.pad != (k - 1) / 2 * c1.dil || c2.pad != (k - 1) / 2) return false;                      // "same" convolutions
   if (e2.pre_act != ACT_LRELU || e2.act != ACT_NONE || e2.bias_override || e2.tout_limit || e2.R != X) return false;
   if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
@@ -692,6 +692,20 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   a.Wx = reinterpret_cast<const unsigned char*>(c1.Wx_); a.Wx2 = reinterpret_cast<const unsigned char*>(c2.Wx_); a.CoPx = c1.CoPx;
   a.fuse_p2 = P2;
   if (c1.CoPx != c2.CoPx) return false;
+  {
+    // the software-pipelined fused pair (conv_x3p.hip): 32 and 64 channels
+    static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+    a.xcd_remap = xcd_env;
+    dim3 gpf;
+    if (conv_x3pf_try(a, T, s, gpf, true)) {
+      ProfTicket tk = conv_prof_begin(s);
+      conv_x3pf_try(a, T, s, gpf, false);
+      const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
+      conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + (C == 32 ? 1 : 5), bytes, &a, (long long)gpf.x, 1);
+      return true;
+    }
+    if (C == 64 && !pair64) return false;
+  }
   const int P = BN + 2 * P1;                                      // staged input columns
   a.ni = (P + 63) / 64;
   const int nchunk = C / 16, NC = nchunk;                         // every channel of the tile resident: one chunk group
@@ -713,9 +727,6 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
-  dim3 gpf;
-  if (C == 32 && BN == 256 && conv_x3pf_try(a, T, s, gpf)) grid = gpf;     // software-pipelined fused pair (conv_x3p.hip)
-  else
   if (C == 64) launch_x3<2, 2, 1, 2, true>(a, grid, lds, s);
   else if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
   else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);

@@ -614,22 +614,27 @@ __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
 // unit ahead of its MFMAs, and the residual tile is read at the very start into registers of its own (32: the tile is narrow) and becomes
 // the initial value of the second pass's accumulators.
 // Tile: 32 rows x 256 intermediate columns = 256 - (KT - 1) output columns; 4 waves side by side (2 column blocks each).
-template <int KT>
-__global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
-  constexpr int NW = 4, AN = 2, BM = 32, BN = 256, R = 4, P2 = (KT - 1) / 2;
-  constexpr int wslot = 2 * BM * 32;                         // [hi | lo][half][32 rows][16 B] = 2 KiB
-  constexpr int XS = 5;                                      // staging slots per wave: 2 chunks x 2 halves x 5 column groups / 4 waves
-  constexpr int NU = 2 * KT;                                 // units per pass
+// WM = 1: 32 channels, 4 waves side by side, 256 intermediate columns (three workgroups per CU); WM = 2: 64 channels, 2 x 2 waves, 128
+// intermediate columns (four chunk buffers of 128 + halo columns: two workgroups per CU).
+template <int KT, int WM>
+__global__ __launch_bounds__(256, WM == 1 ? 3 : 2) void conv_x3pf_kernel(const ConvArgsX p) {
+  constexpr int NW = 4, WN = NW / WM, AN = 2, BM = 32 * WM, BN = WN * AN * 32, R = 4, P2 = (KT - 1) / 2;
+  constexpr int NCK = BM / 16;                               // 16-channel chunks = input buffers
+  constexpr int wslot = 2 * BM * 32;                         // [hi | lo][half][BM rows][16 B]: 2 / 4 KiB
+  constexpr int NIMAX = WM == 1 ? 5 : 3;                     // 64-column groups of the staged tile (256 / 128 + halo <= 64 columns)
+  constexpr int XS = NCK * 2 * NIMAX / NW;                   // staging slots per wave (5 / 6)
+  constexpr int NU = NCK * KT;                               // units per pass
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3f[];
   const int P = p.WROW;                                      // staged input columns: 256 + (KT - 1) * dil  (<= 320)
   const int xplane = P * 32, xhalf = xplane >> 1, xbuf = 2 * xplane;
-  unsigned char* Xs = smem3f;                                // two chunk buffers: x, later the intermediate
-  unsigned char* Ws = smem3f + ((2 * xbuf + 1023) & ~1023);
+  unsigned char* Xs = smem3f;                                // one buffer per chunk: x, later the intermediate
+  unsigned char* Ws = smem3f + ((NCK * xbuf + 1023) & ~1023);
 
   const int tid0 = threadIdx.x;
   int lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
   const int tile_x = (int)(p.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
   const int n0 = tile_x * (BN - 2 * P2);                     // first output column; intermediate column nl <-> position n0 - P2 + nl
   const int bx = n0 - P2 - p.pad;                            // first staged input column
@@ -638,14 +643,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
   const float pre_slope = p.pre_slope, hs = p.fuse_slope;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, (unsigned)p.Ci * (unsigned)p.ldX * 4u);
 
-  // ---- weights: units 0 .. 2 KT - 1 of conv1, then of conv2; every wave requests one piece per unit (waves 2, 3 repeat the pieces of
-  // waves 0, 1: one count for all)
-  const long long lane_w = (long long)(wave & 1) * p.CoPx * 32 + ((long long)lh * p.CoPx + li) * 16;
+  // ---- weights: units 0 .. NCK KT - 1 of conv1, then of conv2; every wave requests one 1-KiB piece per unit (32 channels: a unit is two
+  // pieces, waves 2, 3 repeat those of waves 0, 1 - one count for all; 64 channels: four pieces, (hi | lo, half) = wave)
+  const long long lane_w = WM == 1 ? (long long)(wave & 1) * p.CoPx * 32 + ((long long)lh * p.CoPx + li) * 16
+                                   : (long long)(wave >> 1) * p.CoPx * 32 + ((long long)(wave & 1) * p.CoPx + lane) * 16;
   const long long wstep = (long long)p.CoPx * 64;
   const unsigned char* wsrc = p.Wx + lane_w;
   int slw = 0, uw = 0;
   auto issue_w = [&]() {
-    unsigned char* dst = Ws + slw * wslot + (wave & 1) * 1024;
+    unsigned char* dst = Ws + slw * wslot + (WM == 1 ? (wave & 1) : wave) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     ++uw;
     if (uw == NU) wsrc = p.Wx2 + lane_w;                     // conv2's image
@@ -660,10 +666,10 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
     const int nend = min(p.Tout, n0 + BN - 2 * P2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
       for (int an = 0; an < AN; ++an) {
-        const int n = n0 + (wave * AN + an) * 32 + li;
+        const int n = n0 + (wn * AN + an) * 32 + li;
         rr[an][r] = buf_load(rrs, n < nend ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB);
       }
     }
@@ -672,10 +678,10 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
     float xr[XS][8];
 #pragma unroll
     for (int s = 0; s < XS; ++s) {
-      const int t = wave + NW * s;                            // 0 .. 19: chunk, half, column group
+      const int t = wave + NW * s;                            // chunk, half, column group
       const int cc = t / (2 * ni), g = t - cc * 2 * ni, hb = g >= ni ? 1 : 0, q = (g - hb * ni) * 64 + lane;
       const int x = bx + q;
-      const unsigned voff = (t < 4 * ni && q < P && x >= 0 && x < p.Tin) ? (unsigned)x * 4u : kOOB;
+      const unsigned voff = (t < NCK * 2 * ni && q < P && x >= 0 && x < p.Tin) ? (unsigned)x * 4u : kOOB;
       const unsigned c0 = (unsigned)(cc * 16 + hb * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) xr[s][j] = buf_load(xrs, voff, (c0 + j) * (unsigned)p.ldX * 4u);
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
     for (int s = 0; s < XS; ++s) {
       const int t = wave + NW * s;
       const int cc = t / (2 * ni), g = t - cc * 2 * ni, hb = g >= ni ? 1 : 0, q = (g - hb * ni) * 64 + lane;
-      if (t < 4 * ni && q < P) {
+      if (t < NCK * 2 * ni && q < P) {
         u32x4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -710,8 +716,8 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[an][r] = 0.f;
 
-  const int aoff = lh * (BM * 16) + li * 16;
-  const int boff = lh * xhalf + (wave * AN * 32 + li) * 16;
+  const int aoff = lh * (BM * 16) + (wm * 32 + li) * 16;
+  const int boff = lh * xhalf + (wn * AN * 32 + li) * 16;
   u32x4 ah, al, bh[AN], bl[AN], ahn, aln, bhn[AN], bln[AN];
   auto read_ops = [&](u32x4& a_h, u32x4& a_l, u32x4 (&b_h)[AN], u32x4 (&b_l)[AN], int slot, int xoff) {
     const unsigned char* wa = Ws + slot * wslot + aoff;
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
   {
 #pragma unroll
     for (int an = 0; an < AN; ++an) {
-      const int nl = (wave * AN + an) * 32 + li;
+      const int nl = (wn * AN + an) * 32 + li;
       const int gh = n0 - P2 + nl;
       const bool inside = gh >= 0 && gh < p.Tin;
 #pragma unroll
@@ -781,15 +787,15 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
         u32x4 hl;
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {
-          float a = acc[an][4 * g + 2 * e2] + p.bias1[mb + 4 * lh + 2 * e2];
-          float b = acc[an][4 * g + 2 * e2 + 1] + p.bias1[mb + 4 * lh + 2 * e2 + 1];
+          float a = acc[an][4 * g + 2 * e2] + p.bias1[wm * 32 + mb + 4 * lh + 2 * e2];
+          float b = acc[an][4 * g + 2 * e2 + 1] + p.bias1[wm * 32 + mb + 4 * lh + 2 * e2 + 1];
           a = inside ? fmaxf(a, a * hs) : 0.f;
           b = inside ? fmaxf(b, b * hs) : 0.f;
           unsigned h_, l_;
           split2(a, b, h_, l_);
           hl[e2] = h_; hl[2 + e2] = l_;
         }
-        const int cc = mb >> 4, hb = (mb >> 3) & 1;
+        const int cc = wm * 2 + (mb >> 4), hb = (mb >> 3) & 1;
         unsigned char* row = Xs + cc * xbuf + hb * xhalf + nl * 16 + lh * 8;
         *reinterpret_cast<unsigned long long*>(row) = (unsigned long long)hl[0] | ((unsigned long long)hl[1] << 32);
         *reinterpret_cast<unsigned long long*>(row + xplane) = (unsigned long long)hl[2] | ((unsigned long long)hl[3] << 32);
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
   // ---- pass 2 accumulators: residual + bias2 (nothing but the scale follows the sum)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float bv = p.bias ? p.bias[(r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
+    const float bv = p.bias ? p.bias[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
 #pragma unroll
     for (int an = 0; an < AN; ++an) acc[an][r] = rr[an][r] + bv;
   }
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(256, 3) void conv_x3pf_kernel(const ConvArgsX p) {
     f32x16 a2[1][AN];
 #pragma unroll
     for (int an = 0; an < AN; ++an) a2[0][an] = acc[an];
-    dense_epilogue<1, 4, 1, AN, 4>(pe, a2, 0, 0, n0, 0, wave, li, lh);
+    dense_epilogue<WM, WN, 1, AN, 4>(pe, a2, 0, 0, n0, wm, wn, li, lh);
   }
 }
 
@@ -912,25 +918,34 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   return true;
 }
 
-template <int KT>
+template <int KT, int WM>
 static void launch_x3pf(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3pf_kernel<KT>;
+  auto kern = conv_x3pf_kernel<KT, WM>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
-// a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32, BN = 256).  false: the staged fused kernel takes the pair.
-bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out) {
+// a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32: 256 intermediate columns per tile; C = 64: 128).  false: not
+// this kernel's geometry.
+bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry) {
   static const int on = getenv("RVC_X3PF") ? atoi(getenv("RVC_X3PF")) : 1;
-  if (!on || a.Ci != 32 || a.Co != 32 || !(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
-  const int P = 256 + (a.ktaps - 1) * a.dil;
-  if (P > 320) return false;
+  static const int on64 = getenv("RVC_X3PF64") ? atoi(getenv("RVC_X3PF64")) : 1;
+  if (!on || !(a.Ci == 32 || (a.Ci == 64 && on64)) || a.Co != a.Ci || !(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
+  const int C = a.Ci, BN = C == 32 ? 256 : 128;
+  // 64 channels: the narrow wave tile (32 rows: one operand read per MFMA) only wins where the pair is HBM-bound - k = 3: 220 -> 151 us;
+  // k = 7: 284 -> 296, k = 11: 393 -> 507 against the two split-resident launches (RVC_X3PF64=2 forces it)
+  if (C == 64 && a.ktaps != 3 && on64 < 2) return false;
+  const int P = BN + (a.ktaps - 1) * a.dil;
+  if (P > BN + 64) return false;
+  const int NO = BN - (a.ktaps - 1);
+  if ((long long)(T + NO - 1) / NO < 512) return false;          // short sequences: the unfused path fills the chip better
+  if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64;
-  const size_t lds = (size_t)((2 * 2 * P * 32 + 1023) & ~1023) + 4 * 2048;
-  const int NO = 256 - (a.ktaps - 1);
+  const size_t lds = (size_t)(((C / 16) * 2 * P * 32 + 1023) & ~1023) + 4 * (size_t)(2 * C * 32);
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);
   grid_out = grid;
-  if (a.ktaps == 3) launch_x3pf<3>(a, grid, lds, s); else if (a.ktaps == 7) launch_x3pf<7>(a, grid, lds, s); else launch_x3pf<11>(a, grid, lds, s);
+  if (C == 32) { if (a.ktaps == 3) launch_x3pf<3, 1>(a, grid, lds, s); else if (a.ktaps == 7) launch_x3pf<7, 1>(a, grid, lds, s); else launch_x3pf<11, 1>(a, grid, lds, s); }
+  else { if (a.ktaps == 3) launch_x3pf<3, 2>(a, grid, lds, s); else if (a.ktaps == 7) launch_x3pf<7, 2>(a, grid, lds, s); else launch_x3pf<11, 2>(a, grid, lds, s); }
   return true;
 }
 

@@ -1,4 +1,4 @@
-"""Fused ResBlock pair (C = 32) against the two unfused launches."""
+"""Fused ResBlock pair (PAIR_C = 32 / 64) against the two unfused launches (fp32 / split-resident intermediate)."""
 import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -19,7 +19,10 @@ for k, d in ((3, 1), (3, 5), (7, 3), (11, 5)):
         L.check(L.lib.rvc_conv1d_plan_run(plans[1], None, L.ptr(t1), T, L.ptr(x), L.ptr(y), 1, 0.1, 0, 0.0))
     def fused():
         L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(y), 1.0, 0))
-    for name, fn in (("unfused", unfused), ("fused", fused)):
+    def split():
+        L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(y), 1.0, 0))
+    variants = [("unfused", unfused), ("fused", fused)] + ([("split", split)] if Cc >= 64 else [])
+    for name, fn in variants:
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
