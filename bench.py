@@ -356,7 +356,13 @@ def roofline_pass(_lib, vc, step, torch):
         by = sum(ex[i * 8 + regime + 2] for i in idx); l_ = sum(ex[i * 8 + regime + 3] for i in idx)
         if l_ == 0:
             return None
-        tr = traffic.get(kernel)
+        # the bf16x3 family is four kernels (staged, pipelined conv / GEMM / fused pair): launch-weighted mean of their counters
+        names = [kernel] if kernel != "rvc::conv_x3_kernel" else [kernel, "rvc::conv_x3p_kernel", "rvc::conv_x3g_kernel", "rvc::conv_x3pf_kernel"]
+        trs = [traffic[n] for n in names if n in traffic]
+        tr = None
+        if trs:
+            nl = sum(t_["launches"] for t_ in trs)
+            tr = {"hbm_bytes_per_launch": sum(t_["hbm_bytes_total"] for t_ in trs) / max(nl, 1)}
         e = {"bound": "mfma" if regime == 0 else "hbm"}
         tf = f_ / (t * 1e-3) / 1e12
         if regime == 0:
@@ -373,7 +379,9 @@ def roofline_pass(_lib, vc, step, torch):
                   "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
                                     "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "algorithmic_tflops": round(tf, 2)}})
         return e
-    X3 = "rvc::conv_x3_kernel<WM,WN,AM,AN> (bf16x3 split: 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate)"
+    X3 = ("bf16x3 convolution family: rvc::conv_x3p_kernel<AM,AN,KT,..> (software-pipelined, generator), rvc::conv_x3pf_kernel (fused ResBlock pair), "
+          "rvc::conv_x3g_kernel (k = 1 GEMMs), rvc::conv_x3_kernel<WM,WN,AM,AN> (staged: strided / 2-D / transposed) - 3 v_mfma_f32_32x32x16_bf16 per "
+          "fp32 product block, fp32 accumulate")
     F32 = "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)"
     x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
     split_note = ("launches are split by arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the ridge peak FLOP/s / 8 TB/s: "

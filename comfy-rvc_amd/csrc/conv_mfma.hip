@@ -724,8 +724,10 @@ int conv_prof_dump_csv(const char* path) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? "conv_x3_kernel" : "conv_mfma_kernel", kCfgNames[r.cfg],
-            r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
+    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair)
+    static const char* kX3Fam[4] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel"};
+    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 3] : "conv_mfma_kernel", kCfgNames[r.cfg],
+            r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
             t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0);
   }
   fclose(f);

@@ -512,7 +512,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
       conv_x3g_try(a, s, g, S, false);
-      conv_prof_end(tk, s, flops, 14 + (a.Co > 64 ? 3 : 5), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y * g.z);
+      conv_prof_end(tk, s, flops, 14 + (a.Co > 64 ? 3 : 5), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y * g.z, 2 << 4);
       return true;
     }
   }
@@ -560,7 +560,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
       conv_x3p_try(a, t.AM, t.AN, s, g, false);
-      conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y);
+      conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 1 << 4);
       return true;
     }
   }
@@ -701,7 +701,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
       ProfTicket tk = conv_prof_begin(s);
       conv_x3pf_try(a, T, s, gpf, false);
       const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
-      conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + (C == 32 ? 1 : 5), bytes, &a, (long long)gpf.x, 1);
+      conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + (C == 32 ? 1 : 5), bytes, &a, (long long)gpf.x, 1 | (3 << 4));
       return true;
     }
     if (C == 64 && !pair64) return false;

@@ -375,7 +375,54 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   XPACC(2, t_epi - t_last);
   if constexpr (YSPLIT) {
     ysplit_epilogue<WM, WN, AM, AN>(p, acc, co0, n0, wm, wn, li, lh);
+  } else if (p.ostride != 1) {
+    // ConvTranspose1d: row m = co * u + phase goes to Y[co][n * u + phase] (phase-fastest rows: a tile holds every phase of its
+    // channels, so its stores complete whole cache lines in L2).  No residual / accumulate on this path (host).  u = 2: a lane's rows
+    // come in (phase 0, phase 1) pairs of one channel: one 8-byte store per pair and column.
+    const int u = p.ostride;
+    const float lslope = p.act == ACT_NONE ? 1.f : (p.act == ACT_RELU ? 0.f : p.act_slope);
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)p.orows * (unsigned)p.ldY * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am) {
+      if (u == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // even: phase 0 of channel m / 2
+          const int co = m >> 1;
+          const float bv = (p.bias && m < p.Co) ? p.bias[co] : 0.f;
+#pragma unroll
+          for (int an = 0; an < AN; ++an) {
+            const int n = n0 + (wn * AN + an) * 32 + li;
+            float v0 = acc[am][an][r] + bv, v1 = acc[am][an][r + 1] + bv;
+            v0 = fmaxf(v0, v0 * lslope) * p.out_scale; v1 = fmaxf(v1, v1 * lslope) * p.out_scale;
+            const long long to = 2LL * n;
+            const bool in = m < p.Co && n < p.Tout;
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const unsigned off = ((unsigned)co * (unsigned)p.ldY + (unsigned)to) * 4u;
+            if (in && to + 1 < p.ldY) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(v0), __float_as_uint(v1)}, yrs, (int)off, 0, 0);
+            else if (in && to < p.ldY) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), yrs, (int)off, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int co = m / u, ph = m - co * u;
+          const float bv = (p.bias && m < p.Co) ? p.bias[co] : 0.f;
+#pragma unroll
+          for (int an = 0; an < AN; ++an) {
+            const int n = n0 + (wn * AN + an) * 32 + li;
+            const long long to = (long long)n * u + ph;
+            float v = acc[am][an][r] + bv;
+            v = fmaxf(v, v * lslope) * p.out_scale;
+            const bool ok = m < p.Co && n < p.Tout && to < p.ldY;      // ldY doubles as the true output length for interleaved stores
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)(ok ? ((unsigned)co * (unsigned)p.ldY + (unsigned)to) * 4u : kOOB), 0, 0);
+          }
+        }
+      }
+    }
   } else if (r_init) {
+
     ConvArgsX pe = p;
     pe.R = nullptr; pe.bias = nullptr;                            // already inside the accumulators
     dense_epilogue<WM, WN, AM, AN, 4>(pe, acc, 0, co0, n0, wm, wn, li, lh);
@@ -855,7 +902,9 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   static const int on = getenv("RVC_X3P") ? atoi(getenv("RVC_X3P")) : 1;
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
-  if (a.Wd > 0 || a.stride != 1 || a.ostride != 1 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
+  if (a.Wd > 0 || a.stride != 1 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
+  // transposed conv: plain interleaved store
+  if (a.ostride != 1 && (xs || ys || a.R || a.accumulate || (double)a.orows * (double)a.ldY * 4.0 >= 2147483648.0)) return false;
   if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
   const int BM = 64 * AM, BN = 64 * AN;

@@ -345,16 +345,19 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     unsigned char* t1s = any_split ? A.alloc<unsigned char>(split_image_bytes(Cc, Tn)) : nullptr;
     if (!dry) {
       RVC_REQUIRE(conv1d_out_len(st.up, Tc) == Tn, "ConvTranspose1d geometry must give T_out = u * T_in");
+      // up-sampled signal first (interleaved store of the transposed conv's phases, no read-modify-write), then the noise branch is
+      // added by its own convolution's dense epilogue: the same two-operand fp32 sum as noise first / up-conv accumulating
+      ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f;
+      conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
+      ConvEpilogue En; En.accumulate = 1;
       if (!S->f0) {
         // plain Generator: nothing is added to the up-sampled signal
       } else if (st.noise_k > 1) {
         frames(s, har, fr, (int)N, st.noise_k, st.noise_s, st.noise_s / 2, Tn, 0);
-        conv1d_run(st.noise, s, fr, Tn, Tn, up, Tn, E0);
+        conv1d_run(st.noise, s, fr, Tn, Tn, up, Tn, En);
       } else {
-        conv1d_run(st.noise, s, har, Tn, Tn, up, Tn, E0);
+        conv1d_run(st.noise, s, har, Tn, Tn, up, Tn, En);
       }
-      ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f; Eu.accumulate = S->f0 ? 1 : 0;
-      conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
       if (taps && i == 0) tap(taps->gen_ups0, up, (size_t)Cc * Tn);
       for (int j = 0; j < 3; ++j) {
         const float* in = up;
