@@ -64,8 +64,11 @@ void conv_x3p_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 #endif
 
 // KT = taps (compile-time: the units of a chunk are unrolled, so every vmcnt wait is an immediate - see the counting rules at the waits).
-template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
+// S2: stride 2 (HuBERT's feature encoder, k = 3): the staged input keeps one sub-plane per input phase (even / odd positions), tap t reads
+// phase t & 1 at row offset t >> 1 - unit-stride operand reads, no wasted MFMAs.
+template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool S2 = false>
 __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(const ConvArgsX p) {
+  static_assert(!S2 || (!XSPLIT && !YSPLIT), "strided: fp32 in, fp32 out");
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
   constexpr int R = (AM == 2 && AN == 4) ? RVC_X3P_R24 : 3;  // weight slots in the ring (LDS of two / three workgroups per CU)
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   static_assert(RB == 2 || RB == 4, "64- or 128-row tiles");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3p[];
   const int P = p.WROW;                                     // staged input positions: BN + (KT - 1) * dil
-  const int Pm = XSPLIT ? BN + 64 : P;
+  const int Pm2 = (P + 1) >> 1;                              // (stride 2) rows of one phase sub-plane
+  const int Pm = XSPLIT ? BN + 64 : (S2 ? 2 * Pm2 : P);
   const int xplane = Pm * 32, xhalf = xplane >> 1, xbuf = 2 * xplane;
   unsigned char* Xs = smem3p;
   unsigned char* Ws = smem3p + ((2 * xbuf + 1023) & ~1023);
@@ -90,9 +94,12 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
   const int tile_y = (int)(tile / gridDim.x), tile_x = (int)(tile - (unsigned)tile_y * gridDim.x);
   const int co0 = tile_y * BM, n0 = tile_x * BN;
   const int nck = p.nchunk;                                  // >= 3 (host)
-  const int bx = n0 - p.pad;
+  const int bx = (S2 ? 2 * n0 : n0) - p.pad;
   const int ni = p.ni;                                       // 64-position groups of the staged row
-  const int dil16 = p.dil * 16;
+  auto tap_off = [&](int t) -> int {                         // byte offset of tap t inside a half-plane
+    if constexpr (S2) return ((t & 1) * Pm2 + (t >> 1)) * 16;
+    else return t * (p.dil * 16);
+  };
   const float pre_slope = p.pre_act == ACT_LRELU ? p.pre_slope : 1.f;
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, XSPLIT ? 0u : (unsigned)p.Ci * (unsigned)p.ldX * 4u);
 
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
         split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);       // input activation: leaky ReLU (slope 1 = identity)
         hi[j] = h_; lo[j] = l_;
       }
-      unsigned char* d = Xs + xb * xbuf + hb * xhalf + q * 16;
+      const int row = S2 ? (q & 1) * Pm2 + (q >> 1) : q;
+      unsigned char* d = Xs + xb * xbuf + hb * xhalf + row * 16;
       *reinterpret_cast<u32x4*>(d) = hi;
       *reinterpret_cast<u32x4*>(d + xplane) = lo;
     }
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
       // ---- operands of the second group
       {
         const unsigned char* wa = Ws + sl * wslot + BM * 32 + aoff;
-        const unsigned char* xa = Xs + xb * xbuf + T * dil16 + boff;
+        const unsigned char* xa = Xs + xb * xbuf + tap_off(T) + boff;
 #pragma unroll
         for (int am = 0; am < AM; ++am) al[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
 #pragma unroll
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
         if (!(tail1 && T + R - 1 >= KT)) issue_w();               // unit u + R - 1 into the slot unit u - 1 was read from
         if constexpr (XSPLIT && last_tap) { if (!tail2) issue_x(c + 2, xb); }   // this chunk's buffer is free: every wave is past its last read
         const unsigned char* wa = Ws + sn * wslot + aoff;
-        const unsigned char* xa = Xs + (last_tap ? xb ^ 1 : xb) * xbuf + xplane + (last_tap ? 0 : (T + 1) * dil16) + boff;
+        const unsigned char* xa = Xs + (last_tap ? xb ^ 1 : xb) * xbuf + xplane + (last_tap ? 0 : tap_off(T + 1)) + boff;
 #pragma unroll
         for (int am = 0; am < AM; ++am) ahn[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
 #pragma unroll
@@ -876,9 +884,9 @@ __global__ __launch_bounds__(256, WM == 1 ? 3 : 2) void conv_x3pf_kernel(const C
 }
 
 // ============================================================================ host side
-template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT>
+template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool S2 = false>
 static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3p_kernel<AM, AN, KT, XSPLIT, YSPLIT>;
+  auto kern = conv_x3p_kernel<AM, AN, KT, XSPLIT, YSPLIT, S2>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -902,27 +910,31 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   static const int on = getenv("RVC_X3P") ? atoi(getenv("RVC_X3P")) : 1;
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
-  if (a.Wd > 0 || a.stride != 1 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
+  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
+  // stride 2: the k = 3 layers of HuBERT's feature encoder on 128 x 128 tiles
+  const bool s2 = a.stride == 2;
+  if (a.stride != 1 && !(s2 && a.ktaps == 3 && a.dil == 1 && AM == 2 && AN == 2 && !xs && !ys && a.ostride == 1)) return false;
   // transposed conv: plain interleaved store
   if (a.ostride != 1 && (xs || ys || a.R || a.accumulate || (double)a.orows * (double)a.ldY * 4.0 >= 2147483648.0)) return false;
   if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
   const int BM = 64 * AM, BN = 64 * AN;
-  const int P = BN + (a.ktaps - 1) * a.dil;
-  if (P > 384 || P > BN + 64) return false;                       // three staging slots per wave; split input: BN + 64 rows per half-plane
-  const int Pm = xs ? BN + 64 : P;
+  const int P = s2 ? 2 * (BN - 1) + a.ktaps : BN + (a.ktaps - 1) * a.dil;
+  if (P > 384 || (!s2 && P > BN + 64)) return false;              // three staging slots per wave; split input: BN + 64 rows per half-plane
+  const int Pm = xs ? BN + 64 : (s2 ? 2 * ((P + 1) >> 1) : P);
   const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
   const int wslot = 2 * BM * 32;
   const int R = (AM == 2 && AN == 4) ? RVC_X3P_R24 : 3;
   const size_t lds = (size_t)xbytes + (size_t)R * wslot;
-  if (lds > (size_t)(AM * AN >= 8 ? 80 : 53) * 1024) return false;   // two / three workgroups per CU
+  if (lds > (size_t)(AM * AN >= 8 || s2 ? 80 : 53) * 1024) return false;   // two / three workgroups per CU
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1);
   grid_out = grid;
-  if (AM == 2 && AN == 4) launch_x3p_k<2, 4>(a, grid, lds, s);
+  if (s2) launch_x3p<2, 2, 3, false, false, true>(a, grid, lds, s);
+  else if (AM == 2 && AN == 4) launch_x3p_k<2, 4>(a, grid, lds, s);
   else if (AM == 1 && AN == 4) launch_x3p_k<1, 4>(a, grid, lds, s);
   else launch_x3p_k<2, 2>(a, grid, lds, s);
   return true;
