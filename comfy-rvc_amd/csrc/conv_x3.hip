@@ -512,7 +512,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
       conv_x3g_try(a, s, g, S, false);
-      conv_prof_end(tk, s, flops, 14 + (a.Co > 64 ? 3 : 5), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y * g.z, 2 << 4);
+      conv_prof_end(tk, s, flops, 14 + ((a.Co > 64 && a.Ci > 1024) ? 3 : 5), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y * g.z, 2 << 4);
       return true;
     }
   }

@@ -955,7 +955,9 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   if (!on) return false;
   if (a.Wd > 0 || a.ktaps != 1 || a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 63) || a.Ci < 128) return false;
   if (a.Tin != a.Tout) return false;
-  const int AM = a.Co > 64 ? 2 : 1, BM = 64 * AM, BN = 128;
+  static const int am_env = getenv("RVC_X3G_AM") ? atoi(getenv("RVC_X3G_AM")) : 0;
+  // 64-row tiles for short reductions (K <= 1024: q/k/v 49 -> 40 us, flow 192 -> 192 16 -> 11), 128-row tiles for long ones (FFN2, K = 3072: 61 vs 75 us)
+  const int AM = am_env ? am_env : ((a.Co > 64 && a.Ci > 1024) ? 2 : 1), BM = 64 * AM, BN = 128;
   const int U = a.Ci / 16;
   const long long nblk = (long long)((a.Co + BM - 1) / BM) * ((a.Tout + BN - 1) / BN);
   static const int min_blk = getenv("RVC_X3G_MINBLK") ? atoi(getenv("RVC_X3G_MINBLK")) : 24;
@@ -995,6 +997,7 @@ bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry)
   const int C = a.Ci, BN = C == 32 ? 256 : 128;
   // 64 channels: the narrow wave tile (32 rows: one operand read per MFMA) only wins where the pair is HBM-bound - k = 3: 220 -> 151 us;
   // k = 7: 284 -> 296, k = 11: 393 -> 507 against the two split-resident launches (RVC_X3PF64=2 forces it)
+  // (128 channels, 4 waves on top of each other on 64-column tiles, was tried for k = 3: 307 vs 294 us - no gain, not kept)
   if (C == 64 && a.ktaps != 3 && on64 < 2) return false;
   const int P = BN + (a.ktaps - 1) * a.dil;
   if (P > BN + 64) return false;

@@ -12,7 +12,7 @@ CASES = [  # name, Ci, Co, Tin, k, stride, dil
     ("gen s1 C256 k3", 256, 256, 10 * T, 3, 1, 1), ("gen s1 C256 k11 d5", 256, 256, 10 * T, 11, 1, 5),
     ("gen s2 C128 k3", 128, 128, 100 * T, 3, 1, 1), ("gen s2 C128 k7 d3", 128, 128, 100 * T, 7, 1, 3), ("gen s2 C128 k11", 128, 128, 100 * T, 11, 1, 1), ("gen s2 C128 k11 d5", 128, 128, 100 * T, 11, 1, 5), ("gen s3 C64 k11 d5", 64, 64, 200 * T, 11, 1, 5), ("gen s3 C64 k3", 64, 64, 200 * T, 3, 1, 1),
     ("gen s3 C64 k7", 64, 64, 200 * T, 7, 1, 1), ("gen s4 C32 k3", 32, 32, 400 * T, 3, 1, 1), ("gen s4 C32 k7", 32, 32, 400 * T, 7, 1, 1), ("gen s4 C32 k11 d5", 32, 32, 400 * T, 11, 1, 5),
-    ("hubert ffn1 768->3072", 768, 3072, 1599, 1, 1, 1), ("hubert ffn2 3072->768", 3072, 768, 1599, 1, 1, 1), ("hubert qk 768->1536", 768, 1536, 1599, 1, 1, 1),
+    ("hubert ffn1 768->3072", 768, 3072, 1599, 1, 1, 1), ("hubert ffn2 3072->768", 3072, 768, 1599, 1, 1, 1), ("hubert qk 768->1536", 768, 1536, 1599, 1, 1, 1), ("hubert out 768->768", 768, 768, 1599, 1, 1, 1), ("hubert qkv 768->2304", 768, 2304, 1599, 1, 1, 1), ("flow 192->192", 192, 192, 3198, 1, 1, 1),
     ("hubert conv1 s2", 512, 512, 102399, 3, 2, 1), ("hubert conv2 s2", 512, 512, 51199, 3, 2, 1),
 ]
 sel = sys.argv[1:] 
