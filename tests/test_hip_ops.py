@@ -101,6 +101,9 @@ X3_CONV1D = [
     (48, 64, 100000, 5, 2, 1, "lrelu", "none", False, 1.0, False, 3),
     (128, 128, 160001, 7, 9, 3, "lrelu", "none", True, 1.0, False),     # >= 600 workgroups of 128 x 256: wide tile 2x2x2x4
     (64, 64, 310000, 11, 25, 5, "lrelu", "none", True, 1.0 / 3, True),  # wide tile 1x4x2x4 (64 x 512)
+    (48, 128, 70000, 7, 3, 1, "lrelu", "none", True, 1.0, False),       # pipelined kernel, three chunks: first / last-but-one / last chunk rules all at once
+    (64, 128, 66001, 11, 5, 1, "none", "lrelu", True, 0.5, True),       # four chunks, activation after the sum (residual through the epilogue, not the accumulators)
+    (512, 512, 60001, 3, 0, 1, "none", "none", False, 1.0, False, 2),   # stride 2 on the pipelined kernel (phase sub-planes), odd length
 ]
 
 
