@@ -36,7 +36,7 @@ CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r2k_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r2l_pmc_traffic.json")
 
 
 def launch_ranks(n):
@@ -146,7 +146,7 @@ def cpu_baseline(config=None, seconds=10.0, budget_s=75.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
