@@ -20,5 +20,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 fc=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); wc=$(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py "$fc" "$wc" gpurun_out/${tag}_pmc_traffic.json | head -8
-python3 tools/launch_classes.py gpurun_out/${tag}_launches_pmc_FETCH_SIZE.csv "$fc" "$wc" > gpurun_out/${tag}_launch_classes.md; head -14 gpurun_out/${tag}_launch_classes.md | cut -c1-250
+# (us from the un-profiled event-timed pass of the bench run above; bytes from the counter passes, joined by launch order per kernel)
+python3 tools/launch_classes.py gpurun_out/${tag}_launches.csv "$fc" "$wc" > gpurun_out/${tag}_launch_classes.md; head -14 gpurun_out/${tag}_launch_classes.md | cut -c1-250
 find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +8M -delete
