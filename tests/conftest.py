@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _x3p_wait_count_check():
+    """On a -DRVC_X3P_CHECK build (RVC_HIP_LIB=.../librvc_hip_x3pcheck.so) the pipelined bf16x3 kernels count every wait whose compile-time
+    vmcnt exceeded the exact run-time count; a whole `-m gpu` session must end with none.  Ordinary builds report -1."""
+    yield
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        from comfy_rvc_amd import _lib
+        bad = _lib.lib.rvc_debug_x3p_check()
+    except Exception:
+        return
+    assert bad <= 0, f"{bad} waits of the pipelined kernels had a too large compile-time count"
+
+
 def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
