@@ -450,7 +450,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
 // converted two units ahead of their use), the unit loop is unrolled by four so that the register slot is a compile-time index and every
 // wait an immediate.  Loads and weight requests run past the end of the reduction with out-of-range / repeated addresses instead of
 // stopping (nobody reads what they deliver), so the counts of the steady state hold to the last unit.  blockIdx.z = K split.
-template <int AM, int AN>
+// C2D: 3 x 3 convolution over an H x W image (W a power of two, zero padding 1) as the same GEMM with K = 9 Ci: unit = (chunk, tap), the
+// unit's input piece is loaded from the tap-shifted positions (im2col on the fly; the deep U-Net levels of RMVPE, whose activations live
+// in L2: 512 channels x 404 positions, split over K because 16 tiles do not fill anything).
+template <int AM, int AN, bool C2D = false>
 __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
@@ -522,11 +525,23 @@ __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
   };
   // ---- input: this wave's piece of a unit = 8 channels (half hb) x 64 columns
   const int hb = wave >> 1, xq = (wave & 1) * 64 + lane;
-  const unsigned xvoff = (n0 + xq < p.Tin) ? (unsigned)(n0 + xq) * 4u : kOOB;
+  const int xn = n0 + xq;                                      // this lane's column (1-D) / linear image position (2-D)
+  const unsigned xvoff = (xn < (C2D ? p.Tout : p.Tin)) ? (unsigned)xn * 4u : kOOB;
+  const int wlog = C2D ? 31 - __builtin_clz((unsigned)p.Wd) : 0;
+  const int xh = C2D ? xn >> wlog : 0, xw = C2D ? xn & (p.Wd - 1) : 0;
   float xr[LX][8];
   auto load_unit = [&](int j, int u) {                        // register slot j <- unit u (out of range past the end: zeros, no traffic)
-    const unsigned c0 = (unsigned)((u0 + u) * 16 + hb * 8);
-    const unsigned vo = u < U ? xvoff : kOOB;
+    unsigned c0, vo;
+    if constexpr (C2D) {
+      const int gu = u0 + u, ch = gu / 9, tap = gu - 9 * ch, dh = tap / 3 - 1, dw = tap - 3 * (tap / 3) - 1;
+      const int hh = xh + dh, ww = xw + dw;
+      const bool ok = u < U && xvoff != kOOB && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
+      c0 = (unsigned)(ch * 16 + hb * 8);
+      vo = ok ? (unsigned)((hh << wlog) + ww) * 4u : kOOB;
+    } else {
+      c0 = (unsigned)((u0 + u) * 16 + hb * 8);
+      vo = u < U ? xvoff : kOOB;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) xr[j][i] = buf_load(xrs, vo, (c0 + i) * (unsigned)p.ldX * 4u);
   };
@@ -940,9 +955,9 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   return true;
 }
 
-template <int AM, int AN>
+template <int AM, int AN, bool C2D = false>
 static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3g_kernel<AM, AN>;
+  auto kern = conv_x3g_kernel<AM, AN, C2D>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -953,15 +968,24 @@ static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s)
 bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, bool dry) {
   static const int on = getenv("RVC_X3G") ? atoi(getenv("RVC_X3G")) : 1;
   if (!on) return false;
-  if (a.Wd > 0 || a.ktaps != 1 || a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 63) || a.Ci < 128) return false;
-  if (a.Tin != a.Tout) return false;
+  // 2-D: 3 x 3, pad 1, plain (no 2 x 2 up-sampling interleave), on images small enough that the nine shifted reads come from L2
+  static const int on2d = getenv("RVC_X3G_2D") ? atoi(getenv("RVC_X3G_2D")) : 1;
+  static const int max2d = getenv("RVC_X3G_2D_MAXPOS") ? atoi(getenv("RVC_X3G_2D_MAXPOS")) : 30000;
+  const bool two_d = a.Wd > 0;
+  if (two_d && !(on2d && a.ktaps == 9 && a.KW == 0 && !a.up2 && (a.Wd & (a.Wd - 1)) == 0 && a.Tout <= max2d)) return false;
+  // (measured against the staged kernel + split-K, launch incl. the reduction: 128 / 256 channels 36 -> 31 us, the level changes 50 -> 38;
+  // 512 x 512 on 404 positions 34.5 -> 37: that one stays)
+  if (two_d && a.Ci >= 512 && a.Co <= 512 && a.Tout < 1000 && on2d < 2) return false;
+  if ((!two_d && a.ktaps != 1) || a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 15)) return false;
+  if (!two_d && a.Tin != a.Tout) return false;
   static const int am_env = getenv("RVC_X3G_AM") ? atoi(getenv("RVC_X3G_AM")) : 0;
   // 64-row tiles for short reductions (K <= 1024: q/k/v 49 -> 40 us, flow 192 -> 192 16 -> 11), 128-row tiles for long ones (FFN2, K = 3072: 61 vs 75 us)
-  const int AM = am_env ? am_env : ((a.Co > 64 && a.Ci > 1024) ? 2 : 1), BM = 64 * AM, BN = 128;
-  const int U = a.Ci / 16;
+  const int AM = am_env ? am_env : ((a.Co > 64 && a.Ci * a.ktaps > 1024) ? 2 : 1), BM = 64 * AM, BN = 128;
+  const int U = a.Ci / 16 * a.ktaps;
+  if ((U & 3) || U < 8) return false;                              // unit loop unrolled by four
   const long long nblk = (long long)((a.Co + BM - 1) / BM) * ((a.Tout + BN - 1) / BN);
   static const int min_blk = getenv("RVC_X3G_MINBLK") ? atoi(getenv("RVC_X3G_MINBLK")) : 24;
-  if (nblk < min_blk) return false;
+  if (nblk < (two_d ? 8 : min_blk)) return false;
   // K split: enough workgroups for the chip (a 128 x 128 tile of a K = 768 GEMM is 9 us of MFMAs), at least 8 units per split, groups of 4
   static const int target = getenv("RVC_X3G_BLK") ? atoi(getenv("RVC_X3G_BLK")) : 256;
   int S = 1;
@@ -976,7 +1000,8 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   const size_t lds = (size_t)3 * (2 * BN * 32) + (size_t)3 * (2 * BM * 32);
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
   grid_out = grid; ksplit_out = S;
-  if (AM == 2) launch_x3g<2, 2>(a, grid, lds, s); else launch_x3g<1, 2>(a, grid, lds, s);
+  if (two_d) { if (AM == 2) launch_x3g<2, 2, true>(a, grid, lds, s); else launch_x3g<1, 2, true>(a, grid, lds, s); }
+  else if (AM == 2) launch_x3g<2, 2>(a, grid, lds, s); else launch_x3g<1, 2>(a, grid, lds, s);
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
   return true;
 }

@@ -211,7 +211,9 @@ def test_conv2d3x3_relu_residual(L, case):
 
 
 @pytest.mark.parametrize("case", [(16, 16, 3232, 128), (32, 32, 1616, 64), (64, 32, 1617, 64), (64, 64, 808, 32), (128, 64, 803, 32), (16, 32, 1000, 128),
-                                  (48, 16, 2000, 128)])
+                                  (48, 16, 2000, 128),
+                                  # deep U-Net levels: the pipelined GEMM kernel with tap-shifted input pieces, split over K
+                                  (128, 128, 404, 16), (256, 256, 202, 8), (512, 512, 101, 4), (256, 512, 101, 4), (512, 256, 203, 8), (64, 128, 401, 16)])
 def test_conv2d3x3_bf16x3(L, case):
     """RMVPE U-Net 3x3 convolutions on the bf16x3 kernel (halo patch staged per tile of image rows)."""
     Ci, Co, H, W = case
