@@ -505,8 +505,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;
   ConvArgsX a = a0;
   if (a.Wd == 0) a.ktaps = a0.kreal;                      // true taps (the fp32 kernel folds the stride phases into virtual channels)
-  if (batch == 1 && (a.ktaps == 1 || (a.Wd > 0 && a.ktaps == 9))) {
-    // k = 1 and the 3 x 3 convolutions of small images: the pipelined GEMM kernel (conv_x3p.hip)
+  if (batch == 1 && a.up2 == 0) {
+    // k = 1, the 3 x 3 convolutions of small images and short 1-D sequences: the pipelined GEMM kernel (conv_x3p.hip)
     dim3 g; int S = 1;
     if (conv_x3g_try(a, s, g, S, true)) {
       if (dry) return true;

@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
 // C2D: 3 x 3 convolution over an H x W image (W a power of two, zero padding 1) as the same GEMM with K = 9 Ci: unit = (chunk, tap), the
 // unit's input piece is loaded from the tap-shifted positions (im2col on the fly; the deep U-Net levels of RMVPE, whose activations live
 // in L2: 512 channels x 404 positions, split over K because 16 tiles do not fill anything).
-template <int AM, int AN, bool C2D = false>
+// C2D = 2: 1-D convolution with taps (stride 1, any dilation) the same way, K = ktaps * Ci - the short sequences (100 frames per second) of
+// the text encoder's FFN and the flow's WaveNet, whose grids are too small for the tiled kernels.
+template <int AM, int AN, int C2D = 0>
 __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
@@ -527,12 +529,18 @@ __global__ __launch_bounds__(256, 3) void conv_x3g_kernel(const ConvArgsX p) {
   const int hb = wave >> 1, xq = (wave & 1) * 64 + lane;
   const int xn = n0 + xq;                                      // this lane's column (1-D) / linear image position (2-D)
   const unsigned xvoff = (xn < (C2D ? p.Tout : p.Tin)) ? (unsigned)xn * 4u : kOOB;
-  const int wlog = C2D ? 31 - __builtin_clz((unsigned)p.Wd) : 0;
-  const int xh = C2D ? xn >> wlog : 0, xw = C2D ? xn & (p.Wd - 1) : 0;
+  const int wlog = C2D == 1 ? 31 - __builtin_clz((unsigned)p.Wd) : 0;
+  const int xh = C2D == 1 ? xn >> wlog : 0, xw = C2D == 1 ? xn & (p.Wd - 1) : 0;
   float xr[LX][8];
   auto load_unit = [&](int j, int u) {                        // register slot j <- unit u (out of range past the end: zeros, no traffic)
     unsigned c0, vo;
-    if constexpr (C2D) {
+    if constexpr (C2D == 2) {
+      const int gu = u0 + u, ch = gu / p.ktaps, tap = gu - p.ktaps * ch;
+      const int x = xn - p.pad + tap * p.dil;
+      const bool ok = u < U && xvoff != kOOB && x >= 0 && x < p.Tin;
+      c0 = (unsigned)(ch * 16 + hb * 8);
+      vo = ok ? (unsigned)x * 4u : kOOB;
+    } else if constexpr (C2D == 1) {
       const int gu = u0 + u, ch = gu / 9, tap = gu - 9 * ch, dh = tap / 3 - 1, dw = tap - 3 * (tap / 3) - 1;
       const int hh = xh + dh, ww = xw + dw;
       const bool ok = u < U && xvoff != kOOB && hh >= 0 && hh < p.Tin && ww >= 0 && ww < p.Wd;
@@ -955,7 +963,7 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   return true;
 }
 
-template <int AM, int AN, bool C2D = false>
+template <int AM, int AN, int C2D = 0>
 static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3g_kernel<AM, AN, C2D>;
   static std::once_flag attr_once;
@@ -976,8 +984,12 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   // (measured against the staged kernel + split-K, launch incl. the reduction: 128 / 256 channels 36 -> 31 us, the level changes 50 -> 38;
   // 512 x 512 on 404 positions 34.5 -> 37: that one stays)
   if (two_d && a.Ci >= 512 && a.Co <= 512 && a.Tout < 1000 && on2d < 2) return false;
-  if ((!two_d && a.ktaps != 1) || a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 15)) return false;
-  if (!two_d && a.Tin != a.Tout) return false;
+  // 1-D with taps: only where the tiled kernels would not run (grids below their minimum: the 100-frames-per-second layers)
+  static const int on1d = getenv("RVC_X3G_TAPS") ? atoi(getenv("RVC_X3G_TAPS")) : 1;
+  const bool taps1d = !two_d && a.ktaps > 1;
+  if (taps1d && !(on1d && a.ktaps <= 16 && (long long)((a.Co + 127) / 128) * ((a.Tout + 127) / 128) < 250)) return false;
+  if (a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 15)) return false;
+  if (!two_d && !taps1d && a.Tin != a.Tout) return false;
   static const int am_env = getenv("RVC_X3G_AM") ? atoi(getenv("RVC_X3G_AM")) : 0;
   // 64-row tiles for short reductions (K <= 1024: q/k/v 49 -> 40 us, flow 192 -> 192 16 -> 11), 128-row tiles for long ones (FFN2, K = 3072: 61 vs 75 us)
   const int AM = am_env ? am_env : ((a.Co > 64 && a.Ci * a.ktaps > 1024) ? 2 : 1), BM = 64 * AM, BN = 128;
@@ -1000,7 +1012,8 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
   const size_t lds = (size_t)3 * (2 * BN * 32) + (size_t)3 * (2 * BM * 32);
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), (unsigned)S);
   grid_out = grid; ksplit_out = S;
-  if (two_d) { if (AM == 2) launch_x3g<2, 2, true>(a, grid, lds, s); else launch_x3g<1, 2, true>(a, grid, lds, s); }
+  if (two_d) { if (AM == 2) launch_x3g<2, 2, 1>(a, grid, lds, s); else launch_x3g<1, 2, 1>(a, grid, lds, s); }
+  else if (taps1d) { if (AM == 2) launch_x3g<2, 2, 2>(a, grid, lds, s); else launch_x3g<1, 2, 2>(a, grid, lds, s); }
   else if (AM == 2) launch_x3g<2, 2>(a, grid, lds, s); else launch_x3g<1, 2>(a, grid, lds, s);
   if (S > 1) splitk_reduce_launch(a, S, 1, s);
   return true;

@@ -104,6 +104,9 @@ X3_CONV1D = [
     (48, 128, 70000, 7, 3, 1, "lrelu", "none", True, 1.0, False),       # pipelined kernel, three chunks: first / last-but-one / last chunk rules all at once
     (64, 128, 66001, 11, 5, 1, "none", "lrelu", True, 0.5, True),       # four chunks, activation after the sum (residual through the epilogue, not the accumulators)
     (512, 512, 60001, 3, 0, 1, "none", "none", False, 1.0, False, 2),   # stride 2 on the pipelined kernel (phase sub-planes), odd length
+    (768, 192, 3198, 3, 1, 1, "none", "none", True, 1.0, False),        # text encoder FFN (k = 3, 100 fps): the GEMM kernel with tap-shifted input pieces, split K
+    (192, 768, 3001, 3, 1, 1, "none", "relu", False, 1.0, False),
+    (192, 384, 3198, 5, 4, 2, "lrelu", "none", False, 1.0, False),      # flow WaveNet in_layer, dilated
 ]
 
 
