@@ -556,11 +556,15 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   if (t.WM == 2 && t.WN == 2 && batch == 1) {
     // the generator's stride-1 convolutions: software-pipelined kernel (conv_x3p.hip)
     dim3 g;
-    if (conv_x3p_try(a, t.AM, t.AN, s, g, true)) {
+    // (the stride-2 mode exists for 128 x 128 tiles only: a shorter layer that would take 64-row tiles uses it as long as >= 150 tiles remain)
+    const bool s2_up = a.stride == 2 && a.ktaps == 3 && a.Co >= 128 && !(t.AM == 2 && t.AN == 2) &&
+                       (long long)((a.Co + 127) / 128) * ((a.Tout + 127) / 128) >= 150;
+    const int pam = s2_up ? 2 : t.AM, pan = s2_up ? 2 : t.AN;
+    if (conv_x3p_try(a, pam, pan, s, g, true)) {
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
-      conv_x3p_try(a, t.AM, t.AN, s, g, false);
-      conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 1 << 4);
+      conv_x3p_try(a, pam, pan, s, g, false);
+      conv_prof_end(tk, s, flops, 14 + (s2_up ? 3 : id), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 1 << 4);
       return true;
     }
   }
