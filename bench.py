@@ -83,16 +83,18 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(config=None, seconds=10.0, budget_s=75.0):
-    """The CPU oracle (validated restatement of the reference) timed on this box's host cores as BASELINE.md section 4 describes:
-    BASELINE.json configs[0]'s 10 s clip, 1 warm-up + median of 3 timed runs, torch.set_num_threads(k) with k stated, per-stage
-    seconds.  Bounded: when a run takes longer than budget_s / 4 the remaining repeats are dropped (n_runs says how many were timed)."""
+def cpu_baseline(config=None, seconds=CLIP_SECONDS, seed=100, budget_s=40.0):
+    """The CPU oracle (validated restatement of the reference) timed on this box's host cores as BASELINE.md section 4 describes, on the
+    SAME clip the GPU line converts (same length, same seed: rank 0's clip): 1 s warm-up clip + up to 3 timed runs inside budget_s of CPU
+    time (a 30 s clip takes ~14 s on 32 threads, so normally two), torch.set_num_threads(k) with k stated (bounded by the rank's CPU
+    affinity), per-stage seconds.  n_runs says how many were timed; the median (upper of two) is reported."""
     import numpy as np
     import torch
     from comfy_rvc_amd import synthetic as S
     from oracle import nets, pipeline as opl
     ncpu = os.cpu_count() or 1
-    k = max(1, min(ncpu, 32))                  # torch-CPU conv/GEMM on these sizes stops scaling well before 32 threads
+    navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu      # the rank is pinned to its GPU's NUMA node
+    k = max(1, min(navail, 32))                # torch-CPU conv/GEMM on these sizes stops scaling well before 32 threads
     prev = torch.get_num_threads()
     torch.set_num_threads(k)
     config = config or S.CONFIG_40K_V2
@@ -127,7 +129,7 @@ def cpu_baseline(config=None, seconds=10.0, budget_s=75.0):
         runs = []
         t_all = time.perf_counter()
         for _ in range(3):
-            runs.append(run(seconds, 1))
+            runs.append(run(seconds, seed))
             if time.perf_counter() - t_all + runs[-1][1] > budget_s:
                 break
     finally:
@@ -136,9 +138,9 @@ def cpu_baseline(config=None, seconds=10.0, budget_s=75.0):
     runs.sort(key=lambda r: r[1])
     delivered, dt, st = runs[len(runs) // 2]
     return {"value": round(delivered / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(k), "kind": "port", "cpu": cpu_model(),
-            "host_logical_cpus": int(ncpu), "n_runs": len(runs), "wall_s_median": round(dt, 2),
+            "host_logical_cpus": int(ncpu), "cpus_in_affinity_mask": int(navail), "n_runs": len(runs), "wall_s_median": round(dt, 2),
             "stage_seconds": {n: round(v, 2) for n, v in sorted(st.items())},
-            "sample": f"1 x {seconds:g} s clip (BASELINE.json configs[0] length), 1 s warm-up clip + median of {len(runs)} run(s), same procedural weights, "
+            "sample": f"1 x {seconds:g} s clip = the clip of the GPU line (synthetic.synth_audio seed {seed}), 1 s warm-up clip + median of {len(runs)} run(s), same procedural weights, "
                       f"oracle.pipeline = torch-CPU fp32 restatement of the reference validated against reference goldens, "
                       f"torch.set_num_threads({k})"}
 
@@ -157,29 +159,41 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the process group and run every step's gather (exercises RCCL on a 1-GPU box)")
+    ap.add_argument("--no-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing in this process has initialised HIP
 
-    import numpy as np
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    # CPU affinity first: nothing in this process has touched HIP yet (importing torch / counting devices does not), so the runtime's helper
+    # threads, the lane threads and the side-stream callbacks all inherit the mask.  One NUMA node's worth of CPUs per rank.
+    bound = None
+    if not args.no_bind and not args.dry_run:
+        from comfy_rvc_amd.parallel import bind_rank_to_numa
+        bound = bind_rank_to_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+
+    import numpy as np
+    import torch
     dist = None
     backend = os.environ.get("RVC_BENCH_BACKEND", "nccl")
     use_gpu = not args.dry_run
     if use_gpu:
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:      # the N > 1 control flow on a 1-GPU (or no-GPU, with --dry-run) box: RVC_BENCH_BACKEND=gloo
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = f"cuda:{local_rank}"
     coll_dev = dev if backend == "nccl" else "cpu"      # where the collectives' tensors live
@@ -205,12 +219,18 @@ def main():
         from comfy_rvc_amd.lib.rmvpe import RMVPE
         from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
         cfg = Config(device=dev)
+        # procedural weights: generated ONCE per rank and shared by its lanes (each lane still owns its device replica: handles carry workspaces)
+        hub_sd, rmvpe_sd, syn_ckpt = S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_checkpoint(SYN_CFG, "v2", 0)
+        mdx_sd = None
+        if chain:
+            from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as _MC
+            mdx_sd = S.mdx23c_state_dict(_MC, 0)
 
         def make_lane():
-            hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG, device=dev)
-            vcd = get_vc(S.synth_checkpoint(SYN_CFG, "v2", 0), config=cfg, device=dev)
+            hub = HubertModelWithFinalProj(hub_sd, S.HUBERT_CONFIG, device=dev)
+            vcd = get_vc(syn_ckpt, config=cfg, device=dev)
             lvc = VC(SYN_CFG[-1], cfg)
-            lvc.model_rmvpe = RMVPE(S.rmvpe_state_dict(0), device=dev)
+            lvc.model_rmvpe = RMVPE(rmvpe_sd, device=dev)
             lvc.noise_on_device = True          # the reference draws its noise with the compute device's generator as well
 
             mdx = None
@@ -219,7 +239,7 @@ def main():
                 from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
                 from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
                 mdx = TFC_TDF_net(MDX23C_CONFIG, device=dev)
-                mdx.load_state_dict(S.mdx23c_state_dict(MDX23C_CONFIG, 0))
+                mdx.load_state_dict(mdx_sd)
 
             def convert(clip, i=0):
                 sr_in = 16000
@@ -251,8 +271,8 @@ def main():
         for wav in pool.imap([audio] * (k * n_clips)):
             batch.append(wav)
             if len(batch) == n_clips:
-                if world > 1:
-                    gather_waveforms(np.concatenate(batch), coll_dev)
+                if collective:   # every rank already holds ITS clips on the host (vc_single delivered them); rank 0 keeps the gathered copy in HBM
+                    gather_waveforms(np.concatenate(batch), coll_dev, to_host=False, force_collective=True)
                 batch = []
         return wav
 
@@ -292,7 +312,7 @@ def main():
         roofline = roofline_pass(_lib, vc, step, torch)
     cpu = None
     if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
-        cpu = cpu_baseline(config=SYN_CFG) if not chain else None      # (the CPU oracle of the separation net at full size takes minutes per chunk)
+        cpu = cpu_baseline(config=SYN_CFG, seconds=args.seconds) if not chain else None      # (the CPU oracle of the separation net at full size takes minutes per chunk)
 
     if rank == 0:
         cfg_idx = {"40k_v2": 2, "48k_v2": 3, "uvr_48k_v2": 4}[args.variant]
@@ -302,12 +322,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if use_gpu else "dry-run (stub conversion, NO GPU work: launcher / collective check only)",
             "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
-            "ranks": world, "backend": (backend if world > 1 else None), "nccl_ranks": (world if (world > 1 and backend == "nccl") else None),
+            "ranks": world, "backend": (backend if collective else None), "nccl_ranks": (world if (collective and backend == "nccl") else None),
+            "cpu_affinity": (f"{len(bound)} CPUs of the GPU's NUMA node" if bound else "unbound (topology unknown or --no-bind)"),
             "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
             "config": {"workload": ("MDX23C vocal split (stereo 44.1 kHz, overlap 8) -> " if chain else "") +
                                    f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s {'44.1 kHz stereo' if chain else '16 kHz'} clips, {n_clips} per GPU "
                                    f"per step ({n_lanes} in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
                        "clips_per_step": world * n_clips, "clips_per_gpu_per_step": n_clips, "clips_in_flight_per_gpu": n_lanes,
+                       "gathers_per_step": 1 if collective else 0,
                        "audio_seconds_delivered_per_clip": round(delivered, 3),
                        "one_clip_alone_ms": round(alone_ms, 2), "one_clip_alone_xrt": round(delivered / alone_ms * 1e3, 1),
                        "weights": "procedural (comfy-rvc_amd/synthetic.py)", "noise": "device generator",
@@ -320,28 +342,41 @@ def main():
         dist.destroy_process_group()
 
 
+KERNEL_DESC = {
+    "conv_x3p_kernel": "rvc::conv_x3p_kernel<AM,AN,KT,XSPLIT,YSPLIT,S2> - software-pipelined bf16x3 implicit-GEMM Conv1d (generator ResBlocks / up-samplers, "
+                       "HuBERT stride-2 layers): 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
+    "conv_x3pf_kernel": "rvc::conv_x3pf_kernel<KT,WM> - fused ResBlock pair (32- / 64-channel generator stages), bf16x3",
+    "conv_x3g_kernel": "rvc::conv_x3g_kernel - pipelined bf16x3 GEMM (k = 1 projections, taps / 3x3 modes on short sequences)",
+    "conv_x3s_kernel": "rvc::conv_x3s_kernel - bf16x3 GEMM on split-resident operands (both tiles by LDS-DMA, in-kernel split-K)",
+    "conv_x3_kernel": "rvc::conv_x3_kernel<WM,WN,AM,AN> - staged bf16x3 kernel (2-D 3x3, other strides)",
+    "conv_mfma_kernel": "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> - fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM",
+}
+
+
 def roofline_pass(_lib, vc, step, torch):
     """One extra, untimed-for-the-headline clip with every conv-kernel launch bracketed by HIP events on the stream it is launched on
-    (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes."""
+    (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes.  The per-launch table is grouped by KERNEL:
+    `roofline` is the kernel with the most time per clip (the same kernel tops profiles/*_kernel_stats_lanes1.csv), priced against its own
+    bound (arithmetic intensity of ITS launches against the ridge) with ITS PMC traffic; the other kernels follow in `other_kernels`."""
+    import csv
+    import tempfile
     _lib.check(_lib.lib.rvc_prof_enable(1))
     vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
     step()
     torch.cuda.synchronize()
-    NCFG = 24   # RVC_PROF_CFGS
-    ms = (C.c_double * NCFG)(); fl = (C.c_double * NCFG)(); ln = (C.c_int64 * NCFG)()
-    ex = (C.c_double * (NCFG * 8))()
-    ridge_f32 = FP32_MFMA_PEAK_TFLOPS * 1e12 / HBM_PEAK_BPS
-    ridge_x3 = BF16_MFMA_PEAK_TFLOPS / 3.0 * 1e12 / HBM_PEAK_BPS
-    _lib.check(_lib.lib.rvc_prof_collect_ex(ex, ridge_f32, ridge_x3))
-    _lib.check(_lib.lib.rvc_prof_collect(ms, fl, ln))
     dump = os.environ.get("RVC_PROF_CSV")
-    if dump:                         # per-launch table (shape, tile, us, FLOPs, algorithmic bytes) for profiles/
-        _lib.check(_lib.lib.rvc_prof_dump_csv(dump.encode()))
+    tmp = None
+    if not dump:
+        tmp = tempfile.NamedTemporaryFile(suffix=".csv", delete=False)
+        tmp.close()
+        dump = tmp.name
+    _lib.check(_lib.lib.rvc_prof_dump_csv(dump.encode()))      # per-launch table (shape, tile, us, FLOPs, algorithmic bytes); kept when RVC_PROF_CSV names it
     _lib.check(_lib.lib.rvc_prof_enable(0))
     vc.overlap_streams = True
-    per_cfg = {_lib.lib.rvc_prof_cfg_name(i).decode(): {"launches": int(ln[i]), "ms": round(ms[i], 3),
-                                                        "tflops": round(fl[i] / ms[i] / 1e9, 2) if ms[i] > 0 else 0.0}
-               for i in range(NCFG) if ln[i]}
+    with open(dump) as f:
+        rows = list(csv.DictReader(f))
+    if tmp is not None:
+        os.unlink(tmp.name)
     traffic, traffic_src = {}, None
     try:
         with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
@@ -349,52 +384,58 @@ def roofline_pass(_lib, vc, step, torch):
         traffic, traffic_src = doc["kernels"], f"from file {PMC_TRAFFIC_FILE} (commit {doc.get('commit', '?')}), not measured in this run"
     except (OSError, ValueError, KeyError):
         pass
+    x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+    kernels = {}
+    for r in rows:
+        kernels.setdefault(r["kernel"], []).append(r)
 
-    def family(idx, regime, kernel, desc, peak_tf, note):
-        """One roofline entry: the launches of a kernel family in one regime (0: MFMA-bound, 4: HBM-bound by arithmetic intensity)."""
-        t = sum(ex[i * 8 + regime] for i in idx); f_ = sum(ex[i * 8 + regime + 1] for i in idx)
-        by = sum(ex[i * 8 + regime + 2] for i in idx); l_ = sum(ex[i * 8 + regime + 3] for i in idx)
-        if l_ == 0:
-            return None
-        # the bf16x3 family is four kernels (staged, pipelined conv / GEMM / fused pair): launch-weighted mean of their counters
-        names = [kernel] if kernel != "rvc::conv_x3_kernel" else [kernel, "rvc::conv_x3p_kernel", "rvc::conv_x3g_kernel", "rvc::conv_x3pf_kernel"]
-        trs = [traffic[n] for n in names if n in traffic]
-        tr = None
-        if trs:
-            nl = sum(t_["launches"] for t_ in trs)
-            tr = {"hbm_bytes_per_launch": sum(t_["hbm_bytes_total"] for t_ in trs) / max(nl, 1)}
-        e = {"bound": "mfma" if regime == 0 else "hbm"}
-        tf = f_ / (t * 1e-3) / 1e12
-        if regime == 0:
+    def entry(name, rs):
+        us = sum(float(r["us"]) for r in rs)
+        gf = sum(float(r["alg_gflop"]) for r in rs)
+        mb = sum(float(r["alg_mbytes"]) for r in rs)
+        n = len(rs)
+        x3 = name != "conv_mfma_kernel"
+        peak_tf = x3_peak if x3 else FP32_MFMA_PEAK_TFLOPS
+        ridge = peak_tf * 1e12 / HBM_PEAK_BPS
+        mfma = mb <= 0 or (gf * 1e9) / (mb * 1e6) >= ridge
+        tf = gf / us * 1e3 if us > 0 else 0.0                    # 1 GFLOP / us = 1e15 FLOP/s = 1000 TFLOP/s
+        gbs = mb / us * 1e3 if us > 0 else 0.0                   # 1 MB / us = 1e12 B/s = 1000 GB/s
+        e = {"bound": "mfma" if mfma else "hbm"}
+        if mfma:
             e.update({"achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4)})
         else:
-            ach = by / (t * 1e-3) / 1e9
-            e.update({"achieved": round(ach, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(ach / (HBM_PEAK_BPS / 1e9), 4)})
+            e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)})
+        tr = traffic.get("rvc::" + name)
+        # the launch classes of this kernel (shape -> launches, us, TFLOP/s), largest first
+        cls = {}
+        for r in rs:
+            k = (r["tile"], r["Ci"], r["Co"], r["k"], r["dil"], r["stride"], r["Tout"], r["Wd"], r["fused_pair"], r["ksplit"])
+            c = cls.setdefault(k, [0, 0.0, 0.0, 0.0])
+            c[0] += 1; c[1] += float(r["us"]); c[2] += float(r["alg_gflop"]); c[3] += float(r["alg_mbytes"])
+        top = sorted(cls.items(), key=lambda kv: -kv[1][1])[:8]
         e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                  "traffic_note": None if tr is None else "HBM bytes per launch averaged over ALL launches of this kernel: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                  "traffic_note": None if tr is None else "HBM bytes per launch of THIS kernel (mean over its launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
                                                           "WRITE_SIZE, separate passes (tools/pmc_traffic.py); " + traffic_src,
-                  "kernel": desc, "peak_note": note, "launches_per_clip": int(l_), "avg_launch_us": round(t * 1e3 / l_, 2),
-                  "algorithmic_gflop_per_launch": round(f_ / l_ / 1e9, 3), "algorithmic_mbytes_per_launch": round(by / l_ / 1e6, 2),
-                  "kernel_ms_per_clip": round(t, 2), "algorithmic_tflop_per_clip": round(f_ / 1e12, 3),
-                  "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / (BF16_MFMA_PEAK_TFLOPS / 3.0), 4),
-                                    "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "algorithmic_tflops": round(tf, 2)}})
+                  "kernel": KERNEL_DESC.get(name, "rvc::" + name),
+                  "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product" if x3 else "fp32 MFMA peak") +
+                               f"; bound chosen by this kernel's arithmetic intensity ({gf * 1e3 / mb if mb > 0 else 0:.0f} FLOP/B) against the ridge {ridge:.0f} FLOP/B (8 TB/s)",
+                  "launches_per_clip": n, "avg_launch_us": round(us / n, 2),
+                  "algorithmic_gflop_per_launch": round(gf / n, 3), "algorithmic_mbytes_per_launch": round(mb / n, 2),
+                  "kernel_ms_per_clip": round(us / 1e3, 3), "algorithmic_tflop_per_clip": round(gf / 1e3, 3),
+                  "algorithmic_gbps": round(gbs, 1),
+                  "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / x3_peak, 4),
+                                    "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "hbm_8TBps": round(gbs / (HBM_PEAK_BPS / 1e9), 4),
+                                    "algorithmic_tflops": round(tf, 2)},
+                  "top_classes": [{"tile": k[0], "Ci": int(k[1]), "Co": int(k[2]), "k": int(k[3]), "dil": int(k[4]), "stride": int(k[5]), "Tout": int(k[6]), "Wd": int(k[7]),
+                                   "pair": int(k[8]), "ksplit": int(k[9]), "launches": c[0], "us": round(c[1] / c[0], 1),
+                                   "tflops": round(c[2] / c[1] / 1e-3, 1) if c[1] > 0 else 0.0, "alg_gbps": round(c[3] / c[1] * 1e3, 0) if c[1] > 0 else 0.0}
+                                  for k, c in top]})
         return e
-    X3 = ("bf16x3 convolution family: rvc::conv_x3p_kernel<AM,AN,KT,..> (software-pipelined, generator), rvc::conv_x3pf_kernel (fused ResBlock pair), "
-          "rvc::conv_x3g_kernel (k = 1 GEMMs), rvc::conv_x3_kernel<WM,WN,AM,AN> (staged: strided / 2-D / transposed) - 3 v_mfma_f32_32x32x16_bf16 per "
-          "fp32 product block, fp32 accumulate")
-    F32 = "rvc::conv_mfma_kernel<WM,WN,AM,AN,MODE> (fp32 v_mfma_f32_32x32x2_f32)"
-    x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
-    split_note = ("launches are split by arithmetic intensity (algorithmic FLOP / algorithmic HBM byte) against the ridge peak FLOP/s / 8 TB/s: "
-                  "this entry holds the %s-bound ones")
-    fams = [family(range(14, NCFG), 0, "rvc::conv_x3_kernel", X3, x3_peak, "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product; " + split_note % "MFMA"),
-            family(range(14, NCFG), 4, "rvc::conv_x3_kernel", X3, x3_peak, "HBM 8 TB/s; " + split_note % "HBM"),
-            family(range(0, 14), 0, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak; " + split_note % "MFMA"),
-            family(range(0, 14), 4, "rvc::conv_mfma_kernel", F32, FP32_MFMA_PEAK_TFLOPS, "HBM 8 TB/s; " + split_note % "HBM")]
-    fams = [r for r in fams if r]
-    fams.sort(key=lambda r: -r["kernel_ms_per_clip"])          # the dominant entry = the one with the most kernel time per clip
-    roofline = fams[0]
-    roofline["per_tile_config"] = per_cfg
-    roofline["other_kernels"] = fams[1:]
+    ents = sorted((entry(n, rs) for n, rs in kernels.items()), key=lambda e: -e["kernel_ms_per_clip"])
+    if not ents:
+        return None
+    roofline = ents[0]
+    roofline["other_kernels"] = ents[1:]
     return roofline
 
 

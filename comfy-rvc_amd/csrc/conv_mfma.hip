@@ -733,12 +733,13 @@ int conv_prof_dump_csv(const char* path) {
   fclose(f);
   return i;
 }
-// algorithmic HBM bytes of one launch: input + output (+ residual, + previous output when accumulating) + weights, fp32
+// algorithmic HBM bytes of one launch: input + output (+ residual unless it is the input itself, + previous output when accumulating) + weights, fp32
 double conv_alg_bytes(const ConvArgsX& a, int batch) {
   const double in = (double)a.Ci * (a.Wd > 0 ? (double)a.Tin * a.Wd : (double)a.Tin);
   const double out = (double)a.Co * a.Tout;
   const double w = (double)a.Co * a.Ci * (a.kreal > 0 ? a.kreal : a.ktaps);
-  return 4.0 * (batch * (in + out * (1.0 + (a.R ? 1.0 : 0.0) + (a.accumulate ? 1.0 : 0.0))) + w);
+  const bool r_is_x = a.R != nullptr && a.R == a.X;            // a residual that IS the input tensor crosses HBM once
+  return 4.0 * (batch * (in + out * (1.0 + ((a.R && !r_is_x) ? 1.0 : 0.0) + (a.accumulate ? 1.0 : 0.0))) + w);
 }
 // Per kernel configuration and roofline regime.  A launch counts as HBM-bound when its arithmetic intensity is below the ridge of
 // its kernel (peak FLOP/s / 8 TB/s): out[cfg][0..3] = {ms, flops, bytes, launches} of the MFMA-bound launches, [4..7] of the

@@ -704,7 +704,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
     if (conv_x3pf_try(a, T, s, gpf, true)) {
       ProfTicket tk = conv_prof_begin(s);
       conv_x3pf_try(a, T, s, gpf, false);
-      const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
+      const double bytes = 4.0 * ((double)C * T * (2.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);   // x ONCE (the residual is the same tensor), y [, previous y]
       conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + (C == 32 ? 1 : 5), bytes, &a, (long long)gpf.x, 1 | (3 << 4));
       return true;
     }
@@ -734,8 +734,8 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   if (C == 64) launch_x3<2, 2, 1, 2, true>(a, grid, lds, s);
   else if (BN == 128) launch_x3<1, 4, 1, 1, true>(a, grid, lds, s);
   else launch_x3<1, 4, 1, 2, true>(a, grid, lds, s);
-  // algorithmic traffic of the pair: x read, residual read, y write (+ previous y when accumulating) + both weight sets
-  const double bytes = 4.0 * ((double)C * T * (3.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
+  // algorithmic traffic of the pair: x read (the residual is x itself: one tensor, counted once), y write (+ previous y when accumulating) + both weight sets
+  const double bytes = 4.0 * ((double)C * T * (2.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);   // x ONCE (the residual is the same tensor), y [, previous y]
   conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes, &a, (long long)grid.x, 1);
   return true;
 }

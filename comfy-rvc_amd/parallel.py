@@ -9,11 +9,81 @@ stages (text encoder and flow at 100 fps, the transformer layers, the deep U-Net
 flight, each on its own host thread, HIP streams and model replica (weights 0.85 GB + workspace per lane; 288 GB of HBM make the
 replica free).  Measured on MI355X, 30 s clips: 875 -> 1035 xRT with two lanes; a third adds nothing.
 """
+import glob
+import os
 import threading
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+# ---------------------------------------------------------------------------------------------- CPU affinity of a rank
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys"):
+    """CPUs of the NUMA node the `local_rank`-th GPU hangs off, read from sysfs WITHOUT touching HIP: the KFD topology lists the compute
+    nodes in the order the HIP runtime enumerates them (nodes with simd_count > 0 are GPUs); a node's PCI address is domain : location_id
+    (bus << 8 | device << 3 | function), and the PCI device directory names its NUMA node's CPUs (`local_cpulist`).  {HIP,ROCR}_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES lists of plain indices are honoured.  Returns None when anything is missing (no KFD, single-node box ...)."""
+    try:
+        gpus = []
+        nodes = sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")), key=lambda d: int(os.path.basename(d)))
+        for d in nodes:
+            props = {}
+            with open(os.path.join(d, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+                gpus.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            vis = os.environ.get(var)
+            if vis:
+                idx = [int(t) for t in vis.split(",") if t.strip().lstrip("-").isdigit()]
+                if len(idx) != len([t for t in vis.split(",") if t.strip()]):
+                    return None                      # UUID syntax: not resolvable from sysfs alone
+                gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+        if not (0 <= local_rank < len(gpus)):
+            return None
+        with open(os.path.join(sysfs, "bus/pci/devices", gpus[local_rank], "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def bind_rank_to_numa(local_rank, local_world=1, sysfs="/sys"):
+    """Pins the calling process (and the lane / side-stream threads it starts later) to the CPUs next to its GPU.  MUST run before the first
+    HIP call of the process: the runtime's own helper threads inherit the mask, and nothing is re-exec'ed (a process that has touched the
+    GPU is never replaced; bench.py's ranks are started fresh by its launcher or by torch.distributed.run).  The ranks that share a NUMA
+    node split its CPUs evenly so that N ranks x (lanes + side streams + HIP helper threads) do not sit on each other.  Returns the set of
+    CPUs bound to, or None when the topology is unknown (nothing is changed then)."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = gpu_numa_cpus(local_rank, sysfs)
+    if not cpus:
+        return None
+    allowed = os.sched_getaffinity(0)
+    mine = sorted(cpus & allowed)
+    if not mine:
+        return None
+    sharers = [r for r in range(max(local_world, 1)) if gpu_numa_cpus(r, sysfs) == cpus] or [local_rank]
+    if len(sharers) > 1 and len(mine) >= 2 * len(sharers):
+        k = sharers.index(local_rank) if local_rank in sharers else 0
+        per = len(mine) // len(sharers)
+        mine = mine[k * per:(k + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return set(mine)
 
 
 def shard_indices(n_items, rank=None, world=None):
@@ -23,12 +93,20 @@ def shard_indices(n_items, rank=None, world=None):
     return list(range(rank, n_items, world))
 
 
-def gather_waveforms(wav, device="cpu", dst=0):
-    """Collects one variable-length int16 waveform per rank on `dst`.  Returns the list there and None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [np.asarray(wav)]
+def gather_waveforms(wav, device="cpu", dst=0, to_host=True, force_collective=False):
+    """Collects one variable-length int16 waveform per rank on `dst`.  Returns the list there and None elsewhere.
+
+    `wav` is a host array or an int16 tensor already on `device` (no upload then).  to_host=False leaves the gathered waveforms where the
+    collective delivered them (int16 tensors on `device`: with RCCL the receive buffers in rank `dst`'s HBM) - every rank has already
+    downloaded its OWN clips when it converted them, so rank `dst` need not download everybody's a second time.  force_collective=True
+    runs the collectives even in a process group of one (the single-GPU RCCL test)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
+        return [np.asarray(wav.cpu() if isinstance(wav, torch.Tensor) else wav)]
     world, rank = dist.get_world_size(), dist.get_rank()
-    w = torch.as_tensor(np.ascontiguousarray(wav), dtype=torch.int16).to(device)
+    if isinstance(wav, torch.Tensor):
+        w = wav.to(device=device, dtype=torch.int16).contiguous()
+    else:
+        w = torch.as_tensor(np.ascontiguousarray(wav), dtype=torch.int16).to(device)
     n = torch.tensor([w.numel()], dtype=torch.int64, device=device)
     lens = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(lens, n)
@@ -40,6 +118,8 @@ def gather_waveforms(wav, device="cpu", dst=0):
     dist.gather(raw, out, dst=dst)
     if rank != dst:
         return None
+    if not to_host:
+        return [o.view(torch.int16)[:ln] for o, ln in zip(out, lens)]
     return [o.view(torch.int16)[:ln].cpu().numpy() for o, ln in zip(out, lens)]
 
 

@@ -464,3 +464,11 @@ def mdx23c_state_dict(cfg, seed=0):
             fan = int(np.prod(shape[1:])) if kind == "conv" else int(shape[0] * shape[2] * shape[3])
             sd[name] = _normal(seed, "mdx." + name, shape, 1.0 / np.sqrt(fan))
     return sd
+
+
+def mdx23c_full_chunk(seed=5):
+    """The stereo 44.1 kHz chunk (261120 samples = 5.9 s) of the full-recipe MDX23C fixture (tests/golden/mdx23c_full_chunk.npz): the
+    voice-like test signal on both channels with different seeds plus a noise bed, so that the mask network sees structured input."""
+    a = np.stack([synth_audio(261120 / 44100.0 + 0.01, seed=seed, sr=44100)[:261120], synth_audio(261120 / 44100.0 + 0.01, seed=seed + 1, sr=44100)[:261120]])
+    rng = np.random.default_rng(seed)
+    return (a + 0.02 * rng.standard_normal(a.shape)).astype(np.float32)

@@ -367,6 +367,58 @@ def gen_mdx23c():
     print("mdx23c_small", y.shape, "rms", float(y.pow(2).mean().sqrt()), "demix", est.shape, {k: tuple(v.shape) for k, v in taps.items()})
 
 
+def gen_mdx23c_full():
+    """ONE 5.9 s chunk through the reference's TFC_TDF_net at the SHIPPED recipe (lib/karafan/Data/model_2_stem_full_band_8k.yaml: n_fft 8192,
+    dim_f 4096, dim_t 256, 128 channels + 128 per scale, 5 scales, 112 M procedural parameters; minutes of CPU).  The fixture keeps what a
+    value test needs and stays small: every 64th output sample, one dense window, per-(stem, channel) norms, and norm / sub-sampled taps of the
+    first conv, the first encoder scale, the bottleneck and the mask head.  The input is regenerated from its seed (SHA-256 stored)."""
+    import hashlib
+    import importlib.util
+    import time
+    import yaml
+    spec = importlib.util.spec_from_file_location("ref_tfc_tdf", os.path.join(ref_shim.REF_ROOT, "lib", "karafan", "tfc_tdf.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    def ns(d):
+        return NS({k: ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as cfg
+    ref_yaml = yaml.safe_load(open(os.path.join(ref_shim.REF_ROOT, "lib", "karafan", "Data", "model_2_stem_full_band_8k.yaml")))
+    for sec in ("audio", "model"):      # the recipe the product ships IS the reference's yaml
+        for k, v in cfg[sec].items():
+            assert ref_yaml[sec][k] == v, (sec, k, ref_yaml[sec][k], v)
+    net = m.TFC_TDF_net(ns(cfg)).eval()
+    sd = S.mdx23c_state_dict(cfg, 0)
+    assert [k for k in net.state_dict()] == [n for n, _, _ in S.mdx23c_spec(cfg)], "state-dict layout differs from the reference module"
+    net.load_state_dict(to_torch_sd(sd), strict=True)
+    C = cfg["audio"]["chunk_size"]
+    x = S.mdx23c_full_chunk()
+    assert x.shape == (2, C)
+    taps = {}
+    hooks = [net.first_conv.register_forward_hook(lambda mod, i, o: taps.__setitem__("first_conv", o[0])),
+             net.encoder_blocks[0].tfc_tdf.register_forward_hook(lambda mod, i, o: taps.__setitem__("enc0", o[0])),
+             net.bottleneck_block.register_forward_hook(lambda mod, i, o: taps.__setitem__("bottleneck", o[0])),
+             net.final_conv.register_forward_hook(lambda mod, i, o: taps.__setitem__("mask_out", o[0]))]
+    t0 = time.time()
+    with torch.no_grad():
+        y = net(torch.from_numpy(x)[None])[0]
+    for h in hooks:
+        h.remove()
+    y = np_(y)
+    out = dict(out_sub=y[..., ::64].copy(), out_win=y[..., 100000:104096].copy(),
+               out_norm=np.sqrt((y.astype(np.float64) ** 2).sum(-1)), out_absmax=np.abs(y).max(-1),
+               audio_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest(), dtype=np.uint8))
+    for k, v in taps.items():
+        v = np_(v)
+        out[k + "_norm"] = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim))))       # per channel
+        out[k + "_sub"] = v.reshape(v.shape[0], -1)[::max(1, v.shape[0] // 8), ::997].copy()
+    np.savez_compressed(os.path.join(OUT, "mdx23c_full_chunk.npz"), **out)
+    print("mdx23c_full_chunk", y.shape, "rms", float(np.sqrt((y ** 2).mean())), f"{time.time() - t0:.1f} s", {k: tuple(v.shape) for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load_reference()
@@ -393,6 +445,8 @@ def main():
         gen_pipeline(ns)
     if "mdx23c" in which:
         gen_mdx23c()
+    if "mdx23c_full" in which:       # one chunk at the shipped recipe (minutes of CPU)
+        gen_mdx23c_full()
     if {"full40", "full45", "full48", "rmvpe60"} & set(which):   # BASELINE.json's full-size configurations (minutes of CPU time)
         gen_fullsize(ns, which)
 

@@ -26,6 +26,12 @@ def main():
         P.convert_clips(clips, P.ClipLanes([lambda c, i: (seen.append(i), np.zeros(1, np.int16))[1]]), device="cpu")
         assert sorted(seen) == list(range(rank, 5, world))
         single = P.gather_waveforms(np.arange(10 + rank, dtype=np.int16), "cpu")
+        # tensors in, tensors out (bench.py: the gathered copy stays where the collective delivered it; every rank keeps its own clips)
+        import torch as _t
+        kept = P.gather_waveforms(_t.arange(10 + rank, dtype=_t.int16), "cpu", to_host=False)
+        assert (kept is None) == (rank != 0)
+        if rank == 0:
+            assert all(isinstance(k, _t.Tensor) and k.dtype == _t.int16 for k in kept) and [k.tolist() for k in kept] == [s_.tolist() for s_ in single]
         # training-prep feature dump: files are sharded rank::world with no collective (stub network: host logic only)
         import torch
         from scipy.io import wavfile

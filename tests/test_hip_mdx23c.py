@@ -74,6 +74,25 @@ def test_full_mdx23c_recipe_runs_at_size():
     assert np.abs(z).max() < 1e-6            # all-zero input: the mask multiplies a zero spectrogram branch and every conv is bias-free
 
 
+def test_full_mdx23c_recipe_matches_reference_golden():
+    """VALUES at the shipped recipe: the same 5.9 s stereo chunk the reference's own TFC_TDF_net converted in the build container
+    (tests/golden/mdx23c_full_chunk.npz, oracle/gen_golden.py mdx23c_full): every 64th output sample, a dense 4096-sample window and the
+    per-(stem, channel) energy within 1e-3 of the peak; first-conv / first-scale / bottleneck / mask-head taps are pinned on the oracle side."""
+    import hashlib
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG
+    from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+    g = golden("mdx23c_full_chunk.npz")
+    x = S.mdx23c_full_chunk()
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest(), dtype=np.uint8), g["audio_sha256"])
+    net = TFC_TDF_net(MDX23C_CONFIG)
+    net.load_state_dict(S.mdx23c_state_dict(MDX23C_CONFIG, 0))
+    y = net(x[None])[0].cpu().numpy()
+    assert y.shape == (2, 2, 261120)
+    assert rel_err(y[..., ::64], g["out_sub"]) < 1e-3 and rel_err(y[..., 100000:104096], g["out_win"]) < 1e-3
+    assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), g["out_norm"]) < 1e-3
+    assert rel_err(np.abs(y).max(-1), g["out_absmax"]) < 1e-3
+
+
 def test_uvr_then_vc_chain(small, tmp_path, monkeypatch):
     """BASELINE config C5 in miniature: UVR5Node (karafan MDX23C, reduced recipe with a yaml next to the checkpoint) splits a stereo
     44.1 kHz clip, the vocal stem thunk goes into RVCNode (48k_v2 synthesizer) and comes out as WAV bytes at 48 kHz."""

@@ -57,9 +57,12 @@ def test_pipeline_segmented_matches_reference_golden(models, noise_tape):
 def test_pipeline_rmvpe_matches_reference_golden(models, noise_tape):
     g, wav, sr, vc = _run(models, "pipeline_2s_rmvpe.npz", noise_tape)
     assert wav.shape == g["out_i16"].shape
-    d = np.abs(wav.astype(np.int32) - g["out_i16"].astype(np.int32))
-    # f0 goes through an argmax: a flipped bin in one 10 ms frame is a legitimate discontinuity, so gate on 99.5 % of samples
-    assert np.mean(d <= LSB) > 0.995, (d.max(), np.mean(d <= LSB))
+    from conftest import parity_stats, record_parity
+    st = parity_stats(wav, g["out_i16"], LSB)
+    record_parity("pipeline_2s_rmvpe.npz", st)
+    # f0 goes through an argmax, so a flipped bin in one 10 ms frame would be a legitimate discontinuity - but none flips (measured on
+    # MI355X: every sample within a few LSB), so the gate is the plain 1e-3 bound on EVERY sample; a regression cannot hide in a tail
+    assert st["max"] <= LSB, st
 
 
 def test_generic_callee_path_equals_fused_path(models, noise_tape):
@@ -330,12 +333,12 @@ def test_other_sample_rates_in_and_out(models):
 
 # ------------------------------------------------------------------ BASELINE.json's full-size configurations against the reference
 # Goldens: oracle/gen_golden.py full40 full48 full45 rmvpe60 (the REAL reference, real segmentation constants 1 / 6 / 38 / 41).
-# Gates: >= 99.99 % of the int16 samples within 33 LSB (1e-3 of full scale; the f0 passes through an arg-max, so a frame may legitimately
-# differ) AND the excluded samples are bounded: none further than FS_BOUND from the reference, the 99.99th percentile within 33 LSB.
-# Measured on MI355X (profiles/r2_fullsize_parity.json): every sample within 12 LSB, every f0 frame equal.
-FS_BOUND = 164        # 5e-3 of full scale
-P9999_BOUND = 33      # 1e-3 of full scale
-WITHIN = 0.9999
+# Gate: EVERY int16 sample within 33 LSB (1e-3 of full scale) of the reference's output.  (Round 2 allowed 0.01 % of the samples up to 5e-3
+# because the f0 passes through an arg-max; measured on MI355X - profiles/r2o_fullsize_parity.json - every sample is within 15 / 12 / 8 LSB
+# and every f0 frame equal, so the tail allowance only hid regressions and is gone.)
+FS_BOUND = 33         # 1e-3 of full scale: the largest deviation allowed anywhere
+P9999_BOUND = 33
+WITHIN = 1.0
 
 
 def _fullsize(gname, syn_cfg, noise_tape, repeats=1):
@@ -380,7 +383,7 @@ def _fullsize(gname, syn_cfg, noise_tape, repeats=1):
     st.update({"f0_frames": int(n), "f0_within_1e-3": float(f_ok.mean()), "coarse_equal": float((dc == 0).mean()), "coarse_max_diff": int(dc.max()),
                "voicing_equal": float(((cap["pitchf"][:n] > 0) == (g["pitchf"][:n] > 0)).mean())})
     record_parity(gname, st)
-    assert st["f0_within_1e-3"] >= 0.995 and st["voicing_equal"] >= 0.999 and st["coarse_max_diff"] <= 1, st
+    assert st["f0_within_1e-3"] == 1.0 and st["voicing_equal"] == 1.0 and st["coarse_max_diff"] == 0, st      # every f0 frame and coarse value equals the reference's
     assert st["within"] >= WITHIN and st["max"] <= FS_BOUND and st["p9999"] <= P9999_BOUND, st
     return g, wav, st
 
@@ -468,8 +471,8 @@ def test_c2_rmvpe_60s_matches_reference_golden(models):
           "sub_max_abs_err": float(np.max(np.abs(sal[::50] - g["sal_sub"])))}
     record_parity("rmvpe_60s.npz", st)
     assert st["sal_max_abs_err"] < 1e-3 and st["sub_max_abs_err"] < 1e-3 and st["rowsum_max_rel_err"] < 1e-3, st      # salience is a sigmoid output in [0, 1]
-    assert st["f0_within_1e-3"] >= 0.995 and st["voicing_equal"] >= 0.999 and st["argmax_equal"] >= 0.995 and st["argmax_max_diff"] <= 1, st
-    assert st["f0_max_rel_dev_voiced"] < 0.02, st                  # an arg-max that flips between neighbouring bins moves the 9-bin average by < 20 cents
+    assert st["f0_within_1e-3"] == 1.0 and st["voicing_equal"] == 1.0 and st["argmax_equal"] == 1.0, st      # all 6201 arg-max bins equal the reference's
+    assert st["f0_max_rel_dev_voiced"] < 1e-3, st
 
 
 def test_gru_scan_failure_is_reported_not_silent(models):

@@ -182,3 +182,19 @@ def test_mdx23c_oracle_matches_reference_module():
     assert rel_err(y, g["out"]) < 1e-5
     d = om.demix_mdxv3(sd, cfg, g["clip"], int(g["overlap"]))
     assert rel_err(np.stack([d["Vocals"], d["Instrumental"]]), g["demix"]) < 1e-5
+
+
+def test_mdx23c_oracle_matches_reference_module_at_the_shipped_recipe():
+    """The SHIPPED recipe (lib/karafan/Data/model_2_stem_full_band_8k.yaml: n_fft 8192, dim_f 4096, dim_t 256, 5 scales, 112 M parameters):
+    one 5.9 s chunk through oracle/mdx23c.py against the reference module's own output (oracle/gen_golden.py mdx23c_full; ~30 s of CPU)."""
+    import hashlib
+    from oracle import mdx23c as om
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as cfg
+    g = golden("mdx23c_full_chunk.npz")
+    x = S.mdx23c_full_chunk()
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest(), dtype=np.uint8), g["audio_sha256"])
+    with torch.no_grad():
+        y = om.forward(S.mdx23c_state_dict(cfg, 0), cfg, x).numpy()
+    assert y.shape == (2, 2, cfg["audio"]["chunk_size"])
+    assert rel_err(y[..., ::64], g["out_sub"]) < 2e-5 and rel_err(y[..., 100000:104096], g["out_win"]) < 2e-5
+    assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), g["out_norm"]) < 1e-5
