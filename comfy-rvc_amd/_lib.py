@@ -112,6 +112,7 @@ SIGNATURES = {
     "rvc_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                              c_void_p, c_int]),
     "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "rvc_op_gemm_split": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float] + [c_int] * 3),
     "rvc_op_conv1d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                       [c_int, c_float, c_int, c_float, c_int, c_float, c_int]),
     "rvc_op_conv_transpose1d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_int, c_float, c_int]),
@@ -135,6 +136,7 @@ SIGNATURES = {
     "rvc_prof_cfg_name": (c_char_p, [c_int]),
     "rvc_debug_conv_timing": (c_int, [P(C.c_uint64), c_int]),
     "rvc_debug_x3p_check": (c_int, []),
+    "rvc_debug_gemm_split_bench": (c_int, [c_void_p] + [c_int] * 8 + [P(c_float)]),
     "rvc_op_sine_source": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 3),
 }
 

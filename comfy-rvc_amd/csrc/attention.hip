@@ -225,7 +225,8 @@ __device__ __forceinline__ void x3_block(const unsigned short* ah_, const unsign
 
 __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ Q, const float* __restrict__ K, long long ldqk,
                                                         const float* __restrict__ V, long long ldv, const float* __restrict__ bv,
-                                                        float* __restrict__ out, long long ldo, int T) {
+                                                        float* __restrict__ out, long long ldo, int T,
+                                                        unsigned char* __restrict__ img, long long img_tp, int img_margin) {
   // bf16 hi / lo planes, rows of 64 reduction indices (128 B) + 16 B pad: ds_read_b128 of 32 consecutive rows is conflict-free
   __shared__ __attribute__((aligned(16))) unsigned short Qs[2][64 * kXP], Ks[2][64 * kXP], Vs[2][kAD * kXP], Ps[2][64 * kXP];
   __shared__ float red[2][2][64];          // [stat: max | sum][wm][query]
@@ -337,22 +338,63 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
   }
   ATACC(6, ATICK() - t_begin); ATACC(0, 1);
   const int q = q0 + wn * 32 + li;
-  if (q < T) {
-    const float inv = 1.f / l_run;
+  const float inv = 1.f / l_run;
+  float val[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    val[r] = (o[r] + o1[r]) * inv + (bv ? bv[h * kAD + d] : 0.f);
+  }
+  if (out != nullptr && q < T) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      out[(long long)(h * kAD + d) * ldo + q] = (o[r] + o1[r]) * inv + (bv ? bv[h * kAD + d] : 0.f);
+      out[(long long)(h * kAD + d) * ldo + q] = val[r];
+    }
+  }
+  if (img != nullptr) {
+    // the split-resident image the out-projection GEMM stages (conv_x3s.hip): [16-channel chunk][hi | lo][8-channel half][margin + q][8 ch].
+    // A lane holds rows {0..3, 8..11} + 4 lh of each 16-row chunk; v_permlane32_swap trades quads with the lane 32 away so that every
+    // lane owns one 16-byte row of a half-plane (same exchange as ysplit_epilogue, conv_x3_dev.h).
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      unsigned hA[2], lA[2], hB[2], lB[2];
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        auto split = [](float a, float b, unsigned& hi, unsigned& lo) {
+          const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+          const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
+          hi = bf16_bits_a(ah) | (bf16_bits_a(bh) << 16); lo = bf16_bits_a(al) | (bf16_bits_a(bl) << 16);
+        };
+        split(val[8 * g2 + 2 * e2], val[8 * g2 + 2 * e2 + 1], hA[e2], lA[e2]);
+        split(val[8 * g2 + 4 + 2 * e2], val[8 * g2 + 5 + 2 * e2], hB[e2], lB[e2]);
+      }
+      u32x4a hi, lo;
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const u32x2_t sh = __builtin_amdgcn_permlane32_swap(hA[e2], hB[e2], false, false);
+        const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
+        hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
+      }
+      if (q < T) {
+        const long long chunk = (h * kAD + wm * 32) / 16 + g2;
+        unsigned char* row = img + ((chunk * 4 + lh) * img_tp + img_margin + q) * 16;
+        *reinterpret_cast<u32x4a*>(row) = hi;
+        *reinterpret_cast<u32x4a*>(row + img_tp * 32) = lo;
+      }
     }
   }
 }
 
 // Q, K: channel-major [heads*64][T] (row pitch ldqk); V: row-major [T][heads*64] (row pitch ldv); out channel-major [heads*64][T].
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
-                     float* out, long long ldo, int heads, int dhead, int T) {
+                     float* out, long long ldo, int heads, int dhead, int T, unsigned char* out_img, long long img_tp) {
   RVC_REQUIRE(dhead == kAD, "fused attention is built for head dimension 64");
   static const bool x3 = !(getenv("RVC_ATT_X3") && atoi(getenv("RVC_ATT_X3")) == 0);
-  if (x3) { hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T); return; }
+  RVC_REQUIRE(out != nullptr || out_img != nullptr, "fused attention: no output");
+  RVC_REQUIRE(out_img == nullptr || x3, "the split-image output needs the bf16x3 attention kernel");
+  if (x3) { hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T, out_img, img_tp, (int)kSplitMargin); return; }
   hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T);
 }
 

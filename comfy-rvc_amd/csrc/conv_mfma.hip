@@ -423,6 +423,25 @@ void* stream_scratch(hipStream_t s, int slot, size_t bytes) {
   }
   return b->p;
 }
+// Same pool; the buffer is zero-filled (on `s`, ahead of whatever the caller enqueues next) whenever it is (re)allocated, never otherwise:
+// for words whose users leave them zero (the K-split tickets of conv_x3s_kernel).
+void* stream_scratch_zeroed(hipStream_t s, int slot, size_t bytes, bool* fresh) {
+  int dev = 0;
+  RVC_HIP_CHECK(hipGetDevice(&dev));
+  ScratchBuf* b;
+  { std::lock_guard<std::mutex> lk(scratch_mu()); b = &scratch_pool()[ScratchKey{dev, s, slot}]; }
+  if (fresh) *fresh = false;
+  if (bytes > b->cap) {
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr; b->cap = 0;
+    RVC_HIP_CHECK(hipMalloc(&b->p, bytes));
+    b->cap = bytes;
+    RVC_HIP_CHECK(hipMemsetAsync(b->p, 0, bytes, s));
+    if (fresh) *fresh = true;
+  }
+  return b->p;
+}
 void stream_scratch_release(int device) {
   std::lock_guard<std::mutex> lk(scratch_mu());
   auto& pool = scratch_pool();
@@ -724,9 +743,9 @@ int conv_prof_dump_csv(const char* path) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair)
-    static const char* kX3Fam[4] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel"};
-    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 3] : "conv_mfma_kernel", kCfgNames[r.cfg],
+    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM)
+    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_x3u_kernel", "conv_x3_kernel", "conv_x3_kernel"};
+    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
             r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
             t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0);
   }
@@ -924,13 +943,16 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   }
 }
 
-bool conv1d_split_eligible(const ConvLayer& L, int Tin) {
+bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role) {
   if (L.mode != 1 || !L.Wx_ || L.tconv_u || L.stride != 1 || L.groups != 1 || (L.Co & 31) || (L.Ci & 15)) return false;
+  if (conv1d_out_len(L, Tin) != Tin || L.pad > kSplitMargin) return false;      // the image is addressed as a "same" convolution's: row = margin + t
   ConvArgsX a{};
   a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = Tin; a.Wd = 0; a.ktaps = L.ktaps; a.dil = L.dil; a.stride = 1; a.pad = L.pad;
   a.Tout = conv1d_out_len(L, Tin); a.ostride = 1; a.orows = L.Co; a.ldX = Tin; a.ldY = a.Tout; a.ldR = a.Tout;
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.kreal = L.k;
-  a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_);          // any non-null value: ask for the split-input geometry
+  // any non-null value asks for the role's geometry (dry run: never dereferenced)
+  if (role == SPLIT_PRODUCER) { a.Ys = reinterpret_cast<unsigned char*>(L.Wx_); a.ysTp = split_image_tp(Tin); a.pre_act = ACT_LRELU; a.pre_slope = 0.1f; }
+  else { a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_); a.xsTp = split_image_tp(Tin); }
   return conv_x3_try(a, 1, nullptr, 0.0, true);
 }
 

@@ -497,6 +497,11 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   const bool xs = a0.Xs != nullptr;
   if ((xs || a0.Ys) && (a0.Wd > 0 || a0.stride != 1 || a0.ostride != 1 || (a0.Co & 31) || batch != 1)) return false;
   if (xs && a0.pre_act != ACT_NONE) return false;                     // the producer applied the activation
+  // the image's rows are addressed as margin + t (global_load_lds is not bounds-checked): "same" convolutions whose left halo fits the
+  // margin only, on an image with the documented number of rows per plane
+  if ((xs || a0.Ys) && (a0.pad > kSplitMargin || a0.Tout != a0.Tin)) return false;
+  if (!dry && xs) RVC_REQUIRE(a0.xsTp >= split_image_tp(a0.Tin), "split-resident input image is shorter than split_image_tp(T)");
+  if (!dry && a0.Ys) RVC_REQUIRE(a0.ysTp >= split_image_tp(a0.Tout), "split-resident output image is shorter than split_image_tp(T)");
   const int KH2 = a0.KW > 0 ? a0.KH : 3, KW2 = a0.KW > 0 ? a0.KW : 3;
   if (a0.Wd > 0 && (a0.ktaps != KH2 * KW2 || a0.stride != 1)) return false;
   if ((a0.stride != 1 && a0.dil != 1) || a0.up2 || (a0.ostride != 1 && a0.R) || (a0.Ci & 15) || batch != 1) return false;

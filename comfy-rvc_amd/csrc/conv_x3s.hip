@@ -1,0 +1,480 @@
+// bf16x3 GEMM on SPLIT-RESIDENT operands (gfx950 only): Y[m][n] = epilogue( sum_k W[m][k] X[k][n] ) for the k = 1 projections of the
+// transformer stacks (HuBERT q/k/v, out, FFN; reference modeling_hubert.py:291-477 through lib/infer_pack/loaders.py:55-61).
+//
+// conv_x3g_kernel (conv_x3p.hip) reads the activation as fp32 and converts it to bf16 hi / lo in EVERY workgroup that needs it - a 768 -> 3072
+// projection converts the same 768 x 128 input tile 24 (64-row tiles: 48) times, through registers, 45 VALU instructions per 12 MFMAs - and
+// under-filled grids were cut along K with a second launch summing the partials.  Measured (profiles/r2o_launch_classes.md): 125 - 139
+// TFLOP/s of 833, 4 - 5.7x the algorithmic bytes, 131 reduction launches per clip.  Here the activation LIVES as the image the kernel
+// stages ([16-channel chunk][hi | lo][8-channel half][kSplitMargin + t][8 ch], the same format as the ResBlock intermediates of the
+// generator), written once by its producer (LayerNorm, the attention's epilogue, this kernel's own epilogue), so that
+//   * both operand tiles of a unit (one 16-channel chunk: BM weight rows + BN positions, 64 B each) reach LDS by DMA
+//     (global_load_lds, 1 KiB per wave-instruction), no registers, no VALU; a ring of RS unit slots, a unit requested RS - 1 units ahead,
+//     every wait an immediate (VMEM operations of a wave retire in order and the issue sequence is static);
+//   * the wave runs the three MFMA groups of a unit as in conv_x3p_kernel: (hi_w lo_x), (lo_w hi_x), (hi_w hi_x), the second group's operands
+//     requested before the first is issued, the next unit's before the third; one barrier per unit publishes the next slot;
+//   * tiles are small (128 x 64 default: N = 1599 is 25 x 64 exactly, 600 workgroups for the 768 -> 3072 layer, three per CU) and the K split
+//     of the deep reductions (3072 -> 768) is reduced INSIDE the launch: every slice writes its accumulators as a slab in register order
+//     with write-through (sc1) 16-byte stores, drains, takes a ticket; the slice that draws the last ticket sums the slabs in slice order
+//     (bit-identical whoever is last) with sc1 loads and runs the epilogue.  No fences (they flush the XCD's L2: round 2 measured 61 -> 126 us),
+//     no second launch;
+//   * bias and residual are loaded into slice 0's accumulators at tile start (the oldest VMEM operations of the wave), so the epilogue is
+//     activation + store: fp32 rows, and / or the bf16 hi / lo image for the next GEMM (exact-erf GELU in fp32 before the split).
+#include "conv_x3_dev.h"
+
+namespace rvc {
+
+struct GemmSArgs {
+  const unsigned char* Wx; int CoPx;        // weight image [chunk][hi | lo][half][CoPx rows][16 B]
+  const unsigned char* Xs; long long xsTp;  // activation image [chunk][hi | lo][half][xsTp rows][16 B]; position t lives at row kSplitMargin + t
+  int Co, T, nunits;                        // rows stored, columns, 16-channel chunks of the reduction
+  const float* bias; const float* R; long long ldR;
+  float* Y; long long ldY;                  // fp32 output [Co][ldY] or null
+  unsigned char* Ys; long long ysTp;        // split output image or null
+  int act; float act_slope; int act_before_res; float out_scale;
+  int ksplit; float* slabs; unsigned* tickets;
+  int gx, gy;                               // column / row tiles
+  int xcd_remap;
+};
+
+// exact-erf GELU (torch F.gelu default), branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. ~1e-7 of the
+// activation - far inside the fp32 noise of the 768-term sums that feed it; ocml's erff takes two divergent paths per element)
+__device__ __forceinline__ float x3s_gelu(float v) {
+  const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+  const float erf_abs = fmaf(-poly, e, 1.f);
+  return 0.5f * v * (1.f + copysignf(erf_abs, x));
+}
+template <int N> __device__ __forceinline__ void x3s_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int AM, int AN, int RS>
+__global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(const GemmSArgs p) {
+  constexpr int WN = 2, NW = 4;
+  constexpr int BM = 64 * AM, BN = 64 * AN;
+  constexpr int NPA = BM / 16, NPB = BN / 16, NPW = (NPA + NPB) / NW;      // 1-KiB pieces of a unit: weights, input, per wave
+  static_assert((NPA % NW) == 0 && (NPB % NW) == 0, "every wave's i-th piece is of one kind");
+  constexpr int aslot = BM * 64, bslot = BN * 64, slot = aslot + bslot;    // [hi | lo][half][rows][16 B]
+  static_assert(RS >= 3 && (RS - 2) * NPW <= 63, "ring");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem3s[];
+
+  const int tid0 = threadIdx.x;
+  int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  // 1-D grid: the S slices of a tile are neighbours in an XCD's run of blocks (the reducer reads same-XCD slabs), tiles column-fastest
+  // (an XCD works on a run of row tiles: its weight rows stay in its L2, the activation streams)
+  const unsigned total = gridDim.x;
+  const unsigned bid = p.xcd_remap ? xcd_tile(blockIdx.x, total) : blockIdx.x;
+  const int S = p.ksplit;
+  const int tile = (int)(bid / (unsigned)S), ks = (int)(bid - (unsigned)tile * (unsigned)S);
+  const int tile_y = tile / p.gx, tile_x = tile - tile_y * p.gx;
+  const int co0 = tile_y * BM, n0 = tile_x * BN;
+  const int U = p.nunits / S, u0 = ks * U;
+
+  // ---- accumulators: slice 0 starts from bias (+ residual unless an activation sits between the sum and the residual)
+  const bool r_pre = p.R != nullptr && !(p.act_before_res && p.act != ACT_NONE);
+  f32x16 acc[AM][AN];
+  if (ks == 0 && (p.bias != nullptr || r_pre)) {
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(r_pre ? p.R : (const float*)p.Wx, r_pre ? (unsigned)p.Co * (unsigned)p.ldR * 4u : 0u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float bv = (p.bias && m < p.Co) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          acc[am][an][r] = buf_load(rrs, (r_pre && m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB) + bv;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+  }
+
+  // ---- DMA: piece i of this wave is piece wave + NW i of the unit (pieces 0 .. NPA - 1: weights, then the input)
+  const unsigned char* src[NPW];
+  long long step[NPW];
+  int dsto[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int pi = wave + NW * i;
+    if (i * NW < NPA) {
+      constexpr int RBK = BM / 64;
+      const int plane = pi / RBK, rb = pi - plane * RBK;
+      src[i] = p.Wx + (long long)u0 * p.CoPx * 64 + ((long long)plane * p.CoPx + co0 + rb * 64 + lane) * 16;
+      step[i] = (long long)p.CoPx * 64;
+      dsto[i] = plane * (BM * 16) + rb * 1024;
+    } else {
+      constexpr int CBK = BN / 64;
+      const int pj = pi - NPA, plane = pj / CBK, cb = pj - plane * CBK;
+      src[i] = p.Xs + (((long long)u0 * 4 + plane) * p.xsTp + kSplitMargin + n0 + cb * 64 + lane) * 16;
+      step[i] = p.xsTp * 64;
+      dsto[i] = aslot + plane * (BN * 16) + cb * 1024;
+    }
+  }
+  int slw = 0, uw = 0;
+  auto issue = [&]() {                                       // next unit into slot slw; past the end the last unit is requested again
+    unsigned char* base = smem3s + slw * slot;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i], (__attribute__((address_space(3))) void*)(base + dsto[i]), 16, 0, 0);
+    ++uw;
+    if (uw < U) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) src[i] += step[i];
+    }
+    slw = slw + 1 == RS ? 0 : slw + 1;
+  };
+
+  const int aoff = lh * (BM * 16) + ((wm * AM) * 32 + li) * 16;
+  const int boff = aslot + lh * (BN * 16) + ((wn * AN) * 32 + li) * 16;
+
+  // ---- prologue: [bias / residual] units 0 .. RS - 2
+#pragma unroll
+  for (int i = 0; i < RS - 1; ++i) issue();
+  x3s_wait_vmcnt<(RS - 2) * NPW>();                          // unit 0 (younger: units 1 .. RS - 2)
+#pragma unroll
+  for (int am = 0; am < AM; ++am)
+#pragma unroll
+    for (int an = 0; an < AN; ++an) asm volatile("" : "+v"(acc[am][an]));     // (the residual loads are complete from here on)
+  lds_barrier();
+
+  // Two operand register sets: the reads of unit u + 1 are issued right after the barrier that publishes its slot and land under the
+  // twelve (AM AN 3) MFMAs of unit u - the only stall of a unit is that one wait + barrier.
+  struct Ops { u32x4 ah[AM], al[AM], bh[AN], bl[AN]; };
+  Ops o0, o1;
+  auto read_ops = [&](Ops& o, int slot_i) {
+    const unsigned char* wa = smem3s + slot_i * slot + aoff;
+    const unsigned char* xa = smem3s + slot_i * slot + boff;
+#pragma unroll
+    for (int am = 0; am < AM; ++am) { o.ah[am] = *reinterpret_cast<const u32x4*>(wa + am * 512); o.al[am] = *reinterpret_cast<const u32x4*>(wa + BM * 32 + am * 512); }
+#pragma unroll
+    for (int an = 0; an < AN; ++an) { o.bh[an] = *reinterpret_cast<const u32x4*>(xa + an * 512); o.bl[an] = *reinterpret_cast<const u32x4*>(xa + BN * 32 + an * 512); }
+  };
+  auto mfmas = [&](const Ops& o) {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bl[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.al[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+  };
+  int sl = 0;
+  auto body = [&](const Ops& cur, Ops& nxt) {
+    // unit u + 1 was requested RS - 2 units ago; younger: units u + 2 .. u + RS - 2
+    x3s_wait_vmcnt<(RS - 3) * NPW>();
+    lds_barrier();
+    issue();                                                 // unit u + RS - 1 into the slot unit u - 1 was read from (those reads fed unit u - 1's MFMAs)
+    sl = sl + 1 == RS ? 0 : sl + 1;
+    read_ops(nxt, sl);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(cur);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  read_ops(o0, 0);
+  int u = 0;
+  for (; u + 1 < U; u += 2) { body(o0, o1); body(o1, o0); }
+  if (u < U) body(o0, o1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the requests past the end: nothing may land in LDS after the workgroup has gone)
+
+  // ---- K split: slabs in register order, write-through; the last slice to arrive sums them in slice order
+  if (S > 1) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int QN = AM * AN * 4;                          // 16-byte granules per lane
+    const unsigned slab_bytes = 256u * QN * 16u;
+    const __amdgpu_buffer_rsrc_t srs = make_rsrc(p.slabs, (unsigned)(total) * slab_bytes);
+    const unsigned lane_off = ((unsigned)wave * QN * 64u + (unsigned)lane) * 16u;
+    {
+      const unsigned mine = ((unsigned)tile * (unsigned)S + (unsigned)ks) * slab_bytes + lane_off;
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 v = {__float_as_uint(acc[am][an][4 * q]), __float_as_uint(acc[am][an][4 * q + 1]), __float_as_uint(acc[am][an][4 * q + 2]),
+                             __float_as_uint(acc[am][an][4 * q + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, srs, (int)(mine + (unsigned)(((am * AN + an) * 4 + q) * 64) * 16u), 0, 16);      // aux 16 = sc1
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // EVERY storing wave drains before the ticket
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem3s);    // (the ring is dead: one LDS object throughout)
+    if (tid0 == 0) {
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)S - 1u) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+      *flag = t;
+    }
+    __syncthreads();
+    if (*flag != (unsigned)S - 1u) return;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4_t own = {acc[am][an][4 * q], acc[am][an][4 * q + 1], acc[am][an][4 * q + 2], acc[am][an][4 * q + 3]};
+          f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+          for (int z = 0; z < S; ++z) {
+            f32x4_t v = own;
+            if (z != ks) {
+              const unsigned off = ((unsigned)tile * (unsigned)S + (unsigned)z) * slab_bytes + lane_off + (unsigned)(((am * AN + an) * 4 + q) * 64) * 16u;
+              const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(srs, (int)off, 0, 16);                                   // sc1: past L1, every XCD's view
+              v = f32x4_t{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            }
+            sum = z == 0 ? v : sum + v;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[am][an][4 * q + j] = sum[j];
+        }
+  }
+
+  // ---- epilogue: activation, late residual, scale; fp32 rows and / or the split image.  The activation is chosen once per launch
+  // (wave-uniform branches around straight-line loops); the exact-erf GELU of the reference (F.gelu) is evaluated branch-free.
+  const float oscale = p.out_scale;
+  if (p.act == ACT_GELU) {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] = x3s_gelu(acc[am][an][r]);
+  } else if (p.act != ACT_NONE) {
+    const float slope = p.act == ACT_RELU ? 0.f : p.act_slope;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[am][an][r]; acc[am][an][r] = fmaxf(v, v * slope); }
+  }
+  if (p.R != nullptr && !r_pre) {                              // act(W x + b) + R: the residual after the activation (one batch of loads per accumulator)
+    const __amdgpu_buffer_rsrc_t rrs2 = make_rsrc(p.R, (unsigned)p.Co * (unsigned)p.ldR * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          rv[r] = buf_load(rrs2, (m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] += rv[r];
+      }
+  }
+  if (oscale != 1.f) {
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[am][an][r] *= oscale;
+  }
+  if (p.Y) {
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)p.Co * (unsigned)p.ldY * 4u);
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+        for (int an = 0; an < AN; ++an) {
+          const int n = n0 + (wn * AN + an) * 32 + li;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), yrs, (int)((m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldY + (unsigned)n) * 4u : kOOB), 0, 0);
+        }
+      }
+  }
+  if (p.Ys) {
+    // a lane holds 4 + 4 channels of each 16-channel chunk of its column; v_permlane32_swap trades quads with the lane 32 away so that
+    // every lane owns one 16-B row of a half-plane (see ysplit_epilogue, conv_x3_dev.h)
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        const int mb = co0 + (wm * AM + am) * 32;
+        const long long pos = (long long)n + kSplitMargin;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          unsigned hA[2], lA[2], hB[2], lB[2];
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            split2(acc[am][an][8 * g2 + 2 * e2], acc[am][an][8 * g2 + 2 * e2 + 1], hA[e2], lA[e2]);
+            split2(acc[am][an][8 * g2 + 4 + 2 * e2], acc[am][an][8 * g2 + 5 + 2 * e2], hB[e2], lB[e2]);
+          }
+          u32x4 hi, lo;
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t sh = __builtin_amdgcn_permlane32_swap(hA[e2], hB[e2], false, false);
+            const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
+            hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
+          }
+          if (n < p.T && mb + 16 * g2 < p.Co) {
+            const long long chunk = (mb >> 4) + g2;
+            unsigned char* row = p.Ys + ((chunk * 4 + lh) * p.ysTp + pos) * 16;
+            *reinterpret_cast<u32x4*>(row) = hi;
+            *reinterpret_cast<u32x4*>(row + p.ysTp * 32) = lo;
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------- fp32 [C][T] <-> split image (producers without an image epilogue, tests)
+// One thread = one 16-byte row (8 channels of one position) of the hi and of the lo plane.
+__global__ __launch_bounds__(256) void split_image_kernel(const float* __restrict__ X, long long ldX, int C, int T, unsigned char* __restrict__ img, long long tp) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int hp = blockIdx.y;                                  // chunk * 2 + half
+  if (t >= T) return;
+  const float* x = X + (long long)(hp * 8) * ldX + t;
+  u32x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = (hp * 8 + 2 * j) < C ? x[(long long)(2 * j) * ldX] : 0.f, b = (hp * 8 + 2 * j + 1) < C ? x[(long long)(2 * j + 1) * ldX] : 0.f;
+    unsigned h_, l_;
+    split2(a, b, h_, l_);
+    hi[j] = h_; lo[j] = l_;
+  }
+  const int chunk = hp >> 1, half = hp & 1;
+  unsigned char* row = img + (((long long)chunk * 4 + half) * tp + kSplitMargin + t) * 16;
+  *reinterpret_cast<u32x4*>(row) = hi;
+  *reinterpret_cast<u32x4*>(row + tp * 32) = lo;
+}
+__global__ __launch_bounds__(256) void unsplit_image_kernel(const unsigned char* __restrict__ img, long long tp, int C, int T, float* __restrict__ Y, long long ldY) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int hp = blockIdx.y;
+  if (t >= T) return;
+  const int chunk = hp >> 1, half = hp & 1;
+  const unsigned char* row = img + (((long long)chunk * 4 + half) * tp + kSplitMargin + t) * 16;
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(row), lo = *reinterpret_cast<const u32x4*>(row + tp * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = hp * 8 + 2 * j;
+    if (c < C) Y[(long long)c * ldY + t] = __uint_as_float(hi[j] << 16) + __uint_as_float(lo[j] << 16);
+    if (c + 1 < C) Y[(long long)(c + 1) * ldY + t] = __uint_as_float(hi[j] & 0xffff0000u) + __uint_as_float(lo[j] & 0xffff0000u);
+  }
+}
+void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp) {
+  RVC_REQUIRE((C & 15) == 0, "split image: channels must be a multiple of 16");
+  hipLaunchKernelGGL(split_image_kernel, dim3((T + 255) / 256, C / 8), dim3(256), 0, s, X, ldX, C, T, img, tp);
+}
+void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY) {
+  RVC_REQUIRE((C & 15) == 0, "split image: channels must be a multiple of 16");
+  hipLaunchKernelGGL(unsplit_image_kernel, dim3((T + 255) / 256, C / 8), dim3(256), 0, s, img, tp, C, T, Y, ldY);
+}
+
+// ---------------------------------------------------------------------------- host side
+template <int AM, int AN, int RS>
+static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
+  auto kern = conv_x3s_kernel<AM, AN, RS>;
+  constexpr size_t lds = (size_t)RS * (64 * AM + 64 * AN) * 64;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+}
+
+// Tile and K split for an M x N x K problem: enough workgroups for two per CU (two waves per SIMD from different tiles cover each other's
+// barriers and operand reads), tiles as large as that allows (L2 -> LDS bytes per MFMA fall with the tile), the deep reductions cut along K.
+static thread_local int t_force_s = 0, t_force_am = 0, t_force_an = 0;
+void conv_x3s_force(int ksplit, int am, int an) { t_force_s = ksplit; t_force_am = am; t_force_an = an; }
+static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S) {
+  static const int f_am = getenv("RVC_X3S_AM") ? atoi(getenv("RVC_X3S_AM")) : 0, f_an = getenv("RVC_X3S_AN") ? atoi(getenv("RVC_X3S_AN")) : 0;
+  static const int f_s = getenv("RVC_X3S_SPLIT") ? atoi(getenv("RVC_X3S_SPLIT")) : 0;
+  static const int target = getenv("RVC_X3S_BLK") ? atoi(getenv("RVC_X3S_BLK")) : 440;
+  auto tiles = [&](int am, int an) { return (long long)((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
+  // measured on MI355X at N = 1599 (tools/bench_gemm.py, profiles/r3b_bench_gemm.txt): 768 -> 3072 128 x 64 35 us (64 x 128 the same, 128 x 128 38),
+  // 768 -> 2304 128 x 64 28 us, 768 -> 768 64 x 64 16.3 us un-split (17.6 split in two), 3072 -> 768 64 x 64 split in two 37.8 us (128 x 64 in three 39.0)
+  AM = 2; AN = 2;
+  if (tiles(AM, AN) < target) AN = 1;
+  if (tiles(AM, AN) < target) AM = 1;
+  if (f_am) AM = f_am;
+  if (f_an) AN = f_an;
+  if (t_force_am == 1 || t_force_am == 2) AM = t_force_am;
+  if (t_force_an == 1 || t_force_an == 2) AN = t_force_an;
+  S = 1;
+  const long long nt = tiles(AM, AN);
+  for (int c : {2, 3, 4, 6, 8}) {
+    if (nt * S >= target) break;
+    if (units % c == 0 && units / c >= 32) S = c;             // (a slice shorter than K = 512 does not pay for its slab round trip)
+  }
+  if (f_s) S = (units % f_s == 0) ? f_s : 1;
+  if (t_force_s > 0) S = (units % t_force_s == 0 && units / t_force_s >= 4) ? t_force_s : 1;
+}
+
+bool conv_x3s_eligible(const ConvLayer& L) {
+  return conv_x3_enabled() && L.mode == 1 && L.Wx_ != nullptr && L.k == 1 && L.stride == 1 && L.groups == 1 && L.tconv_u == 0 && (L.Ci & 15) == 0 && L.Ci >= 64;
+}
+
+void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e) {
+  RVC_REQUIRE(conv_x3s_eligible(L), "conv_x3s_run: k = 1 layer with a bf16x3 weight image expected");
+  RVC_REQUIRE(Xs != nullptr && xsTp >= split_image_tp(T), "conv_x3s_run: split-resident input image missing or shorter than split_image_tp(T)");
+  RVC_REQUIRE(Y != nullptr || e.ys_out != nullptr, "conv_x3s_run: no output");
+  RVC_REQUIRE(e.pre_act == ACT_NONE && !e.accumulate && !e.tout_limit && !e.xs_in, "conv_x3s_run: unsupported epilogue option");
+  RVC_REQUIRE(e.act == ACT_NONE || e.act == ACT_LRELU || e.act == ACT_RELU || e.act == ACT_GELU, "conv_x3s_run: activation must be identity / (leaky) ReLU / GELU");
+  RVC_REQUIRE(!e.ys_out || (e.ys_tp >= split_image_tp(T) && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
+  RVC_REQUIRE((double)L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
+  GemmSArgs a{};
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.Xs = Xs; a.xsTp = xsTp;
+  a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16;
+  a.bias = e.bias_override ? e.bias_override : L.bd_; a.R = e.R; a.ldR = e.ldR; a.Y = Y; a.ldY = ldY; a.Ys = e.ys_out; a.ysTp = e.ys_tp;
+  a.act = e.act; a.act_slope = e.act_slope; a.act_before_res = e.act_before_res; a.out_scale = e.out_scale;
+  int AM, AN, S;
+  x3s_plan(L.Co, T, a.nunits, AM, AN, S);
+  const int BM = 64 * AM, BN = 64 * AN;
+  RVC_REQUIRE(L.CoPx % BM == 0, "weight image rows are padded to the tile");
+  a.gx = (T + BN - 1) / BN; a.gy = (L.Co + BM - 1) / BM; a.ksplit = S;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  a.xcd_remap = xcd_env;
+  const unsigned blocks = (unsigned)((long long)a.gx * a.gy * S);
+  if (S > 1) {
+    // slabs + one ticket word per tile (zeroed when the scratch is first handed out and by every launch's last arriver)
+    const size_t slab_bytes = (size_t)blocks * BM * BN * 4;
+    const size_t tick_bytes = ((size_t)a.gx * a.gy * 4 + 255) & ~(size_t)255;
+    static const size_t kTickCap = 64 * 1024;                  // ticket words live in their own scratch slot, sized once: never re-allocated dirty
+    RVC_REQUIRE(tick_bytes <= kTickCap, "too many tiles for the ticket array");
+    bool fresh = false;
+    a.tickets = (unsigned*)stream_scratch_zeroed(s, 7, kTickCap, &fresh);
+    a.slabs = (float*)stream_scratch(s, 6, slab_bytes);
+  }
+  ProfTicket tk = conv_prof_begin(s);
+  static const int rs_env = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 4;      // ring depth (experiments: 3 / 4 / 6)
+  if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 2, 6>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
+  else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 1, 6>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
+  else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }
+  else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 1, 6>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
+  if (tk.on) {
+    ConvArgsX pa{};
+    pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = 1; pa.kreal = 1; pa.dil = 1; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.Wd = 0; pa.ksplit = S;
+    pa.R = e.R; pa.X = nullptr;
+    // algorithmic bytes: the input image (4 B per element, like fp32), the outputs that are written, the residual, the weights
+    const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci);
+    const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
+    conv_prof_end(tk, s, 2.0 * (double)L.Co * T * L.Ci, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
+  }
+}
+
+}  // namespace rvc

@@ -137,36 +137,68 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   }
   float* feat = in;           // [512][T]
   if (taps) tap(taps->conv_stack, feat, (size_t)512 * T);
-  float* ln = A.alloc<float>((size_t)512 * T);
-  float* h = A.alloc<float>((size_t)768 * T);
-  float* hb = A.alloc<float>((size_t)768 * T);
-  if (!dry) {
-    layernorm_c(s, feat, nullptr, H->fp_g.p, H->fp_b.p, ln, 512, T, T, 1e-5f);
-    conv1d_run(H->proj, s, ln, T, T, h, T, E0);
-    if (taps && taps->pos_conv) { ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.tout_limit = T; conv1d_run(H->pos, s, h, T, T, taps->pos_conv, T, Ep); }
-    ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.act_before_res = 1; Ep.R = h; Ep.ldR = T; Ep.tout_limit = T;
-    conv1d_run(H->pos, s, h, T, T, hb, T, Ep);
-    layernorm_c(s, hb, nullptr, H->enc_g.p, H->enc_b.p, h, 768, T, T, 1e-5f);
-  }
+  // Split-resident GEMM path (conv_x3s.hip): the activations that feed a k = 1 projection live as the bf16 hi / lo image the kernel stages,
+  // written by their producers (LayerNorm, the attention's epilogue, FFN1's GELU epilogue); the fp32 copy is kept only where a residual or
+  // the attention reads it.  Needs the bf16x3 weight images (context precision 1 / 2); RVC_X3S=0 selects the fp32-input kernels.
+  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
   int need = version == 1 ? 8 : 11;
   if (n_layers > 0) need = n_layers;
   RVC_REQUIRE(need <= (int)H->layers.size(), "not enough encoder layers loaded");
+  bool gs = x3s_on && conv_x3_enabled() && conv_x3s_eligible(H->proj) && (version != 1 || conv_x3s_eligible(H->final_proj));
+  for (int l = 0; l < need && gs; ++l) {
+    const HubLayer& Y = H->layers[l];
+    gs = conv_x3s_eligible(Y.qk) && conv_x3s_eligible(Y.o) && conv_x3s_eligible(Y.ff1) && conv_x3s_eligible(Y.ff2);
+  }
+  const long long tp = split_image_tp(T);
+  float* ln = gs ? nullptr : A.alloc<float>((size_t)512 * T);
+  unsigned char* ln_s = gs ? A.alloc<unsigned char>(split_image_bytes(512, T)) : nullptr;
+  unsigned char* hs = gs ? A.alloc<unsigned char>(split_image_bytes(768, T)) : nullptr;
+  float* h = A.alloc<float>((size_t)768 * T);
+  float* hb = A.alloc<float>((size_t)768 * T);
+  if (!dry) {
+    if (gs) {
+      layernorm_c_split(s, feat, H->fp_g.p, H->fp_b.p, nullptr, ln_s, tp, kSplitMargin, 512, T, T, 1e-5f);
+      conv_x3s_run(H->proj, s, ln_s, tp, T, h, T, E0);
+    } else {
+      layernorm_c(s, feat, nullptr, H->fp_g.p, H->fp_b.p, ln, 512, T, T, 1e-5f);
+      conv1d_run(H->proj, s, ln, T, T, h, T, E0);
+    }
+    if (taps && taps->pos_conv) { ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.tout_limit = T; conv1d_run(H->pos, s, h, T, T, taps->pos_conv, T, Ep); }
+    ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.act_before_res = 1; Ep.R = h; Ep.ldR = T; Ep.tout_limit = T;
+    conv1d_run(H->pos, s, h, T, T, hb, T, Ep);
+    if (gs) layernorm_c_split(s, hb, H->enc_g.p, H->enc_b.p, h, hs, tp, kSplitMargin, 768, T, T, 1e-5f);
+    else layernorm_c(s, hb, nullptr, H->enc_g.p, H->enc_b.p, h, 768, T, T, 1e-5f);
+  }
   {
     const size_t mark = A.off;
     float* qk = A.alloc<float>((size_t)2304 * T);
     float* vr = A.alloc<float>((size_t)T * 768);
-    float* attn = A.alloc<float>((size_t)768 * T);
-    float* ff = A.alloc<float>((size_t)3072 * T);
+    float* attn = gs ? nullptr : A.alloc<float>((size_t)768 * T);
+    float* ff = gs ? nullptr : A.alloc<float>((size_t)3072 * T);
+    unsigned char* attn_s = gs ? A.alloc<unsigned char>(split_image_bytes(768, T)) : nullptr;
+    unsigned char* ff_s = gs ? A.alloc<unsigned char>(split_image_bytes(3072, T)) : nullptr;
     if (!dry) {
       for (int l = 0; l < need; ++l) {
         HubLayer& Y = H->layers[l];
         if (taps && l == 0) tap(taps->hidden_0, h, (size_t)768 * T);
         if (taps && l == 8) tap(taps->hidden_8, h, (size_t)768 * T);
+        ConvEpilogue Er; Er.R = h; Er.ldR = T;
+        if (gs) {
+          conv_x3s_run(Y.qk, s, hs, tp, T, qk, T, E0);
+          transpose(s, qk + (size_t)1536 * T, vr, 768, T, T, 768, 1, 0, 0);      // V row-major [T][768] for the fused attention
+          attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, nullptr, T, 12, 64, T, attn_s, tp);
+          conv_x3s_run(Y.o, s, attn_s, tp, T, hb, T, Er);
+          layernorm_c_split(s, hb, Y.g1.p, Y.b1.p, h, hs, tp, kSplitMargin, 768, T, T, 1e-5f);
+          ConvEpilogue Eg; Eg.act = ACT_GELU; Eg.ys_out = ff_s; Eg.ys_tp = tp;
+          conv_x3s_run(Y.ff1, s, hs, tp, T, nullptr, T, Eg);                     // GELU in the epilogue, the 3072-channel tensor exists only as the image
+          conv_x3s_run(Y.ff2, s, ff_s, tp, T, hb, T, Er);
+          layernorm_c_split(s, hb, Y.g2.p, Y.b2.p, h, hs, tp, kSplitMargin, 768, T, T, 1e-5f);
+          continue;
+        }
         conv1d_run(Y.qk, s, h, T, T, qk, T, E0);
         transpose(s, qk + (size_t)1536 * T, vr, 768, T, T, 768, 1, 0, 0);      // V row-major [T][768] for the fused attention
         // softmax(K^T Q) V + bv without materialising the [12][T][T] scores (attention.hip)
         attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, attn, T, 12, 64, T);
-        ConvEpilogue Er; Er.R = h; Er.ldR = T;
         conv1d_run(Y.o, s, attn, T, T, hb, T, Er);
         layernorm_c(s, hb, nullptr, Y.g1.p, Y.b1.p, h, 768, T, T, 1e-5f);
         ConvEpilogue Eg; Eg.act = ACT_GELU;
@@ -181,7 +213,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   const float* res = h; int D = 768;
   if (version == 1) {
     float* fp = A.alloc<float>((size_t)256 * T);
-    if (!dry) conv1d_run(H->final_proj, s, h, T, T, fp, T, E0);
+    if (!dry) { if (gs) conv_x3s_run(H->final_proj, s, hs, tp, T, fp, T, E0); else conv1d_run(H->final_proj, s, h, T, T, fp, T, E0); }
     res = fp; D = 256;
   }
   if (!dry) {

@@ -270,6 +270,7 @@ static void mdx23_graph(Mdx23* M, hipStream_t s, Arena& A, const float* audio, l
   size_t big = 0;
   for (int i = 0; i <= n; ++i) big = std::max(big, (size_t)2 * ch[(size_t)i] * Hs[(size_t)i] * Ws[(size_t)i]);
   big = std::max(big, (size_t)((long long)(c0 + dim_c) * FT));
+  big = std::max(big, (size_t)((long long)S * dim_c * FT));        // the mask head's output [S dim_c][f0][T] lands in t1 as well
   MdxScratch K;
   K.t1 = A.alloc<float>(big); K.t2 = A.alloc<float>(big); K.t3 = A.alloc<float>(big); K.sbuf = A.alloc<float>(big);
   K.sc = A.alloc<float>((size_t)2 * ch[(size_t)n] + 64); K.sh = A.alloc<float>((size_t)2 * ch[(size_t)n] + 64);

@@ -339,7 +339,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     bool any_split = false;
     for (int j = 0; j < 3; ++j)
       for (int m = 0; m < 3; ++m) {
-        split_pair[j][m] = split_on && conv1d_split_eligible(st.rb[j].c1[m], Tn) && conv1d_split_eligible(st.rb[j].c2[m], Tn);
+        split_pair[j][m] = split_on && conv1d_split_eligible(st.rb[j].c1[m], Tn, SPLIT_PRODUCER) && conv1d_split_eligible(st.rb[j].c2[m], Tn, SPLIT_CONSUMER);
         any_split = any_split || split_pair[j][m];
       }
     unsigned char* t1s = any_split ? A.alloc<unsigned char>(split_image_bytes(Cc, Tn)) : nullptr;

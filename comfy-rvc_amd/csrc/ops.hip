@@ -83,6 +83,69 @@ void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gam
   hipLaunchKernelGGL(layernorm_c_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, r, gamma, beta, y, C, T, ld, eps);
 }
 
+// The same LayerNorm with a second output: the bf16 hi / lo image of y that the split-resident GEMM stages (conv_x3s.hip;
+// [16-channel chunk][hi | lo][8-channel half][margin + t][8 ch]).  The statistics sweep is the kernel above's; in the second sweep a thread
+// owns GROUPS of 8 consecutive channels of its column (group = slice + 16 j), so that it holds one whole 16-byte image row: per channel
+// the 16 columns of a block are still one 64-byte segment, and the 16 image rows of a (group, block) are 256 contiguous bytes.
+__global__ __launch_bounds__(256) void layernorm_c_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ y, unsigned char* __restrict__ img, long long tp, int margin,
+                                                                int C, int T, long long ld, float eps) {
+  __shared__ float s_a[16][17], s_b[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + col;
+  const bool ok = t < T;
+  const float shift = ok ? x[t] : 0.f;
+  float sum = 0.f, sq = 0.f;
+  const int G = C >> 3;
+  if (ok) {
+    for (int g = sl; g < G; g += 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = x[(long long)(8 * g + j) * ld + t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[j] - shift; sum += d; sq += d * d; }
+    }
+  }
+  s_a[sl][col] = sum; s_b[sl][col] = sq;
+  __syncthreads();
+  float ts = 0.f, tq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ts += s_a[i][col]; tq += s_b[i][col]; }
+  const float md = ts / (float)C;
+  const float var = fmaxf(tq / (float)C - md * md, 0.f);
+  const float mean = md + shift, rstd = rsqrtf(var + eps);
+  if (!ok) return;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  for (int g = sl; g < G; g += 16) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[(long long)(8 * g + j) * ld + t];
+    u32x4_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gamma[8 * g + j] + beta[8 * g + j];
+    if (y) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[(long long)(8 * g + j) * ld + t] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 ah = (__bf16)v[2 * j], bh = (__bf16)v[2 * j + 1];
+      const __bf16 al = (__bf16)(v[2 * j] - (float)ah), bl = (__bf16)(v[2 * j + 1] - (float)bh);
+      hi[j] = (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+      lo[j] = (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+    }
+    const int chunk = g >> 1, half = g & 1;
+    unsigned char* row = img + (((long long)chunk * 4 + half) * tp + margin + t) * 16;
+    *reinterpret_cast<u32x4_t*>(row) = hi;
+    *reinterpret_cast<u32x4_t*>(row + tp * 32) = lo;
+  }
+}
+void layernorm_c_split(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, unsigned char* img, long long tp, int margin,
+                       int C, int T, long long ld, float eps) {
+  RVC_REQUIRE((C & 15) == 0 && img != nullptr, "layernorm_c_split: channels must be a multiple of 16");
+  hipLaunchKernelGGL(layernorm_c_split_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, gamma, beta, y, img, tp, margin, C, T, ld, eps);
+}
+
 // ---------------------------------------------------------------------------------------------- GroupNorm(C, C) over time + GELU
 __global__ __launch_bounds__(256) void groupnorm_t_gelu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int T, long long ld, float eps) {

@@ -51,6 +51,8 @@ int rvc_ctx_create(int device_id, rvc_ctx** out) {
   *out = c;
   RVC_CATCH
 }
+// Destroying the LAST context of a device frees that device's per-stream scratch: the caller must not have calls in flight on that device
+// from other threads at that moment (include/rvc_hip.h says so at rvc_ctx_destroy; handles of a destroyed context are dead anyway).
 int rvc_ctx_destroy(rvc_ctx* ctx) {
   if (!ctx) return 0;
   bool last;
@@ -139,7 +141,9 @@ struct rvc_crepe { Crepe* m; rvc_ctx* ctx; };
 int rvc_crepe_create(rvc_ctx* ctx, int tiny, rvc_crepe** out) {
   RVC_TRY
   RVC_REQUIRE(ctx && out, "null argument");
-  rvc_crepe* c = new rvc_crepe(); c->ctx = ctx; c->m = crepe_create(&ctx->c, tiny); *out = c;
+  rvc_crepe* c = new rvc_crepe(); c->ctx = ctx; c->m = nullptr;
+  try { c->m = crepe_create(&ctx->c, tiny); } catch (...) { delete c; throw; }
+  *out = c;
   RVC_CATCH
 }
 int rvc_crepe_set_tensor(rvc_crepe* c, const char* name, const float* d, const int64_t* shape, int ndim) {
@@ -345,6 +349,32 @@ int rvc_op_conv1d(void* stream, const float* x, const float* w, const float* bia
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_gemm_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, float* ysplit_f32, int Ci, int Co,
+                      int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit, int am, int an) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && (y || ysplit_f32) && Ci > 0 && Co > 0 && T > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, 1, 1, 0, 1, 1); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr;
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident GEMM (Ci % 16 == 0, Ci >= 64, Co >= 32)");
+    const long long tp = split_image_tp(T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    ConvEpilogue e; e.act = act; e.act_slope = act_slope; e.act_before_res = act_before_res; e.out_scale = out_scale; e.R = res; e.ldR = T;
+    if (ysplit_f32) { RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes(Co, T))); e.ys_out = ys; e.ys_tp = tp; }
+    conv_x3s_force(ksplit, am, an);
+    try { conv_x3s_run(L, s, xs, tp, T, y, T, e); } catch (...) { conv_x3s_force(0, 0, 0); throw; }
+    conv_x3s_force(0, 0, 0);
+    if (ysplit_f32) split_image_to_f32(s, ys, tp, Co, T, ysplit_f32, T);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw; }
+  (void)hipFree(xs); if (ys) (void)hipFree(ys);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_conv_transpose1d(void* stream, const float* x, const float* w, const float* bias, float* y, int Ci, int Co, int Tin, int k, int u,
                             int pad, int pre_act, float pre_slope, int accumulate) {
   RVC_TRY
@@ -417,7 +447,7 @@ int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, voi
                                    int accumulate) {
   RVC_TRY
   RVC_REQUIRE(c1 && c2 && x && y, "null argument");
-  RVC_REQUIRE(conv1d_split_eligible(c1->L, T) && conv1d_split_eligible(c2->L, T), "layers not eligible for split-resident tensors at this length");
+  RVC_REQUIRE(conv1d_split_eligible(c1->L, T, SPLIT_PRODUCER) && conv1d_split_eligible(c2->L, T, SPLIT_CONSUMER), "layers not eligible for split-resident tensors at this length");
   hipStream_t s = (hipStream_t)stream;
   unsigned char* img = (unsigned char*)stream_scratch(s, 5, split_image_bytes(c1->L.Co, T));
   ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f; E1.ys_out = img; E1.ys_tp = split_image_tp(T); E1.ys_slope = 0.1f;
@@ -485,5 +515,46 @@ const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 int rvc_debug_x3p_check(void) { return conv_x3p_check_read(); }
+int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out) {
+  RVC_TRY
+  RVC_REQUIRE(us_out && reps > 0 && Ci > 0 && Co > 0 && T > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<float> w((size_t)Co * Ci), b((size_t)Co, 0.01f);
+  uint32_t st = 12345u;
+  for (auto& v : w) { st = st * 1664525u + 1013904223u; v = ((float)(st >> 8) / 8388608.f - 1.f) * 0.05f; }
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w.data(), b.data(), Co, Ci, 1, 1, 0, 1, 1); }
+  float* x = nullptr; float* r = nullptr; float* y = nullptr; unsigned char* xs = nullptr; unsigned char* ys = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  try {
+    const long long tp = split_image_tp(T);
+    std::vector<float> hx((size_t)Ci * T);
+    for (auto& v : hx) { st = st * 1664525u + 1013904223u; v = (float)(st >> 8) / 8388608.f - 1.f; }
+    x = dev_upload(hx.data(), hx.size());
+    RVC_HIP_CHECK(hipMalloc(&r, (size_t)Co * T * 4)); RVC_HIP_CHECK(hipMemset(r, 0, (size_t)Co * T * 4));
+    RVC_HIP_CHECK(hipMalloc(&y, (size_t)Co * T * 4));
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T))); RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes((Co + 15) & ~15, T)));
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    ConvEpilogue e;
+    if (split_out) { e.act = ACT_GELU; e.ys_out = ys; e.ys_tp = tp; } else { e.R = r; e.ldR = T; }
+    conv_x3s_force(ksplit, am, an);
+    conv_x3s_run(L, s, xs, tp, T, split_out ? nullptr : y, T, e);
+    RVC_HIP_CHECK(hipEventCreate(&e0)); RVC_HIP_CHECK(hipEventCreate(&e1));
+    RVC_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) conv_x3s_run(L, s, xs, tp, T, split_out ? nullptr : y, T, e);
+    RVC_HIP_CHECK(hipEventRecord(e1, s));
+    RVC_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f; RVC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *us_out = ms * 1e3f / (float)reps;
+  } catch (...) {
+    conv_x3s_force(0, 0, 0);
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+    dev_free(x); if (r) (void)hipFree(r); if (y) (void)hipFree(y); if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw;
+  }
+  conv_x3s_force(0, 0, 0);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  dev_free(x); (void)hipFree(r); (void)hipFree(y); (void)hipFree(xs); (void)hipFree(ys); conv_layer_free(L);
+  RVC_CATCH
+}
 
 }  // extern "C"

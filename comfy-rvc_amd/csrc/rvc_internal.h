@@ -98,8 +98,11 @@ struct ConvEpilogue {
 constexpr int kSplitMargin = 64;                                                   // positions in front of t = 0 (covers every left halo)
 inline long long split_image_tp(long long T) { return (T + kSplitMargin + 704 + 63) & ~63LL; }   // rows per plane: margin + T + the last tile's overhang
 inline size_t split_image_bytes(int C, long long T) { return (size_t)(C / 16) * 2 * (size_t)split_image_tp(T) * 32; }
-// true when this layer at this length runs on the bf16x3 kernel with a tile that has the split-input / split-output paths
-bool conv1d_split_eligible(const ConvLayer& L, int Tin);
+// true when this layer at this length runs on the bf16x3 kernel with a tile that has the split-resident path of its ROLE: a producer
+// (writes the image: ConvEpilogue::ys_out) and a consumer (stages it: xs_in) take different branches of the tile choice, so each role
+// is dry-run with its own geometry.  pre_lrelu: the producer's input activation (part of the real launch's arguments).
+enum SplitRole : int { SPLIT_CONSUMER = 0, SPLIT_PRODUCER = 1 };
+bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role = SPLIT_CONSUMER);
 
 // host-side packing + upload (weights in PyTorch layouts)
 void conv1d_layer_init(ConvLayer& L, const float* w /*[Co][Ci/groups][k]*/, const float* bias, int Co, int Ci, int k,
@@ -139,12 +142,23 @@ void gemm_tn_run(hipStream_t s, const float* A, long long ldA, long long aBatch,
 void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY,
                 const ConvEpilogue& e);
 
+// bf16x3 GEMM of a k = 1 layer on a SPLIT-RESIDENT activation (conv_x3s.hip): both operand tiles by LDS-DMA, K split reduced inside the
+// launch.  Xs: image of the [Ci][T] input (split_image_tp(T) rows per plane); Y (fp32 [Co][ldY]) and / or e.ys_out (image of the output, the
+// activation e.act - identity, (leaky) ReLU, exact GELU - applied before the split).  e.R: residual, e.bias_override as in conv1d_run.
+bool conv_x3_enabled();                       // bf16x3 kernels not switched off at run time (RVC_X3=0)
+bool conv_x3s_eligible(const ConvLayer& L);
+void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e);
+void conv_x3s_force(int ksplit, int am, int an);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
+void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp);
+void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY);
+
 bool conv2d_kx_try(const ConvLayer& L, hipStream_t s, const float* X, long long ldX, int H, int Wd, float* Y, long long ldY, const ConvEpilogue& e,
                    bool dry = false);
 
 // fused multi-head attention (attention.hip): Q, K channel-major [heads*64][T], V row-major [T][heads*64], out channel-major
+// out (fp32, channel-major) and / or out_img (the split-resident image of conv_x3s.hip, img_tp rows per plane) receive the result
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
-                     float* out, long long ldo, int heads, int dhead, int T);
+                     float* out, long long ldo, int heads, int dhead, int T, unsigned char* out_img = nullptr, long long img_tp = 0);
 
 void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                          const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T);
@@ -158,6 +172,7 @@ void conv_timing_read(unsigned long long* out8, bool reset);   // debug builds (
 // ----------------------------------------------------------------------------- device memory
 float* dev_upload(const float* host, size_t n);
 void* stream_scratch(hipStream_t s, int slot, size_t bytes);   // persistent per-(device, stream) scratch (grows on demand)
+void* stream_scratch_zeroed(hipStream_t s, int slot, size_t bytes, bool* fresh = nullptr);   // zero-filled when (re)allocated; users leave it zero
 void stream_scratch_release(int device);                        // frees the scratch of one device (last context of the device destroyed)
 void dev_free(void* p);
 

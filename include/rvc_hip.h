@@ -35,6 +35,8 @@ const char* rvc_last_error(void);
 const char* rvc_version(void);
 
 int rvc_ctx_create(int device_id, rvc_ctx** out);
+/* Destroying the LAST context of a device also frees that device's per-stream scratch: no call may be in flight on that device from
+ * another thread at that moment (destroy the handles first, then the context, from one thread). */
 int rvc_ctx_destroy(rvc_ctx* ctx);
 /* bytes of activation workspace currently held by the context */
 int64_t rvc_ctx_workspace_bytes(rvc_ctx* ctx);
@@ -215,6 +217,14 @@ int rvc_postprocess(void* stream, float* wav_dev, int64_t N, const double* rms1_
 int rvc_op_conv1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
                   int Ci, int Co, int Tin, int k, int stride, int pad, int dil, int groups, int pre_act, float pre_slope, int act,
                   float act_slope, int act_before_res, float out_scale, int accumulate);
+/* k = 1 projection (torch.nn.Linear over [T, Ci] rows, reference transformers/models/hubert/modeling_hubert.py:291-477 via
+ * lib/infer_pack/loaders.py:55-61) on the split-resident GEMM kernel (csrc/conv_x3s.hip): x_dev [Ci][T] fp32 is first written as the bf16
+ * hi / lo image the kernel stages, y = act(W x + b [+ res]) (act_before_res: act(W x + b) + res).  y_dev fp32 [Co][T] or null;
+ * ysplit_f32_dev [Co][T] or null receives the kernel's SPLIT output image read back as hi + lo.  ksplit > 0 forces the K split (reduced
+ * inside the launch), am / an > 0 force the tile (64 am rows x 64 an columns). */
+int rvc_op_gemm_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
+                      float* ysplit_f32_dev, int Ci, int Co, int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit,
+                      int am, int an);
 /* ConvTranspose1d: w_host [Ci][Co][k]; y_dev [Co][(Tin-1)*u - 2*pad + k] */
 int rvc_op_conv_transpose1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int Ci, int Co,
                             int Tin, int k, int u, int pad, int pre_act, float pre_slope, int accumulate);
@@ -266,8 +276,9 @@ int rvc_resample(void* stream, const float* x_dev, int64_t n_in, const double* t
 /* Matrix-core arithmetic of the Conv1d layers created AFTER the call BY THE CALLING THREAD (thread-local: free-standing ops / plans,
  * and models whose context is left at mode -1; rvc_ctx_set_conv_precision is the per-handle form):
  *   0  fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32; bitwise an fp32 FMA chain)
- *   1  default: the synthesizer's generator convolutions use the bf16x3 split (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on
- *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation; ~1e-5 relative error per layer), everything else fp32
+ *   1  default: every eligible layer of the models (HuBERT incl. its projections, RMVPE, the synthesizer, the feature index, MDX23C,
+ *      CREPE) uses the bf16x3 split (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
+ *      ~1e-5 relative error per layer); grouped / Ci % 16 != 0 / under-filled launches and free-standing ops / plans stay fp32
  *   2  bf16x3 for every eligible layer (stride 1, groups 1, Ci % 16 == 0), including rvc_op_conv1d / plans (parity tests) */
 int rvc_set_conv_precision(int mode);
 
@@ -291,6 +302,10 @@ int rvc_debug_conv_timing(uint64_t* out8, int reset);
 /* debug builds only (-DRVC_X3P_CHECK): number of waits of the pipelined bf16x3 kernel whose compile-time vmcnt exceeded the exact
  * run-time count since the last call (must be 0); -1 in ordinary builds */
 int rvc_debug_x3p_check(void);
+/* kernel benchmark (tools/bench_gemm.py): `reps` back-to-back launches of the split-resident GEMM (csrc/conv_x3s.hip) for an [Co x Ci] layer
+ * on T columns of device-resident random data (input image, fp32 output with a residual); ksplit / am / an as in rvc_op_gemm_split,
+ * split_out != 0 writes the output as the split image (GELU epilogue) instead.  *us_out = mean microseconds per launch (HIP events). */
+int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out);
 
 #ifdef __cplusplus
 }

@@ -539,3 +539,79 @@ def test_fused_resblock_pair(L, Cc, k, d, T, scale, accum):
         assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
+
+
+# ------------------------------------------------------------------ split-resident GEMM (csrc/conv_x3s.hip)
+GEMM_SPLIT = [
+    # Ci, Co, T, act, res, act_before_res, out_scale, ksplit, am, an
+    (768, 3072, 1599, "gelu", False, 0, 1.0, 0, 0, 0),       # HuBERT FFN1 (automatic tile: 128 x 64), GELU before the split
+    (3072, 768, 1599, "none", True, 0, 1.0, 0, 0, 0),        # FFN2: automatic K split, reduced inside the launch
+    (768, 2304, 1599, "none", False, 0, 1.0, 0, 0, 0),       # q / k / v
+    (768, 768, 1599, "none", True, 0, 1.0, 4, 2, 2),         # out projection, forced 4-way split on 128 x 128 tiles
+    (768, 768, 333, "lrelu", True, 1, 0.5, 2, 1, 2),         # act(Wx + b) + res, scaled; 64 x 128 tiles; ragged columns
+    (192, 576, 3198, "relu", False, 0, 1.0, 0, 1, 1),        # text-encoder size, 64 x 64 tiles
+    (512, 360, 100, "none", False, 0, 1.0, 2, 2, 1),         # Co not a multiple of the tile (360 = 2 x 128 + 104), few columns
+    (64, 32, 70, "gelu", True, 1, 1.0, 0, 0, 0),             # the smallest eligible layer
+]
+
+
+@pytest.mark.parametrize("case", GEMM_SPLIT, ids=[f"g{i}" for i in range(len(GEMM_SPLIT))])
+def test_gemm_split_resident(L, case):
+    """Y = act(W X + b [+ R]) with X handed over as the bf16 hi / lo image: fp32 rows AND the split output image (read back as hi + lo)
+    against torch float64; 3-term bf16 split => ~1e-5 relative.  The K split is summed in slice order by whichever slice arrives last:
+    repeated launches are bit-identical."""
+    Ci, Co, T, act, res, abr, scale, ks, am, an = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, T, generator=g) if res else None
+    v = w.double() @ x.double() + b.double()[:, None]
+    if res and not abr:
+        v = v + r.double()
+    v = _act(v, act, 0.1)
+    if res and abr:
+        v = v + r.double()
+    ref = (v * scale).numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    y = torch.full((Co, T), float("nan"), device="cuda")
+    ys = torch.full((Co, T), float("nan"), device="cuda") if Co % 16 == 0 else None
+    wn, bn = w.contiguous().numpy(), b.contiguous().numpy()
+
+    def run(yo, yso):
+        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), L.ptr(rd) if res else None, L.ptr(yo) if yo is not None else None,
+                                        L.ptr(yso) if yso is not None else None, Ci, Co, T, ACT[act], 0.1, abr, scale, ks, am, an))
+    run(y, ys)
+    assert rel_err(y.cpu().numpy(), ref) < 2e-5
+    if ys is not None:
+        assert rel_err(ys.cpu().numpy(), ref) < 2e-5            # hi + lo carries 16 mantissa bits: 2^-17 relative per element
+    y2 = torch.empty_like(y)
+    for _ in range(3):
+        run(y2, None)
+        assert torch.equal(y2, y)                               # whoever reduces, the sum order is the slice order
+
+
+def test_gemm_split_resident_under_load(L):
+    """The in-launch K-split hand-off (write-through slabs, ticket, last arriver reduces) while another stream keeps the chip busy with
+    streaming traffic: 20 launches of the 3072 -> 768 GEMM must all equal the un-split result bit for bit ... up to the sum order, i.e.
+    equal each other exactly and the float64 reference to 2e-5."""
+    Ci, Co, T = 3072, 768, 1599
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(Ci, T, generator=g); w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci); b = torch.randn(Co, generator=g) * 0.1
+    ref = (w.double() @ x.double() + b.double()[:, None]).numpy()
+    xd = dev(x)
+    wn, bn = w.contiguous().numpy(), b.contiguous().numpy()
+    side = torch.cuda.Stream()
+    big = torch.randn(64 * 1024 * 1024, device="cuda")
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            big.mul_(1.0001)                                    # 512 MB of HBM traffic per pass on the other stream
+    for i in range(20):
+        y = torch.full((Co, T), float("nan"), device="cuda")
+        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), None, L.ptr(y), None, Ci, Co, T, 0, 0.0, 0, 1.0, 3 + (i % 2), 2, 1))
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert rel_err(outs[0].cpu().numpy(), ref) < 2e-5 and rel_err(outs[1].cpu().numpy(), ref) < 2e-5
+    for i in range(2, 20):
+        assert torch.equal(outs[i], outs[i % 2])
