@@ -24,9 +24,13 @@
 namespace rvc {
 
 struct GemmSArgs {
-  const unsigned char* Wx; int CoPx;        // weight image [chunk][hi | lo][half][CoPx rows][16 B]
-  const unsigned char* Xs; long long xsTp;  // activation image [chunk][hi | lo][half][xsTp rows][16 B]; position t lives at row kSplitMargin + t
-  int Co, T, nunits;                        // rows stored, columns, 16-channel chunks of the reduction
+  const unsigned char* Wx; int CoPx;        // weight image [chunk][tap][hi | lo][half][CoPx rows][16 B]
+  const unsigned char* Xs; long long xsTp;  // activation image [chunk][hi | lo][half][xsTp rows][16 B]; position t lives at row margin + t
+  unsigned wx_bytes, xs_bytes;              // extents of the two images (buffer descriptors)
+  int Co, T, nunits;                        // rows stored, columns, units of the reduction: (16-channel chunk, tap), tap fastest
+  int ktaps, margin;                        // taps per chunk; image rows in front of position 0 (>= the largest |tap offset|, kept zero by the producers)
+  int toff[16];                             // tap -> position offset (1-D: tap * dil - pad; padded 2-D: dh * padw + dw)
+  int padw; unsigned padmagic;              // padded 2-D images: row pitch (W + 2) - columns 0 and padw - 1 of every row are written as zeros - and ceil(2^32 / padw)
   const float* bias; const float* R; long long ldR;
   float* Y; long long ldY;                  // fp32 output [Co][ldY] or null
   unsigned char* Ys; long long ysTp;        // split output image or null
@@ -45,6 +49,10 @@ __device__ __forceinline__ float x3s_gelu(float v) {
   const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
   const float erf_abs = fmaf(-poly, e, 1.f);
   return 0.5f * v * (1.f + copysignf(erf_abs, x));
+}
+// 1 KiB (16 B per lane) from a buffer straight into LDS: address = descriptor base + per-lane voffset + wave-uniform soffset
+__device__ __forceinline__ void x3s_dma(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_dst, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 }
 template <int N> __device__ __forceinline__ void x3s_wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
@@ -102,37 +110,48 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
         for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
   }
 
-  // ---- DMA: piece i of this wave is piece wave + NW i of the unit (pieces 0 .. NPA - 1: weights, then the input)
-  const unsigned char* src[NPW];
-  long long step[NPW];
-  int dsto[NPW];
+  // ---- DMA: piece i of this wave is piece wave + NW i of the unit (pieces 0 .. NPA - 1: weights, then the input).  Buffer addressing: the
+  // per-lane offset of a piece never changes, what moves from unit to unit is ONE scalar per operand - weights: the next unit's planes;
+  // input: the chunk's planes plus the tap's row offset (im2col by address: a tap is a shifted view of the same image).
+  const __amdgpu_buffer_rsrc_t ars = make_rsrc(p.Wx, p.wx_bytes), brs = make_rsrc(p.Xs, p.xs_bytes);
+  int voff[NPW], dsto[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int pi = wave + NW * i;
     if (i * NW < NPA) {
       constexpr int RBK = BM / 64;
       const int plane = pi / RBK, rb = pi - plane * RBK;
-      src[i] = p.Wx + (long long)u0 * p.CoPx * 64 + ((long long)plane * p.CoPx + co0 + rb * 64 + lane) * 16;
-      step[i] = (long long)p.CoPx * 64;
+      voff[i] = (plane * p.CoPx + co0 + rb * 64 + lane) * 16;
       dsto[i] = plane * (BM * 16) + rb * 1024;
     } else {
       constexpr int CBK = BN / 64;
       const int pj = pi - NPA, plane = pj / CBK, cb = pj - plane * CBK;
-      src[i] = p.Xs + (((long long)u0 * 4 + plane) * p.xsTp + kSplitMargin + n0 + cb * 64 + lane) * 16;
-      step[i] = p.xsTp * 64;
+      voff[i] = (int)((plane * p.xsTp + n0 + cb * 64 + lane) * 16);
       dsto[i] = aslot + plane * (BN * 16) + cb * 1024;
     }
   }
+  const int KT = p.ktaps;
+  const int wstep = p.CoPx * 64, cstep = (int)(p.xsTp * 64);
+  int tap = u0 % KT;
+  int soff_a = u0 * wstep, soff_c = (u0 / KT) * cstep, soff_b = soff_c + (p.margin + p.toff[tap]) * 16;
   int slw = 0, uw = 0;
   auto issue = [&]() {                                       // next unit into slot slw; past the end the last unit is requested again
     unsigned char* base = smem3s + slw * slot;
 #pragma unroll
-    for (int i = 0; i < NPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i], (__attribute__((address_space(3))) void*)(base + dsto[i]), 16, 0, 0);
+    for (int i = 0; i < NPW; ++i) {
+      if (i * NW < NPA) x3s_dma(ars, base + dsto[i], voff[i], soff_a);
+      else x3s_dma(brs, base + dsto[i], voff[i], soff_b);
+    }
     ++uw;
     if (uw < U) {
-#pragma unroll
-      for (int i = 0; i < NPW; ++i) src[i] += step[i];
+      soff_a += wstep;
+      if (KT > 1) {
+        ++tap;
+        if (tap == KT) { tap = 0; soff_c += cstep; }
+        soff_b = soff_c + (p.margin + p.toff[tap]) * 16;
+      } else {
+        soff_b += cstep;
+      }
     }
     slw = slw + 1 == RS ? 0 : slw + 1;
   };
@@ -293,6 +312,19 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[am][an][r] *= oscale;
   }
+  if (p.padw > 0) {                                            // padded 2-D rows: the two pad columns stay zero (they are the next layer's zero padding)
+#pragma unroll
+    for (int an = 0; an < AN; ++an) {
+      const unsigned n = (unsigned)(n0 + (wn * AN + an) * 32 + li);
+      const unsigned q = __umulhi(n, p.padmagic), w = n - q * (unsigned)p.padw;      // exact for n < 2^31 / padw (host)
+      if (w == 0u || w == (unsigned)p.padw - 1u) {
+#pragma unroll
+        for (int am = 0; am < AM; ++am)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[am][an][r] = 0.f;
+      }
+    }
+  }
   if (p.Y) {
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)p.Co * (unsigned)p.ldY * 4u);
 #pragma unroll
@@ -316,7 +348,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       for (int an = 0; an < AN; ++an) {
         const int n = n0 + (wn * AN + an) * 32 + li;
         const int mb = co0 + (wm * AM + am) * 32;
-        const long long pos = (long long)n + kSplitMargin;
+        const long long pos = (long long)n + p.margin;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
           unsigned hA[2], lA[2], hB[2], lB[2];
@@ -426,20 +458,52 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S) {
 }
 
 bool conv_x3s_eligible(const ConvLayer& L) {
-  return conv_x3_enabled() && L.mode == 1 && L.Wx_ != nullptr && L.k == 1 && L.stride == 1 && L.groups == 1 && L.tconv_u == 0 && (L.Ci & 15) == 0 && L.Ci >= 64;
+  if (!conv_x3_enabled() || L.Wx_ == nullptr || (L.Ci & 15) != 0 || L.Ci * L.ktaps < 64 || L.tconv_u != 0 || L.up2 != 0) return false;
+  if (L.mode == 2) return L.ktaps <= 16;                                      // 3 x 3 (or KH x KW) over a padded 2-D image: the caller supplies the geometry
+  return L.mode == 1 && L.stride == 1 && L.groups == 1 && L.k <= 16 && L.pad == (L.k - 1) / 2 * L.dil && (L.k & 1) == 1 &&
+         L.pad <= kSplitMargin;                                               // 1-D "same" convolution, taps as row offsets of the image
 }
 
-void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e) {
-  RVC_REQUIRE(conv_x3s_eligible(L), "conv_x3s_run: k = 1 layer with a bf16x3 weight image expected");
-  RVC_REQUIRE(Xs != nullptr && xsTp >= split_image_tp(T), "conv_x3s_run: split-resident input image missing or shorter than split_image_tp(T)");
+SplitGeom split_geom_2d(int Wd, int KH, int KW, int PH, int PWL) {
+  SplitGeom g; g.padw = Wd + 2; g.ktaps = KH * KW;
+  RVC_REQUIRE(g.ktaps <= 16 && PWL <= 1 && KW - 1 - PWL <= 1, "split_geom_2d: at most one pad column on each side");
+  for (int kh = 0; kh < KH; ++kh) for (int kw = 0; kw < KW; ++kw) g.toff[kh * KW + kw] = (kh - PH) * g.padw + (kw - PWL);
+  int maxoff = 0;
+  for (int t = 0; t < g.ktaps; ++t) maxoff = std::max(maxoff, std::abs(g.toff[t]));
+  g.margin = kSplitMargin;
+  while (g.margin < maxoff) g.margin += 64;
+  return g;
+}
+
+void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
+                  const SplitGeom* geom) {
+  RVC_REQUIRE(conv_x3s_eligible(L), "conv_x3s_run: layer without a bf16x3 weight image or not a stride-1 'same' geometry");
+  SplitGeom g1;
+  if (!geom) {
+    RVC_REQUIRE(L.mode == 1, "conv_x3s_run: a 2-D layer needs its padded-image geometry");
+    g1.ktaps = L.k; g1.margin = kSplitMargin; g1.padw = 0;
+    for (int t = 0; t < L.k; ++t) g1.toff[t] = t * L.dil - L.pad;
+    geom = &g1;
+  }
+  RVC_REQUIRE(geom->ktaps == L.ktaps || (L.mode == 1 && geom->ktaps == L.k), "conv_x3s_run: geometry and layer disagree about the taps");
+  int maxoff = 0;
+  for (int t = 0; t < geom->ktaps; ++t) maxoff = std::max(maxoff, std::abs(geom->toff[t]));
+  RVC_REQUIRE(geom->margin >= maxoff && geom->margin >= kSplitMargin, "conv_x3s_run: image margin smaller than the largest tap offset");
+  RVC_REQUIRE(Xs != nullptr && xsTp >= geom->margin + T + 704, "conv_x3s_run: split-resident input image missing or too short (margin + T + 704 rows per plane)");
   RVC_REQUIRE(Y != nullptr || e.ys_out != nullptr, "conv_x3s_run: no output");
   RVC_REQUIRE(e.pre_act == ACT_NONE && !e.accumulate && !e.tout_limit && !e.xs_in, "conv_x3s_run: unsupported epilogue option");
   RVC_REQUIRE(e.act == ACT_NONE || e.act == ACT_LRELU || e.act == ACT_RELU || e.act == ACT_GELU, "conv_x3s_run: activation must be identity / (leaky) ReLU / GELU");
-  RVC_REQUIRE(!e.ys_out || (e.ys_tp >= split_image_tp(T) && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
+  RVC_REQUIRE(!e.ys_out || (e.ys_tp >= geom->margin + T + 704 && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
   RVC_REQUIRE((double)L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
+  const double xs_bytes = (double)(L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)(L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0;
+  RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
   GemmSArgs a{};
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.Xs = Xs; a.xsTp = xsTp;
-  a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16;
+  a.wx_bytes = (unsigned)wx_bytes; a.xs_bytes = (unsigned)xs_bytes;
+  a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps;
+  a.ktaps = geom->ktaps; a.margin = geom->margin; a.padw = geom->padw;
+  a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
+  for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
   a.bias = e.bias_override ? e.bias_override : L.bd_; a.R = e.R; a.ldR = e.ldR; a.Y = Y; a.ldY = ldY; a.Ys = e.ys_out; a.ysTp = e.ys_tp;
   a.act = e.act; a.act_slope = e.act_slope; a.act_before_res = e.act_before_res; a.out_scale = e.out_scale;
   int AM, AN, S;
@@ -468,12 +532,13 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 1, 6>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
   if (tk.on) {
     ConvArgsX pa{};
-    pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = 1; pa.kreal = 1; pa.dil = 1; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.Wd = 0; pa.ksplit = S;
+    pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = geom->ktaps; pa.kreal = geom->ktaps; pa.dil = L.mode == 1 ? L.dil : 1; pa.stride = 1; pa.Tin = T; pa.Tout = T;
+    pa.Wd = geom->padw > 0 ? geom->padw - 2 : 0; pa.ksplit = S;
     pa.R = e.R; pa.X = nullptr;
     // algorithmic bytes: the input image (4 B per element, like fp32), the outputs that are written, the residual, the weights
-    const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci);
+    const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci * geom->ktaps);
     const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
-    conv_prof_end(tk, s, 2.0 * (double)L.Co * T * L.Ci, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
+    conv_prof_end(tk, s, 2.0 * (double)L.Co * T * L.Ci * geom->ktaps, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
   }
 }
 

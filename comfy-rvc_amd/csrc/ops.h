@@ -39,4 +39,12 @@ void preprocess(hipStream_t s, const void* x, int is64, long long n, const doubl
                 double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch);
 void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n1, int sr2, float rate, short* out, float* rms2, unsigned* maxbits);
 
+// padded 2-D split-resident images (split2d.hip): level changes of RMVPE's U-Net in the layout conv_x3s.hip convolves
+void pool2_pad_split(hipStream_t s, const float* x, long long ldx, bool x_padded, int C, int H, int W, float* y, long long ldy, unsigned char* img,
+                     long long tp, int margin);
+void interleave2_pad_split(hipStream_t s, const float* ph, long long ldp, int Co, int H, int W, float* y, long long ldy, bool y_padded, unsigned char* img,
+                           long long tp, int margin);
+void pad2d_split(hipStream_t s, const float* x, long long ldx, int C, int H, int W, float* y, long long ldy, unsigned char* img, long long tp, int margin);
+void unpad2d(hipStream_t s, const float* x, long long ldx, int C, int H, int W, float* y, long long ldy);
+
 }  // namespace rvc

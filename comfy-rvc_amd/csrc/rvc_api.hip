@@ -350,17 +350,18 @@ int rvc_op_conv1d(void* stream, const float* x, const float* w, const float* bia
   RVC_CATCH
 }
 int rvc_op_gemm_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, float* ysplit_f32, int Ci, int Co,
-                      int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit, int am, int an) {
+                      int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit, int am, int an, int k, int dil) {
   RVC_TRY
-  RVC_REQUIRE(x && w && (y || ysplit_f32) && Ci > 0 && Co > 0 && T > 0, "bad argument");
+  RVC_REQUIRE(x && w && (y || ysplit_f32) && Ci > 0 && Co > 0 && T > 0 && k >= 1 && (k & 1) == 1 && dil >= 1, "bad argument");
   hipStream_t s = (hipStream_t)stream;
   ConvLayer L;
-  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, 1, 1, 0, 1, 1); }
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, k, 1, (k - 1) / 2 * dil, dil, 1); }
   unsigned char* xs = nullptr; unsigned char* ys = nullptr;
   try {
-    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident GEMM (Ci % 16 == 0, Ci >= 64, Co >= 32)");
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident GEMM (Ci % 16 == 0, Ci k >= 64, Co >= 32, pad <= 64)");
     const long long tp = split_image_tp(T);
     RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0, split_image_bytes(Ci, T), s));          // zero margins: the taps' zero padding
     split_image_from_f32(s, x, T, Ci, T, xs, tp);
     ConvEpilogue e; e.act = act; e.act_slope = act_slope; e.act_before_res = act_before_res; e.out_scale = out_scale; e.R = res; e.ldR = T;
     if (ysplit_f32) { RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes(Co, T))); e.ys_out = ys; e.ys_tp = tp; }
@@ -373,6 +374,44 @@ int rvc_op_gemm_split(void* stream, const float* x, const float* w, const float*
   } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw; }
   (void)hipFree(xs); if (ys) (void)hipFree(ys);
   conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_conv2d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, float* ysplit_f32, int Ci, int Co,
+                        int H, int W, int act, int act_before_res, int ksplit, int am, int an) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && y && Ci > 0 && Co > 0 && H > 0 && W >= 2 && (W & 1) == 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv2d3x3_layer_init(L, w, bias, Co, Ci); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr; float* rp = nullptr; float* yp = nullptr; float* t = nullptr;
+  auto cleanup = [&]() { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); if (rp) (void)hipFree(rp); if (yp) (void)hipFree(yp); if (t) (void)hipFree(t); conv_layer_free(L); };
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident kernel (Ci % 16 == 0)");
+    const SplitGeom g = split_geom_2d(W);
+    const int T = H * (W + 2);
+    const long long tp = g.margin + T + 704 + 64;
+    const size_t ib = (size_t)(Ci / 16) * 4 * tp * 16, ob = (size_t)((Co + 15) / 16) * 4 * tp * 16;
+    RVC_HIP_CHECK(hipMalloc(&xs, ib)); RVC_HIP_CHECK(hipMemsetAsync(xs, 0, ib, s));
+    RVC_HIP_CHECK(hipMalloc(&yp, (size_t)Co * T * 4));
+    pad2d_split(s, x, (long long)H * W, Ci, H, W, nullptr, 0, xs, tp, g.margin);
+    ConvEpilogue e; e.act = act; e.act_slope = 0.1f; e.act_before_res = act_before_res;
+    if (res) { RVC_HIP_CHECK(hipMalloc(&rp, (size_t)Co * T * 4)); pad2d_split(s, res, (long long)H * W, Co, H, W, rp, T, nullptr, 0, 0); e.R = rp; e.ldR = T; }
+    if (ysplit_f32) { RVC_HIP_CHECK(hipMalloc(&ys, ob)); RVC_HIP_CHECK(hipMemsetAsync(ys, 0, ob, s)); e.ys_out = ys; e.ys_tp = tp; }
+    conv_x3s_force(ksplit, am, an);
+    try { conv_x3s_run(L, s, xs, tp, T, yp, T, e, &g); } catch (...) { conv_x3s_force(0, 0, 0); throw; }
+    conv_x3s_force(0, 0, 0);
+    unpad2d(s, yp, T, Co, H, W, y, (long long)H * W);
+    if (ysplit_f32) {
+      RVC_REQUIRE((Co & 15) == 0, "split output needs Co % 16 == 0");
+      RVC_HIP_CHECK(hipMalloc(&t, (size_t)Co * T * 4));
+      // (the image's rows start at its own margin: hand the reader the plane origin shifted so that its fixed 64-row margin lands on position 0)
+      split_image_to_f32(s, ys + (size_t)(g.margin - kSplitMargin) * 16, tp, Co, T, t, T);
+      unpad2d(s, t, T, Co, H, W, ysplit_f32, (long long)H * W);
+    }
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { cleanup(); throw; }
+  cleanup();
   RVC_CATCH
 }
 int rvc_op_conv_transpose1d(void* stream, const float* x, const float* w, const float* bias, float* y, int Ci, int Co, int Tin, int k, int u,

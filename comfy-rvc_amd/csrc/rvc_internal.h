@@ -146,8 +146,15 @@ void conv2d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
 // launch.  Xs: image of the [Ci][T] input (split_image_tp(T) rows per plane); Y (fp32 [Co][ldY]) and / or e.ys_out (image of the output, the
 // activation e.act - identity, (leaky) ReLU, exact GELU - applied before the split).  e.R: residual, e.bias_override as in conv1d_run.
 bool conv_x3_enabled();                       // bf16x3 kernels not switched off at run time (RVC_X3=0)
+// Layers with taps run on the same kernel: a unit of the reduction is (16-channel chunk, tap) and a tap is a row offset into the image
+// (im2col by address).  1-D "same" convolutions need nothing else (rows in front of position 0 / behind position T - 1 are the zero padding:
+// producers keep the margins zero).  2-D convolutions run over PADDED images: row pitch W + 2 with a zero column on either side, position
+// p = h (W + 2) + w + 1, T = H (W + 2); the kernel writes zeros into the pad columns of its outputs (SplitGeom from split_geom_2d).
+struct SplitGeom { int ktaps = 1; int toff[16] = {0}; int padw = 0; int margin = kSplitMargin; };
+SplitGeom split_geom_2d(int Wd, int KH = 3, int KW = 3, int PH = 1, int PWL = 1);
 bool conv_x3s_eligible(const ConvLayer& L);
-void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e);
+void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
+                  const SplitGeom* geom = nullptr);
 void conv_x3s_force(int ksplit, int am, int an);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
 void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp);
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY);

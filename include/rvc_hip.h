@@ -221,10 +221,16 @@ int rvc_op_conv1d(void* stream, const float* x_dev, const float* w_host, const f
  * lib/infer_pack/loaders.py:55-61) on the split-resident GEMM kernel (csrc/conv_x3s.hip): x_dev [Ci][T] fp32 is first written as the bf16
  * hi / lo image the kernel stages, y = act(W x + b [+ res]) (act_before_res: act(W x + b) + res).  y_dev fp32 [Co][T] or null;
  * ysplit_f32_dev [Co][T] or null receives the kernel's SPLIT output image read back as hi + lo.  ksplit > 0 forces the K split (reduced
- * inside the launch), am / an > 0 force the tile (64 am rows x 64 an columns). */
+ * inside the launch), am / an > 0 force the tile (64 am rows x 64 an columns).  k > 1: w_host [Co][Ci][k], a 1-D "same" convolution with
+ * dilation dil whose taps are row offsets into the image (odd k, pad (k - 1) / 2 * dil <= 64). */
 int rvc_op_gemm_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
                       float* ysplit_f32_dev, int Ci, int Co, int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit,
-                      int am, int an);
+                      int am, int an, int k, int dil);
+/* Conv2d 3 x 3, pad 1 (reference lib/rmvpe.py:233-268 ConvBlockRes convolutions) on the same kernel over PADDED split-resident images (row pitch
+ * W + 2, taps as row offsets): x_dev [Ci][H][W] plain fp32 is padded and split on the device, y = act(conv(x) + b) with the residual before
+ * or after the activation, returned plain [Co][H][W]; ysplit_f32_dev as above (plain layout). */
+int rvc_op_conv2d_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
+                        float* ysplit_f32_dev, int Ci, int Co, int H, int W, int act, int act_before_res, int ksplit, int am, int an);
 /* ConvTranspose1d: w_host [Ci][Co][k]; y_dev [Co][(Tin-1)*u - 2*pad + k] */
 int rvc_op_conv_transpose1d(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, int Ci, int Co,
                             int Tin, int k, int u, int pad, int pre_act, float pre_slope, int accumulate);

@@ -580,7 +580,7 @@ def test_gemm_split_resident(L, case):
 
     def run(yo, yso):
         L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), L.ptr(rd) if res else None, L.ptr(yo) if yo is not None else None,
-                                        L.ptr(yso) if yso is not None else None, Ci, Co, T, ACT[act], 0.1, abr, scale, ks, am, an))
+                                        L.ptr(yso) if yso is not None else None, Ci, Co, T, ACT[act], 0.1, abr, scale, ks, am, an, 1, 1))
     run(y, ys)
     assert rel_err(y.cpu().numpy(), ref) < 2e-5
     if ys is not None:
@@ -609,9 +609,82 @@ def test_gemm_split_resident_under_load(L):
             big.mul_(1.0001)                                    # 512 MB of HBM traffic per pass on the other stream
     for i in range(20):
         y = torch.full((Co, T), float("nan"), device="cuda")
-        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), None, L.ptr(y), None, Ci, Co, T, 0, 0.0, 0, 1.0, 3 + (i % 2), 2, 1))
+        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), None, L.ptr(y), None, Ci, Co, T, 0, 0.0, 0, 1.0, 3 + (i % 2), 2, 1, 1, 1))
         outs.append(y)
     torch.cuda.synchronize()
     assert rel_err(outs[0].cpu().numpy(), ref) < 2e-5 and rel_err(outs[1].cpu().numpy(), ref) < 2e-5
     for i in range(2, 20):
         assert torch.equal(outs[i], outs[i % 2])
+
+
+CONV_SPLIT_TAPS = [
+    # Ci, Co, T, k, dil, act, res, ksplit, am, an
+    (192, 768, 3198, 3, 1, "relu", False, 0, 0, 0),        # text-encoder FFN1 (attentions.py:383-395: k = 3 "same")
+    (768, 192, 3198, 3, 1, "none", True, 0, 0, 0),         # FFN2 + residual: automatic K split over (chunk, tap) units
+    (192, 384, 3198, 5, 1, "none", False, 0, 0, 0),        # flow WaveNet in-layer (modules.py:184-209)
+    (192, 512, 700, 7, 1, "none", False, 3, 2, 1),         # conv_pre; ragged length, forced 3-way split
+    (64, 64, 515, 3, 5, "lrelu", True, 0, 1, 1),           # dilation 5: offsets -5, 0, 5
+]
+
+
+@pytest.mark.parametrize("case", CONV_SPLIT_TAPS, ids=[f"t{i}" for i in range(len(CONV_SPLIT_TAPS))])
+def test_conv1d_taps_on_split_resident_gemm(L, case):
+    """1-D "same" convolutions as the split-resident GEMM with (chunk, tap) units: a tap is a row offset into the image (im2col by address),
+    the zero padding is the image's zero margin.  Against torch float64, incl. the first / last columns (the padded ones)."""
+    Ci, Co, T, k, dil, act, res, ks, am, an = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / np.sqrt(Ci * k)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, T, generator=g) if res else None
+    v = F.conv1d(x.double()[None], w.double(), b.double(), padding=(k - 1) // 2 * dil, dilation=dil)[0]
+    if res:
+        v = v + r.double()
+    ref = _act(v, act, 0.1).numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    y = torch.full((Co, T), float("nan"), device="cuda")
+    ys = torch.full((Co, T), float("nan"), device="cuda")
+    L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(y), L.ptr(ys),
+                                    Ci, Co, T, ACT[act], 0.1, 0, 1.0, ks, am, an, k, dil))
+    assert rel_err(y.cpu().numpy(), ref) < 2e-5 and rel_err(ys.cpu().numpy(), ref) < 2e-5
+    assert rel_err(y.cpu().numpy()[:, :16], ref[:, :16]) < 2e-5 and rel_err(y.cpu().numpy()[:, -16:], ref[:, -16:]) < 2e-5
+
+
+CONV2D_SPLIT = [
+    # Ci, Co, H, W, act, res, act_before_res, ksplit, am, an
+    (512, 512, 101, 4, "relu", True, 1, 0, 0, 0),          # RMVPE intermediate level (30 s clip): 404 positions, automatic K split
+    (256, 256, 202, 8, "relu", True, 1, 0, 0, 0),
+    (128, 128, 404, 16, "relu", False, 0, 0, 0, 0),
+    (64, 64, 203, 32, "relu", True, 1, 2, 1, 2),           # odd height, forced split / tile
+    (256, 128, 50, 8, "none", False, 0, 0, 0, 0),          # channel change (first block of a level)
+    (64, 48, 64, 32, "relu", False, 0, 0, 1, 1),           # Co not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV2D_SPLIT, ids=[f"p{i}" for i in range(len(CONV2D_SPLIT))])
+def test_conv2d_3x3_on_padded_split_images(L, case):
+    """3 x 3 / pad 1 convolution over padded split-resident images (row pitch W + 2: taps are constant row offsets, the pad columns and the
+    margins are the zero padding) against torch float64 - every border row and column included."""
+    Ci, Co, H, W, act, res, abr, ks, am, an = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)
+    x = torch.randn(Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / np.sqrt(Ci * 9)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, H, W, generator=g) if res else None
+    v = F.conv2d(x.double()[None], w.double(), b.double(), padding=1)[0]
+    if res and not abr:
+        v = v + r.double()
+    v = _act(v, act, 0.1)
+    if res and abr:
+        v = v + r.double()
+    ref = v.numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    y = torch.full((Co, H, W), float("nan"), device="cuda")
+    ys = torch.full((Co, H, W), float("nan"), device="cuda") if Co % 16 == 0 else None
+    L.check(L.lib.rvc_op_conv2d_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(y),
+                                      L.ptr(ys) if ys is not None else None, Ci, Co, H, W, ACT[act], abr, ks, am, an))
+    assert rel_err(y.cpu().numpy(), ref) < 2e-5
+    if ys is not None:
+        assert rel_err(ys.cpu().numpy(), ref) < 2e-5
+    for sl in (np.s_[:, 0, :], np.s_[:, -1, :], np.s_[:, :, 0], np.s_[:, :, -1]):
+        assert rel_err(y.cpu().numpy()[sl], ref[sl]) < 3e-5
