@@ -458,7 +458,7 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S) {
 }
 
 bool conv_x3s_eligible(const ConvLayer& L) {
-  if (!conv_x3_enabled() || L.Wx_ == nullptr || (L.Ci & 15) != 0 || L.Ci * L.ktaps < 64 || L.tconv_u != 0 || L.up2 != 0) return false;
+  if (!conv_x3_enabled() || L.Wx_ == nullptr || (L.Ci & 15) != 0 || L.Ci * L.ktaps < 32 || L.tconv_u != 0 || L.up2 != 0) return false;
   if (L.mode == 2) return L.ktaps <= 16;                                      // 3 x 3 (or KH x KW) over a padded 2-D image: the caller supplies the geometry
   return L.mode == 1 && L.stride == 1 && L.groups == 1 && L.k <= 16 && L.pad == (L.k - 1) / 2 * L.dil && (L.k & 1) == 1 &&
          L.pad <= kSplitMargin;                                               // 1-D "same" convolution, taps as row offsets of the image

@@ -18,6 +18,9 @@ struct Rmvpe {
   float bn_a = 1.f, bn_b = 0.f;
   CBR enc[5][4], inter[4][4], dec[5][4];
   ConvLayer dect[5];
+  ConvLayer dect_t[4];     // the same transposed convolutions as 2 x 2-tap phase convolutions for the split-resident kernel (input levels 5 .. 2)
+  bool pad_ok = false;     // every layer of levels >= 2 has its bf16x3 image: those levels run on padded split-resident images (conv_x3s.hip)
+  const void* img_base = nullptr; size_t img_bytes = 0;   // image block whose margins are known to be zero
   ConvLayer cnn;
   DevVec wihT, b_ih, w_hh, b_hh;
   ConvLayer fc;
@@ -35,6 +38,8 @@ static void rmvpe_free(Rmvpe& R) {
   for (auto& l : R.inter) for (auto& b : l) cbr_free(b);
   for (auto& l : R.dec) for (auto& b : l) cbr_free(b);
   for (auto& c : R.dect) conv_layer_free(c);
+  for (auto& c : R.dect_t) conv_layer_free(c);
+  R.pad_ok = false; R.img_base = nullptr; R.img_bytes = 0;
   conv_layer_free(R.cnn); conv_layer_free(R.fc);
   R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.b_hh.free_();
   dev_free(R.xbuf); dev_free(R.gru_err); R.xbuf = nullptr; R.gru_err = nullptr;
@@ -103,6 +108,19 @@ void rmvpe_finalize(Rmvpe* R) {
     bn_fold(ts, p + "conv1.1", cout, sc, sh);
     for (int ci = 0; ci < cin; ++ci) for (int co = 0; co < cout; ++co) for (int k = 0; k < 9; ++k) w[((size_t)ci * cout + co) * 9 + k] *= sc[co];
     tconv2d_layer_init(R->dect[i], w.data(), sh.data(), cin, cout);
+    if (i < 4 && R->dect[i].Wx_) {
+      // out[2h + a][2w + b] = sum over (dh, dw) in {0, 1}^2 of W[a + 1 - 2 dh][b + 1 - 2 dw] x[h + dh][w + dw]: four phase convolutions with 2 x 2 taps
+      std::vector<float> w4((size_t)4 * cout * cin * 4, 0.f), b4((size_t)4 * cout);
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int co = 0; co < cout; ++co) {
+        b4[(size_t)(a * 2 + b) * cout + co] = sh[co];
+        for (int ci = 0; ci < cin; ++ci) for (int dh = 0; dh < 2; ++dh) for (int dw = 0; dw < 2; ++dw) {
+          const int kh = a + 1 - 2 * dh, kw = b + 1 - 2 * dw;
+          if (kh < 0 || kh > 2 || kw < 0 || kw > 2) continue;
+          w4[(((size_t)(a * 2 + b) * cout + co) * cin + ci) * 4 + dh * 2 + dw] = w[(((size_t)ci * cout + co) * 3 + kh) * 3 + kw];
+        }
+      }
+      conv2d_kx_layer_init(R->dect_t[i], w4.data(), b4.data(), 4 * cout, cin, 2, 2, 0, 0);
+    }
     for (int b = 0; b < 4; ++b) make_cbr(R->dec[i][b], ts, p + "conv2." + std::to_string(b) + ".", b == 0 ? 2 * cout : cout, cout);
     cin = cout;
   }
@@ -122,6 +140,15 @@ void rmvpe_finalize(Rmvpe* R) {
     R->wihT.upload(wT); R->b_ih.upload(bi); R->w_hh.upload(wh); R->b_hh.upload(bh);
   }
   conv1d_layer_init(R->fc, ts.get("fc.1.weight", {360, 512}).data.data(), ts.get("fc.1.bias", {360}).data.data(), 360, 512, 1, 1, 0, 1, 1);
+  {
+    bool ok = true;
+    auto cbr_ok = [&](const CBR& b) { return conv_x3s_eligible(b.c1) && conv_x3s_eligible(b.c2) && (!b.has_sc || conv_x3s_eligible(b.sc)); };
+    for (int i = 2; i < 5; ++i) for (int b = 0; b < 4; ++b) ok = ok && cbr_ok(R->enc[i][b]);
+    for (int i = 0; i < 4; ++i) for (int b = 0; b < 4; ++b) ok = ok && cbr_ok(R->inter[i][b]);
+    for (int i = 0; i < 3; ++i) for (int b = 0; b < 4; ++b) ok = ok && cbr_ok(R->dec[i][b]);
+    for (int i = 0; i < 4; ++i) ok = ok && R->dect_t[i].Wx_ != nullptr && conv_x3s_eligible(R->dect_t[i]);
+    R->pad_ok = ok;
+  }
   RVC_HIP_CHECK(hipMalloc(&R->xbuf, sizeof(unsigned long long) * 2 * 2 * 256));
   RVC_HIP_CHECK(hipMalloc(&R->gru_err, sizeof(int)));
   RVC_HIP_CHECK(hipMemset(R->gru_err, 0, sizeof(int)));
@@ -146,12 +173,132 @@ static void run_cbr(const CBR& B, hipStream_t s, Arena& A, const float* x, int H
   A.off = mark;
 }
 
+
+// Levels 2 .. 5 of the U-Net (64 .. 512 channels, 32 .. 4 mel bins) on padded split-resident images (conv_x3s.hip / split2d.hip): every 3 x 3
+// convolution, shortcut and transposed convolution is one launch of the split-resident GEMM kernel - taps are row offsets into the image,
+// the K split of the small levels is reduced inside the launch - and a ConvBlockRes is 2 (3 with a shortcut) launches:
+//   y1 = relu(c1(x))                      image only
+//   out = relu(c2(y1)) + (sc(x) | x)      fp32 (the next block's residual) + image (the next block's input)
+// in: the encoder's level-1 skip tensor, plain [32][H1][64]; out: the decoder's level-1 up-sampled tensor, plain [32][H1][64] (first half of cat[1]).
+struct PadLevel { int C, H, W, T; long long tp; SplitGeom g; };
+static size_t pad_img_bytes(int C, const PadLevel& L) { return (size_t)(C / 16) * 4 * (size_t)L.tp * 16; }
+
+struct PadPlan { PadLevel lv[6]; unsigned char *ipool[6], *ia[6], *ib[6], *iy[6], *icat[6]; };
+// The images live in a block of their own that NOTHING else of the graph ever occupies (it is allocated before the first temporary of
+// rmvpe_graph): their margins - the vertical zero padding - are zeroed once per layout and stay zero because no kernel writes there.
+static void rmvpe_pad_plan(Rmvpe* R, hipStream_t s, Arena& A, int H1, PadPlan& P) {
+  for (int l = 2; l <= 5; ++l) {
+    PadLevel& L = P.lv[l];
+    L.C = 16 << l; L.H = H1 >> (l - 1); L.W = 128 >> l; L.T = L.H * (L.W + 2); L.g = split_geom_2d(L.W);
+    L.tp = ((long long)L.g.margin + L.T + 704 + 63) & ~63LL;
+  }
+  const size_t img0 = A.off;
+  for (int l = 2; l <= 5; ++l) {
+    P.ipool[l] = A.alloc<unsigned char>(pad_img_bytes(P.lv[l].C / 2 < 16 ? 16 : P.lv[l].C / 2, P.lv[l]));     // the pooled input of the level (C / 2 channels)
+    P.ia[l] = A.alloc<unsigned char>(pad_img_bytes(P.lv[l].C, P.lv[l]));
+    P.ib[l] = A.alloc<unsigned char>(pad_img_bytes(P.lv[l].C, P.lv[l]));
+    P.iy[l] = A.alloc<unsigned char>(pad_img_bytes(P.lv[l].C, P.lv[l]));
+    P.icat[l] = l <= 4 ? A.alloc<unsigned char>(pad_img_bytes(2 * P.lv[l].C, P.lv[l])) : nullptr;              // [deconv out | encoder skip]
+  }
+  const size_t img_bytes = A.off - img0;
+  static const bool rezero = getenv("RVC_RMVPE_REZERO") && atoi(getenv("RVC_RMVPE_REZERO")) != 0;      // debugging: zero the image block on every forward
+  if (!A.dry && (rezero || R->img_base != A.base + img0 || R->img_bytes != img_bytes)) {
+    RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
+    R->img_base = A.base + img0; R->img_bytes = img_bytes;
+  }
+}
+
+static void rmvpe_unet_padded(Rmvpe* R, hipStream_t s, Arena& A, const PadPlan& P, const float* skip1, int H1, float* up1) {
+  const bool dry = A.dry;
+  const PadLevel* lv = P.lv;
+  unsigned char* const* ipool = P.ipool; unsigned char* const* ia = P.ia; unsigned char* const* ib = P.ib; unsigned char* const* iy = P.iy;
+  unsigned char* const* icat = P.icat;
+  // ---- fp32 twins (padded rows, no margins)
+  float *fpool[6], *fa[6], *fb[6], *fsc[6], *fcat[6];
+  for (int l = 2; l <= 5; ++l) {
+    fpool[l] = A.alloc<float>((size_t)(lv[l].C / 2) * lv[l].T);
+    fa[l] = A.alloc<float>((size_t)lv[l].C * lv[l].T); fb[l] = A.alloc<float>((size_t)lv[l].C * lv[l].T); fsc[l] = A.alloc<float>((size_t)lv[l].C * lv[l].T);
+    fcat[l] = l <= 4 ? A.alloc<float>((size_t)2 * lv[l].C * lv[l].T) : nullptr;
+  }
+  size_t ph_need = 0;
+  for (int l = 2; l <= 5; ++l) ph_need = std::max(ph_need, (size_t)4 * (lv[l].C / 2) * lv[l].T);
+  float* ph = A.alloc<float>(ph_need);                            // phase rows [4 Co][T_in] of a transposed conv (largest: level 2 -> 1)
+  if (dry) return;
+  // one ConvBlockRes at level L: (xf, xs) -> (of, os); the image pointers may point into a cat image (channel offset = chunk offset)
+  auto cbr = [&](const CBR& B, const PadLevel& L, const float* xf, const unsigned char* xs, float* of, unsigned char* os, unsigned char* y1s, float* scf) {
+    ConvEpilogue E1; E1.act = ACT_RELU; E1.ys_out = y1s; E1.ys_tp = L.tp;
+    conv_x3s_run(B.c1, s, xs, L.tp, L.T, nullptr, L.T, E1, &L.g);
+    const float* res = xf;
+    if (B.has_sc) {
+      SplitGeom g1 = L.g; g1.ktaps = 1; g1.toff[0] = 0;                          // 1 x 1 shortcut: the same padded positions, no taps
+      ConvEpilogue E0; conv_x3s_run(B.sc, s, xs, L.tp, L.T, scf, L.T, E0, &g1);
+      res = scf;
+    }
+    ConvEpilogue E2; E2.act = ACT_RELU; E2.act_before_res = 1; E2.R = res; E2.ldR = L.T; E2.ys_out = os; E2.ys_tp = L.tp;
+    conv_x3s_run(B.c2, s, y1s, L.tp, L.T, of, L.T, E2, &L.g);
+  };
+  // ---- encoder levels 2 .. 4
+  const float* prev_f = skip1; bool prev_padded = false; int prevC = 32, prevH = H1, prevW = 64; long long prev_ld = (long long)H1 * 64;
+  for (int l = 2; l <= 4; ++l) {
+    const PadLevel& L = lv[l];
+    pool2_pad_split(s, prev_f, prev_ld, prev_padded, prevC, prevH, prevW, fpool[l], L.T, ipool[l], L.tp, L.g.margin);
+    const float* xf = fpool[l]; const unsigned char* xs = ipool[l];
+    float* skip_f = fcat[l] + (size_t)L.C * L.T; unsigned char* skip_s = icat[l] + pad_img_bytes(L.C, L);
+    for (int k = 0; k < 4; ++k) {
+      float* of = k == 3 ? skip_f : ((k & 1) ? fb[l] : fa[l]);
+      unsigned char* os = k == 3 ? skip_s : ((k & 1) ? ib[l] : ia[l]);
+      cbr(R->enc[l][k], L, xf, xs, of, os, iy[l], fsc[l]);
+      xf = of; xs = os;
+    }
+    prev_f = skip_f; prev_padded = true; prevC = L.C; prevH = L.H; prevW = L.W; prev_ld = L.T;
+  }
+  // ---- intermediate: level 5
+  const float* cur_f; const unsigned char* cur_s;
+  {
+    const PadLevel& L = lv[5];
+    pool2_pad_split(s, prev_f, prev_ld, true, prevC, prevH, prevW, fpool[5], L.T, ipool[5], L.tp, L.g.margin);
+    cur_f = fpool[5]; cur_s = ipool[5];
+    for (int i = 0; i < 4; ++i)
+      for (int k = 0; k < 4; ++k) {
+        const bool to_a = cur_f != fa[5];
+        cbr(R->inter[i][k], L, cur_f, cur_s, to_a ? fa[5] : fb[5], to_a ? ia[5] : ib[5], iy[5], fsc[5]);
+        cur_f = to_a ? fa[5] : fb[5]; cur_s = to_a ? ia[5] : ib[5];
+      }
+  }
+  // ---- decoder: input levels 5 .. 2 (output levels 4 .. 1)
+  for (int i = 0; i < 4; ++i) {
+    const int lin = 5 - i, lout = lin - 1;
+    const PadLevel& Li = lv[lin];
+    const int Co = Li.C / 2;                                                    // channels of the output level
+    const SplitGeom g2 = [&] { SplitGeom g = split_geom_2d(Li.W, 2, 2, 0, 0); g.margin = Li.g.margin; return g; }();
+    ConvEpilogue Er; Er.act = ACT_RELU;
+    conv_x3s_run(R->dect_t[i], s, cur_s, Li.tp, Li.T, ph, Li.T, Er, &g2);       // [4 Co][T_in]: phase-major rows, BatchNorm folded, ReLU
+    if (lout >= 2) {
+      const PadLevel& Lo = lv[lout];
+      interleave2_pad_split(s, ph, Li.T, Co, Li.H, Li.W, fcat[lout], Lo.T, true, icat[lout], Lo.tp, Lo.g.margin);
+      const float* xf = fcat[lout]; const unsigned char* xs = icat[lout];
+      for (int k = 0; k < 4; ++k) {
+        float* of = (k & 1) ? fb[lout] : fa[lout]; unsigned char* os = (k & 1) ? ib[lout] : ia[lout];
+        cbr(R->dec[i][k], Lo, xf, xs, of, os, iy[lout], fsc[lout]);
+        xf = of; xs = os;
+      }
+      cur_f = xf; cur_s = xs;
+    } else {
+      interleave2_pad_split(s, ph, Li.T, Co, Li.H, Li.W, up1, (long long)(2 * Li.H) * (2 * Li.W), false, nullptr, 0, 0);     // plain [32][H1][64]
+    }
+  }
+}
+
 static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, long long L, float thred, float* mel_out, float* sal_out,
                         double* f0_out, const RmvpeTaps* taps) {
   const bool dry = A.dry;
   ConvEpilogue E0;
   const int n = (int)(L / 160) + 1;
   const int Tr = 32 * ((n - 1) / 32 + 1);
+  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  const bool padded = x3s_on && R->pad_ok && conv_x3_enabled();       // levels >= 2 on padded split-resident images (rmvpe_unet_padded)
+  PadPlan pplan;
+  if (padded) rmvpe_pad_plan(R, s, A, Tr >> 1, pplan);                // first allocation of the graph: the image block is never aliased
   // ---- log-mel
   float* mel = A.alloc<float>((size_t)128 * n);
   {
@@ -177,25 +324,28 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
   float* cat[5];
   for (int i = 0; i < 5; ++i) cat[i] = A.alloc<float>((size_t)2 * (16 << i) * Hs[i] * Ws[i]);   // [deconv out | encoder skip]
   const float* cur = x0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < (padded ? 2 : 5); ++i) {
     const int C = 16 << i; const long long plane = (long long)Hs[i] * Ws[i];
     float* a = A.alloc<float>((size_t)C * plane); float* b = A.alloc<float>((size_t)C * plane);
     float* skip = cat[i] + (size_t)C * plane;
     const float* in = cur;
     for (int k = 0; k < 4; ++k) { float* o = (k == 3) ? skip : ((k & 1) ? b : a); run_cbr(R->enc[i][k], s, A, in, Hs[i], Ws[i], o); in = o; }
+    if (padded && i == 1) break;                                      // the level change 1 -> 2 pools straight into the padded layout
     float* pooled = A.alloc<float>((size_t)C * Hs[i + 1] * Ws[i + 1]);
     if (!dry) avgpool2(s, skip, pooled, C, Hs[i], Ws[i], plane);
     cur = pooled;
   }
-  {
+  if (padded) {
+    rmvpe_unet_padded(R, s, A, pplan, cat[1] + (size_t)32 * Hs[1] * Ws[1], Hs[1], cat[1]);
+  } else {
     const long long plane = (long long)Hs[5] * Ws[5];
     float* a = A.alloc<float>((size_t)512 * plane); float* b = A.alloc<float>((size_t)512 * plane);
     for (int i = 0; i < 4; ++i)
       for (int k = 0; k < 4; ++k) { float* o = (cur == a) ? b : a; run_cbr(R->inter[i][k], s, A, cur, Hs[5], Ws[5], o); cur = o; }
   }
-  for (int i = 0; i < 5; ++i) {
+  for (int i = (padded ? 3 : 0); i < 5; ++i) {
     const int lvl = 4 - i; const int C = 16 << lvl; const long long plane = (long long)Hs[lvl] * Ws[lvl];
-    if (!dry) { ConvEpilogue Er; Er.act = ACT_RELU; conv2d_run(R->dect[i], s, cur, (long long)Hs[lvl + 1] * Ws[lvl + 1], Hs[lvl + 1], Ws[lvl + 1], cat[lvl], plane, Er); }
+    if (!dry && !(padded && i == 3)) { ConvEpilogue Er; Er.act = ACT_RELU; conv2d_run(R->dect[i], s, cur, (long long)Hs[lvl + 1] * Ws[lvl + 1], Hs[lvl + 1], Ws[lvl + 1], cat[lvl], plane, Er); }
     float* a = A.alloc<float>((size_t)C * plane); float* b = A.alloc<float>((size_t)C * plane);
     const float* in = cat[lvl];
     for (int k = 0; k < 4; ++k) { float* o = (k & 1) ? b : a; run_cbr(R->dec[i][k], s, A, in, Hs[lvl], Ws[lvl], o); in = o; }
