@@ -37,6 +37,8 @@ struct EncLayer {
 };
 struct FlowLayer {
   ConvLayer pre, post, in[3], res[2], skip[3];
+  ConvLayer rs[2];         // res_skip_layers 0 / 1 whole (2 H rows: residual | skip) and
+  ConvLayer post_neg;      // post with negated weights (x1 - m as a plain residual add): the split-resident path (conv_x3s.hip)
   DevVec cond_w, cond_b;   // weight-normed cond_layer [2*H*3][gin]
 };
 struct ResBlock { ConvLayer c1[3], c2[3]; };
@@ -60,6 +62,7 @@ struct Synth {
   DevVec dec_cond_w, dec_cond_b, conv_post_w;   // conv_post_w: raw [Ci][7] weights of the 1-channel output conv (ops.hip::conv_to1)
   std::vector<GenStage> stages;
   float lin_w = 1.f, lin_b = 0.f;
+  const void* img_base = nullptr; size_t img_bytes = 0; int img_T = -1;   // split-resident image block whose margins are known to be zero (synth_graph)
   bool f0 = true;        // false: the *_nono family (no pitch embedding, plain Generator: reference models.py:244-311,:812-1022)
 };
 
@@ -69,10 +72,11 @@ static void synth_free(Synth& S) {
   for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
   S.enc.clear();
   fl(S.proj);
-  for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); f.cond_w.free_(); f.cond_b.free_(); }
+  for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
   fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_(); S.conv_post_w.free_();
   for (auto& st : S.stages) { fl(st.up); fl(st.noise); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
   S.stages.clear();
+  S.img_base = nullptr; S.img_bytes = 0; S.img_T = -1;
 }
 
 Synth* synth_create(Ctx* ctx, const SynthConfig& c) {
@@ -147,12 +151,14 @@ void synth_finalize(Synth* S) {
     const std::string p = "flow.flows." + std::to_string(2 * f) + ".";
     F.pre = make_conv1d(ts, p + "pre", 1, 0, 1, false);
     F.post = make_conv1d(ts, p + "post", 1, 0, 1, false);
+    F.post_neg = make_conv1d(ts, p + "post", 1, 0, 1, false, true, -1.f);
     for (int i = 0; i < 3; ++i) {
       F.in[i] = make_conv1d(ts, p + "enc.in_layers." + std::to_string(i), 1, 2, 1, true);
       const std::string rs = p + "enc.res_skip_layers." + std::to_string(i);
       if (i < 2) {
         F.res[i] = make_conv1d(ts, rs, 1, 0, 1, true, true, 1.f, 0, C);
         F.skip[i] = make_conv1d(ts, rs, 1, 0, 1, true, true, 1.f, C, C);
+        F.rs[i] = make_conv1d(ts, rs, 1, 0, 1, true);
       } else {
         F.skip[i] = make_conv1d(ts, rs, 1, 0, 1, true);
       }
@@ -211,6 +217,35 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     if (!dry && dst) RVC_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   };
   ConvEpilogue E0;
+  // ---- split-resident front (conv_x3s.hip): the activations that feed enc_p's / the flow's / conv_pre's projections live as bf16 hi / lo
+  // images written by their producers; k = 3 / 5 / 7 layers read them with taps as row offsets, so the images' margins (the zero padding)
+  // must stay zero: the block is the graph's first allocation (nothing else ever occupies it) and is zeroed once per layout.
+  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  bool gs = x3s_on && conv_x3_enabled() && (C & 15) == 0 && (IC & 31) == 0 && conv_x3s_eligible(S->proj) && conv_x3s_eligible(S->conv_pre);
+  for (int l = 0; l < S->n_layers && gs; ++l) {
+    const EncLayer& e = S->enc[l];
+    gs = conv_x3s_eligible(e.qk) && conv_x3s_eligible(e.o) && conv_x3s_eligible(e.ffn1) && conv_x3s_eligible(e.ffn2);
+  }
+  for (int f = 0; f < 4 && gs; ++f) {
+    const FlowLayer& F = S->flow[f];
+    gs = conv_x3s_eligible(F.pre) && conv_x3s_eligible(F.post_neg) && conv_x3s_eligible(F.skip[2]);
+    for (int i = 0; i < 3 && gs; ++i) gs = conv_x3s_eligible(F.in[i]) && (i == 2 || conv_x3s_eligible(F.rs[i]));
+  }
+  const long long tp = split_image_tp(T);
+  unsigned char *x_s = nullptr, *attn_s = nullptr, *ff_s = nullptr, *x0_s = nullptr, *hw_s = nullptr, *acts_s = nullptr, *z_s = nullptr;
+  if (gs) {
+    const size_t img0 = A.off;
+    x_s = A.alloc<unsigned char>(split_image_bytes(C, T)); attn_s = A.alloc<unsigned char>(split_image_bytes(C, T));
+    ff_s = A.alloc<unsigned char>(split_image_bytes(S->filt, T));
+    x0_s = A.alloc<unsigned char>(split_image_bytes(IC / 2, T)); hw_s = A.alloc<unsigned char>(split_image_bytes(2 * C, T));
+    acts_s = A.alloc<unsigned char>(split_image_bytes(C, T)); z_s = A.alloc<unsigned char>(split_image_bytes(IC, T));
+    const size_t img_bytes = A.off - img0;
+    // (a shorter sequence in the same allocation leaves the longer one's rows behind its end: the length is part of the layout)
+    if (!dry && (S->img_base != A.base + img0 || S->img_bytes != img_bytes || S->img_T != T)) {
+      RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
+      S->img_base = A.base + img0; S->img_bytes = img_bytes; S->img_T = T;
+    }
+  }
   // ---- speaker conditioning vectors
   const float* g = S->emb_g.p + (size_t)sid * S->gin;
   float* pre_bias = A.alloc<float>(S->up_init);
@@ -226,6 +261,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   if (!dry) {
     gemm_tn_run(s, S->emb_phone_wT.p, C, 0, feat_cm, T, 0, x, T, 0, C, T, S->feat_dim, 1, S->emb_phone_b.p, 0, E0);
     encp_embed(s, x, S->f0 ? S->emb_pitch.p : nullptr, pitch, C, T);
+    if (gs) split_image_from_f32(s, x, T, C, T, x_s, tp);
   }
   {
     const size_t mark = A.off;
@@ -237,10 +273,11 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     float* relk = A.alloc<float>((size_t)H * 21 * T);
     float* pb = A.alloc<float>((size_t)H * 21 * T);
     float* attn = A.alloc<float>((size_t)C * T);
-    float* ff = A.alloc<float>((size_t)S->filt * T);
+    float* ff = gs ? nullptr : A.alloc<float>((size_t)S->filt * T);
     if (!dry) {
       for (int l = 0; l < S->n_layers; ++l) {
         EncLayer& e = S->enc[l];
+        if (gs) conv_x3s_run(e.qk, s, x_s, tp, T, qk, T, E0); else
         conv1d_run(e.qk, s, x, T, T, qk, T, E0);
         transpose(s, qk + (size_t)2 * C * T, vr, C, T, T, C, 1, 0, 0);                                       // V row-major [T][C] (bias later)
         for (int h = 0; h < H; ++h) conv1d_run(e.relk, s, qk + (size_t)h * kc * T, T, T, relk + (size_t)h * 21 * T, T, E0);
@@ -256,6 +293,17 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
         ConvEpilogue Ea; Ea.accumulate = 1;
         for (int h = 0; h < H; ++h) conv1d_run(e.relv, s, pb + (size_t)h * 21 * T, T, T, attn + (size_t)h * kc * T, T, Ea);
         ConvEpilogue Er; Er.R = x; Er.ldR = T;
+        if (gs) {
+          split_image_from_f32(s, attn, T, C, T, attn_s, tp);
+          conv_x3s_run(e.o, s, attn_s, tp, T, xb, T, Er);
+          layernorm_c_split(s, xb, e.g1.p, e.b1.p, x, x_s, tp, kSplitMargin, C, T, T, 1e-5f);
+          ConvEpilogue Ef; Ef.act = ACT_RELU; Ef.ys_out = ff_s; Ef.ys_tp = tp;
+          conv_x3s_run(e.ffn1, s, x_s, tp, T, nullptr, T, Ef);                  // k = 3: taps are row offsets into the image
+          conv_x3s_run(e.ffn2, s, ff_s, tp, T, xb, T, Er);
+          layernorm_c_split(s, xb, e.g2.p, e.b2.p, x, x_s, tp, kSplitMargin, C, T, T, 1e-5f);
+          if (l == 0 && taps) tap(taps->enc_p_layer0, x, (size_t)C * T);
+          continue;
+        }
         conv1d_run(e.o, s, attn, T, T, xb, T, Er);
         layernorm_c(s, xb, nullptr, e.g1.p, e.b1.p, x, C, T, T, 1e-5f);
         ConvEpilogue Ef; Ef.act = ACT_RELU;
@@ -271,6 +319,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   float* z = A.alloc<float>((size_t)IC * T);
   float* zf = A.alloc<float>((size_t)IC * T);
   if (!dry) {
+    if (gs) conv_x3s_run(S->proj, s, x_s, tp, T, stats, T, E0); else
     conv1d_run(S->proj, s, x, T, T, stats, T, E0);
     if (taps) { tap(taps->m_p, stats, (size_t)IC * T); tap(taps->logs_p, stats + (size_t)IC * T, (size_t)IC * T); }
     zp_sample(s, stats, noise_z, z, IC, T);
@@ -279,10 +328,10 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   // ---- flow (reverse)
   {
     const size_t mark = A.off;
-    float* h = A.alloc<float>((size_t)C * T);
+    float* hw = A.alloc<float>((size_t)2 * C * T);               // [h | wo]: the WaveNet's residual stream and its skip sum, adjacent rows
+    float* h = hw; float* wo = hw + (size_t)C * T;
     float* xin = A.alloc<float>((size_t)2 * C * T);
-    float* acts = A.alloc<float>((size_t)C * T);
-    float* wo = A.alloc<float>((size_t)C * T);
+    float* acts = gs ? nullptr : A.alloc<float>((size_t)C * T);
     const int half = IC / 2;
     if (!dry) {
       float* cur = z; float* oth = zf;
@@ -290,6 +339,24 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
         FlowLayer& F = S->flow[f];
         flip_c(s, cur, oth, IC, T);
         std::swap(cur, oth);
+        if (gs) {
+          // every layer one launch of the split-resident GEMM: the res / skip pair of a WaveNet layer is ONE 2 H-row layer accumulating in place
+          // onto [h | wo] (its image output is the next in-layer's input), post is packed negated (x1 - m = x1 + (-W) wo + (-b))
+          split_image_from_f32(s, cur, T, half, T, x0_s, tp);
+          unsigned char* wo_s = hw_s + split_image_bytes(C, T);
+          ConvEpilogue Eh; Eh.ys_out = hw_s; Eh.ys_tp = tp;
+          conv_x3s_run(F.pre, s, x0_s, tp, T, h, T, Eh);
+          fill(s, wo, 0.f, (long long)C * T);
+          for (int i = 0; i < 3; ++i) {
+            conv_x3s_run(F.in[i], s, hw_s, tp, T, xin, T, E0);                   // k = 5 over the first H channels of the [h | wo] image
+            wn_gate_split(s, xin, gcond[f] + (size_t)i * 2 * C, acts_s, tp, kSplitMargin, C, T);
+            if (i < 2) { ConvEpilogue Ea; Ea.R = hw; Ea.ldR = T; Ea.ys_out = hw_s; Ea.ys_tp = tp; conv_x3s_run(F.rs[i], s, acts_s, tp, T, hw, T, Ea); }
+            else { ConvEpilogue Ea; Ea.R = wo; Ea.ldR = T; Ea.ys_out = wo_s; Ea.ys_tp = tp; conv_x3s_run(F.skip[2], s, acts_s, tp, T, wo, T, Ea); }
+          }
+          ConvEpilogue Ep; Ep.R = cur + (size_t)half * T; Ep.ldR = T;
+          conv_x3s_run(F.post_neg, s, wo_s, tp, T, cur + (size_t)half * T, T, Ep);    // x1 = x1 - m
+          continue;
+        }
         conv1d_run(F.pre, s, cur, T, T, h, T, E0);
         for (int i = 0; i < 3; ++i) {
           conv1d_run(F.in[i], s, h, T, T, xin, T, E0);
@@ -319,7 +386,11 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     }
   }
   float* cur = A.alloc<float>((size_t)S->up_init * T);
-  if (!dry) { ConvEpilogue Eb; Eb.bias_override = pre_bias; conv1d_run(S->conv_pre, s, z, T, T, cur, T, Eb); }
+  if (!dry) {
+    ConvEpilogue Eb; Eb.bias_override = pre_bias;
+    if (gs) { split_image_from_f32(s, z, T, IC, T, z_s, tp); conv_x3s_run(S->conv_pre, s, z_s, tp, T, cur, T, Eb); }     // k = 7
+    else conv1d_run(S->conv_pre, s, z, T, T, cur, T, Eb);
+  }
   int Tc = T;
   const int nu = (int)S->stages.size();
   for (int i = 0; i < nu; ++i) {

@@ -5,6 +5,7 @@
 namespace rvc {
 
 // LayerNorm over channels that ALSO writes y as the split-resident image of conv_x3s.hip (y may be null: image only); margin = kSplitMargin
+void wn_gate_split(hipStream_t s, const float* a, const float* g, unsigned char* img, long long tp, int margin, int H, int T);   // WN gate -> split image only
 void layernorm_c_split(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, unsigned char* img, long long tp, int margin,
                        int C, int T, long long ld, float eps);
 void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gamma, const float* beta, float* y, int C, int T,

@@ -273,6 +273,40 @@ void wn_gate(hipStream_t s, const float* a, const float* g, float* out, int H, i
   hipLaunchKernelGGL(wn_gate_kernel, dim3(blocks), dim3(256), 0, s, a, g, out, H, T);
 }
 
+// The same gate with the result written ONLY as the split-resident image the res / skip GEMM stages (conv_x3s.hip): one thread = 8 channels of
+// one frame = one 16-byte row of the hi and of the lo plane.
+__global__ __launch_bounds__(256) void wn_gate_split_kernel(const float* __restrict__ a, const float* __restrict__ g, unsigned char* __restrict__ img, long long tp,
+                                                            int margin, int H, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (t >= T) return;
+  const long long n = (long long)H * T;
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = grp * 8 + j;
+    const long long i = (long long)c * T + t;
+    const float ta = a[i] + g[c], sa = a[i + n] + g[c + H];
+    v[j] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+  }
+  u32x4_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 ah = (__bf16)v[2 * j], bh = (__bf16)v[2 * j + 1];
+    const __bf16 al = (__bf16)(v[2 * j] - (float)ah), bl = (__bf16)(v[2 * j + 1] - (float)bh);
+    hi[j] = (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+    lo[j] = (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+  }
+  unsigned char* row = img + (((long long)(grp >> 1) * 4 + (grp & 1)) * tp + margin + t) * 16;
+  *reinterpret_cast<u32x4_t*>(row) = hi;
+  *reinterpret_cast<u32x4_t*>(row + tp * 32) = lo;
+}
+void wn_gate_split(hipStream_t s, const float* a, const float* g, unsigned char* img, long long tp, int margin, int H, int T) {
+  RVC_REQUIRE((H & 15) == 0, "wn_gate_split: hidden channels must be a multiple of 16");
+  hipLaunchKernelGGL(wn_gate_split_kernel, dim3((T + 255) / 256, H / 8), dim3(256), 0, s, a, g, img, tp, margin, H, T);
+}
+
 // y = W x + b for a single vector (speaker conditioning: cond layers applied to g = emb_g[sid]).
 __global__ __launch_bounds__(64) void gemv_kernel(const float* __restrict__ W, const float* __restrict__ x, const float* __restrict__ b,
                                                    float* __restrict__ y, int K, const float* __restrict__ add) {

@@ -554,45 +554,51 @@ const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 int rvc_debug_x3p_check(void) { return conv_x3p_check_read(); }
-int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out) {
+int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out, int w2d, int nlayers) {
   RVC_TRY
-  RVC_REQUIRE(us_out && reps > 0 && Ci > 0 && Co > 0 && T > 0, "bad argument");
+  RVC_REQUIRE(us_out && reps > 0 && Ci > 0 && Co > 0 && T > 0 && nlayers >= 1 && nlayers <= 64, "bad argument");
   hipStream_t s = (hipStream_t)stream;
-  std::vector<float> w((size_t)Co * Ci), b((size_t)Co, 0.01f);
+  const int kt = w2d > 0 ? 9 : 1;
+  std::vector<float> w((size_t)Co * Ci * kt), b((size_t)Co, 0.01f);
   uint32_t st = 12345u;
-  for (auto& v : w) { st = st * 1664525u + 1013904223u; v = ((float)(st >> 8) / 8388608.f - 1.f) * 0.05f; }
-  ConvLayer L;
-  { ConvBuildScope scope(2); conv1d_layer_init(L, w.data(), b.data(), Co, Ci, 1, 1, 0, 1, 1); }
+  std::vector<ConvLayer> Ls((size_t)nlayers);
   float* x = nullptr; float* r = nullptr; float* y = nullptr; unsigned char* xs = nullptr; unsigned char* ys = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() {
+    conv_x3s_force(0, 0, 0);
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+    dev_free(x); if (r) (void)hipFree(r); if (y) (void)hipFree(y); if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys);
+    for (auto& L : Ls) conv_layer_free(L);
+  };
   try {
-    const long long tp = split_image_tp(T);
+    for (auto& L : Ls) {      // distinct weights per layer: cycled through, they come from HBM like a model's layers do
+      for (auto& v : w) { st = st * 1664525u + 1013904223u; v = ((float)(st >> 8) / 8388608.f - 1.f) * 0.05f; }
+      ConvBuildScope scope(2);
+      if (w2d > 0) conv2d3x3_layer_init(L, w.data(), b.data(), Co, Ci); else conv1d_layer_init(L, w.data(), b.data(), Co, Ci, 1, 1, 0, 1, 1);
+    }
+    SplitGeom g; if (w2d > 0) g = split_geom_2d(w2d);
+    const long long tp = ((long long)g.margin + T + 704 + 63) & ~63LL;
     std::vector<float> hx((size_t)Ci * T);
     for (auto& v : hx) { st = st * 1664525u + 1013904223u; v = (float)(st >> 8) / 8388608.f - 1.f; }
     x = dev_upload(hx.data(), hx.size());
     RVC_HIP_CHECK(hipMalloc(&r, (size_t)Co * T * 4)); RVC_HIP_CHECK(hipMemset(r, 0, (size_t)Co * T * 4));
     RVC_HIP_CHECK(hipMalloc(&y, (size_t)Co * T * 4));
-    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T))); RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes((Co + 15) & ~15, T)));
-    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    const size_t ib = (size_t)(Ci / 16) * 4 * tp * 16, ob = (size_t)((Co + 15) / 16) * 4 * tp * 16;
+    RVC_HIP_CHECK(hipMalloc(&xs, ib)); RVC_HIP_CHECK(hipMemset(xs, 0, ib)); RVC_HIP_CHECK(hipMalloc(&ys, ob)); RVC_HIP_CHECK(hipMemset(ys, 0, ob));
+    split_image_from_f32(s, x, T, Ci, T, xs + (size_t)(g.margin - kSplitMargin) * 16, tp);
     ConvEpilogue e;
     if (split_out) { e.act = ACT_GELU; e.ys_out = ys; e.ys_tp = tp; } else { e.R = r; e.ldR = T; }
     conv_x3s_force(ksplit, am, an);
-    conv_x3s_run(L, s, xs, tp, T, split_out ? nullptr : y, T, e);
+    for (auto& L : Ls) conv_x3s_run(L, s, xs, tp, T, split_out ? nullptr : y, T, e, w2d > 0 ? &g : nullptr);
     RVC_HIP_CHECK(hipEventCreate(&e0)); RVC_HIP_CHECK(hipEventCreate(&e1));
     RVC_HIP_CHECK(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) conv_x3s_run(L, s, xs, tp, T, split_out ? nullptr : y, T, e);
+    for (int i = 0; i < reps; ++i) conv_x3s_run(Ls[(size_t)(i % nlayers)], s, xs, tp, T, split_out ? nullptr : y, T, e, w2d > 0 ? &g : nullptr);
     RVC_HIP_CHECK(hipEventRecord(e1, s));
     RVC_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f; RVC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     *us_out = ms * 1e3f / (float)reps;
-  } catch (...) {
-    conv_x3s_force(0, 0, 0);
-    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
-    dev_free(x); if (r) (void)hipFree(r); if (y) (void)hipFree(y); if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw;
-  }
-  conv_x3s_force(0, 0, 0);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  dev_free(x); (void)hipFree(r); (void)hipFree(y); (void)hipFree(xs); (void)hipFree(ys); conv_layer_free(L);
+  } catch (...) { cleanup(); throw; }
+  cleanup();
   RVC_CATCH
 }
 

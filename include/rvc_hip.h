@@ -310,8 +310,11 @@ int rvc_debug_conv_timing(uint64_t* out8, int reset);
 int rvc_debug_x3p_check(void);
 /* kernel benchmark (tools/bench_gemm.py): `reps` back-to-back launches of the split-resident GEMM (csrc/conv_x3s.hip) for an [Co x Ci] layer
  * on T columns of device-resident random data (input image, fp32 output with a residual); ksplit / am / an as in rvc_op_gemm_split,
- * split_out != 0 writes the output as the split image (GELU epilogue) instead.  *us_out = mean microseconds per launch (HIP events). */
-int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out);
+ * split_out != 0 writes the output as the split image (GELU epilogue) instead.  w2d > 0: a 3 x 3 convolution over a padded image of width w2d
+ * (T = H (w2d + 2) positions).  nlayers distinct weight sets are cycled through (a model's layers are read once per clip: cold weights).
+ * *us_out = mean microseconds per launch (HIP events). */
+int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out, int w2d,
+                               int nlayers);
 
 #ifdef __cplusplus
 }
