@@ -145,23 +145,56 @@ def cpu_baseline(config=None, seconds=CLIP_SECONDS, seed=100, budget_s=40.0):
                       f"torch.set_num_threads({k})"}
 
 
+def cpu_baseline_rmvpe(seconds=60.0, seed=100, budget_s=30.0):
+    """oracle.nets.rmvpe_infer_from_audio (the validated CPU restatement of lib/rmvpe.RMVPE) on the GPU line's clip: 1 s warm-up, up to 3 runs."""
+    import torch
+    from comfy_rvc_amd import synthetic as S
+    from oracle import nets
+    navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    k = max(1, min(navail, 32))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(k)
+    sd = S.rmvpe_state_dict(0)
+    try:
+        nets.rmvpe_infer_from_audio(sd, S.synth_audio(1.0, seed=2))
+        audio = S.synth_audio(seconds, seed=seed)
+        runs, t_all = [], time.perf_counter()
+        for _ in range(3):
+            t0 = time.perf_counter()
+            nets.rmvpe_infer_from_audio(sd, audio)
+            runs.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all + runs[-1] > budget_s:
+                break
+    finally:
+        torch.set_num_threads(prev)
+    runs.sort()
+    dt = runs[len(runs) // 2]
+    return {"value": round(seconds / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(k), "kind": "port", "cpu": cpu_model(), "n_runs": len(runs),
+            "wall_s_median": round(dt, 2),
+            "sample": f"1 x {seconds:g} s clip = the clip of the GPU line (synthetic.synth_audio seed {seed}), 1 s warm-up + median of {len(runs)} run(s), "
+                      f"oracle.nets.rmvpe_infer_from_audio (torch-CPU fp32 restatement validated against reference goldens), torch.set_num_threads({k})"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--seconds", type=float, default=CLIP_SECONDS)
+    ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default 30 s; 60 s for --variant rmvpe_60s)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default 12; 8 for --variant 48k_v2 as BASELINE.json configs[3] states)")
-    ap.add_argument("--variant", choices=["40k_v2", "48k_v2", "uvr_48k_v2"], default="40k_v2",
+    ap.add_argument("--variant", choices=["40k_v2", "48k_v2", "uvr_48k_v2", "rmvpe_60s"], default="40k_v2",
                     help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model; uvr_48k_v2 = "
-                         "configs[4]'s chain: MDX23C vocal split of a stereo 44.1 kHz clip (overlap 8) -> VC of the vocal stem with the 48k_v2 model")
+                         "configs[4]'s chain: MDX23C vocal split of a stereo 44.1 kHz clip (overlap 8) -> VC of the vocal stem with the 48k_v2 model; "
+                         "rmvpe_60s = configs[1]: lib/rmvpe.RMVPE pitch extraction alone on 60 s clips (host audio in -> float64 f0 out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the process group and run every step's gather (exercises RCCL on a 1-GPU box)")
     ap.add_argument("--no-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     args = ap.parse_args()
+    if args.seconds <= 0:
+        args.seconds = 60.0 if args.variant == "rmvpe_60s" else CLIP_SECONDS
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing in this process has initialised HIP
@@ -203,6 +236,7 @@ def main():
 
     n_lanes = max(1, args.lanes)
     chain = args.variant == "uvr_48k_v2"
+    pitch_only = args.variant == "rmvpe_60s"
     n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else (3 if chain else 12))
     SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
     if chain:      # stereo 44.1 kHz "song": the voice-like synthetic signal on both channels plus different noise beds
@@ -220,13 +254,25 @@ def main():
         from comfy_rvc_amd.vc_infer_pipeline import VC, get_vc, vc_single
         cfg = Config(device=dev)
         # procedural weights: generated ONCE per rank and shared by its lanes (each lane still owns its device replica: handles carry workspaces)
-        hub_sd, rmvpe_sd, syn_ckpt = S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_checkpoint(SYN_CFG, "v2", 0)
+        rmvpe_sd = S.rmvpe_state_dict(0)
+        hub_sd, syn_ckpt = (None, None) if pitch_only else (S.hubert_state_dict(0), S.synth_checkpoint(SYN_CFG, "v2", 0))
         mdx_sd = None
         if chain:
             from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as _MC
             mdx_sd = S.mdx23c_state_dict(_MC, 0)
 
+        def make_pitch_lane():
+            rm = RMVPE(rmvpe_sd, device=dev)
+
+            def convert(clip, i=0):      # RMVPE.infer_from_audio (reference lib/rmvpe.py:614-659): 16 kHz audio -> f0 per 10 ms frame, float64, on the host
+                f0 = rm.infer_from_audio(clip, thred=0.03)
+                assert f0.dtype == np.float64 and f0.shape[0] == clip.shape[0] // 160 + 1
+                return f0
+            return convert, None
+
         def make_lane():
+            if pitch_only:
+                return make_pitch_lane()
             hub = HubertModelWithFinalProj(hub_sd, S.HUBERT_CONFIG, device=dev)
             vcd = get_vc(syn_ckpt, config=cfg, device=dev)
             lvc = VC(SYN_CFG[-1], cfg)
@@ -257,7 +303,7 @@ def main():
 
         def stub(clip, i=0):                    # --dry-run: the documented output length, no compute
             time.sleep(0.002)
-            return np.zeros(n_out, dtype=np.int16)
+            return np.zeros(clip.shape[0] // 160 + 1, dtype=np.float64) if pitch_only else np.zeros(n_out, dtype=np.int16)
         lanes = [(stub, None) for _ in range(n_lanes)]
         pool = ClipLanes([fn for fn, _ in lanes], device=None)
 
@@ -272,7 +318,7 @@ def main():
             batch.append(wav)
             if len(batch) == n_clips:
                 if collective:   # every rank already holds ITS clips on the host (vc_single delivered them); rank 0 keeps the gathered copy in HBM
-                    gather_waveforms(np.concatenate(batch), coll_dev, to_host=False, force_collective=True)
+                    gather_waveforms(np.concatenate(batch).view(np.int16), coll_dev, to_host=False, force_collective=True)     # (f0 vectors travel as their bytes)
                 batch = []
         return wav
 
@@ -294,7 +340,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    delivered = wav.shape[0] / float(SYN_CFG[-1])                       # audio seconds of one converted clip
+    delivered = args.seconds if pitch_only else wav.shape[0] / float(SYN_CFG[-1])       # audio seconds of one converted clip (pitch: of one analysed clip)
     value = delivered * n_clips * world * args.steps / dt
 
     # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
@@ -310,14 +356,18 @@ def main():
     roofline = None
     if rank == 0 and use_gpu and not args.no_roofline:
         roofline = roofline_pass(_lib, vc, step, torch)
+        if roofline is not None and pitch_only:
+            roofline["note"] = ("conv-kernel launches only: the BiGRU recurrence (rvc::gru_scan_kernel, latency-bound serial scan on 16 workgroups) is the "
+                                "largest single kernel of this variant and has no FLOP / byte roofline; see profiles/*_kernel_stats_rmvpe60.csv")
     cpu = None
     if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
-        cpu = cpu_baseline(config=SYN_CFG, seconds=args.seconds) if not chain else None      # (the CPU oracle of the separation net at full size takes minutes per chunk)
+        cpu = None if chain else (cpu_baseline_rmvpe(seconds=args.seconds) if pitch_only else cpu_baseline(config=SYN_CFG, seconds=args.seconds))      # (the CPU oracle of the separation net at full size takes minutes per chunk)
 
     if rank == 0:
-        cfg_idx = {"40k_v2": 2, "48k_v2": 3, "uvr_48k_v2": 4}[args.variant]
+        cfg_idx = {"40k_v2": 2, "48k_v2": 3, "uvr_48k_v2": 4, "rmvpe_60s": 1}[args.variant]
         line = {
-            "metric": f"audio-sec/wall-sec (xRT), {args.variant} end-to-end VC", "value": round(value, 2), "unit": "audio-sec/wall-sec",
+            "metric": ("audio-sec/wall-sec (xRT), RMVPE pitch extraction alone" if pitch_only else f"audio-sec/wall-sec (xRT), {args.variant} end-to-end VC"),
+            "value": round(value, 2), "unit": "audio-sec/wall-sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if use_gpu else "dry-run (stub conversion, NO GPU work: launcher / collective check only)",
@@ -325,7 +375,9 @@ def main():
             "ranks": world, "backend": (backend if collective else None), "nccl_ranks": (world if (collective and backend == "nccl") else None),
             "cpu_affinity": (f"{len(bound)} CPUs of the GPU's NUMA node" if bound else "unbound (topology unknown or --no-bind)"),
             "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
-            "config": {"workload": ("MDX23C vocal split (stereo 44.1 kHz, overlap 8) -> " if chain else "") +
+            "config": {"workload": (f"lib/rmvpe.RMVPE pitch extraction alone (log-mel -> Deep U-Net -> BiGRU -> Linear -> decode), {args.seconds:g} s 16 kHz clips, {n_clips} per GPU per step "
+                                    f"({n_lanes} in flight concurrently), host audio in -> float64 f0 on the host (BASELINE.json configs[1])") if pitch_only else
+                                   ("MDX23C vocal split (stereo 44.1 kHz, overlap 8) -> " if chain else "") +
                                    f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s {'44.1 kHz stereo' if chain else '16 kHz'} clips, {n_clips} per GPU "
                                    f"per step ({n_lanes} in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
                        "clips_per_step": world * n_clips, "clips_per_gpu_per_step": n_clips, "clips_in_flight_per_gpu": n_lanes,
@@ -361,7 +413,8 @@ def roofline_pass(_lib, vc, step, torch):
     import csv
     import tempfile
     _lib.check(_lib.lib.rvc_prof_enable(1))
-    vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
+    if vc is not None:
+        vc.overlap_streams = False      # serialise the two front-ends so that event-bracketed kernel times are not inflated by overlap
     step()
     torch.cuda.synchronize()
     dump = os.environ.get("RVC_PROF_CSV")
@@ -372,7 +425,8 @@ def roofline_pass(_lib, vc, step, torch):
         dump = tmp.name
     _lib.check(_lib.lib.rvc_prof_dump_csv(dump.encode()))      # per-launch table (shape, tile, us, FLOPs, algorithmic bytes); kept when RVC_PROF_CSV names it
     _lib.check(_lib.lib.rvc_prof_enable(0))
-    vc.overlap_streams = True
+    if vc is not None:
+        vc.overlap_streams = True
     with open(dump) as f:
         rows = list(csv.DictReader(f))
     if tmp is not None:

@@ -634,7 +634,19 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
               unsigned long long* xbuf, int* err, int T, unsigned spin_limit, int fault) {
   (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
   (void)hipMemsetAsync(err, 0, sizeof(int), s);
-  hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, spin_limit ? spin_limit : (1u << 24), fault);
+  // RVC_GRU_COOP=1: cooperative launch - the runtime checks that the whole grid (64 workgroups of 768 threads, 16 of which work) can be
+  // resident at once and dispatches it as one unit.  Measured with three clips in flight (round 3, one gpurun call): 1793 -> 1621 xRT - a
+  // cooperative dispatch waits until the grid is launchable as a whole, which idles the chip under the other lanes' kernels - so the plain
+  // launch stays the default: its 16 working slices become resident as soon as ANY 16 CUs have 12 free waves (every other kernel of the path
+  // terminates without waiting for anything), and the bounded spin + status word report the case that they do not.
+  static const bool coop = getenv("RVC_GRU_COOP") && atoi(getenv("RVC_GRU_COOP")) != 0;
+  unsigned sl = spin_limit ? spin_limit : (1u << 24);
+  if (coop) {
+    void* args[] = {(void*)&gi, (void*)&b_ih, (void*)&w_hh, (void*)&b_hh, (void*)&out, (void*)&xbuf, (void*)&err, (void*)&T, (void*)&sl, (void*)&fault};
+    RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel), dim3(64), dim3(768), args, 0, s));
+  } else {
+    hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- RMVPE decode
