@@ -411,9 +411,13 @@ template <int D, int WK, bool REL>
 __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __restrict__ Q, const float* __restrict__ K, long long ldqk,
                                                                const float* __restrict__ V, long long ldv, const float* __restrict__ bv,
                                                                const float* __restrict__ rel, float* __restrict__ pb, int win,
-                                                               float* __restrict__ out, long long ldo, int T) {
+                                                               float* __restrict__ out, long long ldo, int T,
+                                                               const float* __restrict__ ek, const float* __restrict__ ev) {
+  // ek / ev (REL only): emb_rel_k / emb_rel_v [2 win + 1][D] - the two relative-position projections computed HERE instead of by four small
+  // convolution launches per layer: rq[r][query] = E_k[r] . Q[query] right after the Q tile is staged (`rel` is then not read), and
+  // out[d][query] += sum_r P_band[r][query] E_v[r][d] in the merge (`pb` may then be null).
   constexpr int NT = 64 * WK, KT = 32 * WK, DP = D + 4, VP = KT + 4, PP = 36, DT = D / 32, OP = 33;
-  constexpr int kQs = 32 * DP, kKs = KT * DP, kVs = D * VP, kPs = WK * 32 * PP, kSb = REL ? 21 * 32 : 0;
+  constexpr int kQs = 32 * DP, kKs = KT * DP, kVs = D * VP, kPs = WK * 32 * PP, kSb = REL ? 3 * 21 * 32 : 0;      // raw band scores | rq | band probabilities
   static_assert(WK * (D * OP + 64) <= kKs + kVs, "merge buffers must fit the K / V tiles");
   extern __shared__ __attribute__((aligned(16))) float smem_att[];
   float* Qs = smem_att; float* Ks = Qs + kQs; float* Vs = Ks + kKs; float* Ps = Vs + kVs; float* sb = Ps + kPs;
@@ -423,7 +427,8 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
   const float* Qh = Q + (long long)h * D * ldqk;
   const float* Kh = K + (long long)h * D * ldqk;
   const float* Vh = V + h * D;
-  const float* relh = REL ? rel + (long long)h * (2 * win + 1) * T : nullptr;
+  const float* relh = (REL && rel) ? rel + (long long)h * (2 * win + 1) * T : nullptr;
+  float* rq = sb + 21 * 32; float* pbs = sb + 2 * 21 * 32;
 
   // Q tile -> Qs[query][d]
   for (int e = tid; e < 32 * D / 4; e += NT) {
@@ -432,6 +437,17 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (q0 + j < T) ? Qh[(long long)(d0 + i) * ldqk + q0 + j] : 0.f;
     *reinterpret_cast<f32x4*>(Qs + j * DP + d0) = v;
+  }
+  if (REL && ek) {
+    lds_barrier();                          // the Q tile is staged
+    for (int e = tid; e < (2 * win + 1) * 32; e += NT) {
+      const int rr = e >> 5, j = e & 31;
+      const float* er = ek + rr * D; const float* qr = Qs + j * DP;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < D; d += 2) { a0 = fmaf(er[d], qr[d], a0); a1 = fmaf(er[d + 1], qr[d + 1], a1); }
+      rq[e] = a0 + a1;
+    }
   }
   f32x16 o[DT];
 #pragma unroll
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
           const int key = kw + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int rr = key - q + win;
           if (rr >= 0 && rr <= 2 * win && key < T && q < T) {
-            s0[r] += relh[(long long)rr * T + q];
+            s0[r] += relh ? relh[(long long)rr * T + q] : rq[rr * 32 + li];
             sb[rr * 32 + li] = s0[r];
           }
         }
@@ -564,6 +580,21 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
     for (int r = 0; r < 16; ++r) Oc[(w * D + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * OP + li] = o[t][r];
   if (lh == 0) { ml[(w * 2 + 0) * 32 + li] = m_run; ml[(w * 2 + 1) * 32 + li] = l_run; }
   lds_barrier();
+  if (REL) {                                    // band probabilities first: the value-side projection below needs them
+    for (int e = tid; e < (2 * win + 1) * 32; e += NT) {
+      const int rr = e >> 5, j = e & 31;
+      const int qq = q0 + j, key = qq + rr - win;
+      float m = -1.0e30f, l = 0.f;
+#pragma unroll
+      for (int x = 0; x < WK; ++x) m = fmaxf(m, ml[(x * 2) * 32 + j]);
+#pragma unroll
+      for (int x = 0; x < WK; ++x) l += ml[(x * 2 + 1) * 32 + j] * expf(ml[(x * 2) * 32 + j] - m);
+      const float pv = (qq < T && key >= 0 && key < T) ? expf(sb[rr * 32 + j] - m) / l : 0.f;
+      pbs[e] = pv;
+      if (pb && qq < T) pb[((long long)h * (2 * win + 1) + rr) * T + qq] = pv;
+    }
+    lds_barrier();
+  }
   for (int e = tid; e < D * 32; e += NT) {
     const int d = e >> 5, j = e & 31;
     float m = -1.0e30f;
@@ -576,40 +607,33 @@ __global__ __launch_bounds__(64 * WK) void attention_ks_kernel(const float* __re
       l += ml[(x * 2 + 1) * 32 + j] * sc;
       acc += Oc[(x * D + d) * OP + j] * sc;
     }
-    if (q0 + j < T) out[(long long)(h * D + d) * ldo + q0 + j] = acc / l + (bv ? bv[h * D + d] : 0.f);
-  }
-  if (REL) {
-    for (int e = tid; e < (2 * win + 1) * 32; e += NT) {
-      const int rr = e >> 5, j = e & 31;
-      const int qq = q0 + j, key = qq + rr - win;
-      if (qq >= T) continue;
-      float m = -1.0e30f, l = 0.f;
-#pragma unroll
-      for (int x = 0; x < WK; ++x) m = fmaxf(m, ml[(x * 2) * 32 + j]);
-#pragma unroll
-      for (int x = 0; x < WK; ++x) l += ml[(x * 2 + 1) * 32 + j] * expf(ml[(x * 2) * 32 + j] - m);
-      pb[((long long)h * (2 * win + 1) + rr) * T + qq] = (key >= 0 && key < T) ? expf(sb[rr * 32 + j] - m) / l : 0.f;
+    float v = acc / l + (bv ? bv[h * D + d] : 0.f);
+    if (REL && ev) {
+      float r0 = 0.f;
+      for (int rr = 0; rr < 2 * win + 1; ++rr) r0 = fmaf(pbs[rr * 32 + j], ev[rr * D + d], r0);
+      v += r0;
     }
+    if (q0 + j < T) out[(long long)(h * D + d) * ldo + q0 + j] = v;
   }
 }
 
 template <int D, int WK, bool REL>
 static void launch_att_ks(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
-                          const float* rel, float* pb, int win, float* out, long long ldo, int heads, int T) {
+                          const float* rel, float* pb, int win, float* out, long long ldo, int heads, int T, const float* ek, const float* ev) {
   constexpr int KT = 32 * WK;
-  const size_t lds = sizeof(float) * (32 * (D + 4) + KT * (D + 4) + D * (KT + 4) + WK * 32 * 36 + (REL ? 21 * 32 : 0));
+  const size_t lds = sizeof(float) * (32 * (D + 4) + KT * (D + 4) + D * (KT + 4) + WK * 32 * 36 + (REL ? 3 * 21 * 32 : 0));
   auto kern = attention_ks_kernel<D, WK, REL>;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
-  hipLaunchKernelGGL(kern, dim3((T + 31) / 32, heads), dim3(64 * WK), lds, s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, T);
+  hipLaunchKernelGGL(kern, dim3((T + 31) / 32, heads), dim3(64 * WK), lds, s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, T, ek, ev);
 }
 
 // Text-encoder attention of the synthesizer (2 heads x 96): relative-position bias rel [heads][2 win + 1][T] in, banded probabilities
 // pb [heads][2 win + 1][T] out.  Q, K channel-major (Q pre-scaled), V row-major, out channel-major.
 void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
-                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T) {
-  RVC_REQUIRE(dhead == 96 && win == 10 && rel && pb, "fused relative-position attention is built for head dimension 96, window 10");
-  launch_att_ks<96, 4, true>(s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, heads, T);
+                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T, const float* ek, const float* ev) {
+  RVC_REQUIRE(dhead == 96 && win == 10 && (rel || ek) && (pb || ev), "fused relative-position attention is built for head dimension 96, window 10");
+  launch_att_ks<96, 4, true>(s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, heads, T, ek, ev);
 }
 
 }  // namespace rvc

@@ -31,7 +31,8 @@ static ConvLayer make_conv1d(const TensorStore& ts, const std::string& p, int st
 struct EncLayer {
   ConvLayer qk;            // fused conv_q (pre-scaled by 1/sqrt(kc)) and conv_k: C -> 2C
   DevVec bv;               // conv_v's bias, added after P.V; its rows are part of the qk layer (C -> 3 C)
-  ConvLayer relk, relv;    // emb_rel_k as a 21-row projection of Q; emb_rel_v as a 21 -> kc projection of banded P
+  ConvLayer relk, relv;    // emb_rel_k as a 21-row projection of Q; emb_rel_v as a 21 -> kc projection of banded P (unfused path)
+  DevVec ek, ev;           // the raw [21][kc] tables: the fused attention kernel does both projections itself
   ConvLayer o, ffn1, ffn2;
   DevVec g1, b1, g2, b2;
 };
@@ -69,7 +70,7 @@ struct Synth {
 static void synth_free(Synth& S) {
   auto fl = [](ConvLayer& L) { conv_layer_free(L); };
   S.emb_phone_wT.free_(); S.emb_phone_b.free_(); S.emb_pitch.free_(); S.emb_g.free_();
-  for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
+  for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); e.ek.free_(); e.ev.free_(); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
   S.enc.clear();
   fl(S.proj);
   for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
@@ -135,6 +136,7 @@ void synth_finalize(Synth* S) {
     const HostTensor& rv = ts.get(p + "emb_rel_v", {1, 21, kc});
     std::vector<float> rvT = transpose2d(rv.data.data(), 21, kc);                           // [d][r]: out[d][q] = sum_r E_v[r][d] Pb[r][q]
     conv1d_layer_init(e.relv, rvT.data(), nullptr, kc, 21, 1, 1, 0, 1, 1);
+    e.ek.upload(rk.data); e.ev.upload(rv.data);
     e.o = make_conv1d(ts, p + "conv_o", 1, 0, 1, false);
     const std::string f = "enc_p.encoder.ffn_layers." + std::to_string(l) + ".";
     e.ffn1 = make_conv1d(ts, f + "conv_1", 1, (S->ksz - 1) / 2, 1, false);
@@ -280,6 +282,11 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
         if (gs) conv_x3s_run(e.qk, s, x_s, tp, T, qk, T, E0); else
         conv1d_run(e.qk, s, x, T, T, qk, T, E0);
         transpose(s, qk + (size_t)2 * C * T, vr, C, T, T, C, 1, 0, 0);                                       // V row-major [T][C] (bias later)
+        static const bool rel_in = !(getenv("RVC_ENCP_REL_FUSED") && atoi(getenv("RVC_ENCP_REL_FUSED")) == 0);
+        if (fused_att && rel_in) {
+          // softmax(K^T Q + banded rel-k bias) V + bv + banded P . E_v in ONE kernel: both relative-position projections included
+          attention_rel_fused(s, qk, qk + (size_t)C * T, T, vr, C, e.bv.p, nullptr, nullptr, 10, attn, T, H, kc, T, e.ek.p, e.ev.p);
+        } else {
         for (int h = 0; h < H; ++h) conv1d_run(e.relk, s, qk + (size_t)h * kc * T, T, T, relk + (size_t)h * 21 * T, T, E0);
         if (fused_att) {
           // softmax(K^T Q + banded rel-k bias) V + bv in one kernel; the band of probabilities comes back in pb for the rel-v projection
@@ -292,6 +299,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
         }
         ConvEpilogue Ea; Ea.accumulate = 1;
         for (int h = 0; h < H; ++h) conv1d_run(e.relv, s, pb + (size_t)h * 21 * T, T, T, attn + (size_t)h * kc * T, T, Ea);
+        }
         ConvEpilogue Er; Er.R = x; Er.ldR = T;
         if (gs) {
           split_image_from_f32(s, attn, T, C, T, attn_s, tp);

@@ -504,9 +504,9 @@ int rvc_op_attention(void* stream, const float* q, const float* k, const float* 
   RVC_CATCH
 }
 int rvc_op_attention_rel(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, const float* rel, float* pb,
-                         float* out, int heads, int T) {
+                         float* out, int heads, int T, const float* ek, const float* ev) {
   RVC_TRY
-  attention_rel_fused((hipStream_t)stream, q, k, T, v_rm, (long long)heads * 96, bv, rel, pb, 10, out, T, heads, 96, T);
+  attention_rel_fused((hipStream_t)stream, q, k, T, v_rm, (long long)heads * 96, bv, rel, pb, 10, out, T, heads, 96, T, ek, ev);
   check_launch();
   RVC_CATCH
 }

@@ -167,8 +167,11 @@ bool conv2d_kx_try(const ConvLayer& L, hipStream_t s, const float* X, long long 
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                      float* out, long long ldo, int heads, int dhead, int T, unsigned char* out_img = nullptr, long long img_tp = 0);
 
+// ek / ev: emb_rel_k / emb_rel_v [2 win + 1][dhead] (shared by the heads): the relative-position projections are then computed inside the
+// kernel (rel / pb may be null); without them rel holds Q . E_k and pb returns the band for a separate value-side projection
 void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
-                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T);
+                         const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T, const float* ek = nullptr,
+                         const float* ev = nullptr);
 
 // per-launch HIP-event profiling of the conv kernels (bench.py's roofline leg)
 void conv_prof_enable(bool on);

@@ -39,10 +39,13 @@ def gpu_numa_cpus(local_rank, sysfs="/sys"):
         nodes = sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")), key=lambda d: int(os.path.basename(d)))
         for d in nodes:
             props = {}
-            with open(os.path.join(d, "properties")) as f:
-                for line in f:
-                    k, _, v = line.strip().partition(" ")
-                    props[k] = v
+            try:
+                with open(os.path.join(d, "properties")) as f:
+                    for line in f:
+                        k, _, v = line.strip().partition(" ")
+                        props[k] = v
+            except OSError:
+                continue                 # a GPU of the machine this container was not given (its node is listed but unreadable): HIP does not see it either
             if int(props.get("simd_count", "0")) > 0:
                 loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
                 gpus.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7))

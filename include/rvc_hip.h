@@ -264,9 +264,11 @@ int rvc_op_attention(void* stream, const float* q_dev, const float* k_dev, const
                      int heads, int T);
 /* the synthesizer text encoder's attention (reference lib/infer_pack/attentions.py:230-267), head dimension 96, window 10:
  * softmax over keys of K^T Q + rel[k - q + 10][q] (|k - q| <= 10), times V, + bv.  rel_dev [heads][21][T] in (the Q . emb_rel_k
- * projection), pb_dev [heads][21][T] out: pb[r][q] = P[q][q + r - 10] (0 outside the sequence), the input of the rel-v projection. */
+ * projection), pb_dev [heads][21][T] out: pb[r][q] = P[q][q + r - 10] (0 outside the sequence), the input of the rel-v projection.
+ * ek_dev / ev_dev (both or neither): emb_rel_k / emb_rel_v [21][96], shared by the heads - the kernel then computes both projections itself
+ * (rel = Q . E_k on the staged Q tile, out += P_band . E_v in the merge); rel_dev / pb_dev may be null in that form. */
 int rvc_op_attention_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, const float* rel_dev,
-                         float* pb_dev, float* out_dev, int heads, int T);
+                         float* pb_dev, float* out_dev, int heads, int T, const float* ek_dev, const float* ev_dev);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                        int C, int T);
 /* optional debug outputs: rad_dev [T] per-frame phase increment, tmp_dev [T] scaled frame cumsum, phase_dev [T*upp] running phase (cycles) */

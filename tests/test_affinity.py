@@ -31,6 +31,11 @@ def test_gpu_numa_cpus_reads_kfd_order_and_visible_devices(tmp_path, monkeypatch
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")
     assert P.gpu_numa_cpus(0, str(tmp_path)) is None
     assert P.gpu_numa_cpus(0, str(tmp_path / "nothing")) is None            # no KFD at all: unknown, nothing is bound
+    # a machine with more GPUs than the container may touch: their nodes are listed but unreadable and do not count
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    os.remove(tmp_path / "class/kfd/kfd/topology/nodes/1/properties")
+    os.mkdir(tmp_path / "class/kfd/kfd/topology/nodes/1/properties")       # open() fails with an OSError, like EPERM does
+    assert P.gpu_numa_cpus(0, str(tmp_path)) == {0, 1, 2, 3, 8, 9, 10, 11} and P.gpu_numa_cpus(1, str(tmp_path)) == {4, 5, 6, 7, 12, 13, 14, 15}
 
 
 @pytest.mark.skipif(not hasattr(os, "sched_setaffinity"), reason="Linux only")

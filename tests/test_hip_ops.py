@@ -335,10 +335,31 @@ def test_fused_relative_attention(L, heads, T):
     out = torch.empty(heads * D, T, device="cuda")
     pb = torch.full((heads, 2 * W + 1, T), 7.0, device="cuda")            # every entry must be written (zeros outside the sequence)
     qd, kd, vd, bd, rd = dev(q), dev(k), dev(v), dev(bv), dev(rel)
-    L.check(L.lib.rvc_op_attention_rel(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), L.ptr(rd), L.ptr(pb), L.ptr(out), heads, T))
+    L.check(L.lib.rvc_op_attention_rel(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), L.ptr(rd), L.ptr(pb), L.ptr(out), heads, T, None, None))
     torch.cuda.synchronize()
     assert rel_err(out.cpu().double(), ref) < 2e-5
     assert (pb.cpu().double() - pb_ref).abs().max() < 2e-6
+    # both relative-position projections inside the kernel: rel = Q . E_k (heads share the table), out += P_band . E_v
+    ek = torch.randn(2 * W + 1, D, generator=g) * 0.5
+    ev = torch.randn(2 * W + 1, D, generator=g) * 0.5
+    rel2 = torch.einsum("rd,hdq->hrq", ek.double(), qh)
+    sc2 = torch.einsum("hdq,hdk->hqk", qh, kh)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        sc2[:, qi[ok], ki[ok]] += rel2[:, r, qi[ok]]
+    p2 = torch.softmax(sc2, dim=-1)
+    ref2 = torch.einsum("hqk,hkd->hdq", p2, vh)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        ref2[:, :, qi[ok]] += p2[:, qi[ok], ki[ok]][:, None, :] * ev.double()[r][None, :, None]
+    ref2 = ref2.reshape(heads * D, T) + bv.double()[:, None]
+    out2 = torch.empty(heads * D, T, device="cuda")
+    ekd, evd = dev(ek), dev(ev)
+    L.check(L.lib.rvc_op_attention_rel(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), None, None, L.ptr(out2), heads, T, L.ptr(ekd), L.ptr(evd)))
+    torch.cuda.synchronize()
+    assert rel_err(out2.cpu().double(), ref2) < 2e-5
 
 
 def test_layernorm_channels(L):
