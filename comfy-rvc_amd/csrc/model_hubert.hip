@@ -20,6 +20,7 @@ struct Hubert {
   bool ready = false;
   ConvLayer conv[7];
   DevVec gn_g, gn_b, fp_g, fp_b, enc_g, enc_b;
+  DevVec w0;            // conv_layers.0 raw [512][10]: the fused conv0 + GroupNorm + GELU kernels evaluate it from the audio
   ConvLayer proj, pos, final_proj;
   std::vector<HubLayer> layers;
 };
@@ -38,7 +39,7 @@ void hubert_set_tensor(Hubert* H, const char* name, const float* d, const long l
 
 static void hubert_free(Hubert& H) {
   for (auto& c : H.conv) conv_layer_free(c);
-  H.gn_g.free_(); H.gn_b.free_(); H.fp_g.free_(); H.fp_b.free_(); H.enc_g.free_(); H.enc_b.free_();
+  H.w0.free_(); H.gn_g.free_(); H.gn_b.free_(); H.fp_g.free_(); H.fp_b.free_(); H.enc_g.free_(); H.enc_b.free_();
   conv_layer_free(H.proj); conv_layer_free(H.pos); conv_layer_free(H.final_proj);
   for (auto& l : H.layers) { conv_layer_free(l.qk); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
   H.layers.clear();
@@ -57,6 +58,7 @@ void hubert_finalize(Hubert* H) {
   ConvBuildScope x3scope(H->ctx->precision);
   // conv0: Conv1d(1, 512, 10, stride 5) == Linear(10 -> 512) over im2col frames
   conv1d_layer_init(H->conv[0], ts.get("feature_extractor.conv_layers.0.conv.weight", {512, 1, 10}).data.data(), nullptr, 512, 10, 1, 1, 0, 1, 1);
+  H->w0.upload(ts.get("feature_extractor.conv_layers.0.conv.weight", {512, 1, 10}).data);
   for (int i = 1; i < 7; ++i)
     conv1d_layer_init(H->conv[i], ts.get("feature_extractor.conv_layers." + std::to_string(i) + ".conv.weight", {512, 512, kKern[i]}).data.data(),
                       nullptr, 512, 512, kKern[i], kStride[i], 0, 1, 1);
@@ -122,13 +124,20 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   for (int i = 0; i < 7; ++i) Tc[i + 1] = (Tc[i] - kKern[i]) / kStride[i] + 1;
   const int T = Tc[7];
   // ---- feature encoder
-  float* fr = A.alloc<float>((size_t)10 * Tc[1]);
+  static const bool fuse0 = !(getenv("RVC_HUBERT_FUSE0") && atoi(getenv("RVC_HUBERT_FUSE0")) == 0);
+  float* fr = fuse0 ? nullptr : A.alloc<float>((size_t)10 * Tc[1]);
   float* c0 = A.alloc<float>((size_t)512 * Tc[1]);
   float* c1 = A.alloc<float>((size_t)512 * Tc[2]);
+  double* c0part = fuse0 ? A.alloc<double>(hubert_conv0_scratch_doubles(512, Tc[1])) : nullptr;
+  float* c0stat = fuse0 ? A.alloc<float>(1024) : nullptr;
   if (!dry) {
-    frames(s, audio, fr, (int)L, 10, 5, 0, Tc[1], 0);
-    conv1d_run(H->conv[0], s, fr, Tc[1], Tc[1], c0, Tc[1], E0);
-    groupnorm_t_gelu(s, c0, H->gn_g.p, H->gn_b.p, 512, Tc[1], Tc[1], 1e-5f);
+    if (fuse0) {
+      hubert_conv0_gn_gelu(s, audio, L, H->w0.p, H->gn_g.p, H->gn_b.p, 512, Tc[1], 1e-5f, c0, Tc[1], c0part, c0stat);
+    } else {
+      frames(s, audio, fr, (int)L, 10, 5, 0, Tc[1], 0);
+      conv1d_run(H->conv[0], s, fr, Tc[1], Tc[1], c0, Tc[1], E0);
+      groupnorm_t_gelu(s, c0, H->gn_g.p, H->gn_b.p, 512, Tc[1], Tc[1], 1e-5f);
+    }
   }
   float* in = c0; float* outb = c1;
   for (int i = 1; i < 7; ++i) {

@@ -6,6 +6,11 @@ namespace rvc {
 
 // LayerNorm over channels that ALSO writes y as the split-resident image of conv_x3s.hip (y may be null: image only); margin = kSplitMargin
 void wn_gate_split(hipStream_t s, const float* a, const float* g, unsigned char* img, long long tp, int margin, int H, int T);   // WN gate -> split image only
+// HuBERT feature-encoder layer 0 fused: Conv1d(1, C, 10, stride 5) -> GroupNorm(C, C) -> GELU from the raw audio (the convolution is
+// evaluated twice instead of being stored: ops.hip).  partial: hubert_conv0_scratch_doubles(C, T1) doubles, stat: 2 C floats.
+void hubert_conv0_gn_gelu(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
+                          float* out, long long ld, double* partial, float* stat);
+size_t hubert_conv0_scratch_doubles(int C, int T1);
 void layernorm_c_split(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, unsigned char* img, long long tp, int margin,
                        int C, int T, long long ld, float eps);
 void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gamma, const float* beta, float* y, int C, int T,

@@ -173,6 +173,112 @@ void groupnorm_t_gelu(hipStream_t s, float* x, const float* gamma, const float* 
   hipLaunchKernelGGL(groupnorm_t_gelu_kernel, dim3(C), dim3(256), 0, s, x, gamma, beta, T, ld, eps);
 }
 
+// ---------------------------------------------------------------------------------------------- HuBERT conv0 + GroupNorm + GELU, fused
+// feature_extractor.conv_layers[0] (transformers modeling_hubert.py:108-133 with feat_extract_norm = "group"): Conv1d(1, 512, 10, stride 5,
+// no bias) -> GroupNorm(512, 512) (= per-channel statistics over time) -> GELU.  An output element costs 10 FMAs on the raw audio, the
+// tensor is 512 x 102399 (210 MB at 30 s): instead of writing the convolution, re-reading it twice for the statistics and once more to
+// normalise (frames + GEMM + groupnorm_t_gelu_kernel: 15 + 90 + 387 us), the convolution is evaluated TWICE from the 2 MB of audio - once
+// for per-tile partial sums (fixed-order reduction: repeats are bit-identical), once fused with the normalisation and GELU - and the
+// tensor crosses HBM exactly once, as the write of the result.
+// Tile: 1024 positions x 64 channels per 256-thread block; a thread owns 4 positions (t, t + 256, ..) and walks the tile's channels with
+// wave-uniform weights (scalar loads).
+constexpr int kC0T = 1024, kC0C = 64, kC0K = 10, kC0S = 5;
+constexpr int kC0ST = 512;                                  // positions per statistics tile
+__device__ __forceinline__ float gelu_bf(float v) {        // exact-erf GELU, branch-free (Abramowitz & Stegun 7.1.26: |erf error| <= 1.5e-7)
+  const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+  return 0.5f * v * (1.f + copysignf(fmaf(-poly, e, 1.f), x));
+}
+// Statistics pass: a thread IS a channel (its 10 weights in registers) and walks the tile's positions - every thread reads the same audio
+// samples (LDS broadcast), so there is no cross-thread reduction at all: partial[tile][c] = {sum, sum of squares} over 512 positions,
+// accumulated in float64 in groups of 8 positions.
+__global__ __launch_bounds__(256) void hubert_conv0_stats_kernel(const float* __restrict__ audio, long long L, const float* __restrict__ w, int C, int T1,
+                                                                 double* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float xs[kC0ST * kC0S + kC0K + 6];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * kC0ST, c = blockIdx.y * 256 + tid;
+  const long long a0 = (long long)t0 * kC0S;
+  for (int i = tid; i < kC0ST * kC0S + kC0K; i += 256) xs[i] = (a0 + i < L) ? audio[a0 + i] : 0.f;
+  __syncthreads();
+  float wc[kC0K];
+#pragma unroll
+  for (int k = 0; k < kC0K; ++k) wc[k] = c < C ? w[(long long)c * kC0K + k] : 0.f;
+  const int np = min(kC0ST, T1 - t0);
+  double s1 = 0.0, s2 = 0.0;
+  for (int p0 = 0; p0 < np; p0 += 8) {
+    float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* xp = xs + (p0 + j) * kC0S;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < kC0K; ++k) a = fmaf(wc[k], xp[k], a);
+      if (p0 + j < np) { f1 += a; f2 = fmaf(a, a, f2); }
+    }
+    s1 += (double)f1; s2 += (double)f2;
+  }
+  if (c < C) { double* q = partial + ((long long)blockIdx.x * C + c) * 2; q[0] = s1; q[1] = s2; }
+}
+// per channel: fixed-order sum of the tile partials (16 lanes per channel, then a fixed shuffle tree) -> mean and rstd * gamma
+__global__ __launch_bounds__(256) void hubert_conv0_reduce_kernel(const double* __restrict__ partial, int stiles, int C, int T1, const float* __restrict__ gamma,
+                                                                  float eps, float* __restrict__ stat) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int i = part; i < stiles; i += 16) { s1 += partial[((long long)i * C + c) * 2]; s2 += partial[((long long)i * C + c) * 2 + 1]; }
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+  if (part == 0 && c < C) {
+    const double mean = s1 / (double)T1;
+    double var = s2 / (double)T1 - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[2 * c] = (float)mean; stat[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+  }
+}
+// Apply pass: tile of 1024 positions x 64 channels; a thread owns 4 positions (t, t + 256, ..) and walks the channels with wave-uniform
+// weights and statistics.
+__global__ __launch_bounds__(256) void hubert_conv0_apply_kernel(const float* __restrict__ audio, long long L, const float* __restrict__ w, int C, int T1,
+                                                                 const float* __restrict__ stat, const float* __restrict__ beta, float* __restrict__ out, long long ld) {
+  __shared__ float xs[kC0T * kC0S + kC0K];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * kC0T, c0 = blockIdx.y * kC0C;
+  const long long a0 = (long long)t0 * kC0S;
+  for (int i = tid; i < kC0T * kC0S + kC0K; i += 256) xs[i] = (a0 + i < L) ? audio[a0 + i] : 0.f;
+  __syncthreads();
+  float x[4][kC0K];
+  bool ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tl = tid + 256 * j;
+    ok[j] = t0 + tl < T1;
+#pragma unroll
+    for (int k = 0; k < kC0K; ++k) x[j][k] = xs[tl * kC0S + k];
+  }
+  for (int cc = 0; cc < kC0C; ++cc) {
+    const int c = c0 + cc;
+    if (c >= C) break;
+    const float* wc = w + (long long)c * kC0K;
+    const float mean = stat[2 * c], sc = stat[2 * c + 1], b = beta[c];          // sc = rstd * gamma
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < kC0K; ++k) a = fmaf(wc[k], x[j][k], a);
+      if (ok[j]) out[(long long)c * ld + t0 + tid + 256 * j] = gelu_bf(fmaf(a - mean, sc, b));
+    }
+  }
+}
+void hubert_conv0_gn_gelu(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
+                          float* out, long long ld, double* partial, float* stat) {
+  const int stiles = (T1 + kC0ST - 1) / kC0ST, tiles = (T1 + kC0T - 1) / kC0T;
+  hipLaunchKernelGGL(hubert_conv0_stats_kernel, dim3((unsigned)stiles, (unsigned)((C + 255) / 256)), dim3(256), 0, s, audio, L, w, C, T1, partial);
+  hipLaunchKernelGGL(hubert_conv0_reduce_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, partial, stiles, C, T1, gamma, eps, stat);
+  hipLaunchKernelGGL(hubert_conv0_apply_kernel, dim3((unsigned)tiles, (unsigned)((C + kC0C - 1) / kC0C)), dim3(256), 0, s, audio, L, w, C, T1, stat, beta, out, ld);
+}
+size_t hubert_conv0_scratch_doubles(int C, int T1) { return (size_t)((T1 + kC0ST - 1) / kC0ST) * C * 2; }
+
 // ---------------------------------------------------------------------------------------------- column softmax of S^T [Tk][Tq]
 // Softmax over the key axis (rows) for every query column; optional relative-position bias
 // rel[(k - q + win)][q] for |k - q| <= win (enc_p, reference attentions.py:230-239) and optional gather of the banded
@@ -382,9 +488,44 @@ __global__ __launch_bounds__(256) void conv_to1_kernel(const float* __restrict__
   }
   y[t] = act_tanh ? tanhf(acc) : acc;
 }
+// k <= 9 with rows that start 16-byte aligned: a thread owns FOUR consecutive outputs and reads its 12-sample window as three float4 per channel
+// (the one-output kernel issued 7 dword loads + 7 max + 7 FMAs per output and channel: instruction-bound at 0.78 TB/s on the 164 MB input)
+__global__ __launch_bounds__(256) void conv_to1x4_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w, int Ci, int K,
+                                                         int pad, int T, float pre_slope, int act_tanh, float* __restrict__ y) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t0 >= T) return;
+  const bool inner = t0 >= 4 && t0 + 8 <= T;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int c = 0; c < Ci; ++c) {
+    const float* xr = x + (long long)c * ldx;
+    float v[12];
+    if (inner) {
+      const f4 l = *reinterpret_cast<const f4*>(xr + t0 - 4), m = *reinterpret_cast<const f4*>(xr + t0), r = *reinterpret_cast<const f4*>(xr + t0 + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = l[i]; v[4 + i] = m[i]; v[8 + i] = r[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { const int q = t0 - 4 + i; v[i] = (q >= 0 && q < T) ? xr[q] : 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = fmaxf(v[i], v[i] * pre_slope);
+    const float* wc = w + c * 7;                                // (k = 7, pad = 3: compile-time indices keep v[] in registers)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {                               // output t0 + o reads v[4 + o + j - 3]
+      const float wj = wc[j];
+      a0 = fmaf(wj, v[1 + j], a0); a1 = fmaf(wj, v[2 + j], a1); a2 = fmaf(wj, v[3 + j], a2); a3 = fmaf(wj, v[4 + j], a3);
+    }
+  }
+  const float o[4] = {a0, a1, a2, a3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (t0 + i < T) y[t0 + i] = act_tanh ? tanhf(o[i]) : o[i];
+}
 void conv_to1(hipStream_t s, const float* x, long long ldx, const float* w, int Ci, int K, int pad, int T, float pre_slope, int act_tanh,
               float* y) {
-  hipLaunchKernelGGL(conv_to1_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, ldx, w, Ci, K, pad, T, pre_slope, act_tanh, y);
+  const bool x4 = K == 7 && pad == 3 && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  if (x4) hipLaunchKernelGGL(conv_to1x4_kernel, dim3((T + 1023) / 1024), dim3(256), 0, s, x, ldx, w, Ci, K, pad, T, pre_slope, act_tanh, y);
+  else hipLaunchKernelGGL(conv_to1_kernel, dim3((T + 255) / 256), dim3(256), 0, s, x, ldx, w, Ci, K, pad, T, pre_slope, act_tanh, y);
 }
 
 // ---------------------------------------------------------------------------------------------- rational resampling

@@ -61,7 +61,7 @@ class FeatureExtractor:
     def load_index(self, file_index):
         """(index, big_npy) for feature retrieval (reference :52-73).  Accepts the reference's preloaded tuple, "" (no index),
         a `.npy` file holding big_npy [N, D] (what `train_index` saves next to the faiss file as total_fea.npy), or a faiss
-        `.index` file when faiss is importable; the search object is always a device-resident exact index (lib/feature_index.py).
+        `.index` file (IVF*,Flat and Flat files are read natively, lib/faiss_io.py; other types need faiss); the search object is always a device-resident exact index (lib/feature_index.py).
         Errors are printed and turn into "no index", as in the reference."""
         index = big_npy = None
         try:
@@ -75,9 +75,15 @@ class FeatureExtractor:
                 big_npy = np.load(file_index).astype(np.float32)
                 index = self._device_index(big_npy)
             else:
-                import faiss   # noqa: PLC0415 - optional, absent offline
-                fidx = faiss.read_index(file_index)
-                big_npy = fidx.reconstruct_n(0, fidx.ntotal)
+                # the `added_IVF*_Flat_*.index` files RVC users have: the stored vectors in id order are all the conversion needs (what
+                # faiss.read_index + reconstruct_n(0, ntotal) returns); read natively - faiss is optional (lib/faiss_io.py)
+                from .lib.faiss_io import read_index_vectors   # noqa: PLC0415
+                try:
+                    big_npy, _ = read_index_vectors(file_index)
+                except ValueError:
+                    import faiss   # noqa: PLC0415 - other index types (PQ ...): only faiss can decode them
+                    fidx = faiss.read_index(file_index)
+                    big_npy = fidx.reconstruct_n(0, fidx.ntotal)
                 index = self._device_index(big_npy)
         except Exception as e:   # noqa: BLE001 - reference behaviour
             print(f"Could not open Faiss index file for reading. {e}")

@@ -1,4 +1,6 @@
 """GPU: end-to-end VC.pipeline / vc_single on the HIP path against the reference's golden outputs and the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -156,6 +158,16 @@ def test_pipeline_with_index_matches_oracle(models, noise_tape):
     out0 = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
                      file_index="", index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
     assert np.max(np.abs(out0[0].astype(np.int32) - ref.astype(np.int32))) > 10 * LSB
+    # the same index as the FILE users have (`added_IVF*_Flat_*.index`, faiss's on-disk layout): read natively, same audio as the tuple form
+    import tempfile
+    from comfy_rvc_amd.lib.faiss_io import write_ivf_flat
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "added_IVF16_Flat_nprobe_1_test_v2.index")
+        write_ivf_flat(path, big, 16)
+        it = iter(tape)
+        out_f = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
+                          file_index=path, index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
+    assert out_f is not None and np.array_equal(out_f[0], out[0])
 
 
 @pytest.mark.parametrize("variant", ["48k_v2", "40k_v1", "32k_v1", "48k_v1", "32k_v2"])

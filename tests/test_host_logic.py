@@ -195,3 +195,31 @@ def test_crepe_host_decoding_matches_oracle():
         assert np.array_equal(oc.filter_median(pa, 3)[0].numpy(), pc.filter_median(pb, 3))
         assert np.allclose(oc.filter_mean(a, 3)[0].numpy(), pc.filter_mean(b, 3), rtol=1e-6, equal_nan=True)
     assert len(set(np.round(b))) > 50                               # the ridge case really moves across bins
+
+
+def test_faiss_ivf_flat_reader_roundtrip(tmp_path):
+    """lib/faiss_io.py: an IVF{n},Flat file written in faiss's on-disk layout (full and sparse list-size tables, empty lists, ids in list
+    order) comes back as big_npy in id order - what faiss.read_index + reconstruct_n(0, ntotal) gives the reference (pitch_extraction.py:52-73)."""
+    import struct
+    from comfy_rvc_amd.lib import faiss_io as F
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((700, 48)).astype(np.float32)
+    for nlist, sparse in ((16, False), (64, True), (5, None)):
+        p = str(tmp_path / f"added_IVF{nlist}_Flat_nprobe_1_v2.index")
+        cent = x[rng.choice(700, nlist, replace=False)] if sparse is not True else np.concatenate([x[:8], 100 + rng.standard_normal((nlist - 8, 48)).astype(np.float32)])
+        assign = F.write_ivf_flat(p, x, nlist, centroids=cent, sparse=sparse)
+        v, info = F.read_index_vectors(p)
+        assert v.dtype == np.float32 and np.array_equal(v, x)
+        assert info["kind"] == "ivf_flat" and info["nlist"] == nlist and info["ntotal"] == 700 and info["d"] == 48 and info["metric"] == 1
+        assert np.array_equal(info["list_of"], assign) and np.array_equal(info["centroids"], cent)
+        raw = open(p, "rb").read()
+        assert raw[:4] == b"IwFl" and struct.unpack_from("<i", raw, 4)[0] == 48 and struct.unpack_from("<q", raw, 8)[0] == 700
+        assert (b"sprs" in raw) == (sparse is True)
+    # a flat file, a truncated file, an unsupported type
+    flat = b"IxF2" + struct.pack("<iqqqBi", 48, 700, 1 << 20, 1 << 20, 1, 1) + struct.pack("<Q", 700 * 48) + x.tobytes()
+    v, info = F.read_index_vectors(flat)
+    assert np.array_equal(v, x) and info["kind"] == "flat"
+    with pytest.raises(ValueError):
+        F.read_index_vectors(raw[:len(raw) // 2])
+    with pytest.raises(ValueError, match="IwPQ"):
+        F.read_index_vectors(b"IwPQ" + raw[4:])
