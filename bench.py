@@ -345,12 +345,14 @@ def main():
 
     # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
     sync()
-    t1 = time.perf_counter()
-    for _ in range(3):
+    alone = []
+    for _ in range(9):
+        t1 = time.perf_counter()
         step()
-    if use_gpu:
-        torch.cuda.synchronize()
-    alone_ms = (time.perf_counter() - t1) / 3 * 1e3
+        if use_gpu:
+            torch.cuda.synchronize()
+        alone.append(time.perf_counter() - t1)
+    alone_ms = sorted(alone)[len(alone) // 2] * 1e3          # median of 9
     sync()
 
     roofline = None

@@ -110,7 +110,7 @@ SIGNATURES = {
     "rvc_index_search": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "rvc_index_blend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rvc_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                             c_void_p, c_int]),
+                             c_void_p, c_int, c_void_p, c_void_p]),
     "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),
     "rvc_op_gemm_split": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float] + [c_int] * 5),
     "rvc_op_conv2d_split": (c_int, [c_void_p] * 7 + [c_int] * 9),

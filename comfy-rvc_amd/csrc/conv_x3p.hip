@@ -32,6 +32,11 @@ constexpr int x3p_cv(int t, int KT, int XS) {
 }
 constexpr int x3p_cvsum(int t0, int t1, int KT, int XS) { int n = 0; for (int t = t0; t <= t1; ++t) n += x3p_cv(t, KT, XS); return n; }
 
+#ifdef RVC_X3P_SETPRIO
+#define X3P_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define X3P_PRIO(n) do {} while (0)
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -298,11 +303,13 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- group 1: hi_w * lo_x
+      X3P_PRIO(1);
 #pragma unroll
       for (int am = 0; am < AM; ++am)
 #pragma unroll
         for (int an = 0; an < AN; ++an)
           acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
+      X3P_PRIO(0);
       // ---- input of chunk c + 1: slot s is converted and stored during tap (s * KT) / XS, its registers refilled with chunk c + 2
       if constexpr (!XSPLIT) {
         auto stage = [&](auto sc) {
@@ -325,11 +332,13 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- group 2: lo_w * hi_x
+      X3P_PRIO(1);
 #pragma unroll
       for (int am = 0; am < AM; ++am)
 #pragma unroll
         for (int an = 0; an < AN; ++an)
           acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+      X3P_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       // ---- next unit: its weight slot (and, at a chunk boundary, its input buffer) published; the slot of unit u - 1 refilled
       constexpr bool last_tap = T + 1 == KT;
@@ -371,11 +380,13 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3p_kernel(c
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- group 3: hi_w * hi_x
+      X3P_PRIO(1);
 #pragma unroll
       for (int am = 0; am < AM; ++am)
 #pragma unroll
         for (int an = 0; an < AN; ++an)
           acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+      X3P_PRIO(0);
 #pragma unroll
       for (int am = 0; am < AM; ++am) ah[am] = ahn[am];
     };

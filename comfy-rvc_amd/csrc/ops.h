@@ -42,7 +42,8 @@ void sine_source(hipStream_t s, const float* f0, const float* noise, float* har,
                  int T, int upp, float sr, float lw, float lb, float* phase_out = nullptr);
 
 void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
-                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch);
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch, const double* sos = nullptr,
+                const double* sos_zi = nullptr);      // sos [3][6] + sosfilt_zi [3][2]: block-propagated cascade evaluation (ops.hip)
 void postprocess(hipStream_t s, float* x, long long N, const double* rms1, int n1, int sr2, float rate, short* out, float* rms2, unsigned* maxbits);
 
 // padded 2-D split-resident images (split2d.hip): level changes of RMVPE's U-Net in the layout conv_x3s.hip convolves

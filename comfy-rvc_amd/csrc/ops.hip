@@ -1022,6 +1022,11 @@ struct IirArgs {
   double* yr;                     // forward output, time-reversed [Np]: yr[N - 1 - j] = y_fwd[j]
   double* filt;                   // final output [n]
   int L, W, nchunks;
+  // block-propagated evaluation (iir_block_kernel) of the SAME filter as a cascade of second-order sections: sos[k] = {b0, b1, b2, 1, a1, a2},
+  // state 2 per section; M = state transition over one block of L samples; zero-state final states; true initial states; zis = sosfilt_zi
+  double sos[3][6], zis[6];
+  double M[6 * 6], Mg[6 * 6];       // state transition over one block / over the g blocks a lane of the scan owns
+  double* Z0; double* Zin; int nb;
 };
 
 // odd extension, evaluated in the input's own precision like scipy's odd_ext; zero fill up to Np
@@ -1098,6 +1103,159 @@ __global__ void iir_chunk_kernel(const IirArgs p) {
   }
 }
 
+// ---- the same filter, block-propagated (round 3).  The overlap-discard kernel above runs W + L = 5632 recurrence steps per 512 outputs and
+// walks its window with per-lane strided loads (one 64-byte group in flight): 330 us per direction, latency-bound, at the very start of
+// every conversion.  The filter is linear, so the state at a block boundary is  z_{c+1} = Z0_c + M z_c  with Z0_c the final state of block
+// c run from a ZERO state and M the state transition over L samples:
+//   pass 1 (parallel over blocks of L samples): Z0_c;   pass 2 (one thread, nb steps of a 6 x 6 product): the true z_c;
+//   pass 3 (parallel): the block again, from z_c, writing the outputs.
+// That needs a well-conditioned state: in the transfer-function form scipy.signal.filtfilt(b, a) runs (direct form II transposed, 5 states)
+// M has entries of 1e7 that cancel to O(1) - the same ill-conditioning that makes that form amplify float64 rounding 3e8 x - and the
+// propagation loses everything.  So the filter is evaluated as the cascade of its second-order sections (scipy.signal.butter(output="sos"),
+// initial state sosfilt_zi * x[0]: what scipy.signal.sosfiltfilt does; identical to filtfilt(b, a) in exact arithmetic): states and M are
+// O(1), the result is accurate to ~1e-13 and therefore differs from the reference's transfer-function evaluation by THAT evaluation's own
+// rounding noise (~4e-8 of full scale, one float32 ulp of what the networks consume; tests/test_hip_ops.py gates 3e-7).
+// 2 L steps per L outputs, and the samples travel through LDS tiles: 64 blocks x 32 samples are loaded as 256-byte rows (coalesced) and read
+// back one row per lane (row pitch 33 doubles: conflict-free).
+constexpr int kIirTile = 32, kSosN = 6;
+__device__ __forceinline__ double sos_step(const IirArgs& p, double (&z)[kSosN], double x) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double y = fma(p.sos[k][0], x, z[2 * k]);
+    z[2 * k] = fma(-p.sos[k][4], y, fma(p.sos[k][1], x, z[2 * k + 1]));
+    z[2 * k + 1] = fma(-p.sos[k][5], y, p.sos[k][2] * x);
+    x = y;
+  }
+  return x;
+}
+template <int DIR, bool OUT>
+__global__ __launch_bounds__(64) void iir_block_kernel(const IirArgs p) {
+  __shared__ double tile[2][64][kIirTile + 1];
+  __shared__ double ytile[64][kIirTile + 1];
+  const int lane = threadIdx.x;
+  const int c0 = blockIdx.x * 64, c = c0 + lane;
+  const double* __restrict__ src = DIR == 0 ? p.ext : p.yr;
+  const int L = p.L, ntile = L / kIirTile;
+  double z[kSosN];
+#pragma unroll
+  for (int i = 0; i < kSosN; ++i) z[i] = (OUT && c < p.nb) ? p.Zin[(long long)c * kSosN + i] : 0.0;
+  const int lr = lane >> 5, lc = lane & 31;              // loader: two rows of 32 samples per pass
+  auto load_tile = [&](int t, double (&v)[32]) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int row = 2 * k + lr;
+      v[k] = (c0 + row < p.nb) ? src[(long long)(c0 + row) * L + t * kIirTile + lc] : 0.0;
+    }
+  };
+  double v[32];
+  load_tile(0, v);
+  for (int t = 0; t < ntile; ++t) {
+    double (*tl)[kIirTile + 1] = tile[t & 1];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) tl[2 * k + lr][lc] = v[k];
+    if (t + 1 < ntile) load_tile(t + 1, v);                // in flight under this tile's recurrence
+    __syncthreads();
+#pragma unroll 8
+    for (int sidx = 0; sidx < kIirTile; ++sidx) {
+      const double y = sos_step(p, z, tl[lane][sidx]);
+      if (OUT) ytile[lane][sidx] = y;
+    }
+    if (OUT) {
+      __syncthreads();
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {
+        const int row = 2 * k + lr;
+        const long long j = (long long)(c0 + row) * L + t * kIirTile + lc;          // position in the filtered sequence
+        const double y = ytile[row][lc];
+        if (c0 + row < p.nb) {
+          if (DIR == 0) { const long long e = p.N - 1 - j; if (e >= 0) p.yr[e] = y; }             // reversed for the backward pass
+          else { const long long i = p.N - 1 - j - p.padlen; if (i >= 0 && i < p.n) p.filt[i] = y; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!OUT && c < p.nb) {
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) p.Z0[(long long)c * kSosN + i] = z[i];
+  }
+}
+// pass 2: z_0 = sosfilt_zi * x[0], z_{c+1} = Z0_c + M z_c - as a two-level scan in LDS by ONE wave (a thread walking the nb states through
+// global memory took 300 us: one dependent load + store per block): lane l owns the g = ceil(nb / 64) consecutive blocks [l g, l g + g),
+//   (i) runs them from a zero state -> V_l;  (ii) lane 0 chains the 64 groups: z_{l+1} = V_l + Mg z_l with Mg = M^g (host, by the recurrence
+//   itself over g L zero samples);  (iii) every lane runs its blocks again from its true initial state, leaving z_c where Z0_c was.
+// The nb x 6 states live in LDS (lane pitch g 6 + 1 doubles: conflict-free), read and written back with coalesced sweeps.
+template <int DIR>
+__global__ __launch_bounds__(256) void iir_scan_kernel(const IirArgs p) {
+  extern __shared__ double zs[];                           // [64][g * 6 + 1] | V [64][7]
+  const int lane = threadIdx.x;                            // 256 threads move the states, the first 64 scan
+  const int nb = p.nb, g = (nb + 63) / 64, pitch = g * kSosN + 1;
+  double* V = zs + 64 * pitch;
+  for (int c = lane; c < nb; c += 256) {
+    const double2* q = reinterpret_cast<const double2*>(p.Z0 + (long long)c * kSosN);
+    const double2 a = q[0], b = q[1], d = q[2];
+    double* dst = zs + (c / g) * pitch + (c % g) * kSosN;
+    dst[0] = a.x; dst[1] = a.y; dst[2] = b.x; dst[3] = b.y; dst[4] = d.x; dst[5] = d.y;
+  }
+  __syncthreads();
+  auto advance = [&](double (&z)[kSosN], const double* z0, const double* Mx) {
+    double zn[kSosN];
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) {
+      double a = z0[i];
+#pragma unroll
+      for (int jj = 0; jj < kSosN; ++jj) a = fma(Mx[i * kSosN + jj], z[jj], a);
+      zn[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) z[i] = zn[i];
+  };
+  double* mine = zs + (lane & 63) * pitch;
+  double Mr[kSosN * kSosN];                                // (register copy: indexing the kernel argument re-loads it through the scalar cache every step)
+#pragma unroll
+  for (int i = 0; i < kSosN * kSosN; ++i) Mr[i] = p.M[i];
+  if (lane < 64) {
+    double z[kSosN] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < g; ++i) if (lane * g + i < nb) advance(z, mine + i * kSosN, Mr);
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) V[lane * 7 + i] = z[i];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const double x0 = (DIR == 0 ? p.ext : p.yr)[0];
+    double z[kSosN], Mgr[kSosN * kSosN];
+#pragma unroll
+    for (int i = 0; i < kSosN * kSosN; ++i) Mgr[i] = p.Mg[i];
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) z[i] = p.zis[i] * x0;
+    for (int l = 0; l < 64; ++l) {
+      double v[kSosN];
+#pragma unroll
+      for (int i = 0; i < kSosN; ++i) { v[i] = V[l * 7 + i]; V[l * 7 + i] = z[i]; }      // V_l is replaced by the group's initial state
+      advance(z, v, Mgr);
+    }
+  }
+  __syncthreads();
+  if (lane < 64) {
+    double z[kSosN];
+#pragma unroll
+    for (int i = 0; i < kSosN; ++i) z[i] = V[lane * 7 + i];
+    for (int i = 0; i < g; ++i) {
+      if (lane * g + i >= nb) break;
+      double z0[kSosN];
+#pragma unroll
+      for (int k = 0; k < kSosN; ++k) { z0[k] = mine[i * kSosN + k]; mine[i * kSosN + k] = z[k]; }
+      advance(z, z0, Mr);
+    }
+  }
+  __syncthreads();
+  for (int c = lane; c < nb; c += 256) {
+    const double* src = zs + (c / g) * pitch + (c % g) * kSosN;
+    double2* q = reinterpret_cast<double2*>(p.Zin + (long long)c * kSosN);
+    q[0] = double2{src[0], src[1]}; q[1] = double2{src[2], src[3]}; q[2] = double2{src[4], src[5]};
+  }
+}
+
 // np.pad(x, t_pad, mode="reflect") + float32 cast; pads wider than the signal reflect repeatedly (period 2 (n - 1)), as numpy does
 // for clips shorter than the 1 s pad
 __global__ void pad_reflect_f32_kernel(const double* __restrict__ x, long long n, int t_pad, float* __restrict__ out) {
@@ -1126,17 +1284,66 @@ __global__ __launch_bounds__(256) void rms_frames_f64_kernel(const double* __res
 }
 
 void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
-                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* 2 * (n + 2 padlen + 8) */) {
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* 2 * (n + 2 padlen + 512) */,
+                const double* sos, const double* sos_zi) {
   IirArgs p{};
   for (int i = 0; i <= kIirOrder; ++i) { p.b[i] = b[i] / a[0]; p.a[i] = a[i] / a[0]; }
   for (int i = 0; i < kIirOrder; ++i) p.zi[i] = zi[i];
-  p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen; p.Np = (p.N + 7) & ~7LL;
-  p.L = 512; p.W = 5120; p.nchunks = (int)((p.Np + p.L - 1) / p.L);
+  static const bool blocked_env = !(getenv("RVC_IIR_BLOCKED") && atoi(getenv("RVC_IIR_BLOCKED")) == 0);
+  const bool blocked = blocked_env && sos != nullptr && sos_zi != nullptr;
+  p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen;
+  p.L = 512; p.W = 5120;
+  static const int blk_env = getenv("RVC_IIR_L") ? atoi(getenv("RVC_IIR_L")) : 256;      // block length of the propagated evaluation (power of two >= 32)
+  if (blocked) { p.L = blk_env; while ((p.N + p.L - 1) / p.L > 3072) p.L *= 2; }                  // the scan keeps all block states in LDS (6 doubles each)
+  p.Np = blocked ? ((p.N + p.L - 1) / p.L) * p.L : (p.N + 7) & ~7LL;          // whole blocks (zero-filled behind N)
+  p.nchunks = (int)((p.Np + p.L - 1) / p.L); p.nb = p.nchunks;
   p.ext = scratch; p.yr = scratch + p.Np; p.filt = filt;
   hipLaunchKernelGGL(iir_extend_kernel, dim3((unsigned)((p.Np + 255) / 256)), dim3(256), 0, s, p);
-  const dim3 grid((p.nchunks + 63) / 64), blk(64);
-  hipLaunchKernelGGL((iir_chunk_kernel<0>), grid, blk, 0, s, p);
-  hipLaunchKernelGGL((iir_chunk_kernel<1>), grid, blk, 0, s, p);
+  if (blocked) {
+    for (int k = 0; k < 3; ++k) {
+      RVC_REQUIRE(sos[k * 6 + 3] == 1.0, "sos sections must be normalised (a0 = 1)");
+      for (int i = 0; i < 6; ++i) p.sos[k][i] = sos[k * 6 + i];
+    }
+    for (int i = 0; i < 6; ++i) p.zis[i] = sos_zi[i];
+    // M / Mg: column j = the cascade's state after L (g L) zero-input samples from the unit state e_j (the recurrence itself, float64: O(1) entries)
+    const int gsz = (p.nb + 63) / 64;
+    auto transition = [&](long long steps, double* out) {
+      for (int j = 0; j < 6; ++j) {
+        double z[6] = {0, 0, 0, 0, 0, 0}; z[j] = 1.0;
+        for (long long t = 0; t < steps; ++t) {
+          double xx = 0.0;
+          for (int k = 0; k < 3; ++k) {
+            const double y = std::fma(p.sos[k][0], xx, z[2 * k]);
+            z[2 * k] = std::fma(-p.sos[k][4], y, std::fma(p.sos[k][1], xx, z[2 * k + 1]));
+            z[2 * k + 1] = std::fma(-p.sos[k][5], y, p.sos[k][2] * xx);
+            xx = y;
+          }
+        }
+        for (int i = 0; i < 6; ++i) out[i * 6 + j] = z[i];
+      }
+    };
+    transition(p.L, p.M);
+    transition((long long)p.L * gsz, p.Mg);
+    double* st = (double*)stream_scratch(s, 8, (size_t)2 * p.nb * 6 * sizeof(double));
+    p.Z0 = st; p.Zin = st + (size_t)p.nb * 6;
+    const dim3 g((unsigned)((p.nb + 63) / 64));
+    hipLaunchKernelGGL((iir_block_kernel<0, false>), g, dim3(64), 0, s, p);
+    const size_t scan_lds = ((size_t)64 * (gsz * 6 + 1) + 64 * 7) * sizeof(double);
+    static std::once_flag scan_once;
+    std::call_once(scan_once, [&] {
+      RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(iir_scan_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(iir_scan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    });
+    hipLaunchKernelGGL((iir_scan_kernel<0>), dim3(1), dim3(256), scan_lds, s, p);
+    hipLaunchKernelGGL((iir_block_kernel<0, true>), g, dim3(64), 0, s, p);
+    hipLaunchKernelGGL((iir_block_kernel<1, false>), g, dim3(64), 0, s, p);
+    hipLaunchKernelGGL((iir_scan_kernel<1>), dim3(1), dim3(256), scan_lds, s, p);
+    hipLaunchKernelGGL((iir_block_kernel<1, true>), g, dim3(64), 0, s, p);
+  } else {
+    const dim3 grid((p.nchunks + 63) / 64), blk(64);
+    hipLaunchKernelGGL((iir_chunk_kernel<0>), grid, blk, 0, s, p);
+    hipLaunchKernelGGL((iir_chunk_kernel<1>), grid, blk, 0, s, p);
+  }
   if (padded) {
     const long long np = n + 2LL * t_pad;
     hipLaunchKernelGGL(pad_reflect_f32_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, filt, n, t_pad, padded);

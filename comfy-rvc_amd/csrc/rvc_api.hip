@@ -311,14 +311,15 @@ int rvc_index_blend(rvc_index* h, void* stream, const float* feats_cm, const int
 }
 
 int rvc_preprocess(void* stream, const void* audio, int is_f64, int64_t n, const double* b6, const double* a6, const double* zi5, int t_pad,
-                   double* filt, float* padded, double* rms1, int n1) {
+                   double* filt, float* padded, double* rms1, int n1, const double* sos18, const double* sos_zi6) {
   RVC_TRY
   RVC_REQUIRE(audio && b6 && a6 && zi5 && filt && n > 3 * 6 + 1 && t_pad >= 0, "bad argument");
   RVC_REQUIRE(a6[0] != 0.0, "a[0] must be non-zero");
   RVC_REQUIRE(rms1 == nullptr || n1 == (int)(n / 8000) + 1, "rms1 must hold n / 8000 + 1 frames");
   hipStream_t st = (hipStream_t)stream;
-  double* scratch = (double*)stream_scratch(st, 2, (size_t)(2 * (n + 36 + 8)) * sizeof(double));
-  preprocess(st, audio, is_f64, n, b6, a6, zi5, t_pad, filt, padded, rms1, n1, 16000, 8000, scratch);
+  double* scratch = (double*)stream_scratch(st, 2, (size_t)(2 * (n + 36 + 65536)) * sizeof(double));      // ext | yr, each rounded up to whole blocks (512 samples; longer for clips beyond 98 s)
+  RVC_REQUIRE((sos18 == nullptr) == (sos_zi6 == nullptr), "sos and its initial state come together");
+  preprocess(st, audio, is_f64, n, b6, a6, zi5, t_pad, filt, padded, rms1, n1, 16000, 8000, scratch, sos18, sos_zi6);
   check_launch();
   RVC_CATCH
 }

@@ -29,6 +29,9 @@ from .pitch_extraction import FeatureExtractor
 bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)   # 48 Hz zero-phase high-pass (reference :21)
 _BH, _AH = np.ascontiguousarray(bh, dtype=np.float64), np.ascontiguousarray(ah, dtype=np.float64)
 _ZI = np.ascontiguousarray(signal.lfilter_zi(bh, ah), dtype=np.float64)   # filtfilt's initial conditions (device path)
+# the same Butterworth design as second-order sections: the device evaluates the filter block-propagated in this (well-conditioned) form
+_SOS = np.ascontiguousarray(signal.butter(N=5, Wn=48, btype="high", fs=16000, output="sos"), dtype=np.float64)      # [3][6], a0 = 1
+_SOS_ZI = np.ascontiguousarray(signal.sosfilt_zi(_SOS), dtype=np.float64)
 
 
 class VC(FeatureExtractor):
@@ -213,7 +216,7 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     with torch.cuda.device(dev):
         _lib.check(_lib.lib.rvc_preprocess(_lib.current_stream(), _lib.ptr(raw_d), 1 if audio.dtype == np.float64 else 0, n, _lib.ptr(_BH),
                                            _lib.ptr(_AH), _lib.ptr(_ZI), int(self.t_pad), _lib.ptr(filt_d), _lib.ptr(a_dev), _lib.ptr(rms1),
-                                           0 if rms1 is None else rms1.numel()))
+                                           0 if rms1 is None else rms1.numel(), _lib.ptr(_SOS), _lib.ptr(_SOS_ZI)))
     opt_ts = self._cut_points(filt_d.cpu().numpy()) if n + self.window > self.t_max else []
     bounds, s0 = [], 0
     for t in opt_ts:

@@ -204,9 +204,15 @@ int rvc_index_blend(rvc_index* h, void* stream, const float* feats_cm_dev, const
  * padding by t_pad with the float32 cast the networks consume (:141) and the RMS frames of the filtered input that change_rms
  * uses (lib/model_utils.py:45; frame 1 s, hop 0.5 s at 16 kHz, n1 = n / 8000 + 1; may be NULL).
  * audio_dev [n] float32 (is_f64 = 0) or float64 (1); b6 / a6 / zi5 are HOST arrays (butter coefficients, lfilter_zi);
- * filt_dev [n] float64 = filtered signal, padded_dev [n + 2 t_pad] float32 (may be NULL). */
+ * filt_dev [n] float64 = filtered signal, padded_dev [n + 2 t_pad] float32 (may be NULL).
+ * sos18_host / sos_zi6_host (both or neither, HOST arrays): the SAME filter as three second-order sections [3][6] = {b0, b1, b2, 1, a1, a2}
+ * (scipy.signal.butter(..., output="sos"); a first-order section has b2 = a2 = 0) and scipy.signal.sosfilt_zi [3][2].  With them the filter
+ * runs block-propagated in the cascade form (3 launches per direction of 2 x 512 steps per thread instead of 5632: ~20 x less work at the
+ * start of every conversion); equal to filtfilt(b, a) in exact arithmetic, different from scipy's transfer-function evaluation by that
+ * evaluation's float64 rounding noise (~4e-8 of full scale).  Without them: the overlap-discard transfer-function kernels. */
 int rvc_preprocess(void* stream, const void* audio_dev, int is_f64, int64_t n, const double* b6_host, const double* a6_host,
-                   const double* zi5_host, int t_pad, double* filt_dev, float* padded_dev, double* rms1_dev, int n1);
+                   const double* zi5_host, int t_pad, double* filt_dev, float* padded_dev, double* rms1_dev, int n1,
+                   const double* sos18_host, const double* sos_zi6_host);
 /* Output post-processing of VC.pipeline on the device: change_rms (lib/model_utils.py:39-57; skipped when rms_mix_rate >= 1 or
  * rms1_dev == NULL) followed by peak normalisation to int16 (vc_infer_pipeline.py:188-189).  wav_dev [N] float32 is modified in
  * place; rms1_dev = RMS frames of the 16 kHz input (float64 [n1], hop 0.5 s); sr2 = output rate. */

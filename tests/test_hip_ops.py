@@ -431,10 +431,18 @@ def test_preprocess_filtfilt_pad_rms(L, n, dtype, t_pad):
     padded = torch.empty(n + 2 * t_pad, dtype=torch.float32, device="cuda")
     n1 = n // 8000 + 1
     rms1 = torch.empty(n1, dtype=torch.float64, device="cuda")
+    from comfy_rvc_amd.vc_infer_pipeline import _SOS, _SOS_ZI
     L.check(L.lib.rvc_preprocess(None, L.ptr(xd), int(dtype == np.float64), n, L.ptr(_BH), L.ptr(_AH), L.ptr(_ZI), t_pad, L.ptr(filt),
-                                 L.ptr(padded), L.ptr(rms1), n1))
+                                 L.ptr(padded), L.ptr(rms1), n1, L.ptr(_SOS), L.ptr(_SOS_ZI)))
     torch.cuda.synchronize()
     got = filt.cpu().numpy()
+    # the transfer-function form (overlap-discard kernels, no sections given) is still there and agrees with both
+    filt_tf = torch.empty(n, dtype=torch.float64, device="cuda")
+    L.check(L.lib.rvc_preprocess(None, L.ptr(xd), int(dtype == np.float64), n, L.ptr(_BH), L.ptr(_AH), L.ptr(_ZI), t_pad, L.ptr(filt_tf),
+                                 None, None, 0, None, None))
+    torch.cuda.synchronize()
+    assert np.abs(filt_tf.cpu().numpy() - ref).max() <= 3e-7 * np.abs(ref).max()
+    assert np.abs(got - signal.sosfiltfilt(_SOS, x, padtype="odd", padlen=18)).max() <= 1e-11 * np.abs(ref).max()     # the cascade itself: float64-exact
     assert np.abs(got - ref).max() <= 3e-7 * np.abs(ref).max()
     ref_pad = np.pad(ref, (t_pad, t_pad), mode="reflect").astype(np.float32)
     gp = padded.cpu().numpy()
