@@ -487,6 +487,28 @@ static thread_local bool g_x3_default = false;
 static thread_local int g_precision = 1;      // 0: fp32 kernel only, 1: layers initialised under conv_x3_set_default(true), 2: every eligible layer
 bool conv_x3_set_default(bool on) { const bool prev = g_x3_default; g_x3_default = on; return prev; }
 int conv_set_precision(int mode) { const int prev = g_precision; if (mode >= 0) g_precision = mode; return prev; }
+// grouped layers (HuBERT's positional convolution: 16 groups of 48 -> 48 channels, k = 128): one image per group, rows padded to 64 (the
+// split-resident kernel's 64-row tile, conv_x3s.hip) - [group][chunk][tap][hi | lo][half][CoPx rows][8 ch]
+static void pack_x3_grouped(ConvLayer& L, const float* w /*[groups * Cog][Cig][k]*/, int groups, int Cog, int Cig, int k) {
+  L.CoPx = (Cog + 63) & ~63;
+  const int nch = Cig / 16;
+  L.wxBatch = (long long)nch * k * 2 * L.CoPx * 16;        // uint16 elements per group
+  std::vector<uint16_t> P((size_t)groups * L.wxBatch, 0);
+  for (int g = 0; g < groups; ++g)
+    for (int co = 0; co < Cog; ++co)
+      for (int ci = 0; ci < Cig; ++ci)
+        for (int u = 0; u < k; ++u) {
+          const float v = w[((size_t)(g * Cog + co) * Cig + ci) * k + u];
+          const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+          const int chunk = ci >> 4, c16 = ci & 15;
+          const size_t base = (((size_t)chunk * k + u) * 2 * 2 + (size_t)(c16 >> 3)) * L.CoPx + co;
+          uint16_t* Q = P.data() + (size_t)g * L.wxBatch;
+          Q[base * 8 + (c16 & 7)] = hi;
+          Q[(base + 2 * (size_t)L.CoPx) * 8 + (c16 & 7)] = lo;
+        }
+  RVC_HIP_CHECK(hipMalloc(&L.Wx_, P.size() * sizeof(uint16_t)));
+  RVC_HIP_CHECK(hipMemcpy(L.Wx_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+}
 static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
   L.CoPx = (Co + 127) & ~127;
   const int nch = Ci / 16;
@@ -531,6 +553,8 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
         }
   upload_layer(L, P, bias, Co);
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups > 1 && stride == 1 && Cig % 16 == 0 && Cog % 16 == 0 && dil >= 1)
+    pack_x3_grouped(L, w, groups, Cog, Cig, k);            // only conv_x3s_run reads it (the tiled bf16x3 kernels refuse groups > 1)
 }
 
 // ConvTranspose1d as u polyphase stride-1 convolutions: GEMM row co * u + r = output channel co, phase r, i.e. the PHASE is the fastest

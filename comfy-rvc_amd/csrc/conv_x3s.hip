@@ -30,6 +30,9 @@ struct GemmSArgs {
   int Co, T, nunits;                        // rows stored, columns, units of the reduction: (16-channel chunk, tap), tap fastest
   int ktaps, margin;                        // taps per chunk; image rows in front of position 0 (>= the largest |tap offset|, kept zero by the producers)
   int toff[16];                             // tap -> position offset (1-D: tap * dil - pad; padded 2-D: dh * padw + dw)
+  int groups, co_g, rows_pg, cig_chunks;    // grouped convolution: groups, output rows per group, row tiles per group, input chunks per group
+  unsigned wg_bytes;                        // weight image bytes per group (groups > 1)
+  int tdil, tpad;                           // 1-D taps beyond the table (ktaps > 16): offset = tap * tdil - tpad
   int padw; unsigned padmagic;              // padded 2-D images: row pitch (W + 2) - columns 0 and padw - 1 of every row are written as zeros - and ceil(2^32 / padw)
   const float* bias; const float* R; long long ldR;
   float* Y; long long ldY;                  // fp32 output [Co][ldY] or null
@@ -81,24 +84,26 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const int S = p.ksplit;
   const int tile = (int)(bid / (unsigned)S), ks = (int)(bid - (unsigned)tile * (unsigned)S);
   const int tile_y = tile / p.gx, tile_x = tile - tile_y * p.gx;
-  const int co0 = tile_y * BM, n0 = tile_x * BN;
+  const int grp = tile_y / p.rows_pg;                       // (1 group: rows_pg = gy, grp = 0)
+  const int co0 = (tile_y - grp * p.rows_pg) * BM, n0 = tile_x * BN;      // first row INSIDE the group
+  const int row0 = grp * p.co_g, CoG = p.co_g;              // global row = row0 + m for m < CoG
   const int U = p.nunits / S, u0 = ks * U;
 
   // ---- accumulators: slice 0 starts from bias (+ residual unless an activation sits between the sum and the residual)
   const bool r_pre = p.R != nullptr && !(p.act_before_res && p.act != ACT_NONE);
   f32x16 acc[AM][AN];
   if (ks == 0 && (p.bias != nullptr || r_pre)) {
-    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(r_pre ? p.R : (const float*)p.Wx, r_pre ? (unsigned)p.Co * (unsigned)p.ldR * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(r_pre ? p.R : (const float*)p.Wx, r_pre ? (unsigned)(p.groups * p.co_g) * (unsigned)p.ldR * 4u : 0u);
 #pragma unroll
     for (int am = 0; am < AM; ++am)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float bv = (p.bias && m < p.Co) ? p.bias[m] : 0.f;
+        const float bv = (p.bias && m < CoG) ? p.bias[row0 + m] : 0.f;
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
           const int n = n0 + (wn * AN + an) * 32 + li;
-          acc[am][an][r] = buf_load(rrs, (r_pre && m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB) + bv;
+          acc[am][an][r] = buf_load(rrs, (r_pre && m < CoG && n < p.T) ? ((unsigned)(row0 + m) * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB) + bv;
         }
       }
   } else {
@@ -133,7 +138,9 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const int KT = p.ktaps;
   const int wstep = p.CoPx * 64, cstep = (int)(p.xsTp * 64);
   int tap = u0 % KT;
-  int soff_a = u0 * wstep, soff_c = (u0 / KT) * cstep, soff_b = soff_c + (p.margin + p.toff[tap]) * 16;
+  const bool arith = KT > 16;                                // long 1-D kernels: offsets by formula instead of the table
+  auto tap_off = [&](int t) { return arith ? t * p.tdil - p.tpad : p.toff[t & 15]; };
+  int soff_a = (int)((unsigned)grp * p.wg_bytes) + u0 * wstep, soff_c = (grp * p.cig_chunks + u0 / KT) * cstep, soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
   int slw = 0, uw = 0;
   auto issue = [&]() {                                       // next unit into slot slw; past the end the last unit is requested again
     unsigned char* base = smem3s + slw * slot;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       if (KT > 1) {
         ++tap;
         if (tap == KT) { tap = 0; soff_c += cstep; }
-        soff_b = soff_c + (p.margin + p.toff[tap]) * 16;
+        soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
       } else {
         soff_b += cstep;
       }
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
         for (int r = 0; r < 16; ++r) { const float v = acc[am][an][r]; acc[am][an][r] = fmaxf(v, v * slope); }
   }
   if (p.R != nullptr && !r_pre) {                              // act(W x + b) + R: the residual after the activation (one batch of loads per accumulator)
-    const __amdgpu_buffer_rsrc_t rrs2 = make_rsrc(p.R, (unsigned)p.Co * (unsigned)p.ldR * 4u);
+    const __amdgpu_buffer_rsrc_t rrs2 = make_rsrc(p.R, (unsigned)(p.groups * p.co_g) * (unsigned)p.ldR * 4u);
 #pragma unroll
     for (int am = 0; am < AM; ++am)
 #pragma unroll
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          rv[r] = buf_load(rrs2, (m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB);
+          rv[r] = buf_load(rrs2, (m < CoG && n < p.T) ? ((unsigned)(row0 + m) * (unsigned)p.ldR + (unsigned)n) * 4u : kOOB);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[am][an][r] += rv[r];
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
     }
   }
   if (p.Y) {
-    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)p.Co * (unsigned)p.ldY * 4u);
+    const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)(p.groups * p.co_g) * (unsigned)p.ldY * 4u);
 #pragma unroll
     for (int am = 0; am < AM; ++am)
 #pragma unroll
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
           const int n = n0 + (wn * AN + an) * 32 + li;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), yrs, (int)((m < p.Co && n < p.T) ? ((unsigned)m * (unsigned)p.ldY + (unsigned)n) * 4u : kOOB), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[am][an][r]), yrs, (int)((m < CoG && n < p.T) ? ((unsigned)(row0 + m) * (unsigned)p.ldY + (unsigned)n) * 4u : kOOB), 0, 0);
         }
       }
   }
@@ -365,8 +372,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
             const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
             hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
           }
-          if (n < p.T && mb + 16 * g2 < p.Co) {
-            const long long chunk = (mb >> 4) + g2;
+          if (n < p.T && mb + 16 * g2 < CoG) {
+            const long long chunk = ((row0 + mb) >> 4) + g2;
             unsigned char* row = p.Ys + ((chunk * 4 + lh) * p.ysTp + pos) * 16;
             *reinterpret_cast<u32x4*>(row) = hi;
             *reinterpret_cast<u32x4*>(row + p.ysTp * 32) = lo;
@@ -433,19 +440,20 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
 // barriers and operand reads), tiles as large as that allows (L2 -> LDS bytes per MFMA fall with the tile), the deep reductions cut along K.
 static thread_local int t_force_s = 0, t_force_am = 0, t_force_an = 0;
 void conv_x3s_force(int ksplit, int am, int an) { t_force_s = ksplit; t_force_am = am; t_force_an = an; }
-static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S) {
+static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int groups = 1) {
   static const int f_am = getenv("RVC_X3S_AM") ? atoi(getenv("RVC_X3S_AM")) : 0, f_an = getenv("RVC_X3S_AN") ? atoi(getenv("RVC_X3S_AN")) : 0;
   static const int f_s = getenv("RVC_X3S_SPLIT") ? atoi(getenv("RVC_X3S_SPLIT")) : 0;
   static const int target = getenv("RVC_X3S_BLK") ? atoi(getenv("RVC_X3S_BLK")) : 440;
-  auto tiles = [&](int am, int an) { return (long long)((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
+  auto tiles = [&](int am, int an) { return (long long)groups * ((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
   // measured on MI355X at N = 1599 (tools/bench_gemm.py, profiles/r3b_bench_gemm.txt): 768 -> 3072 128 x 64 35 us (64 x 128 the same, 128 x 128 38),
   // 768 -> 2304 128 x 64 28 us, 768 -> 768 64 x 64 16.3 us un-split (17.6 split in two), 3072 -> 768 64 x 64 split in two 37.8 us (128 x 64 in three 39.0)
   AM = 2; AN = 2;
   if (tiles(AM, AN) < target) AN = 1;
   if (tiles(AM, AN) < target) AM = 1;
-  if (f_am) AM = f_am;
+  if (groups > 1) AM = 1;                                    // (a group's rows fit one 64-row tile: pack_x3_grouped)
+  if (f_am && groups == 1) AM = f_am;
   if (f_an) AN = f_an;
-  if (t_force_am == 1 || t_force_am == 2) AM = t_force_am;
+  if ((t_force_am == 1 || t_force_am == 2) && groups == 1) AM = t_force_am;
   if (t_force_an == 1 || t_force_an == 2) AN = t_force_an;
   S = 1;
   const long long nt = tiles(AM, AN);
@@ -460,8 +468,9 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S) {
 bool conv_x3s_eligible(const ConvLayer& L) {
   if (!conv_x3_enabled() || L.Wx_ == nullptr || (L.Ci & 15) != 0 || L.Ci * L.ktaps < 32 || L.tconv_u != 0 || L.up2 != 0) return false;
   if (L.mode == 2) return L.ktaps <= 16;                                      // 3 x 3 (or KH x KW) over a padded 2-D image: the caller supplies the geometry
-  return L.mode == 1 && L.stride == 1 && L.groups == 1 && L.k <= 16 && L.pad == (L.k - 1) / 2 * L.dil && (L.k & 1) == 1 &&
-         L.pad <= kSplitMargin;                                               // 1-D "same" convolution, taps as row offsets of the image
+  if (L.mode != 1 || L.stride != 1 || L.pad > kSplitMargin || (L.k - 1) * L.dil - L.pad > kSplitMargin) return false;
+  if (L.groups > 1) return (L.Co & 15) == 0 && (L.CoPx & 63) == 0 && L.CoPx <= 64;        // grouped: one 64-row tile per group (pack_x3_grouped)
+  return L.k <= 16 && L.pad == (L.k - 1) / 2 * L.dil && (L.k & 1) == 1;        // 1-D "same" convolution, taps as row offsets of the image
 }
 
 SplitGeom split_geom_2d(int Wd, int KH, int KW, int PH, int PWL) {
@@ -482,20 +491,22 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   if (!geom) {
     RVC_REQUIRE(L.mode == 1, "conv_x3s_run: a 2-D layer needs its padded-image geometry");
     g1.ktaps = L.k; g1.margin = kSplitMargin; g1.padw = 0;
-    for (int t = 0; t < L.k; ++t) g1.toff[t] = t * L.dil - L.pad;
+    for (int t = 0; t < L.k && t < 16; ++t) g1.toff[t] = t * L.dil - L.pad;      // (longer kernels: the offsets follow tap * dil - pad in the kernel)
     geom = &g1;
   }
   RVC_REQUIRE(geom->ktaps == L.ktaps || (L.mode == 1 && geom->ktaps == L.k), "conv_x3s_run: geometry and layer disagree about the taps");
-  int maxoff = 0;
-  for (int t = 0; t < geom->ktaps; ++t) maxoff = std::max(maxoff, std::abs(geom->toff[t]));
+  int maxoff = L.mode == 1 ? std::max(L.pad, (L.k - 1) * L.dil - L.pad) : 0;
+  for (int t = 0; t < geom->ktaps && t < 16; ++t) maxoff = std::max(maxoff, std::abs(geom->toff[t]));
   RVC_REQUIRE(geom->margin >= maxoff && geom->margin >= kSplitMargin, "conv_x3s_run: image margin smaller than the largest tap offset");
   RVC_REQUIRE(Xs != nullptr && xsTp >= geom->margin + T + 704, "conv_x3s_run: split-resident input image missing or too short (margin + T + 704 rows per plane)");
   RVC_REQUIRE(Y != nullptr || e.ys_out != nullptr, "conv_x3s_run: no output");
   RVC_REQUIRE(e.pre_act == ACT_NONE && !e.accumulate && !e.tout_limit && !e.xs_in, "conv_x3s_run: unsupported epilogue option");
   RVC_REQUIRE(e.act == ACT_NONE || e.act == ACT_LRELU || e.act == ACT_RELU || e.act == ACT_GELU, "conv_x3s_run: activation must be identity / (leaky) ReLU / GELU");
   RVC_REQUIRE(!e.ys_out || (e.ys_tp >= geom->margin + T + 704 && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
-  RVC_REQUIRE((double)L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
-  const double xs_bytes = (double)(L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)(L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0;
+  RVC_REQUIRE((double)L.groups * L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.groups * L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
+  const int G = L.mode == 1 ? L.groups : 1;
+  const double xs_bytes = (double)G * (L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)G * (L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0;
+  RVC_REQUIRE(G == 1 || (!e.ys_out || (L.Co & 15) == 0), "grouped layer: rows per group must be a multiple of 16 for the image output");
   RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
   GemmSArgs a{};
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.Xs = Xs; a.xsTp = xsTp;
@@ -504,13 +515,16 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.ktaps = geom->ktaps; a.margin = geom->margin; a.padw = geom->padw;
   a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
   for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
+  a.tdil = L.mode == 1 ? L.dil : 1; a.tpad = L.mode == 1 ? L.pad : 0;
+  a.groups = G; a.co_g = L.Co; a.cig_chunks = L.Ci / 16; a.wg_bytes = (unsigned)((double)(L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0);
   a.bias = e.bias_override ? e.bias_override : L.bd_; a.R = e.R; a.ldR = e.ldR; a.Y = Y; a.ldY = ldY; a.Ys = e.ys_out; a.ysTp = e.ys_tp;
   a.act = e.act; a.act_slope = e.act_slope; a.act_before_res = e.act_before_res; a.out_scale = e.out_scale;
   int AM, AN, S;
-  x3s_plan(L.Co, T, a.nunits, AM, AN, S);
+  x3s_plan(L.Co, T, a.nunits, AM, AN, S, G);
   const int BM = 64 * AM, BN = 64 * AN;
   RVC_REQUIRE(L.CoPx % BM == 0, "weight image rows are padded to the tile");
-  a.gx = (T + BN - 1) / BN; a.gy = (L.Co + BM - 1) / BM; a.ksplit = S;
+  a.rows_pg = (L.Co + BM - 1) / BM;
+  a.gx = (T + BN - 1) / BN; a.gy = a.rows_pg * G; a.ksplit = S;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
   const unsigned blocks = (unsigned)((long long)a.gx * a.gy * S);
@@ -538,7 +552,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
     // algorithmic bytes: the input image (4 B per element, like fp32), the outputs that are written, the residual, the weights
     const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci * geom->ktaps);
     const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
-    conv_prof_end(tk, s, 2.0 * (double)L.Co * T * L.Ci * geom->ktaps, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
+    conv_prof_end(tk, s, 2.0 * (double)G * L.Co * T * L.Ci * geom->ktaps, 14 + id, bytes * (G > 1 ? (double)G : 1.0), &pa, (long long)blocks, 4 << 4);
   }
 }
 

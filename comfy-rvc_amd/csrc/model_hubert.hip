@@ -18,6 +18,7 @@ struct Hubert {
   Arena arena;
   TensorStore ts;
   bool ready = false;
+  const void* img_base = nullptr; size_t img_bytes = 0; int img_T = -1;   // image of the positional convolution's input: margins known to be zero
   ConvLayer conv[7];
   DevVec gn_g, gn_b, fp_g, fp_b, enc_g, enc_b;
   DevVec w0;            // conv_layers.0 raw [512][10]: the fused conv0 + GroupNorm + GELU kernels evaluate it from the audio
@@ -43,6 +44,7 @@ static void hubert_free(Hubert& H) {
   conv_layer_free(H.proj); conv_layer_free(H.pos); conv_layer_free(H.final_proj);
   for (auto& l : H.layers) { conv_layer_free(l.qk); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
   H.layers.clear();
+  H.img_base = nullptr; H.img_bytes = 0; H.img_T = -1;
 }
 void hubert_destroy(Hubert* H) { if (H) { hubert_free(*H); H->arena.release(); delete H; } }
 
@@ -123,6 +125,21 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   int Tc[8]; Tc[0] = (int)L;
   for (int i = 0; i < 7; ++i) Tc[i + 1] = (Tc[i] - kKern[i]) / kStride[i] + 1;
   const int T = Tc[7];
+  // the positional convolution (k = 128, 16 groups) reads its input as a split-resident image through row offsets -64 .. +63: the margins
+  // of that image are its zero padding, so it lives in a block of its own (first allocation, never aliased) that is zeroed per (layout, T)
+  static const bool x3s_on0 = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  static const bool pos_on = !(getenv("RVC_X3S_POS") && atoi(getenv("RVC_X3S_POS")) == 0);
+  const bool pos_s = x3s_on0 && pos_on && conv_x3_enabled() && conv_x3s_eligible(H->pos) && conv_x3s_eligible(H->proj);
+  unsigned char* hpos_s = nullptr;
+  if (pos_s) {
+    const size_t img0 = A.off;
+    hpos_s = A.alloc<unsigned char>(split_image_bytes(768, T));
+    const size_t ib = A.off - img0;
+    if (!dry && (H->img_base != A.base + img0 || H->img_bytes != ib || H->img_T != T)) {
+      RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, ib, s));
+      H->img_base = A.base + img0; H->img_bytes = ib; H->img_T = T;
+    }
+  }
   // ---- feature encoder
   static const bool fuse0 = !(getenv("RVC_HUBERT_FUSE0") && atoi(getenv("RVC_HUBERT_FUSE0")) == 0);
   float* fr = fuse0 ? nullptr : A.alloc<float>((size_t)10 * Tc[1]);
@@ -167,14 +184,16 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   if (!dry) {
     if (gs) {
       layernorm_c_split(s, feat, H->fp_g.p, H->fp_b.p, nullptr, ln_s, tp, kSplitMargin, 512, T, T, 1e-5f);
-      conv_x3s_run(H->proj, s, ln_s, tp, T, h, T, E0);
+      ConvEpilogue Epj; if (pos_s) { Epj.ys_out = hpos_s; Epj.ys_tp = tp; }
+      conv_x3s_run(H->proj, s, ln_s, tp, T, h, T, Epj);
     } else {
       layernorm_c(s, feat, nullptr, H->fp_g.p, H->fp_b.p, ln, 512, T, T, 1e-5f);
       conv1d_run(H->proj, s, ln, T, T, h, T, E0);
     }
     if (taps && taps->pos_conv) { ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.tout_limit = T; conv1d_run(H->pos, s, h, T, T, taps->pos_conv, T, Ep); }
     ConvEpilogue Ep; Ep.act = ACT_GELU; Ep.act_before_res = 1; Ep.R = h; Ep.ldR = T; Ep.tout_limit = T;
-    conv1d_run(H->pos, s, h, T, T, hb, T, Ep);
+    if (gs && pos_s) { Ep.tout_limit = 0; conv_x3s_run(H->pos, s, hpos_s, tp, T, hb, T, Ep); }      // 16 groups x one 64-row tile, 384 (chunk, tap) units
+    else conv1d_run(H->pos, s, h, T, T, hb, T, Ep);
     if (gs) layernorm_c_split(s, hb, H->enc_g.p, H->enc_b.p, h, hs, tp, kSplitMargin, 768, T, T, 1e-5f);
     else layernorm_c(s, hb, nullptr, H->enc_g.p, H->enc_b.p, h, 768, T, T, 1e-5f);
   }

@@ -377,6 +377,29 @@ int rvc_op_gemm_split(void* stream, const float* x, const float* w, const float*
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_conv1d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int T, int k, int pad,
+                        int dil, int groups, int act, int act_before_res) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && y && Ci > 0 && Co > 0 && T > 0 && k >= 1 && groups >= 1, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, k, 1, pad, dil, groups); }
+  unsigned char* xs = nullptr;
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident kernel");
+    const long long tp = split_image_tp(T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0, split_image_bytes(Ci, T), s));
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    ConvEpilogue e; e.act = act; e.act_slope = 0.1f; e.act_before_res = act_before_res; e.R = res; e.ldR = T;
+    conv_x3s_run(L, s, xs, tp, T, y, T, e);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); conv_layer_free(L); throw; }
+  (void)hipFree(xs);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_conv2d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, float* ysplit_f32, int Ci, int Co,
                         int H, int W, int act, int act_before_res, int ksplit, int am, int an) {
   RVC_TRY

@@ -232,6 +232,11 @@ int rvc_op_conv1d(void* stream, const float* x_dev, const float* w_host, const f
 int rvc_op_gemm_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
                       float* ysplit_f32_dev, int Ci, int Co, int T, int act, float act_slope, int act_before_res, float out_scale, int ksplit,
                       int am, int an, int k, int dil);
+/* General stride-1 Conv1d on the same kernel, grouped and with long kernels (HuBERT's positional convolution, transformers modeling_hubert.py:
+ * 61-106: Conv1d(768, 768, 128, padding 64, groups 16), output cut to T, GELU, + residual): w_host [Co][Ci / groups][k], output length T
+ * (the first T positions), taps are row offsets tap * dil - pad into the zero-margined image. */
+int rvc_op_conv1d_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
+                        int Ci, int Co, int T, int k, int pad, int dil, int groups, int act, int act_before_res);
 /* Conv2d 3 x 3, pad 1 (reference lib/rmvpe.py:233-268 ConvBlockRes convolutions) on the same kernel over PADDED split-resident images (row pitch
  * W + 2, taps as row offsets): x_dev [Ci][H][W] plain fp32 is padded and split on the device, y = act(conv(x) + b) with the residual before
  * or after the activation, returned plain [Co][H][W]; ysplit_f32_dev as above (plain layout). */

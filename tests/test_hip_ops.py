@@ -717,3 +717,29 @@ def test_conv2d_3x3_on_padded_split_images(L, case):
         assert rel_err(ys.cpu().numpy(), ref) < 2e-5
     for sl in (np.s_[:, 0, :], np.s_[:, -1, :], np.s_[:, :, 0], np.s_[:, :, -1]):
         assert rel_err(y.cpu().numpy()[sl], ref[sl]) < 3e-5
+
+
+@pytest.mark.parametrize("case", [(768, 768, 1599, 128, 64, 1, 16, "gelu", True, 1), (768, 768, 77, 128, 64, 1, 16, "gelu", True, 1),
+                                  (192, 96, 333, 9, 4, 1, 2, "none", False, 0), (256, 256, 500, 4, 2, 1, 4, "relu", True, 0)],
+                         ids=["posconv", "posconv_short", "g2_k9", "g4_k4_even"])
+def test_grouped_long_kernel_conv1d_on_split_resident_gemm(L, case):
+    """Grouped stride-1 convolutions with long / even kernels on the split-resident kernel (one 64-row tile per group, tap offsets by
+    formula): HuBERT's positional convolution (768 -> 768, k = 128, padding 64, 16 groups, cut to T, GELU, + residual) against torch float64."""
+    Ci, Co, T, k, pad, dil, groups, act, res, abr = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci // groups, k, generator=g) / np.sqrt(Ci // groups * k)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, T, generator=g) if res else None
+    v = F.conv1d(x.double()[None], w.double(), b.double(), padding=pad, dilation=dil, groups=groups)[0][:, :T]
+    if res and not abr:
+        v = v + r.double()
+    v = _act(v, act, 0.1)
+    if res and abr:
+        v = v + r.double()
+    ref = v.numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    y = torch.full((Co, T), float("nan"), device="cuda")
+    L.check(L.lib.rvc_op_conv1d_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(y),
+                                      Ci, Co, T, k, pad, dil, groups, ACT[act], abr))
+    assert rel_err(y.cpu().numpy(), ref) < 2e-5

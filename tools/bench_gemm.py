@@ -34,4 +34,5 @@ for name, Ci, Co, T, w2d in SHAPES:
                 print(f"{name:24s} {'split-out+gelu' if split_out else 'fp32-out+res  '} {tag:28s} {us.value:8.1f} us {fl / us.value / 1e6:7.1f} TFLOP/s")
                 if am and ks and (best is None or us.value < best[0]):
                     best = (us.value, tag)
-        print(f"{name:24s} best: {best[1]}  {best[0]:.1f} us  {fl / best[0] / 1e6:.1f} TFLOP/s\n")
+        if best:
+            print(f"{name:24s} best: {best[1]}  {best[0]:.1f} us  {fl / best[0] / 1e6:.1f} TFLOP/s\n")

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void dma_kernel(const unsigned char* __restric
 }
 
 int main() {
-  const size_t bytes = 512u << 20;
+  const size_t bytes = (size_t)1536 << 20;
   unsigned char* buf; unsigned* sink; CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&sink, 64)); CK(hipMemset(buf, 1, bytes));
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
@@ -56,17 +56,17 @@ int main() {
     printf("%-10s D %2d  WG/CU %d  span %4d KB %s: %8.1f us  %6.2f TB/s  %6.1f GB/s/CU  %5.1f B/clk/CU @2.1GHz\n", name, D, wgs_per_cu, span >> 10,
            stride ? "private" : "shared ", best * 1e3, tot / best / 1e9, tot / best / 1e6 / cus, tot / (best * 1e-3) / cus / 2.1e9);
   };
-  for (int wg : {1, 2, 3, 4}) {
-    for (long long stride : {0LL, 65536LL}) {
-      run(dma_kernel<2, true>, 2, wg, 16384, stride, "lds-dma");
-      run(dma_kernel<4, true>, 4, wg, 16384, stride, "lds-dma");
-      run(dma_kernel<8, true>, 8, wg, 16384, stride, "lds-dma");
-      run(dma_kernel<16, true>, 16, wg, 16384, stride, "lds-dma");
-      run(dma_kernel<8, false>, 8, wg, 16384, stride, "vgpr-load");
+  // L1-resident (16 KB per workgroup), L2-resident (128 KB / 512 KB per workgroup: 3 per CU x 32 CUs per XCD = 12 / 48 MB per XCD > 4 MB L2 for the
+  // larger one), shared stream (every workgroup walks the SAME 4 MB: one L2 copy per XCD, the GEMM's weight operand)
+  for (int wg : {1, 2, 3}) {
+    for (int span_kb : {16, 128, 512}) {
+      const long long stride = (long long)span_kb << 10;
+      run(dma_kernel<4, true>, 4, wg, span_kb << 10, stride, "lds-dma");
+      run(dma_kernel<16, true>, 16, wg, span_kb << 10, stride, "lds-dma");
+      run(dma_kernel<8, false>, 8, wg, span_kb << 10, stride, "vgpr-load");
     }
+    run(dma_kernel<4, true>, 4, wg, 4 << 20, 0, "lds-dma");
+    run(dma_kernel<16, true>, 16, wg, 4 << 20, 0, "lds-dma");
   }
-  // larger private spans: beyond L2 (MALL-resident)
-  run(dma_kernel<8, true>, 8, 3, 1 << 20, 1 << 20, "lds-dma");
-  run(dma_kernel<16, true>, 16, 3, 1 << 20, 1 << 20, "lds-dma");
   return 0;
 }
