@@ -127,6 +127,9 @@ SIGNATURES = {
     "rvc_conv1d_plan_pair_split_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int]),
     "rvc_conv1d_plan_destroy": (c_int, [c_void_p]),
     "rvc_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "rvc_op_attention_split": (c_int, [c_void_p] * 7 + [c_int, c_int]),
+    "rvc_op_attention_split_rel": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int]),
+    "rvc_op_gemm_split_swapped": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "rvc_op_attention_rel": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),
     "rvc_resample": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),

@@ -41,6 +41,8 @@ struct GemmSArgs {
   int ksplit; float* slabs; unsigned* tickets;
   int gx, gy;                               // column / row tiles
   int xcd_remap;
+  int ymargin;                              // output image: position n lives at row ymargin + n (= margin except for the swapped product)
+  int zero_tail;                            // rows >= Co of the last stored 16-row chunk are written as zeros (swapped product: keys past the end)
 };
 
 // exact-erf GELU (torch F.gelu default), branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. ~1e-7 of the
@@ -347,6 +349,18 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       }
   }
   if (p.Ys) {
+    if (p.zero_tail) {
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = co0 + (wm * AM + am) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= CoG) {
+#pragma unroll
+            for (int an = 0; an < AN; ++an) acc[am][an][r] = 0.f;
+          }
+        }
+    }
     // a lane holds 4 + 4 channels of each 16-channel chunk of its column; v_permlane32_swap trades quads with the lane 32 away so that
     // every lane owns one 16-B row of a half-plane (see ysplit_epilogue, conv_x3_dev.h)
 #pragma unroll
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       for (int an = 0; an < AN; ++an) {
         const int n = n0 + (wn * AN + an) * 32 + li;
         const int mb = co0 + (wm * AM + am) * 32;
-        const long long pos = (long long)n + p.margin;
+        const long long pos = (long long)n + p.ymargin;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
           unsigned hA[2], lA[2], hB[2], lB[2];
@@ -418,12 +432,11 @@ __global__ __launch_bounds__(256) void unsplit_image_kernel(const unsigned char*
   }
 }
 void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp) {
-  RVC_REQUIRE((C & 15) == 0, "split image: channels must be a multiple of 16");
-  hipLaunchKernelGGL(split_image_kernel, dim3((T + 255) / 256, C / 8), dim3(256), 0, s, X, ldX, C, T, img, tp);
+  // (channels past C inside the last 16-channel chunk are written as zeros)
+  hipLaunchKernelGGL(split_image_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, X, ldX, C, T, img, tp);
 }
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY) {
-  RVC_REQUIRE((C & 15) == 0, "split image: channels must be a multiple of 16");
-  hipLaunchKernelGGL(unsplit_image_kernel, dim3((T + 255) / 256, C / 8), dim3(256), 0, s, img, tp, C, T, Y, ldY);
+  hipLaunchKernelGGL(unsplit_image_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, img, tp, C, T, Y, ldY);
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -434,6 +447,14 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+}
+
+static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hipStream_t s) {
+  static const int rs_env = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 4;      // ring depth (experiments: 3 / 4 / 6)
+  if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 2, 6>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
+  else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 1, 6>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
+  else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }
+  else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 1, 6>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
 }
 
 // Tile and K split for an M x N x K problem: enough workgroups for two per CU (two waves per SIMD from different tiles cover each other's
@@ -512,7 +533,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.Xs = Xs; a.xsTp = xsTp;
   a.wx_bytes = (unsigned)wx_bytes; a.xs_bytes = (unsigned)xs_bytes;
   a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps;
-  a.ktaps = geom->ktaps; a.margin = geom->margin; a.padw = geom->padw;
+  a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw;
   a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
   for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
   a.tdil = L.mode == 1 ? L.dil : 1; a.tpad = L.mode == 1 ? L.pad : 0;
@@ -539,11 +560,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
     a.slabs = (float*)stream_scratch(s, 6, slab_bytes);
   }
   ProfTicket tk = conv_prof_begin(s);
-  static const int rs_env = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 4;      // ring depth (experiments: 3 / 4 / 6)
-  if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 2, 6>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
-  else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 1, 6>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
-  else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }
-  else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 1, 6>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
+  x3s_dispatch(a, AM, AN, blocks, s);
   if (tk.on) {
     ConvArgsX pa{};
     pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = geom->ktaps; pa.kreal = geom->ktaps; pa.dil = L.mode == 1 ? L.dil : 1; pa.stride = 1; pa.Tin = T; pa.Tout = T;
@@ -553,6 +570,43 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
     const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci * geom->ktaps);
     const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
     conv_prof_end(tk, s, 2.0 * (double)G * L.Co * T * L.Ci * geom->ktaps, 14 + id, bytes * (G > 1 ? (double)G : 1.0), &pa, (long long)blocks, 4 << 4);
+  }
+}
+
+// The SWAPPED product on the same kernel: out[t][j] = sum_c X[c][t] W[row0 + j][c] (j < rows) - the activation image is the row operand
+// (its rows are positions), the layer's weight image the column operand - written as the image of the TRANSPOSED tensor:
+// [16-position chunk][hi | lo][8-position half][kSplitMargin + j][8 positions].  That is the V^T operand of the attention's P V product
+// (attention_dma.hip): the reduction of P V runs over keys, so the keys must be the 8-element rows.  No bias (the caller adds V's bias
+// after the attention: softmax rows sum to 1); rows >= T of the last chunk are written as zeros.
+void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp) {
+  RVC_REQUIRE(L.Wx_ != nullptr && L.mode == 1 && L.k == 1 && L.groups == 1 && (L.Ci & 15) == 0, "conv_x3s_run_swapped: a k = 1 projection with a bf16x3 weight image");
+  RVC_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.Co && (row0 & 15) == 0, "conv_x3s_run_swapped: row range");
+  RVC_REQUIRE(Xs != nullptr && xsTp >= kSplitMargin + T + 704 && Ys != nullptr && ysTp >= kSplitMargin + rows, "conv_x3s_run_swapped: images missing or too short");
+  const double xs_bytes = (double)(L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)(L.Ci / 16) * 4.0 * (double)L.CoPx * 16.0;
+  RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
+  GemmSArgs a{};
+  a.Wx = Xs + (size_t)kSplitMargin * 16; a.CoPx = (int)xsTp; a.wx_bytes = (unsigned)xs_bytes - (unsigned)kSplitMargin * 16u;
+  a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_) + (size_t)row0 * 16; a.xsTp = L.CoPx; a.xs_bytes = (unsigned)wx_bytes - (unsigned)row0 * 16u;
+  a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1;
+  a.groups = 1; a.co_g = T; a.cig_chunks = L.Ci / 16; a.tdil = 1;
+  a.Ys = Ys; a.ysTp = ysTp; a.act = ACT_NONE; a.out_scale = 1.f;
+  int AM, AN, S;
+  x3s_plan(T, rows, a.nunits, AM, AN, S, 1);
+  S = 1;                                                       // (48-unit reductions: never split)
+  const int BM = 64 * AM, BN = 64 * AN;
+  RVC_REQUIRE((long long)((T + BM - 1) / BM) * BM <= xsTp - kSplitMargin && (long long)row0 + (long long)((rows + BN - 1) / BN) * BN <= L.CoPx, "conv_x3s_run_swapped: a tile would read past an operand image");
+  a.rows_pg = (T + BM - 1) / BM; a.gx = (rows + BN - 1) / BN; a.gy = a.rows_pg; a.ksplit = 1;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  a.xcd_remap = xcd_env;
+  const unsigned blocks = (unsigned)((long long)a.gx * a.gy);
+  ProfTicket tk = conv_prof_begin(s);
+  x3s_dispatch(a, AM, AN, blocks, s);
+  if (tk.on) {
+    ConvArgsX pa{};
+    pa.Ci = L.Ci; pa.Co = rows; pa.ktaps = 1; pa.kreal = 1; pa.dil = 1; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.ksplit = 1;
+    const double bytes = 4.0 * ((double)L.Ci * T + (double)rows * T + (double)rows * L.Ci);
+    const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
+    conv_prof_end(tk, s, 2.0 * (double)rows * T * L.Ci, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
   }
 }
 

@@ -199,22 +199,36 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   }
   {
     const size_t mark = A.off;
-    float* qk = A.alloc<float>((size_t)2304 * T);
-    float* vr = A.alloc<float>((size_t)T * 768);
+    // attention on split-resident operands (attention_dma.hip): q / k as one image, V^T by the swapped product; RVC_ATT_DMA=0: fp32 q / k / v
+    static const bool att_dma = !(getenv("RVC_ATT_DMA") && atoi(getenv("RVC_ATT_DMA")) == 0);
+    const bool ad = gs && att_dma;
+    float* qk = ad ? nullptr : A.alloc<float>((size_t)2304 * T);
+    float* vr = ad ? nullptr : A.alloc<float>((size_t)T * 768);
+    unsigned char* qk_s = ad ? A.alloc<unsigned char>(split_image_bytes(1536, T)) : nullptr;
+    unsigned char* vt_s = ad ? A.alloc<unsigned char>(attention_vt_bytes(768, T)) : nullptr;
     float* attn = gs ? nullptr : A.alloc<float>((size_t)768 * T);
     float* ff = gs ? nullptr : A.alloc<float>((size_t)3072 * T);
     unsigned char* attn_s = gs ? A.alloc<unsigned char>(split_image_bytes(768, T)) : nullptr;
     unsigned char* ff_s = gs ? A.alloc<unsigned char>(split_image_bytes(3072, T)) : nullptr;
     if (!dry) {
+      if (ad) attention_vt_clear_tail(s, vt_s, 768, T);
       for (int l = 0; l < need; ++l) {
         HubLayer& Y = H->layers[l];
         if (taps && l == 0) tap(taps->hidden_0, h, (size_t)768 * T);
         if (taps && l == 8) tap(taps->hidden_8, h, (size_t)768 * T);
         ConvEpilogue Er; Er.R = h; Er.ldR = T;
         if (gs) {
-          conv_x3s_run(Y.qk, s, hs, tp, T, qk, T, E0);
-          transpose(s, qk + (size_t)1536 * T, vr, 768, T, T, 768, 1, 0, 0);      // V row-major [T][768] for the fused attention
-          attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, nullptr, T, 12, 64, T, attn_s, tp);
+          if (ad) {
+            ConvLayer qkL = Y.qk; qkL.Co = 1536;                                 // the q and k rows of the 2304-row projection -> image only
+            ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
+            conv_x3s_run(qkL, s, hs, tp, T, nullptr, T, Eqk);
+            conv_x3s_run_swapped(Y.qk, 1536, 768, s, hs, tp, T, vt_s, attention_vt_tp(768));      // V^T image (v's bias after the attention)
+            attention_split(s, qk_s, tp, 1536, 0, 48, vt_s, 12, 64, T, 1.f, Y.bv.p, nullptr, T, attn_s, tp);
+          } else {
+            conv_x3s_run(Y.qk, s, hs, tp, T, qk, T, E0);
+            transpose(s, qk + (size_t)1536 * T, vr, 768, T, T, 768, 1, 0, 0);      // V row-major [T][768] for the fused attention
+            attention_fused(s, qk, qk + (size_t)768 * T, T, vr, 768, Y.bv.p, nullptr, T, 12, 64, T, attn_s, tp);
+          }
           conv_x3s_run(Y.o, s, attn_s, tp, T, hb, T, Er);
           layernorm_c_split(s, hb, Y.g1.p, Y.b1.p, h, hs, tp, kSplitMargin, 768, T, T, 1e-5f);
           ConvEpilogue Eg; Eg.act = ACT_GELU; Eg.ys_out = ff_s; Eg.ys_tp = tp;

@@ -33,6 +33,8 @@ struct EncLayer {
   DevVec bv;               // conv_v's bias, added after P.V; its rows are part of the qk layer (C -> 3 C)
   ConvLayer relk, relv;    // emb_rel_k as a 21-row projection of Q; emb_rel_v as a 21 -> kc projection of banded P (unfused path)
   DevVec ek, ev;           // the raw [21][kc] tables: the fused attention kernel does both projections itself
+  DevVec rel_img;          // the same tables as the MFMA operand images of attention_split (kc = 96): E_k image, then E_v^T image (bf16 hi / lo)
+  size_t evt_off = 0;      // byte offset of the E_v^T image
   ConvLayer o, ffn1, ffn2;
   DevVec g1, b1, g2, b2;
 };
@@ -70,7 +72,7 @@ struct Synth {
 static void synth_free(Synth& S) {
   auto fl = [](ConvLayer& L) { conv_layer_free(L); };
   S.emb_phone_wT.free_(); S.emb_phone_b.free_(); S.emb_pitch.free_(); S.emb_g.free_();
-  for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); e.ek.free_(); e.ev.free_(); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
+  for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); e.ek.free_(); e.ev.free_(); e.rel_img.free_(); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
   S.enc.clear();
   fl(S.proj);
   for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
@@ -137,6 +139,13 @@ void synth_finalize(Synth* S) {
     std::vector<float> rvT = transpose2d(rv.data.data(), 21, kc);                           // [d][r]: out[d][q] = sum_r E_v[r][d] Pb[r][q]
     conv1d_layer_init(e.relv, rvT.data(), nullptr, kc, 21, 1, 1, 0, 1, 1);
     e.ek.upload(rk.data); e.ev.upload(rv.data);
+    if (kc == 96) {
+      std::vector<uint16_t> eki, evi;
+      attention_rel_images(rk.data.data(), rv.data.data(), kc, 10, eki, evi);
+      e.evt_off = eki.size() * 2;
+      eki.insert(eki.end(), evi.begin(), evi.end());
+      e.rel_img.upload(reinterpret_cast<const float*>(eki.data()), eki.size() / 2);
+    }
     e.o = make_conv1d(ts, p + "conv_o", 1, 0, 1, false);
     const std::string f = "enc_p.encoder.ffn_layers." + std::to_string(l) + ".";
     e.ffn1 = make_conv1d(ts, f + "conv_1", 1, (S->ksz - 1) / 2, 1, false);
@@ -267,22 +276,46 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   }
   {
     const size_t mark = A.off;
-    float* qk = A.alloc<float>((size_t)3 * C * T);
-    float* vr = A.alloc<float>((size_t)T * C);
+    // attention on split-resident operands (attention_dma_kernel.h): q / k as one image, V^T by the swapped product; RVC_ATT_DMA=0: fp32 q / k / v
+    static const bool att_dma = !(getenv("RVC_ATT_DMA") && atoi(getenv("RVC_ATT_DMA")) == 0);
+    static const bool rel_in = !(getenv("RVC_ENCP_REL_FUSED") && atoi(getenv("RVC_ENCP_REL_FUSED")) == 0);
+    const bool ad = gs && att_dma && rel_in && kc == 96 && !(getenv("RVC_ENCP_FUSED") && atoi(getenv("RVC_ENCP_FUSED")) == 0);
+    unsigned char* qk_s = ad ? A.alloc<unsigned char>(split_image_bytes(2 * C, T)) : nullptr;
+    unsigned char* vt_s = ad ? A.alloc<unsigned char>(attention_vt_bytes(C, T)) : nullptr;
+    float* qk = ad ? nullptr : A.alloc<float>((size_t)3 * C * T);
+    float* vr = ad ? nullptr : A.alloc<float>((size_t)T * C);
     static const bool fused_env = [] { const char* e = getenv("RVC_ENCP_FUSED"); return !e || atoi(e) != 0; }();
     const bool fused_att = fused_env && kc == 96;
     float* Sc = fused_att ? nullptr : A.alloc<float>((size_t)H * T * T);
-    float* relk = A.alloc<float>((size_t)H * 21 * T);
-    float* pb = A.alloc<float>((size_t)H * 21 * T);
-    float* attn = A.alloc<float>((size_t)C * T);
+    float* relk = ad ? nullptr : A.alloc<float>((size_t)H * 21 * T);
+    float* pb = ad ? nullptr : A.alloc<float>((size_t)H * 21 * T);
+    float* attn = ad ? nullptr : A.alloc<float>((size_t)C * T);
     float* ff = gs ? nullptr : A.alloc<float>((size_t)S->filt * T);
     if (!dry) {
+      if (ad) attention_vt_clear_tail(s, vt_s, C, T);
       for (int l = 0; l < S->n_layers; ++l) {
         EncLayer& e = S->enc[l];
+        if (ad) {
+          ConvLayer qkL = e.qk; qkL.Co = 2 * C;                                   // the q and k rows of the 3 C-row projection -> image only
+          ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
+          conv_x3s_run(qkL, s, x_s, tp, T, nullptr, T, Eqk);
+          conv_x3s_run_swapped(e.qk, 2 * C, C, s, x_s, tp, T, vt_s, attention_vt_tp(C));
+          const unsigned char* ri = reinterpret_cast<const unsigned char*>(e.rel_img.p);
+          // softmax(K^T Q + banded rel-k bias) V + bv + banded P . E_v, written as the image the out-projection stages
+          attention_split(s, qk_s, tp, 2 * C, 0, C / 16, vt_s, H, kc, T, 1.f, e.bv.p, nullptr, T, attn_s, tp, 10, ri, ri + e.evt_off);
+          ConvEpilogue Er; Er.R = x; Er.ldR = T;
+          conv_x3s_run(e.o, s, attn_s, tp, T, xb, T, Er);
+          layernorm_c_split(s, xb, e.g1.p, e.b1.p, x, x_s, tp, kSplitMargin, C, T, T, 1e-5f);
+          ConvEpilogue Ef; Ef.act = ACT_RELU; Ef.ys_out = ff_s; Ef.ys_tp = tp;
+          conv_x3s_run(e.ffn1, s, x_s, tp, T, nullptr, T, Ef);
+          conv_x3s_run(e.ffn2, s, ff_s, tp, T, xb, T, Er);
+          layernorm_c_split(s, xb, e.g2.p, e.b2.p, x, x_s, tp, kSplitMargin, C, T, T, 1e-5f);
+          if (l == 0 && taps) tap(taps->enc_p_layer0, x, (size_t)C * T);
+          continue;
+        }
         if (gs) conv_x3s_run(e.qk, s, x_s, tp, T, qk, T, E0); else
         conv1d_run(e.qk, s, x, T, T, qk, T, E0);
         transpose(s, qk + (size_t)2 * C * T, vr, C, T, T, C, 1, 0, 0);                                       // V row-major [T][C] (bias later)
-        static const bool rel_in = !(getenv("RVC_ENCP_REL_FUSED") && atoi(getenv("RVC_ENCP_REL_FUSED")) == 0);
         if (fused_att && rel_in) {
           // softmax(K^T Q + banded rel-k bias) V + bv + banded P . E_v in ONE kernel: both relative-position projections included
           attention_rel_fused(s, qk, qk + (size_t)C * T, T, vr, C, e.bv.p, nullptr, nullptr, 10, attn, T, H, kc, T, e.ek.p, e.ev.p);

@@ -377,6 +377,93 @@ int rvc_op_gemm_split(void* stream, const float* x, const float* w, const float*
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_gemm_split_swapped(void* stream, const float* x, const float* w, float* yt, int Ci, int Co, int T, int row0, int rows) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && yt && Ci > 0 && Co > 0 && T > 0 && rows > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, nullptr, Co, Ci, 1, 1, 0, 1, 1); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr;
+  try {
+    const long long tp = split_image_tp(T), vtp = attention_vt_tp(rows);
+    const size_t vbytes = attention_vt_bytes(rows, T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0xff, split_image_bytes(Ci, T), s));       // NaN patterns past T: the tail rows must come out as zeros regardless
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    RVC_HIP_CHECK(hipMalloc(&ys, vbytes));
+    RVC_HIP_CHECK(hipMemsetAsync(ys, 0xff, vbytes, s));
+    conv_x3s_run_swapped(L, row0, rows, s, xs, tp, T, ys, vtp);
+    attention_vt_clear_tail(s, ys, rows, T);
+    split_image_to_f32(s, ys, vtp, (T + 63) / 64 * 64, rows, yt, rows);          // yt [ceil64(T)][rows]
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw; }
+  (void)hipFree(xs); (void)hipFree(ys);
+  conv_layer_free(L);
+  RVC_CATCH
+}
+int rvc_op_attention_split(void* stream, const float* q, const float* k, const float* v, const float* bv, float* out, float* out_img_f32, int heads, int T) {
+  RVC_TRY
+  RVC_REQUIRE(q && k && v && (out || out_img_f32) && heads > 0 && T > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = heads * 64;
+  unsigned char* qk = nullptr; unsigned char* vt = nullptr; unsigned char* oi = nullptr; float* vtf = nullptr;
+  try {
+    const long long tp = split_image_tp(T), vtp = attention_vt_tp(C);
+    RVC_HIP_CHECK(hipMalloc(&qk, split_image_bytes(2 * C, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(qk, 0xff, split_image_bytes(2 * C, T), s));     // rows past T hold NaN patterns: masked keys must not leak
+    split_image_from_f32(s, q, T, C, T, qk, tp);
+    split_image_from_f32(s, k, T, C, T, qk + split_image_bytes(C, T), tp);
+    RVC_HIP_CHECK(hipMalloc(&vtf, (size_t)T * C * 4));
+    transpose((hipStream_t)s, v, vtf, C, T, T, C, 1, 0, 0);
+    RVC_HIP_CHECK(hipMalloc(&vt, attention_vt_bytes(C, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(vt, 0xff, attention_vt_bytes(C, T), s));
+    split_image_from_f32(s, vtf, C, T, C, vt, vtp);                              // "channels" = keys, "positions" = model channels
+    attention_vt_clear_tail(s, vt, C, T);
+    if (out_img_f32) { RVC_HIP_CHECK(hipMalloc(&oi, split_image_bytes(C, T))); }
+    attention_split(s, qk, tp, 2 * C, 0, C / 16, vt, heads, 64, T, 1.f, bv, out, T, oi, tp);
+    if (out_img_f32) split_image_to_f32(s, oi, tp, C, T, out_img_f32, T);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { (void)hipFree(qk); (void)hipFree(vt); (void)hipFree(oi); (void)hipFree(vtf); throw; }
+  (void)hipFree(qk); (void)hipFree(vt); (void)hipFree(oi); (void)hipFree(vtf);
+  RVC_CATCH
+}
+int rvc_op_attention_split_rel(void* stream, const float* q, const float* k, const float* v, const float* bv, const float* ek_host, const float* ev_host,
+                               float* out, float* out_img_f32, int heads, int T, int kz) {
+  RVC_TRY
+  RVC_REQUIRE(q && k && v && ek_host && ev_host && (out || out_img_f32) && heads > 0 && T > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = heads * 96;
+  unsigned char* qk = nullptr; unsigned char* vt = nullptr; unsigned char* oi = nullptr; float* vtf = nullptr; unsigned char* tab = nullptr;
+  try {
+    std::vector<uint16_t> eki, evi;
+    attention_rel_images(ek_host, ev_host, 96, 10, eki, evi);
+    RVC_HIP_CHECK(hipMalloc(&tab, (eki.size() + evi.size()) * 2));
+    RVC_HIP_CHECK(hipMemcpy(tab, eki.data(), eki.size() * 2, hipMemcpyHostToDevice));
+    RVC_HIP_CHECK(hipMemcpy(tab + eki.size() * 2, evi.data(), evi.size() * 2, hipMemcpyHostToDevice));
+    const long long tp = split_image_tp(T), vtp = attention_vt_tp(C);
+    RVC_HIP_CHECK(hipMalloc(&qk, split_image_bytes(2 * C, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(qk, 0xff, split_image_bytes(2 * C, T), s));
+    split_image_from_f32(s, q, T, C, T, qk, tp);
+    split_image_from_f32(s, k, T, C, T, qk + split_image_bytes(C, T), tp);
+    RVC_HIP_CHECK(hipMalloc(&vtf, (size_t)T * C * 4));
+    transpose((hipStream_t)s, v, vtf, C, T, T, C, 1, 0, 0);
+    RVC_HIP_CHECK(hipMalloc(&vt, attention_vt_bytes(C, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(vt, 0xff, attention_vt_bytes(C, T), s));
+    split_image_from_f32(s, vtf, C, T, C, vt, vtp);
+    attention_vt_clear_tail(s, vt, C, T);
+    if (out_img_f32) { RVC_HIP_CHECK(hipMalloc(&oi, split_image_bytes(C, T))); }
+    attention_split_force_kz(kz);
+    try { attention_split(s, qk, tp, 2 * C, 0, C / 16, vt, heads, 96, T, 1.f, bv, out, T, oi, tp, 10, tab, tab + eki.size() * 2); } catch (...) { attention_split_force_kz(0); throw; }
+    attention_split_force_kz(0);
+    if (out_img_f32) split_image_to_f32(s, oi, tp, C, T, out_img_f32, T);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { (void)hipFree(qk); (void)hipFree(vt); (void)hipFree(oi); (void)hipFree(vtf); (void)hipFree(tab); throw; }
+  (void)hipFree(qk); (void)hipFree(vt); (void)hipFree(oi); (void)hipFree(vtf); (void)hipFree(tab);
+  RVC_CATCH
+}
 int rvc_op_conv1d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int T, int k, int pad,
                         int dil, int groups, int act, int act_before_res) {
   RVC_TRY

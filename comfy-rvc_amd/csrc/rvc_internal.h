@@ -155,6 +155,8 @@ SplitGeom split_geom_2d(int Wd, int KH = 3, int KW = 3, int PH = 1, int PWL = 1)
 bool conv_x3s_eligible(const ConvLayer& L);
 void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
                   const SplitGeom* geom = nullptr);
+// the swapped product: out[t][j] = sum_c X[c][t] W[row0 + j][c], written as the image of the transposed tensor (V^T for attention_split)
+void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp);
 void conv_x3s_force(int ksplit, int am, int an);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
 void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp);
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY);
@@ -169,6 +171,17 @@ void attention_fused(hipStream_t s, const float* Q, const float* K, long long ld
 
 // ek / ev: emb_rel_k / emb_rel_v [2 win + 1][dhead] (shared by the heads): the relative-position projections are then computed inside the
 // kernel (rel / pb may be null); without them rel holds Q . E_k and pb returns the band for a separate value-side projection
+// attention on split-resident operands (attention_dma.hip): q / k channels in one image (head h's chunks at q_chunk0 / k_chunk0 + 4 h), V^T image
+// [16-key chunk][plane][attention_vt_tp rows][16 B] (conv_x3s_run_swapped; key chunks past T zeroed by attention_vt_clear_tail)
+long long attention_vt_tp(int channels);
+size_t attention_vt_bytes(int channels, int T);
+void attention_vt_clear_tail(hipStream_t s, unsigned char* vt_img, int channels, int T);
+void attention_split(hipStream_t s, const unsigned char* qk_img, long long qk_tp, int qk_channels, int q_chunk0, int k_chunk0, const unsigned char* vt_img,
+                     int heads, int dhead, int T, float scale, const float* bv, float* out, long long ldo, unsigned char* out_img, long long img_tp,
+                     int win = 0, const unsigned char* ek_img = nullptr, const unsigned char* evt_img = nullptr);
+void attention_split_force_kz(int kz);
+// the synthesizer's text encoder (head dimension 96, window 10): emb_rel_k / emb_rel_v [2 win + 1][D] (host) -> the operand images attention_split takes
+void attention_rel_images(const float* ek, const float* ev, int D, int win, std::vector<uint16_t>& ek_img, std::vector<uint16_t>& evt_img);
 void attention_rel_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                          const float* rel, float* pb, int win, float* out, long long ldo, int heads, int dhead, int T, const float* ek = nullptr,
                          const float* ev = nullptr);

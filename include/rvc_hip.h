@@ -278,6 +278,17 @@ int rvc_op_attention(void* stream, const float* q_dev, const float* k_dev, const
  * projection), pb_dev [heads][21][T] out: pb[r][q] = P[q][q + r - 10] (0 outside the sequence), the input of the rel-v projection.
  * ek_dev / ev_dev (both or neither): emb_rel_k / emb_rel_v [21][96], shared by the heads - the kernel then computes both projections itself
  * (rel = Q . E_k on the staged Q tile, out += P_band . E_v in the merge); rel_dev / pb_dev may be null in that form. */
+/* attention on split-resident operands (attention_dma.hip; HuBERT's encoder layers, modeling_hubert.py:291-477): q, k, v fp32 channel-major
+ * [heads*64][T]; the op builds the q / k image and the V^T image itself.  out fp32 [heads*64][T] and / or the output image read back as fp32. */
+int rvc_op_attention_split(void* stream, const float* q_dev, const float* k_dev, const float* v_dev, const float* bv_dev, float* out_dev,
+                           float* out_img_f32_dev, int heads, int T);
+/* the text encoder's variant (head dimension 96, relative positions within +-10: reference attentions.py:230-267): ek / ev host [21][96];
+ * kz > 0 forces the number of key slices merged inside the launch (0: automatic). */
+int rvc_op_attention_split_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_dev, const float* bv_dev, const float* ek_host,
+                               const float* ev_host, float* out_dev, float* out_img_f32_dev, int heads, int T, int kz);
+/* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
+ * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
+int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);
 int rvc_op_attention_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, const float* rel_dev,
                          float* pb_dev, float* out_dev, int heads, int T, const float* ek_dev, const float* ev_dev);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,

@@ -307,6 +307,86 @@ def test_fused_attention(L, heads, T):
     assert rel_err(out.cpu().double(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("heads,T", [(12, 1599), (2, 64), (2, 65), (3, 1000), (2, 130), (1, 7), (2, 1540)])
+def test_attention_on_split_resident_operands(L, heads, T):
+    """attention_dma.hip: Q / K / V^T handed over as bf16 hi / lo images (DMA-staged key tiles, softmax and probabilities in registers);
+    fp32 rows AND the output image against torch float64.  The images' rows past T hold NaN bit patterns: masked keys must not leak."""
+    g = torch.Generator().manual_seed(31 + T)
+    D = 64
+    q = torch.randn(heads * D, T, generator=g) * 0.35
+    k = torch.randn(heads * D, T, generator=g)
+    v = torch.randn(heads * D, T, generator=g)
+    bv = torch.randn(heads * D, generator=g) * 0.1
+    qh = q.double().view(heads, D, T); kh = k.double().view(heads, D, T); vh = v.double().view(heads, D, T)
+    p = torch.softmax(torch.einsum("hdq,hdk->hqk", qh, kh), dim=-1)
+    ref = torch.einsum("hqk,hdk->hdq", p, vh).reshape(heads * D, T) + bv.double()[:, None]
+    out = torch.empty(heads * D, T, device="cuda"); oimg = torch.empty(heads * D, T, device="cuda")
+    qd, kd, vd, bd = dev(q), dev(k), dev(v), dev(bv)
+    L.check(L.lib.rvc_op_attention_split(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), L.ptr(out), L.ptr(oimg), heads, T))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().double(), ref) < 2e-5
+    assert rel_err(oimg.cpu().double(), ref) < 2e-5
+    assert (oimg - out).abs().max().item() <= 2.0 ** -15 * ref.abs().max().item()      # the image is hi + lo of the same fp32 values
+
+
+@pytest.mark.parametrize("heads,T,kz", [(2, 3198, 0), (2, 3198, 1), (2, 1000, 3), (2, 150, 0), (2, 20, 0), (3, 129, 1), (2, 5, 0), (2, 700, 5)])
+def test_relative_attention_on_split_resident_operands(L, heads, T, kz):
+    """The text encoder's attention on images (attention_dma_kernel<96, .., REL>): rel-k bias by an in-kernel MFMA block, band probabilities
+    x E_v by another, key tiles cut into kz slices merged by the last arriver.  float64 torch restatement of attentions.py:230-267;
+    repeated launches are bit-identical (the merge order is the slice order)."""
+    g = torch.Generator().manual_seed(37 + T)
+    D, W = 96, 10
+    q = torch.randn(heads * D, T, generator=g) * 0.3
+    k = torch.randn(heads * D, T, generator=g)
+    v = torch.randn(heads * D, T, generator=g)
+    bv = torch.randn(heads * D, generator=g) * 0.1
+    ek = torch.randn(2 * W + 1, D, generator=g) * 0.5
+    ev = torch.randn(2 * W + 1, D, generator=g) * 0.5
+    qh = q.double().view(heads, D, T); kh = k.double().view(heads, D, T); vh = v.double().view(heads, D, T)
+    rel = torch.einsum("rd,hdq->hrq", ek.double(), qh)
+    sc = torch.einsum("hdq,hdk->hqk", qh, kh)
+    qi = torch.arange(T)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        sc[:, qi[ok], ki[ok]] += rel[:, r, qi[ok]]
+    p = torch.softmax(sc, dim=-1)
+    ref = torch.einsum("hqk,hdk->hdq", p, vh)
+    for r in range(2 * W + 1):
+        ki = qi + r - W
+        ok = (ki >= 0) & (ki < T)
+        ref[:, :, qi[ok]] += p[:, qi[ok], ki[ok]][:, None, :] * ev.double()[r][None, :, None]
+    ref = ref.reshape(heads * D, T) + bv.double()[:, None]
+    qd, kd, vd, bd = dev(q), dev(k), dev(v), dev(bv)
+    outs = []
+    for _ in range(3):
+        out = torch.empty(heads * D, T, device="cuda"); oimg = torch.empty(heads * D, T, device="cuda")
+        L.check(L.lib.rvc_op_attention_split_rel(None, L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(bd), ek.contiguous().data_ptr(), ev.contiguous().data_ptr(),
+                                                 L.ptr(out), L.ptr(oimg), heads, T, kz))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert rel_err(outs[0].cpu().double(), ref) < 2e-5
+    assert rel_err(oimg.cpu().double(), ref) < 2e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("Ci,Co,T,row0,rows", [(768, 2304, 1599, 1536, 768), (768, 2304, 100, 1536, 768), (64, 256, 333, 128, 128), (192, 192, 1000, 0, 192)])
+def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
+    """out[t][j] = sum_c x[c][t] w[row0 + j][c] written as the image of the transposed tensor (the attention's V^T operand): rows t < T
+    against float64, rows T .. ceil64(T) exact zeros although the input image holds NaN patterns there."""
+    g = torch.Generator().manual_seed(5 + T)
+    x = torch.randn(Ci, T, generator=g); w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci)
+    ref = x.double().t() @ w.double()[row0:row0 + rows].t()
+    T64 = (T + 63) // 64 * 64
+    yt = torch.full((T64, rows), 3.0, device="cuda")
+    xd = dev(x); wh = w.contiguous()
+    L.check(L.lib.rvc_op_gemm_split_swapped(None, L.ptr(xd), wh.data_ptr(), L.ptr(yt), Ci, Co, T, row0, rows))
+    torch.cuda.synchronize()
+    y = yt.cpu().double()
+    assert rel_err(y[:T], ref) < 2e-5
+    assert torch.equal(y[T:], torch.zeros(T64 - T, rows, dtype=torch.float64))
+
+
 @pytest.mark.parametrize("heads,T", [(2, 3001), (2, 150), (2, 20), (3, 129), (2, 5)])
 def test_fused_relative_attention(L, heads, T):
     """The text encoder's windowed relative-position attention in one kernel (reference attentions.py:230-267): scores of keys within

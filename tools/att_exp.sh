@@ -1,0 +1,19 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests/test_hip_models.py tests/test_hip_pipeline.py tests/test_hip_nodes.py -q -x 2>&1 | tail -8
+for v in 1 0; do
+echo "== RVC_ATT_DMA=$v"; RVC_ATT_DMA=$v timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['config'].get('one_clip_alone_ms'))"
+done
+rm -rf gpurun_out/att_prof
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/att_prof -o att -- python3 bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 - <<'PY'
+import csv,glob,os,sys
+f=glob.glob('gpurun_out/att_prof/**/*kernel_stats.csv',recursive=True)
+rows=list(csv.DictReader(open(f[0])))
+tot=sum(int(r['TotalDurationNs']) for r in rows)
+print('total ms', round(tot/1e6,1), 'launches', sum(int(r['Calls']) for r in rows))
+for r in rows[:12]: print(r['Name'][:80], r['Calls'], r['TotalDurationNs'], r['AverageNs'])
+for r in rows:
+    if 'attention' in r['Name']: print(r['Name'][:80], r['Calls'], r['TotalDurationNs'], r['AverageNs'])
+PY
