@@ -75,14 +75,14 @@ void attention_split(hipStream_t s, const unsigned char* qk_img, long long qk_tp
   if (rel) {
     // two heads: the key tiles are also cut across workgroups until the grid covers the chip (each slice at least two tiles)
     const int qt = (T + 127) / 128, ntiles = (T + 63) / 64;
-    int kz = t_force_kz > 0 ? t_force_kz : kz_env > 0 ? kz_env : (256 + qt * heads - 1) / (qt * heads);
+    int kz = t_force_kz > 0 ? t_force_kz : kz_env > 0 ? kz_env : 256 / (qt * heads);      // (measured at T = 3198: 5 slices 49 us, 4: 53, 6: 67 - a second round of workgroups)
     kz = std::max(1, std::min(kz, ntiles / 2));
     a.kz = kz;
     const size_t sb = (size_t)heads * (2 * win + 1) * T * 4;
     RVC_REQUIRE(sb < 2147483648.0, "attention_split: band scratch exceeds 32-bit buffer addressing");
     a.sband = (float*)stream_scratch(s, 11, sb); a.sband_bytes = (unsigned)sb;
     if (kz > 1) {
-      const size_t pbytes = (size_t)qt * heads * kz * 4 * (2 + 16 * 3) * 64 * 4;
+      const size_t pbytes = (size_t)qt * heads * kz * 4 * (4 * 3 + 1) * 64 * 16;
       RVC_REQUIRE((size_t)qt * heads * 4 <= 16 * 1024 && pbytes < 2147483648.0, "attention_split: too many query tiles for the ticket array");
       a.tickets = (unsigned*)stream_scratch_zeroed(s, 9, 16 * 1024);
       a.part = (float*)stream_scratch(s, 10, pbytes); a.part_bytes = (unsigned)pbytes;

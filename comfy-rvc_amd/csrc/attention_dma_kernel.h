@@ -143,13 +143,13 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; ++r) {                         // straight-line: table read at a clamped index, store dropped out of range
           const int key = it * 64 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int rr = key - qq + p.win;
-          if (rr >= 0 && rr <= 2 * p.win && key < T && qq < T) {
-            s[kb][r] += rqs[rr * 32 + li];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s[kb][r]), brs, (int)(((unsigned)(h * (2 * p.win + 1) + rr) * (unsigned)T + (unsigned)qq) * 4u), 0, 16);   // sc1
-          }
+          const bool ok = rr >= 0 && rr <= 2 * p.win && key < T && qq < T;
+          const float bias = rqs[(ok ? rr : 0) * 32 + li];
+          s[kb][r] += ok ? bias : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s[kb][r]), brs, ok ? (int)(((unsigned)(h * (2 * p.win + 1) + rr) * (unsigned)T + (unsigned)qq) * 4u) : (int)kOOB, 0, 16);   // sc1
         }
     }
     if (it * 64 + 64 > T) {
@@ -255,20 +255,25 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
     }
   }
   if (kz > 1) {
-    // ---- merge the key slices: slabs [slice][wave][value][lane], write-through; the last arriver sums them in slice order
-    constexpr int NV = 2 + 16 * DB;
+    // ---- merge the key slices: slabs [slice][wave][quad][lane] of 16-byte granules (O in register order, then (m, l)), write-through;
+    // the last arriver reads ALL slices back (its own included: one code path, the sum order is the slice order whoever is last),
+    // a slice's 4 DB + 1 loads in flight together
+    constexpr int NQ = 4 * DB + 1;
     const unsigned qt = blockIdx.y * gridDim.x + blockIdx.x;
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(p.part, p.part_bytes);
-    const unsigned slab = (unsigned)(NWQ * NV * 64) * 4u;
-    const unsigned lane_off = ((unsigned)(wave * NV) * 64u + (unsigned)lane) * 4u;
+    const unsigned slab = (unsigned)(NWQ * NQ * 64) * 16u;
+    const unsigned lane_off = ((unsigned)(wave * NQ) * 64u + (unsigned)lane) * 16u;
     {
       const unsigned mine = (qt * (unsigned)kz + (unsigned)z) * slab + lane_off;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_run), prs, (int)mine, 0, 16);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_run), prs, (int)(mine + 256u), 0, 16);
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[db][r]), prs, (int)(mine + (unsigned)(2 + db * 16 + r) * 256u), 0, 16);
+        for (int qd = 0; qd < 4; ++qd) {
+          const u32x4 v = {__float_as_uint(o[db][4 * qd]), __float_as_uint(o[db][4 * qd + 1]), __float_as_uint(o[db][4 * qd + 2]), __float_as_uint(o[db][4 * qd + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, prs, (int)(mine + (unsigned)(db * 4 + qd) * 1024u), 0, 16);      // aux 16 = sc1
+        }
+      const u32x4 ml = {__float_as_uint(m_run), __float_as_uint(l_run), 0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(ml, prs, (int)(mine + (unsigned)(4 * DB) * 1024u), 0, 16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave drains (slabs and band scores) before the ticket
     __syncthreads();
@@ -282,33 +287,27 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
     if (*flag != (unsigned)kz - 1u) return;
     float m = -3.0e38f;
     for (int zz = 0; zz < kz; ++zz) {
-      const float mz = zz == z ? m_run : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (int)((qt * (unsigned)kz + (unsigned)zz) * slab + lane_off), 0, 16));
-      m = fmaxf(m, mz);
+      const u32x4 ml = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((qt * (unsigned)kz + (unsigned)zz) * slab + lane_off + (unsigned)(4 * DB) * 1024u), 0, 16);
+      m = fmaxf(m, __uint_as_float(ml[0]));
     }
     float l = 0.f;
-    f32x16 om[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) om[db][r] = 0.f;
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     for (int zz = 0; zz < kz; ++zz) {
       const unsigned base = (qt * (unsigned)kz + (unsigned)zz) * slab + lane_off;
-      const bool own = zz == z;
-      const float mz = own ? m_run : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (int)base, 0, 16));
-      const float lz = own ? l_run : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (int)(base + 256u), 0, 16));
-      const float az = __builtin_amdgcn_exp2f((mz - m) * c2);
-      l = fmaf(lz, az, l);
+      u32x4 v[NQ];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(base + (unsigned)i * 1024u), 0, 16);
+      const float az = __builtin_amdgcn_exp2f((__uint_as_float(v[4 * DB][0]) - m) * c2);
+      l = fmaf(__uint_as_float(v[4 * DB][1]), az, l);
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float ov = own ? o[db][r] : __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, (int)(base + (unsigned)(2 + db * 16 + r) * 256u), 0, 16));
-          om[db][r] = fmaf(ov, az, om[db][r]);
-        }
+        for (int r = 0; r < 16; ++r) o[db][r] = fmaf(__uint_as_float(v[db * 4 + (r >> 2)][r & 3]), az, o[db][r]);
     }
     m_run = m; l_run = l;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) o[db] = om[db];
   }
   // ---- normalise, + bv; fp32 rows and / or the image the out-projection stages
   const int q = q0 + li;

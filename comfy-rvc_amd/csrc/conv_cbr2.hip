@@ -1,0 +1,264 @@
+// One ConvBlockRes of RMVPE's U-Net at the two shallow levels (16 and 32 channels; reference lib/rmvpe.py:233-268) in ONE launch (gfx950 only):
+//   out = relu(conv3x3_2(relu(conv3x3_1(x) + b1)) + b2) + x        (BatchNorm folded into both convolutions, in == out channels)
+//
+// At these levels the tensors are large (16 x 3232 x 128 fp32 = 26 MB) and the arithmetic small (0.15 GFLOP per MB): the staged kernel
+// ran each convolution at 0.17 of the HBM rate (profiles/r3m_launch_classes.md: 50 us / 26 us per launch, 28 launches per clip).  Here a
+// workgroup owns a TH x 64 tile of positions:
+//   * the input tile with a 2-position halo is converted ONCE to the bf16 hi / lo image the MFMAs read ([chunk][hi | lo][half][position][8 ch],
+//     position = (row + 2) P + (col + 2), P = 68: a 3 x 3 tap is the constant offset dh P + dw) - positions outside the image are zeros, the
+//     convolution's padding;
+//   * the weights of a convolution (9 or 18 (chunk, tap) units x hi / lo) live in REGISTERS: the only LDS reads are the position operands,
+//     two 16-byte reads per three MFMAs;
+//   * conv1 runs over the tile + 1 halo; its result (bias, ReLU, zero outside the image) stays in accumulators until every wave has finished
+//     reading x, then overwrites x in LDS as the image conv2 reads - the intermediate never leaves the CU;
+//   * conv2's epilogue adds bias, ReLU and the fp32 residual (read again from global: L2) and stores fp32 rows.
+#include "conv_x3_dev.h"
+#include "ops.h"
+#include <type_traits>
+
+namespace rvc {
+
+#ifdef RVC_CONV_TIMING
+__device__ unsigned long long g_cbr_timing[8];   // [0] workgroups, [1] staging (loads + convert), [2] conv1, [3] y1 -> LDS, [4] conv2, [5] epilogue, [6] total
+#define CTICK() wall_clock64()
+#define CTACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_cbr_timing[i], (unsigned long long)(v)); } while (0)
+void cbr2_timing_read(unsigned long long* out8, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cbr_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cbr_timing), z, sizeof(z)); }
+}
+#else
+#define CTICK() 0ull
+#define CTACC(i, v) do {} while (0)
+#endif
+
+// LDS bytes of cbr2_small_kernel<C, TH> (the kernel's NPOS, restated for the launch)
+constexpr size_t cbr2_lds_bytes(int C, int TH) {
+  const int P = 68, NP1 = (TH + 4) * P, NB1 = ((TH + 2) * P + 31) / 32, NB2 = (TH * P + 31) / 32;
+  const int END1 = P + 32 * NB1 + P + 2, END2 = 2 * P + 32 * NB2 + P + 2, ENDM = END1 > END2 ? END1 : END2;
+  const int SLACK = ENDM > NP1 ? ((ENDM - NP1 + 15) & ~15) : 16;
+  return (size_t)(C / 16) * 4 * (16 + NP1 + SLACK) * 16;
+}
+
+struct Cbr2Args {
+  const float* __restrict__ X; float* __restrict__ Y; long long plane;      // [C][H W] fp32, channel pitch `plane`
+  int H, W;
+  const unsigned char* W1; const unsigned char* W2; int CoPx1, CoPx2;      // bf16x3 weight images (pack_x3, 9 taps)
+  const float* b1; const float* b2;
+};
+
+template <int C, int TH>
+__global__ __launch_bounds__(256, 2) void cbr2_small_kernel(const Cbr2Args p) {
+  constexpr int TW = 64, P = TW + 4, NCH = C / 16, NU = NCH * 9;
+  constexpr int FRONT = 16, NP1 = (TH + 4) * P;
+  constexpr int N1 = (TH + 2) * P, NB1 = (N1 + 31) / 32, NBW1 = (NB1 + 3) / 4;  // conv1: rows -1 .. TH, every column of the pitch
+  constexpr int N2 = TH * P, NB2 = (N2 + 31) / 32, NBW2 = (NB2 + 3) / 4;        // conv2: rows 0 .. TH - 1
+  // slack behind the tile: the last block of 32 may end past the region, + the largest tap offset
+  constexpr int END1 = P + 32 * NB1 + P + 2, END2 = 2 * P + 32 * NB2 + P + 2, ENDM = END1 > END2 ? END1 : END2;
+  constexpr int SLACK = ENDM > NP1 ? ((ENDM - NP1 + 15) & ~15) : 16, NPOS = FRONT + NP1 + SLACK;
+  constexpr int RB = C == 16 ? 1 : 2;                       // 16-row chunks of output channels that exist (rows 16 .. 31 of a 16-channel layer are zero weights)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cbr[];      // [chunk][plane 4][NPOS][16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int r0 = blockIdx.y * TH, c0 = blockIdx.x * TW;
+  const int H = p.H, W = p.W;
+
+  // ---- weights of a convolution -> registers: unit u = chunk * 9 + tap, lane (row li, half lh).  Requested first: their latency hides
+  // behind the staging of x.
+  const unsigned long long t_begin = CTICK();
+  u32x4 wh[NU], wl[NU];
+  auto load_w = [&](const unsigned char* Wimg, int CoPx) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const unsigned char* a = Wimg + ((long long)(u * 4 + lh) * CoPx + li) * 16;
+      wh[u] = *reinterpret_cast<const u32x4*>(a);
+      wl[u] = *reinterpret_cast<const u32x4*>(a + (long long)2 * CoPx * 16);
+    }
+  };
+  load_w(p.W1, p.CoPx1);
+
+  // ---- stage x: one task = 8 channels of one position -> one 16-byte row of the hi and of the lo plane.  Two passes over a compile-time
+  // number of tasks per thread: every global load of the tile is in flight before the first conversion waits for one
+  {
+    constexpr int NTASK = NP1 * (C / 8), NIT = (NTASK + 255) / 256;
+    float v[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int task = tid + 256 * it;
+      const int g = task / NP1, pos = task - g * NP1;
+      const int row = pos / P, col = pos - row * P;
+      const int ir = r0 - 2 + row, ic = c0 - 2 + col;
+      const bool ok = task < NTASK && ir >= 0 && ir < H && ic >= 0 && ic < W;
+      const float* src = p.X + (long long)(g * 8) * p.plane + (long long)ir * W + ic;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = ok ? src[(long long)j * p.plane] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int task = tid + 256 * it;
+      const int g = task / NP1, pos = task - g * NP1;
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { unsigned h_, l_; split2(v[it][2 * j], v[it][2 * j + 1], h_, l_); hi[j] = h_; lo[j] = l_; }
+      if (task < NTASK) {
+        unsigned char* dst = smem_cbr + ((((g >> 1) * 4 + (g & 1)) * NPOS) + FRONT + pos) * 16;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 2 * NPOS * 16) = lo;
+      }
+    }
+  }
+  // the slack on either side of the tile: finite values (they only ever reach outputs that are discarded)
+  for (int task = tid; task < (FRONT + SLACK) * NCH * 4; task += 256) {
+    const int pl = task / (FRONT + SLACK), q = task - pl * (FRONT + SLACK);
+    const int pos = q < FRONT ? q : NP1 + q;
+    *reinterpret_cast<u32x4*>(smem_cbr + (pl * NPOS + pos) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  __syncthreads();
+  const unsigned long long t_staged = CTICK();
+  CTACC(1, t_staged - t_begin);
+
+  // this wave's blocks of 32 positions (block wave + 4 i starts at LDS position qbase + 32 (wave + 4 i)): acc[i][co][position] over the 9 taps x
+  // NCH chunks.  The (chunk, tap) unit is the OUTER loop: the blocks are independent accumulation chains (a lone chain would wait out the
+  // latency of every MFMA: 27 or 54 dependent ones per block), and a unit's weights are read from registers once for all of them.
+  auto conv_blocks = [&](auto& acc, auto nbw_c, int nb, int qbase) {
+    constexpr int NBW = decltype(nbw_c)::value;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // straight-line: every wave runs NBW blocks (a wave with fewer repeats the last block of the region; the copy is discarded), so the
+    // operand reads of the next unit can be scheduled under the MFMAs of this one
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int off = (t / 3 - 1) * P + (t % 3 - 1);
+        const int u = ch * 9 + t;
+        u32x4 bh[NBW], bl[NBW];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          const unsigned char* b = smem_cbr + ((ch * 4 + lh) * NPOS + FRONT + qbase + 32 * min(wave + 4 * i, nb - 1) + li + off) * 16;
+          bh[i] = *reinterpret_cast<const u32x4*>(b); bl[i] = *reinterpret_cast<const u32x4*>(b + 2 * NPOS * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[u]), __builtin_bit_cast(bf16x8, bl[i]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[u]), __builtin_bit_cast(bf16x8, bh[i]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[u]), __builtin_bit_cast(bf16x8, bh[i]), acc[i], 0, 0, 0);
+      }
+  };
+  // this lane's bias values (rows (r & 3) + 8 (r >> 2) + 4 lh), requested before the first convolution
+  float bias1[8 * RB], bias2[8 * RB];
+#pragma unroll
+  for (int r = 0; r < 8 * RB; ++r) { const int co = (r & 3) + 8 * (r >> 2) + 4 * lh; bias1[r] = p.b1[co]; bias2[r] = p.b2[co]; }
+
+  // ---- conv1 over rows -1 .. TH (LDS rows 1 .. TH + 2): bias, ReLU, zero outside the image; kept in registers
+  f32x16 y1[NBW1];
+  conv_blocks(y1, std::integral_constant<int, NBW1>{}, NB1, P);
+#pragma unroll
+  for (int i = 0; i < NBW1; ++i) {
+    const int blk = wave + 4 * i;
+    if (blk < NB1) {
+      const int q = P + 32 * blk + li, row = q / P, col = q - row * P;
+      const int ir = r0 - 2 + row, ic = c0 - 2 + col;
+      const bool ok = ir >= 0 && ir < H && ic >= 0 && ic < W && q < P + N1;
+#pragma unroll
+      for (int r = 0; r < 8 * RB; ++r) y1[i][r] = ok ? fmaxf(y1[i][r] + bias1[r], 0.f) : 0.f;
+    }
+  }
+  const unsigned long long t_c1 = CTICK();
+  CTACC(2, t_c1 - t_staged);
+  load_w(p.W2, p.CoPx2);                                      // (conv1's MFMAs have read their weight registers: in order)
+  __syncthreads();                                             // every wave has finished reading x
+#pragma unroll
+  for (int i = 0; i < NBW1; ++i) {
+    const int blk = wave + 4 * i;
+    if (blk < NB1) {
+      const int q = P + 32 * blk + li;
+#pragma unroll
+      for (int g2 = 0; g2 < RB; ++g2) {
+        unsigned hA[2], lA[2], hB[2], lB[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          split2(y1[i][8 * g2 + 2 * e2], y1[i][8 * g2 + 2 * e2 + 1], hA[e2], lA[e2]);
+          split2(y1[i][8 * g2 + 4 + 2 * e2], y1[i][8 * g2 + 5 + 2 * e2], hB[e2], lB[e2]);
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t sh = __builtin_amdgcn_permlane32_swap(hA[e2], hB[e2], false, false);
+          const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
+          hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
+        }
+        unsigned char* dst = smem_cbr + ((g2 * 4 + lh) * NPOS + FRONT + q) * 16;      // chunk g2, half lh, position q
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + 2 * NPOS * 16) = lo;
+      }
+    }
+  }
+  __syncthreads();
+
+  const unsigned long long t_y1 = CTICK();
+  CTACC(3, t_y1 - t_c1);
+  // ---- conv2 over rows 0 .. TH - 1: bias, ReLU, + x, fp32 rows
+  f32x16 y2[NBW2];
+  conv_blocks(y2, std::integral_constant<int, NBW2>{}, NB2, 2 * P);
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t_c2 = CTICK();
+  CTACC(4, t_c2 - t_y1);
+  float res[NBW2][8 * RB];
+  long long oidx[NBW2];
+#pragma unroll
+  for (int i = 0; i < NBW2; ++i) {                             // every residual load of the wave in flight before the first store
+    const int blk = wave + 4 * i;
+    const int q = 2 * P + 32 * blk + li, row = q / P, col = q - row * P;
+    const int ir = r0 - 2 + row, ic = c0 - 2 + col;
+    const bool ok = blk < NB2 && row < TH + 2 && ir < H && col >= 2 && col < TW + 2 && ic < W;
+    oidx[i] = ok ? (long long)ir * W + ic : -1;
+#pragma unroll
+    for (int r = 0; r < 8 * RB; ++r) { const int co = (r & 3) + 8 * (r >> 2) + 4 * lh; res[i][r] = ok ? p.X[(long long)co * p.plane + oidx[i]] : 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < NBW2; ++i) {
+    if (oidx[i] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 8 * RB; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        p.Y[(long long)co * p.plane + oidx[i]] = fmaxf(y2[i][r] + bias2[r], 0.f) + res[i][r];
+      }
+    }
+  }
+  const unsigned long long t_end = CTICK();
+  CTACC(5, t_end - t_c2); CTACC(6, t_end - t_begin); CTACC(0, 1);
+}
+
+template <int C, int TH>
+static void launch_cbr2(const Cbr2Args& a, hipStream_t s) {
+  auto kern = cbr2_small_kernel<C, TH>;
+  constexpr size_t lds = cbr2_lds_bytes(C, TH);
+  static_assert(lds <= 160 * 1024, "LDS");
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, dim3((a.W + 63) / 64, (a.H + TH - 1) / TH), dim3(256), lds, s, a);
+}
+
+bool cbr2_small_eligible(const ConvLayer& c1, const ConvLayer& c2) {
+  auto ok = [](const ConvLayer& L) { return L.mode == 2 && L.Wx_ != nullptr && L.ktaps == 9 && L.kh == 3 && L.kw == 3 && L.up2 == 0 && L.tconv_u == 0 && L.bd_ != nullptr; };
+  return conv_x3_enabled() && ok(c1) && ok(c2) && c1.Ci == c1.Co && c2.Ci == c2.Co && c1.Co == c2.Co && (c1.Co == 16 || c1.Co == 32);
+}
+
+// out = relu(c2(relu(c1(x)))) + x for a 16- or 32-channel ConvBlockRes; x, out fp32 [C][H W] (distinct buffers)
+void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out) {
+  RVC_REQUIRE(cbr2_small_eligible(c1, c2), "cbr2_small_run: two 3 x 3 convolutions of 16 or 32 channels with bf16x3 weight images");
+  RVC_REQUIRE(x != out, "cbr2_small_run: in place is not supported");
+  Cbr2Args a{};
+  a.X = x; a.Y = out; a.plane = (long long)H * W; a.H = H; a.W = W;
+  a.W1 = reinterpret_cast<const unsigned char*>(c1.Wx_); a.W2 = reinterpret_cast<const unsigned char*>(c2.Wx_); a.CoPx1 = c1.CoPx; a.CoPx2 = c2.CoPx;
+  a.b1 = c1.bd_; a.b2 = c2.bd_;
+  if (c1.Co == 16) launch_cbr2<16, 8>(a, s); else launch_cbr2<32, 4>(a, s);
+}
+
+}  // namespace rvc

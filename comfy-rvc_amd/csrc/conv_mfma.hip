@@ -375,6 +375,7 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s) {
 void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
+void cbr2_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 8);
@@ -382,6 +383,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   unsigned long long x3[8]; conv_x3_timing_read(x3, reset);
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   attention_timing_read(x3, reset);
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  cbr2_timing_read(x3, reset);          // (fused ConvBlockRes: [0] workgroups, [1] staging, [2] conv1, [3] y1 -> LDS, [4] conv2, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3p_timing_read(x3, reset);      // (pipelined kernel: [0] tiles, [1] prologue, [2] compute, [3] weight wait, [4] barrier, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];

@@ -159,6 +159,12 @@ void rmvpe_finalize(Rmvpe* R) {
 // one ConvBlockRes: out = relu(bn(conv(relu(bn(conv(x)))))) + (shortcut(x) | x)       (reference lib/rmvpe.py:264-268)
 static void run_cbr(const CBR& B, hipStream_t s, Arena& A, const float* x, int H, int W, float* out) {
   const long long plane = (long long)H * W;
+  // the 16- and 32-channel blocks without a shortcut: both convolutions and the residual in one launch, the intermediate in LDS (conv_cbr2.hip)
+  static const bool fuse_small = !(getenv("RVC_RMVPE_CBR2") && atoi(getenv("RVC_RMVPE_CBR2")) == 0);
+  if (fuse_small && !B.has_sc && x != out && cbr2_small_eligible(B.c1, B.c2)) {
+    if (!A.dry) cbr2_small_run(B.c1, B.c2, s, x, H, W, out);
+    return;
+  }
   const size_t mark = A.off;
   float* y1 = A.alloc<float>((size_t)B.cout * plane);
   float* scb = B.has_sc ? A.alloc<float>((size_t)B.cout * plane) : nullptr;

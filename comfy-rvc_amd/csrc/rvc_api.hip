@@ -464,6 +464,20 @@ int rvc_op_attention_split_rel(void* stream, const float* q, const float* k, con
   (void)hipFree(qk); (void)hipFree(vt); (void)hipFree(oi); (void)hipFree(vtf); (void)hipFree(tab);
   RVC_CATCH
 }
+int rvc_op_cbr2_small(void* stream, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y, int C, int H, int W) {
+  RVC_TRY
+  RVC_REQUIRE(x && w1 && b1 && w2 && b2 && y && (C == 16 || C == 32) && H > 0 && W > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer c1, c2;
+  { ConvBuildScope scope(2); conv2d3x3_layer_init(c1, w1, b1, C, C); conv2d3x3_layer_init(c2, w2, b2, C, C); }
+  try {
+    cbr2_small_run(c1, c2, s, x, H, W, y);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { conv_layer_free(c1); conv_layer_free(c2); throw; }
+  conv_layer_free(c1); conv_layer_free(c2);
+  RVC_CATCH
+}
 int rvc_op_conv1d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int T, int k, int pad,
                         int dil, int groups, int act, int act_before_res) {
   RVC_TRY

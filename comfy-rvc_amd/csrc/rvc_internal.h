@@ -157,7 +157,10 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
                   const SplitGeom* geom = nullptr);
 // the swapped product: out[t][j] = sum_c X[c][t] W[row0 + j][c], written as the image of the transposed tensor (V^T for attention_split)
 void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp);
-void conv_x3s_force(int ksplit, int am, int an);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
+void conv_x3s_force(int ksplit, int am, int an);
+// one ConvBlockRes of 16 or 32 channels (3 x 3, 3 x 3, + x) in one launch (conv_cbr2.hip): x, out fp32 [C][H W], distinct
+bool cbr2_small_eligible(const ConvLayer& c1, const ConvLayer& c2);
+void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
 void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp);
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY);
 

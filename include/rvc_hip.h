@@ -286,6 +286,10 @@ int rvc_op_attention_split(void* stream, const float* q_dev, const float* k_dev,
  * kz > 0 forces the number of key slices merged inside the launch (0: automatic). */
 int rvc_op_attention_split_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_dev, const float* bv_dev, const float* ek_host,
                                const float* ev_host, float* out_dev, float* out_img_f32_dev, int heads, int T, int kz);
+/* one ConvBlockRes of RMVPE's shallow U-Net levels in one launch (conv_cbr2.hip; reference lib/rmvpe.py:233-268 with BatchNorm folded):
+ * y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2) + x; x, y device fp32 [C][H][W] (distinct), w host [C][C][3][3], C = 16 or 32. */
+int rvc_op_cbr2_small(void* stream, const float* x_dev, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
+                      float* y_dev, int C, int H, int W);
 /* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
  * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
 int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);

@@ -370,6 +370,23 @@ def test_relative_attention_on_split_resident_operands(L, heads, T, kz):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("C,H,W", [(16, 64, 128), (16, 37, 128), (16, 5, 64), (32, 48, 64), (32, 33, 64), (32, 3, 128), (16, 200, 192)])
+def test_conv_block_res_small_channels_fused(L, C, H, W):
+    """conv_cbr2.hip: relu(conv3x3(relu(conv3x3(x) + b1)) + b2) + x in one launch (RMVPE's 16 / 32-channel ConvBlockRes, lib/rmvpe.py:233-268):
+    the intermediate lives in LDS as a bf16 hi / lo image, image borders and tile halos are zeros / recomputed.  float64 torch reference."""
+    g = torch.Generator().manual_seed(41 + H)
+    x = torch.randn(C, H, W, generator=g)
+    w1 = torch.randn(C, C, 3, 3, generator=g) / np.sqrt(9 * C); b1 = torch.randn(C, generator=g) * 0.2
+    w2 = torch.randn(C, C, 3, 3, generator=g) / np.sqrt(9 * C); b2 = torch.randn(C, generator=g) * 0.2
+    xd = x.double()[None]
+    y1 = F.relu(F.conv2d(xd, w1.double(), b1.double(), padding=1))
+    ref = (F.relu(F.conv2d(y1, w2.double(), b2.double(), padding=1)) + xd)[0]
+    y = torch.full((C, H, W), 9.0, device="cuda"); xdev = dev(x)
+    L.check(L.lib.rvc_op_cbr2_small(None, L.ptr(xdev), w1.contiguous().data_ptr(), b1.data_ptr(), w2.contiguous().data_ptr(), b2.data_ptr(), L.ptr(y), C, H, W))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("Ci,Co,T,row0,rows", [(768, 2304, 1599, 1536, 768), (768, 2304, 100, 1536, 768), (64, 256, 333, 128, 128), (192, 192, 1000, 0, 192)])
 def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
     """out[t][j] = sum_c x[c][t] w[row0 + j][c] written as the image of the transposed tensor (the attention's V^T operand): rows t < T
