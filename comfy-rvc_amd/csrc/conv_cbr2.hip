@@ -75,38 +75,44 @@ __global__ __launch_bounds__(256, 2) void cbr2_small_kernel(const Cbr2Args p) {
       wl[u] = *reinterpret_cast<const u32x4*>(a + (long long)2 * CoPx * 16);
     }
   };
-  load_w(p.W1, p.CoPx1);
+  if constexpr (C == 16) load_w(p.W1, p.CoPx1);              // (32 channels: 144 weight registers + the staging registers would spill - loaded after the staging)
 
-  // ---- stage x: one task = 8 channels of one position -> one 16-byte row of the hi and of the lo plane.  Two passes over a compile-time
-  // number of tasks per thread: every global load of the tile is in flight before the first conversion waits for one
+  // ---- stage x: one task = 8 channels x 4 consecutive columns (16-byte loads over the 16-byte-aligned superset of the tile's columns,
+  // image columns c0 - 4 .. c0 + TW + 3) -> up to four 16-byte rows of the hi and of the lo plane.  Two passes over a compile-time number of
+  // tasks per thread: every global load of the tile is in flight before the first conversion waits for one
   {
-    constexpr int NTASK = NP1 * (C / 8), NIT = (NTASK + 255) / 256;
-    float v[NIT][8];
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int NQ = (TW + 8) / 4, NTASK = (C / 8) * (TH + 4) * NQ, NIT = (NTASK + 255) / 256;
+    f32x4_t v[NIT][8];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int task = tid + 256 * it;
-      const int g = task / NP1, pos = task - g * NP1;
-      const int row = pos / P, col = pos - row * P;
-      const int ir = r0 - 2 + row, ic = c0 - 2 + col;
-      const bool ok = task < NTASK && ir >= 0 && ir < H && ic >= 0 && ic < W;
-      const float* src = p.X + (long long)(g * 8) * p.plane + (long long)ir * W + ic;
+      const int gr = task / NQ, k = task - gr * NQ, g = gr / (TH + 4), row = gr - g * (TH + 4);
+      const int ir = r0 - 2 + row, icq = c0 - 4 + 4 * k;
+      const bool ok = task < NTASK && ir >= 0 && ir < H && icq >= 0 && icq < W;
+      const float* src = p.X + (long long)(g * 8) * p.plane + (long long)ir * W + icq;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[it][j] = ok ? src[(long long)j * p.plane] : 0.f;
+      for (int j = 0; j < 8; ++j) v[it][j] = ok ? *reinterpret_cast<const f32x4_t*>(src + (long long)j * p.plane) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int task = tid + 256 * it;
-      const int g = task / NP1, pos = task - g * NP1;
-      u32x4 hi, lo;
+      const int gr = task / NQ, k = task - gr * NQ, g = gr / (TH + 4), row = gr - g * (TH + 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { unsigned h_, l_; split2(v[it][2 * j], v[it][2 * j + 1], h_, l_); hi[j] = h_; lo[j] = l_; }
-      if (task < NTASK) {
-        unsigned char* dst = smem_cbr + ((((g >> 1) * 4 + (g & 1)) * NPOS) + FRONT + pos) * 16;
-        *reinterpret_cast<u32x4*>(dst) = hi;
-        *reinterpret_cast<u32x4*>(dst + 2 * NPOS * 16) = lo;
+      for (int e = 0; e < 4; ++e) {
+        const int col = 4 * k + e - 2;                          // column of the pitch
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { unsigned h_, l_; split2(v[it][2 * j][e], v[it][2 * j + 1][e], h_, l_); hi[j] = h_; lo[j] = l_; }
+        if (task < NTASK && col >= 0 && col < P) {
+          unsigned char* dst = smem_cbr + ((((g >> 1) * 4 + (g & 1)) * NPOS) + FRONT + row * P + col) * 16;
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + 2 * NPOS * 16) = lo;
+        }
       }
     }
   }
+  if constexpr (C != 16) load_w(p.W1, p.CoPx1);
   // the slack on either side of the tile: finite values (they only ever reach outputs that are discarded)
   for (int task = tid; task < (FRONT + SLACK) * NCH * 4; task += 256) {
     const int pl = task / (FRONT + SLACK), q = task - pl * (FRONT + SLACK);
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void cbr2_small_kernel(const Cbr2Args p) {
   }
   const unsigned long long t_c1 = CTICK();
   CTACC(2, t_c1 - t_staged);
-  load_w(p.W2, p.CoPx2);                                      // (conv1's MFMAs have read their weight registers: in order)
+  if constexpr (C == 16) load_w(p.W2, p.CoPx2);              // (conv1's MFMAs have read their weight registers: in order)
   __syncthreads();                                             // every wave has finished reading x
 #pragma unroll
   for (int i = 0; i < NBW1; ++i) {
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void cbr2_small_kernel(const Cbr2Args p) {
       }
     }
   }
+  if constexpr (C != 16) load_w(p.W2, p.CoPx2);              // (32 channels: after the intermediate has left the registers)
   __syncthreads();
 
   const unsigned long long t_y1 = CTICK();
@@ -209,26 +216,40 @@ __global__ __launch_bounds__(256, 2) void cbr2_small_kernel(const Cbr2Args p) {
   asm volatile("s_nop 0" ::: "memory");
   const unsigned long long t_c2 = CTICK();
   CTACC(4, t_c2 - t_y1);
-  float res[NBW2][8 * RB];
-  long long oidx[NBW2];
+  // epilogue through LDS: relu(acc + b2) as an fp32 tile [co][row][col] over the dead image, then 16-byte residual loads / stores
+  // (the MFMA layout holds one position per lane: 4-byte accesses, 5x the instructions)
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int NTO = C * TH * (TW / 4), NITO = NTO / 256;
+  static_assert(NTO % 256 == 0, "output tasks per thread");
+  f32x4_t res[NITO];
 #pragma unroll
-  for (int i = 0; i < NBW2; ++i) {                             // every residual load of the wave in flight before the first store
-    const int blk = wave + 4 * i;
-    const int q = 2 * P + 32 * blk + li, row = q / P, col = q - row * P;
-    const int ir = r0 - 2 + row, ic = c0 - 2 + col;
-    const bool ok = blk < NB2 && row < TH + 2 && ir < H && col >= 2 && col < TW + 2 && ic < W;
-    oidx[i] = ok ? (long long)ir * W + ic : -1;
-#pragma unroll
-    for (int r = 0; r < 8 * RB; ++r) { const int co = (r & 3) + 8 * (r >> 2) + 4 * lh; res[i][r] = ok ? p.X[(long long)co * p.plane + oidx[i]] : 0.f; }
+  for (int it = 0; it < NITO; ++it) {                          // residual quads requested first: they fly during the transpose
+    const int task = tid + 256 * it, kq = task % (TW / 4), cr = task / (TW / 4), row = cr % TH, co = cr / TH;
+    const int ir = r0 + row, ic = c0 + 4 * kq;
+    res[it] = (ir < H && ic < W) ? *reinterpret_cast<const f32x4_t*>(p.X + (long long)co * p.plane + (long long)ir * W + ic) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
+  __syncthreads();                                             // every wave's conv2 operand reads are done
+  float* ot = reinterpret_cast<float*>(smem_cbr);
 #pragma unroll
   for (int i = 0; i < NBW2; ++i) {
-    if (oidx[i] >= 0) {
+    const int blk = wave + 4 * i;
+    const int q = 2 * P + 32 * blk + li, row = q / P - 2, col = q - (row + 2) * P - 2;
+    if (blk < NB2 && row < TH && col >= 0 && col < TW) {
 #pragma unroll
       for (int r = 0; r < 8 * RB; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        p.Y[(long long)co * p.plane + oidx[i]] = fmaxf(y2[i][r] + bias2[r], 0.f) + res[i][r];
+        ot[(co * TH + row) * TW + col] = fmaxf(y2[i][r] + bias2[r], 0.f);
       }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NITO; ++it) {
+    const int task = tid + 256 * it, kq = task % (TW / 4), cr = task / (TW / 4), row = cr % TH, co = cr / TH;
+    const int ir = r0 + row, ic = c0 + 4 * kq;
+    if (ir < H && ic < W) {
+      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(ot + (co * TH + row) * TW + 4 * kq) + res[it];
+      *reinterpret_cast<f32x4_t*>(p.Y + (long long)co * p.plane + (long long)ir * W + ic) = o;
     }
   }
   const unsigned long long t_end = CTICK();
@@ -254,6 +275,7 @@ bool cbr2_small_eligible(const ConvLayer& c1, const ConvLayer& c2) {
 void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out) {
   RVC_REQUIRE(cbr2_small_eligible(c1, c2), "cbr2_small_run: two 3 x 3 convolutions of 16 or 32 channels with bf16x3 weight images");
   RVC_REQUIRE(x != out, "cbr2_small_run: in place is not supported");
+  RVC_REQUIRE((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "cbr2_small_run: 16-byte rows (W a multiple of 4, aligned tensors)");
   Cbr2Args a{};
   a.X = x; a.Y = out; a.plane = (long long)H * W; a.H = H; a.W = W;
   a.W1 = reinterpret_cast<const unsigned char*>(c1.Wx_); a.W2 = reinterpret_cast<const unsigned char*>(c2.Wx_); a.CoPx1 = c1.CoPx; a.CoPx2 = c2.CoPx;
