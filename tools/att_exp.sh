@@ -2,6 +2,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_hip_ops.py -q -x -k "conv_block_res_small" 2>&1 | tail -3
+RVC_HIP_LIB=comfy-rvc_amd/csrc/variants/librvc_hip_timing.so timeout 300 python tools/time_cbr2.py 2>&1 | tail -2
 rm -rf gpurun_out/att_prof
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/att_prof -o att -- python3 bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 - <<'PY'
