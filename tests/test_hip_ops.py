@@ -630,11 +630,12 @@ def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
 
 @pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(32, 11, 5, 140003, 1.0 / 3, True), (32, 7, 3, 131072, 1.0, False), (32, 3, 1, 200001, 1.0, False),
                                                   (32, 3, 5, 136100, 1.0 / 3, True), (32, 11, 1, 150000, 1.0, False),
+                                                  (32, 11, 5, 140004, 1.0 / 3, True), (32, 11, 3, 131076, 1.0, False), (32, 7, 5, 128000, 1.0 / 3, True), (32, 7, 1, 130052, 1.0, False), (32, 3, 3, 160000, 1.0, False),
                                                   (64, 3, 5, 70001, 1.0 / 3, True), (64, 3, 3, 66000, 1.0, False), (64, 3, 1, 80003, 1.0, False)])   # (64 channels: k = 3 only by default)
 def test_fused_resblock_pair(L, Cc, k, d, T, scale, accum):
     """One ResBlock1 pair of the generator's 32-channel stage in a single launch (conv_x3_kernel FUSE: the intermediate stays in LDS,
     zero outside the sequence like the second conv's padding) against fp64 torch: y = (x + c2(lrelu(c1_d(lrelu(x))))) * s [+ y].
-    32 channels: 256-column tiles; 64 channels: 128-column tiles (conv_x3pf_kernel)."""
+    32 channels: 256-column tiles; 64 channels: 128-column tiles (conv_x3pf_kernel); lengths with and without a multiple of 4."""
     g = torch.Generator().manual_seed(1000 + 37 * k + d)
     x = torch.randn(Cc, T, generator=g)
     w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
@@ -661,7 +662,8 @@ def test_fused_resblock_pair(L, Cc, k, d, T, scale, accum):
     assert rel_err(y.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
     # sequence ends and tile seams (tiles of 256 - (k - 1) columns) carry the same error as the interior
     NO = (256 if Cc == 32 else 128) - (k - 1)
-    for c0 in (0, NO - 2, 7 * NO - 3, T - 40):
+    TN = 256 - 4 * ((k - 1 + 3) // 4)
+    for c0 in (0, NO - 2, 7 * NO - 3, TN - 20, 9 * TN - 20, T - 40):
         assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
