@@ -87,6 +87,9 @@ void layernorm_c(hipStream_t s, const float* x, const float* r, const float* gam
 // [16-channel chunk][hi | lo][8-channel half][margin + t][8 ch]).  The statistics sweep is the kernel above's; in the second sweep a thread
 // owns GROUPS of 8 consecutive channels of its column (group = slice + 16 j), so that it holds one whole 16-byte image row: per channel
 // the 16 columns of a block are still one 64-byte segment, and the 16 image rows of a (group, block) are 256 contiguous bytes.
+// NG = groups of 8 channels per thread (C <= 128 NG): the column's values stay in registers between the statistics and the normalisation - the
+// tensor is read once (NG = 0: any C, second sweep from memory)
+template <int NG>
 __global__ __launch_bounds__(256) void layernorm_c_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ y, unsigned char* __restrict__ img, long long tp, int margin,
                                                                 int C, int T, long long ld, float eps) {
@@ -97,7 +100,20 @@ __global__ __launch_bounds__(256) void layernorm_c_split_kernel(const float* __r
   const float shift = ok ? x[t] : 0.f;
   float sum = 0.f, sq = 0.f;
   const int G = C >> 3;
-  if (ok) {
+  constexpr int NGC = NG > 0 ? NG : 1;
+  float vc[NGC][8];
+  if (NG > 0) {
+#pragma unroll
+    for (int i = 0; i < NGC; ++i) {
+      const int g = sl + 16 * i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vc[i][j] = (ok && g < G) ? x[(long long)(8 * g + j) * ld + t] : shift;
+    }
+#pragma unroll
+    for (int i = 0; i < NGC; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = vc[i][j] - shift; sum += d; sq += d * d; }      // (absent groups hold `shift`: d = 0)
+  } else if (ok) {
     for (int g = sl; g < G; g += 16) {
       float v[8];
 #pragma unroll
@@ -116,10 +132,7 @@ __global__ __launch_bounds__(256) void layernorm_c_split_kernel(const float* __r
   const float mean = md + shift, rstd = rsqrtf(var + eps);
   if (!ok) return;
   typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  for (int g = sl; g < G; g += 16) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = x[(long long)(8 * g + j) * ld + t];
+  auto emit = [&](int g, float (&v)[8]) {
     u32x4_t hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gamma[8 * g + j] + beta[8 * g + j];
@@ -138,12 +151,26 @@ __global__ __launch_bounds__(256) void layernorm_c_split_kernel(const float* __r
     unsigned char* row = img + (((long long)chunk * 4 + half) * tp + margin + t) * 16;
     *reinterpret_cast<u32x4_t*>(row) = hi;
     *reinterpret_cast<u32x4_t*>(row + tp * 32) = lo;
+  };
+  if (NG > 0) {
+#pragma unroll
+    for (int i = 0; i < NGC; ++i) { const int g = sl + 16 * i; if (g < G) emit(g, vc[i]); }
+  } else {
+    for (int g = sl; g < G; g += 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = x[(long long)(8 * g + j) * ld + t];
+      emit(g, v);
+    }
   }
 }
 void layernorm_c_split(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, unsigned char* img, long long tp, int margin,
                        int C, int T, long long ld, float eps) {
   RVC_REQUIRE((C & 15) == 0 && img != nullptr, "layernorm_c_split: channels must be a multiple of 16");
-  hipLaunchKernelGGL(layernorm_c_split_kernel, dim3((T + 15) / 16), dim3(256), 0, s, x, gamma, beta, y, img, tp, margin, C, T, ld, eps);
+  const dim3 grid((T + 15) / 16);
+  if (C <= 256) hipLaunchKernelGGL(layernorm_c_split_kernel<2>, grid, dim3(256), 0, s, x, gamma, beta, y, img, tp, margin, C, T, ld, eps);
+  else if (C <= 768) hipLaunchKernelGGL(layernorm_c_split_kernel<6>, grid, dim3(256), 0, s, x, gamma, beta, y, img, tp, margin, C, T, ld, eps);
+  else hipLaunchKernelGGL(layernorm_c_split_kernel<0>, grid, dim3(256), 0, s, x, gamma, beta, y, img, tp, margin, C, T, ld, eps);
 }
 
 // ---------------------------------------------------------------------------------------------- GroupNorm(C, C) over time + GELU
