@@ -45,7 +45,7 @@ struct FlowLayer {
   DevVec cond_w, cond_b;   // weight-normed cond_layer [2*H*3][gin]
 };
 struct ResBlock { ConvLayer c1[3], c2[3]; };
-struct GenStage { ConvLayer up, noise; int u = 1, k = 1, noise_k = 1, noise_s = 1; ResBlock rb[3]; };
+struct GenStage { ConvLayer up, noise; DevVec noise_w, noise_b; int u = 1, k = 1, noise_k = 1, noise_s = 1; ResBlock rb[3]; };   // noise_w / _b: raw [C][k] / [C] for the streaming kernel (k <= 8)
 
 struct Synth {
   Ctx* ctx = nullptr;
@@ -77,7 +77,7 @@ static void synth_free(Synth& S) {
   fl(S.proj);
   for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
   fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_(); S.conv_post_w.free_();
-  for (auto& st : S.stages) { fl(st.up); fl(st.noise); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
+  for (auto& st : S.stages) { fl(st.up); fl(st.noise); st.noise_w.free_(); st.noise_b.free_(); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
   S.stages.clear();
   S.img_base = nullptr; S.img_bytes = 0; S.img_T = -1;
 }
@@ -204,6 +204,7 @@ void synth_finalize(Synth* S) {
       const HostTensor& nw = ts.get(nc + ".weight", {cout, 1, st.noise_k});
       // Conv1d(1, C, k, stride) == Linear(k -> C) on the im2col frames of the source
       conv1d_layer_init(st.noise, nw.data.data(), ts.get(nc + ".bias", {cout}).data.data(), cout, st.noise_k, 1, 1, 0, 1, 1);
+      if (st.noise_k <= 8) { st.noise_w.upload(nw.data); st.noise_b.upload(ts.get(nc + ".bias", {cout}).data); }
     }
     for (int j = 0; j < 3; ++j) {
       const std::string rb = "dec.resblocks." + std::to_string(i * 3 + j) + ".";
@@ -462,8 +463,11 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f;
       conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
       ConvEpilogue En; En.accumulate = 1;
+      static const bool noise_stream = !(getenv("RVC_NOISE_STREAM") && atoi(getenv("RVC_NOISE_STREAM")) == 0);
       if (!S->f0) {
         // plain Generator: nothing is added to the up-sampled signal
+      } else if (noise_stream && st.noise_w.p && noise_add(s, up, Tn, Cc, Tn, har, N, st.noise_k, st.noise_s, st.noise_k > 1 ? st.noise_s / 2 : 0, st.noise_w.p, st.noise_b.p)) {
+        // narrow stages (k <= 8 taps of the one source channel): a streaming add instead of im2col + GEMM
       } else if (st.noise_k > 1) {
         frames(s, har, fr, (int)N, st.noise_k, st.noise_s, st.noise_s / 2, Tn, 0);
         conv1d_run(st.noise, s, fr, Tn, Tn, up, Tn, En);

@@ -643,6 +643,54 @@ void frames(hipStream_t s, const float* src, float* out, int L, int k, int strid
   hipLaunchKernelGGL(frames_kernel, dim3(blocks), dim3(256), 0, s, src, out, L, k, stride, pad, Tout, reflect);
 }
 
+// ---------------------------------------------------------------------------------------------- NSF noise branch of the narrow generator stages
+// x[c][t] += b[c] + sum_j w[c][j] src[t stride + j - pad]  (reference models.py GeneratorNSF.forward: x = ups(x) + noise_convs(har), Conv1d(1, C, 2 s, stride s,
+// padding s / 2) resp. Conv1d(1, C, 1) in the last stage).  K <= 8 taps on ONE source channel: 2 K FLOP per 8 bytes moved - a streaming kernel (16-byte
+// accesses of x, the source window of a quad from L1), where the im2col + fp32-MFMA GEMM ran at 0.30 - 0.41 of the HBM rate.
+template <int K>
+__global__ __launch_bounds__(256) void noise_add_kernel(float* __restrict__ x, long long ld, int C, int T, const float* __restrict__ src, long long L, int stride, int pad,
+                                                        const float* __restrict__ w, const float* __restrict__ b) {
+  // a thread owns 4 consecutive positions and walks 16 channels: the source window (4 K samples) is fetched once per 64 outputs, the
+  // weights of a channel are wave-uniform (scalar loads)
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const int c0 = blockIdx.y * 16;
+  const int t4 = 4 * (blockIdx.x * 256 + threadIdx.x);
+  if (t4 >= T) return;
+  float sv[4][K];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long p0 = (long long)(t4 + e) * stride - pad;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { const long long q = p0 + j; sv[e][j] = (q >= 0 && q < L) ? src[q] : 0.f; }
+  }
+  f32x4_t v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = (c0 + i < C) ? *reinterpret_cast<const f32x4_t*>(x + (long long)(c0 + i) * ld + t4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + i;
+    if (c < C) {
+      const float bc = b[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = bc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) a = fmaf(w[c * K + j], sv[e][j], a);
+        v[i][e] += a;
+      }
+      *reinterpret_cast<f32x4_t*>(x + (long long)c * ld + t4) = v[i];
+    }
+  }
+}
+bool noise_add(hipStream_t s, float* x, long long ld, int C, int T, const float* src, long long L, int k, int stride, int pad, const float* w, const float* b) {
+  if ((T & 3) || (ld & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || !(k == 1 || k == 4 || k == 8)) return false;
+  const dim3 grid((unsigned)((T / 4 + 255) / 256), (unsigned)((C + 15) / 16));
+  if (k == 1) hipLaunchKernelGGL(noise_add_kernel<1>, grid, dim3(256), 0, s, x, ld, C, T, src, L, stride, pad, w, b);
+  else if (k == 4) hipLaunchKernelGGL(noise_add_kernel<4>, grid, dim3(256), 0, s, x, ld, C, T, src, L, stride, pad, w, b);
+  else hipLaunchKernelGGL(noise_add_kernel<8>, grid, dim3(256), 0, s, x, ld, C, T, src, L, stride, pad, w, b);
+  return true;
+}
+
 // |STFT|: mag[f][t] = sqrt(re^2 + im^2) with re = ft[f][t], im = ft[f + F][t]   (reference lib/rmvpe.py:143-147)
 __global__ void magnitude_kernel(const float* __restrict__ ft, float* __restrict__ mag, int F, int T) {
   const long long n = (long long)F * T;
