@@ -18,6 +18,15 @@
 
 namespace rvc {
 
+#ifdef RVC_CONV_TIMING
+void attention_dma_rel_timing_read(unsigned long long* out8, bool reset);      // attention_dma_rel.hip
+void attention_dma_timing_read(unsigned long long* out8, bool reset) {
+  unsigned long long r[8];
+  attd_timing_read_tu(out8, reset); attention_dma_rel_timing_read(r, reset);
+  for (int i = 0; i < 8; ++i) out8[i] += r[i];
+}
+#endif
+
 void attention_dma_rel_launch(const AttnDmaArgs& a, int heads, hipStream_t s);      // attention_dma_rel.hip
 
 // rows of the V^T image per plane and its size for T keys (4 key chunks per 64-key tile, whole tiles)

@@ -17,10 +17,25 @@ struct AttnDmaArgs {
   // key split across workgroups (blockIdx.z = slice of the key tiles): partial (m, l, O) states as write-through slabs, a ticket per
   // (query tile, head); the workgroup that draws the last ticket merges the slices in slice order and runs the epilogue
   int kz; float* part; unsigned part_bytes; unsigned* tickets;
+  int nqt, heads, xcd_remap;                                    // query tiles, heads (grid decoding; set by the launcher)
   // relative-position terms of the synthesizer's text encoder (REL): E_k as an image [D / 16 chunks][plane][32 rows r][8 d] (rows past
   // 2 win zero), E_v^T as [2 chunks of r][plane][D rows][8 r]; the raw band scores sband [heads][2 win + 1][T] (write-through scratch)
   int win; const unsigned char* ek_img; const unsigned char* evt_img; float* sband; unsigned sband_bytes;
 };
+
+#ifdef RVC_CONV_TIMING
+static __device__ unsigned long long g_attd_timing[8];   // [0] workgroups, [1] prologue, [2] tile loop, [3] slab store + ticket, [4] merge, [5] epilogue, [6] total (all: first wave of each workgroup)
+static inline void attd_timing_read_tu(unsigned long long* out8, bool reset) {      // this translation unit's copy
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attd_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attd_timing), z, sizeof(z)); }
+}
+#define DTICK() wall_clock64()
+#define DTACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_attd_timing[i], (unsigned long long)(v)); } while (0)
+#else
+#define DTICK() 0ull
+#define DTACC(i, v) do {} while (0)
+#endif
 
 __device__ __forceinline__ void att_dma(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_dst, int voffset, int soffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
@@ -33,14 +48,20 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
   static_assert(NPK % NWQ == 0 && NPV % NWQ == 0, "every wave's i-th piece is of one kind");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_att[];
 
+  const unsigned long long dt0 = DTICK();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
   // KS wave groups share the workgroup's queries and take the key tiles round-robin, each with its own (m, l, O) and its own pair of
   // tile buffers: two waves per SIMD, one's softmax (VALU) under the other's MFMAs; the groups' states are merged once at the end
   const int grp = wave_wg / NWQ, wave = wave_wg - grp * NWQ;
   const int li = lane & 31, lh = lane >> 5;
-  const int h = blockIdx.y;
-  const int q0 = (blockIdx.x * NWQ + wave) * 32;
+  // 1-D grid, renumbered so that an XCD (consecutive hardware ids go round-robin to the 8 XCDs, each with its own 4 MB L2) works on ONE
+  // contiguous run of (key slice, head, query tile) with the query tile fastest: the workgroups that stream the same K / V^T tiles share an L2
+  // (with (x, y, z) = (query tile, head, slice) every XCD touched every head's K / V: 4.9 - 9.8 MB through each 4 MB L2)
+  const unsigned bid = p.xcd_remap ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int qtx = (int)(bid % (unsigned)p.nqt), hz = (int)(bid / (unsigned)p.nqt);
+  const int h = hz % p.heads;
+  const int q0 = (qtx * NWQ + wave) * 32;
   const int T = p.T;
   unsigned char* const smem_g = smem_att + grp * (2 * BUF);
 
@@ -68,7 +89,7 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
     }
   };
   // this workgroup's slice of the key tiles
-  const int ntiles_all = (T + 63) / 64, kz = p.kz, z = blockIdx.z;
+  const int ntiles_all = (T + 63) / 64, kz = p.kz, z = hz / p.heads;
   const int tile0 = (int)((long long)z * ntiles_all / kz), ntiles = (int)((long long)(z + 1) * ntiles_all / kz) - tile0, nsteps = (ntiles + KS - 1) / KS;
   if (grp < ntiles) issue(tile0 + grp, 0);
 
@@ -107,6 +128,8 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
   const float c2 = p.scale * 1.4426950408889634f;              // exp(s scale - m scale) = exp2((s - m) c2)
   float m_run = -3.0e38f, l_run = 0.f;
 
+  const unsigned long long dt1 = DTICK();
+  DTACC(1, dt1 - dt0);
   for (int st = 0; st < nsteps; ++st) {
     const int itl = st * KS + grp, it = tile0 + itl;           // tile inside the slice, absolute tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the tile (and, the first time, its queries)
@@ -226,6 +249,8 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
     }
   }
 
+  const unsigned long long dt2 = DTICK();
+  DTACC(2, dt2 - dt1);
   if (KS > 1) {
     // ---- merge the groups' states into group 0 (through the dead tile buffers): m = max m_g, l = sum l_g 2^((m_g - m) c2), O likewise
     constexpr int NV = 2 + 16 * DB;
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
     // the last arriver reads ALL slices back (its own included: one code path, the sum order is the slice order whoever is last),
     // a slice's 4 DB + 1 loads in flight together
     constexpr int NQ = 4 * DB + 1;
-    const unsigned qt = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned qt = (unsigned)(h * p.nqt + qtx);
     const __amdgpu_buffer_rsrc_t prs = make_rsrc(p.part, p.part_bytes);
     const unsigned slab = (unsigned)(NWQ * NQ * 64) * 16u;
     const unsigned lane_off = ((unsigned)(wave * NQ) * 64u + (unsigned)lane) * 16u;
@@ -284,31 +309,53 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
       *flag = t;
     }
     __syncthreads();
-    if (*flag != (unsigned)kz - 1u) return;
-    float m = -3.0e38f;
-    for (int zz = 0; zz < kz; ++zz) {
-      const u32x4 ml = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((qt * (unsigned)kz + (unsigned)zz) * slab + lane_off + (unsigned)(4 * DB) * 1024u), 0, 16);
-      m = fmaxf(m, __uint_as_float(ml[0]));
-    }
-    float l = 0.f;
+    const unsigned long long dt3 = DTICK();
+    DTACC(3, dt3 - dt2);
+    if (*flag != (unsigned)kz - 1u) { DTACC(0, 1); DTACC(6, dt3 - dt0); return; }
+    // up to KZB slices per batch, EVERY load of a batch in flight before the first is used (a slab lives in another XCD's write-through
+    // path: one round trip of ~2 us per dependent batch); slices past kz read through a zero-extent offset and weigh 0
+    constexpr int KZB = 5;
+    float m = -3.0e38f, l = 0.f;
+    f32x16 om[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    for (int zz = 0; zz < kz; ++zz) {
-      const unsigned base = (qt * (unsigned)kz + (unsigned)zz) * slab + lane_off;
-      u32x4 v[NQ];
+      for (int r = 0; r < 16; ++r) om[db][r] = 0.f;
+    for (int z0 = 0; z0 < kz; z0 += KZB) {
+      u32x4 v[KZB][NQ];
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(base + (unsigned)i * 1024u), 0, 16);
-      const float az = __builtin_amdgcn_exp2f((__uint_as_float(v[4 * DB][0]) - m) * c2);
-      l = fmaf(__uint_as_float(v[4 * DB][1]), az, l);
+      for (int j = 0; j < KZB; ++j) {
+        const bool in = z0 + j < kz;
+        const unsigned base = (qt * (unsigned)kz + (unsigned)(z0 + j)) * slab + lane_off;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) v[j][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, in ? (int)(base + (unsigned)i * 1024u) : (int)kOOB, 0, 16);
+      }
+      float mb = m;
+#pragma unroll
+      for (int j = 0; j < KZB; ++j) if (z0 + j < kz) mb = fmaxf(mb, __uint_as_float(v[j][4 * DB][0]));
+      const float a0 = __builtin_amdgcn_exp2f((m - mb) * c2);       // what the earlier batches have summed, re-based (1 for the first batch: nothing summed)
+      l *= a0;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = fmaf(__uint_as_float(v[db * 4 + (r >> 2)][r & 3]), az, o[db][r]);
+        for (int r = 0; r < 16; ++r) om[db][r] *= a0;
+      m = mb;
+#pragma unroll
+      for (int j = 0; j < KZB; ++j) {
+        const float az = (z0 + j < kz) ? __builtin_amdgcn_exp2f((__uint_as_float(v[j][4 * DB][0]) - m) * c2) : 0.f;
+        l = fmaf(__uint_as_float(v[j][4 * DB][1]), az, l);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) om[db][r] = fmaf(__uint_as_float(v[j][db * 4 + (r >> 2)][r & 3]), az, om[db][r]);
+      }
     }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[db] = om[db];
     m_run = m; l_run = l;
   }
+  const unsigned long long dt4 = DTICK();
+  DTACC(4, dt4 - dt2);
   // ---- normalise, + bv; fp32 rows and / or the image the out-projection stages
   const int q = q0 + li;
   const float inv = 1.f / l_run;
@@ -383,6 +430,8 @@ __global__ __launch_bounds__(64 * NWQ * KS) void attention_dma_kernel(const Attn
       }
     }
   }
+  const unsigned long long dt5 = DTICK();
+  DTACC(5, dt5 - dt4); DTACC(6, dt5 - dt0); DTACC(0, 1);
 }
 
 template <int D, int NWQ, int KS, bool REL>
@@ -392,7 +441,11 @@ static void launch_att_dma(const AttnDmaArgs& a, int heads, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
-  hipLaunchKernelGGL(kern, dim3((a.T + 32 * NWQ - 1) / (32 * NWQ), heads, a.kz), dim3(64 * NWQ * KS), lds, s, a);
+  AttnDmaArgs b = a;
+  b.nqt = (a.T + 32 * NWQ - 1) / (32 * NWQ); b.heads = heads;
+  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  b.xcd_remap = xcd_env;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nqt * heads * a.kz)), dim3(64 * NWQ * KS), lds, s, b);
 }
 
 }  // namespace rvc

@@ -4,6 +4,9 @@
 
 namespace rvc {
 
+#ifdef RVC_CONV_TIMING
+void attention_dma_rel_timing_read(unsigned long long* out8, bool reset) { attd_timing_read_tu(out8, reset); }
+#endif
 void attention_dma_rel_launch(const AttnDmaArgs& a, int heads, hipStream_t s) { launch_att_dma<96, 4, 1, true>(a, heads, s); }
 
 }  // namespace rvc

@@ -376,6 +376,7 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
 void cbr2_timing_read(unsigned long long* out8, bool reset);
+void attention_dma_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 8);
@@ -383,6 +384,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   unsigned long long x3[8]; conv_x3_timing_read(x3, reset);
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   attention_timing_read(x3, reset);
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  attention_dma_timing_read(x3, reset); // (attention on images: [0] workgroups, [1] prologue, [2] tile loop, [3] slab store + ticket, [4] merge, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   cbr2_timing_read(x3, reset);          // (fused ConvBlockRes: [0] workgroups, [1] staging, [2] conv1, [3] y1 -> LDS, [4] conv2, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
