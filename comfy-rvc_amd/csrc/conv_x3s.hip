@@ -435,6 +435,34 @@ void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, i
   // (channels past C inside the last 16-channel chunk are written as zeros)
   hipLaunchKernelGGL(split_image_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, X, ldX, C, T, img, tp);
 }
+// x [C][T][M] fp32 (per channel: T rows of M contiguous values, M a multiple of 8) -> the image of the (C M) x T tensor whose channel index is
+// c M + m (RMVPE: the 3 x 128 output of its last convolution flattened per frame, lib/rmvpe.py:356): 8 consecutive channels are 32 contiguous bytes
+__global__ __launch_bounds__(256) void split_image_tm_kernel(const float* __restrict__ x, int C, int T, int M, unsigned char* __restrict__ img, long long tp) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int hp = blockIdx.y;                                  // group of 8 channels = chunk * 2 + half
+  if (t >= T) return;
+  const int f0 = hp * 8, c = f0 / M, m0 = f0 - c * M;
+  u32x4 hi, lo;
+  if (c < C) {
+    const float* src = x + ((long long)c * T + t) * M + m0;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + 4);
+    unsigned h_, l_;
+    split2(a[0], a[1], h_, l_); hi[0] = h_; lo[0] = l_;
+    split2(a[2], a[3], h_, l_); hi[1] = h_; lo[1] = l_;
+    split2(b[0], b[1], h_, l_); hi[2] = h_; lo[2] = l_;
+    split2(b[2], b[3], h_, l_); hi[3] = h_; lo[3] = l_;
+  } else {
+    hi = u32x4{0u, 0u, 0u, 0u}; lo = hi;
+  }
+  unsigned char* row = img + (((long long)(hp >> 1) * 4 + (hp & 1)) * tp + kSplitMargin + t) * 16;
+  *reinterpret_cast<u32x4*>(row) = hi;
+  *reinterpret_cast<u32x4*>(row + tp * 32) = lo;
+}
+void split_image_from_tm(hipStream_t s, const float* x, int C, int T, int M, unsigned char* img, long long tp) {
+  RVC_REQUIRE((M & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "split_image_from_tm: rows of a multiple of 8 values, 16-byte aligned");
+  hipLaunchKernelGGL(split_image_tm_kernel, dim3((T + 255) / 256, (C * M + 15) / 16 * 2), dim3(256), 0, s, x, C, T, M, img, tp);
+}
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY) {
   hipLaunchKernelGGL(unsplit_image_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, img, tp, C, T, Y, ldY);
 }
@@ -577,11 +605,14 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
 // (its rows are positions), the layer's weight image the column operand - written as the image of the TRANSPOSED tensor:
 // [16-position chunk][hi | lo][8-position half][kSplitMargin + j][8 positions].  That is the V^T operand of the attention's P V product
 // (attention_dma.hip): the reduction of P V runs over keys, so the keys must be the 8-element rows.  No bias (the caller adds V's bias
-// after the attention: softmax rows sum to 1); rows >= T of the last chunk are written as zeros.
-void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp) {
+// after the attention: softmax rows sum to 1); rows >= T of the last chunk are written as zeros.  Yrm (optional): the same product as fp32 rows
+// out[t][j] with pitch ldYrm - a time-major result without a transposition pass (RMVPE's GRU input projection).
+void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp,
+                          float* Yrm, long long ldYrm) {
   RVC_REQUIRE(L.Wx_ != nullptr && L.mode == 1 && L.k == 1 && L.groups == 1 && (L.Ci & 15) == 0, "conv_x3s_run_swapped: a k = 1 projection with a bf16x3 weight image");
   RVC_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.Co && (row0 & 15) == 0, "conv_x3s_run_swapped: row range");
-  RVC_REQUIRE(Xs != nullptr && xsTp >= kSplitMargin + T + 704 && Ys != nullptr && ysTp >= kSplitMargin + rows, "conv_x3s_run_swapped: images missing or too short");
+  RVC_REQUIRE(Xs != nullptr && xsTp >= kSplitMargin + T + 704 && (Ys != nullptr || Yrm != nullptr) && (!Ys || ysTp >= kSplitMargin + rows), "conv_x3s_run_swapped: images missing or too short");
+  RVC_REQUIRE(!Yrm || (ldYrm >= rows && (double)T * (double)ldYrm * 4.0 < 2147483648.0), "conv_x3s_run_swapped: row-major output pitch");
   const double xs_bytes = (double)(L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)(L.Ci / 16) * 4.0 * (double)L.CoPx * 16.0;
   RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
   GemmSArgs a{};
@@ -590,6 +621,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1;
   a.groups = 1; a.co_g = T; a.cig_chunks = L.Ci / 16; a.tdil = 1;
   a.Ys = Ys; a.ysTp = ysTp; a.act = ACT_NONE; a.out_scale = 1.f;
+  a.Y = Yrm; a.ldY = ldYrm;                                    // fp32 out[t][j], row-major (the GRU's input projection)
   int AM, AN, S;
   x3s_plan(T, rows, a.nunits, AM, AN, S, 1);
   S = 1;                                                       // (48-unit reductions: never split)

@@ -24,6 +24,7 @@ struct Rmvpe {
   ConvLayer cnn;
   DevVec wihT, b_ih, w_hh, b_hh;
   ConvLayer fc;
+  ConvLayer wih;           // GRU input projection [1536][384] (both directions) as a k = 1 layer: its weight image feeds the swapped split-resident product
   unsigned long long* xbuf = nullptr; int* gru_err = nullptr;
   int gru_fault = 0; unsigned gru_spin_limit = 0;          // test hooks (rmvpe_debug_fault)
 };
@@ -40,7 +41,7 @@ static void rmvpe_free(Rmvpe& R) {
   for (auto& c : R.dect) conv_layer_free(c);
   for (auto& c : R.dect_t) conv_layer_free(c);
   R.pad_ok = false; R.img_base = nullptr; R.img_bytes = 0; R.img_H1 = -1;
-  conv_layer_free(R.cnn); conv_layer_free(R.fc);
+  conv_layer_free(R.cnn); conv_layer_free(R.fc); conv_layer_free(R.wih);
   R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.b_hh.free_();
   dev_free(R.xbuf); dev_free(R.gru_err); R.xbuf = nullptr; R.gru_err = nullptr;
 }
@@ -138,6 +139,9 @@ void rmvpe_finalize(Rmvpe* R) {
       std::copy(b2.data.begin(), b2.data.end(), bh.begin() + d * 768);
     }
     R->wihT.upload(wT); R->b_ih.upload(bi); R->w_hh.upload(wh); R->b_hh.upload(bh);
+    std::vector<float> wrow((size_t)1536 * 384);            // [g][f] = wT[f][g]
+    for (int g = 0; g < 1536; ++g) for (int k = 0; k < 384; ++k) wrow[(size_t)g * 384 + k] = wT[(size_t)k * 1536 + g];
+    conv1d_layer_init(R->wih, wrow.data(), nullptr, 1536, 384, 1, 1, 0, 1, 1);
   }
   conv1d_layer_init(R->fc, ts.get("fc.1.weight", {360, 512}).data.data(), ts.get("fc.1.bias", {360}).data.data(), 360, 512, 1, 1, 0, 1, 1);
   {
@@ -362,13 +366,23 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
   // ---- cnn -> BiGRU -> Linear -> sigmoid
   float* c3 = A.alloc<float>((size_t)3 * Tr * 128);
   float* feat = A.alloc<float>((size_t)384 * Tr);
+  static const bool gi_env = !(getenv("RVC_RMVPE_GI_X3S") && atoi(getenv("RVC_RMVPE_GI_X3S")) == 0);
+  const bool gi_x3s = gi_env && x3s_on && conv_x3_enabled() && R->wih.Wx_ != nullptr;
+  unsigned char* feat_s = gi_x3s ? A.alloc<unsigned char>(split_image_bytes(384, Tr)) : nullptr;
   float* gi = A.alloc<float>((size_t)Tr * 1536);
   float* hid = A.alloc<float>((size_t)512 * Tr);
   float* sal = A.alloc<float>((size_t)360 * Tr);
   if (!dry) {
     conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
-    transpose(s, c3, feat, Tr, 128, 128, Tr, 3, (long long)Tr * 128, 128LL * Tr);           // [c][t][m] -> [c*128+m][t]
-    gemm_tn_run(s, feat, Tr, 0, R->wihT.p, 1536, 0, gi, 1536, 0, Tr, 1536, 384, 1, nullptr, 0, E0);
+    if (gi_x3s) {
+      // gi[t][g] = sum_f W_ih[g][f] feat[f][t], f = c 128 + m: the frame features go straight from [c][t][m] into the image, the product is the
+      // swapped split-resident GEMM writing fp32 rows [t][1536] (no transposition pass, no fp32-MFMA GEMM: 97 + 10 us -> ~25)
+      split_image_from_tm(s, c3, 3, Tr, 128, feat_s, split_image_tp(Tr));
+      conv_x3s_run_swapped(R->wih, 0, 1536, s, feat_s, split_image_tp(Tr), Tr, nullptr, 0, gi, 1536);
+    } else {
+      transpose(s, c3, feat, Tr, 128, 128, Tr, 3, (long long)Tr * 128, 128LL * Tr);           // [c][t][m] -> [c*128+m][t]
+      gemm_tn_run(s, feat, Tr, 0, R->wihT.p, 1536, 0, gi, 1536, 0, Tr, 1536, 384, 1, nullptr, 0, E0);
+    }
     gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr, R->gru_spin_limit, R->gru_fault);
     if (taps && taps->gru) RVC_HIP_CHECK(hipMemcpyAsync(taps->gru, hid, (size_t)512 * Tr * sizeof(float), hipMemcpyDeviceToDevice, s));
     ConvEpilogue Es; Es.act = ACT_SIGMOID;
