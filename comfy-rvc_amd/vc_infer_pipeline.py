@@ -38,6 +38,7 @@ class VC(FeatureExtractor):
     noise_fn = None        # optional callable(shape) -> CPU float tensor replacing the global-RNG draws (tests / replay)
     noise_on_device = False  # True: draw the synthesizer noise with the GPU generator (faster, not CPU-replayable)
     overlap_streams = True   # HuBERT on a side stream while RMVPE runs (False: one stream, for per-kernel profiling)
+    device_f0_post = True    # plain "rmvpe": transpose + mel quantisation of the pitch on the device, no host round trip before the synthesizer
 
     def _draw(self, shape):
         if self.noise_fn is not None:
@@ -258,14 +259,33 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
         noises.append((nz.to(dev, torch.float32).contiguous(), ns, torch.empty(T * net_g.upp, dtype=torch.float32, device=dev)))
     # pitch on the main stream (RMVPE) + host post-processing at 100 fps
     pitch_d = pitchf_d = None
+    deferred_status = None
     if if_f0:
-        x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
-        pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
-                                    f0_min, f0_max)
-        _mark("f0 ready (rmvpe sync + host post)")
-        p_len = min(pitch.shape[0], pitchf.shape[0])
-        pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
-        pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
+        m = f0_method[0] if isinstance(f0_method, (list, tuple)) and len(f0_method) == 1 else f0_method
+        plain_rmvpe = (m == "rmvpe" and not f0_autotune and self.device_f0_post and "get_f0" not in self.__dict__      # (an instance-level get_f0 override is honoured)
+                       and getattr(self.f0_method_dict.get("rmvpe"), "__func__", None) is type(self).get_rmvpe)
+        if plain_rmvpe:
+            # RMVPE with nothing spliced in (the default front end): the 100-fps post-processing of get_f0 (pitch_extraction.py:176-185, reference
+            # vc_infer_pipeline.py / pitch_extraction.py: transpose, mel-scale quantisation to 1 .. 255) runs on the device in float64 like the numpy
+            # original, so nothing waits for the pitch on the host: the synthesizer is enqueued behind RMVPE.  The GRU scan's status word is
+            # checked after the clip (below) instead of before the synthesizer.
+            rm = self._rmvpe()
+            f0 = rm.infer(a_dev, 0.03)["f0"] * pow(2, f0_up_key / 12)
+            mel_min, mel_max = 2595 * np.log10(1 + f0_min / 700), 2595 * np.log10(1 + f0_max / 700)      # lib/audio.py hz_to_mel
+            f0_mel = (2595 * torch.log10(1 + f0 / 700) - mel_min) * (self.f0_bins - 2) / (mel_max - mel_min) + 1
+            pitch_d = torch.round(torch.clamp(f0_mel, 1, self.f0_bins - 1)).to(torch.int64)      # (round half to even, as np.rint)
+            pitchf_d = f0.to(torch.float32)
+            deferred_status = rm
+            _mark("f0 enqueued (rmvpe + device post)")
+        else:
+            x_f0 = a_dev if f0_method in ("rmvpe", "rmvpe+") else a_dev.cpu().numpy().astype(np.float64)
+            pitch, pitchf = self.get_f0(x_f0, f0_up_key, f0_method, merge_type, filter_radius, crepe_hop_length, f0_autotune, rmvpe_onnx, None,
+                                        f0_min, f0_max)
+            _mark("f0 ready (rmvpe sync + host post)")
+            p_len = min(pitch.shape[0], pitchf.shape[0])
+            pitch_d = torch.from_numpy(pitch[:p_len].astype(np.int64)).to(dev)
+            pitchf_d = torch.from_numpy(pitchf[:p_len].astype(np.float32)).to(dev)
+    self.last_pitch = (pitch_d, pitchf_d)      # device tensors (coarse int64, Hz float32) of this clip, for inspection
     main.wait_stream(side)
     sid_i = int(torch.as_tensor(sid).reshape(-1)[0])
     D = 256 if version == "v1" else 768
@@ -293,6 +313,8 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     _mark("post enqueued")
     res = i16.cpu().numpy()
     _mark("result on host")
+    if deferred_status is not None:
+        deferred_status.check_status()      # raises RvcHipError if the GRU scan of this clip's RMVPE forward timed out (f0 was NaN then)
     if _tr is not None:
         print("trace ms: " + " | ".join(f"{n} {1e3 * (t - _tr[i][1]):.1f}" for i, (n, t) in enumerate(_tr[1:])))
     return res
