@@ -746,6 +746,9 @@ void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long
 // XCD (measured: 6.3 -> 5.0 ms for 3200 steps).  Agent-scope loads are correct for any placement; workgroup-scope (sc0) polling
 // was tried for an L2-local hand-off and never observes the remote store (it is served from the CU's L1).
 // gi: [T][1536] = W_ih x + (bias added here); out: channel-major [512][T].   nn.GRU gate order r, z, n.
+#ifndef RVC_GRU_SLEEP
+#define RVC_GRU_SLEEP 1      // back-off of the polling loop, in units of 64 cycles (measured: see DESIGN.md)
+#endif
 __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                        const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                        float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
@@ -753,8 +756,11 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
   constexpr int H = 256, HS = 32;
   constexpr int HP = 36;                                   // padded pitch of one 32-value segment of h in LDS (float4 reads of the
                                                            // eight segments then fall on disjoint banks)
-  __shared__ __attribute__((aligned(16))) float hs[8 * HP];
-  __shared__ float ghs[96];
+  // h and the gate pre-activations are double-buffered by step parity: the gate threads of step s read buffer s & 1 while the other threads
+  // already gather / multiply step s + 1 in the other one - no barrier at the end of a step; the data dependency orders the rest (nobody passes
+  // the gather of step s + 1 before every slice, this one included, has published h_s).  Same-box A/B, 6201 steps: 6.33 -> 6.11 ms.
+  __shared__ __attribute__((aligned(16))) float hs[2][8 * HP];
+  __shared__ float ghs[2][96];
   const int xcd = blockIdx.x & 7;
   if (xcd != 0 && xcd != 4) return;
   const int dir = xcd >> 2, sl = blockIdx.x >> 3;
@@ -782,9 +788,10 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
     c_r = BI[unit] + BH[unit]; c_z = BI[H + unit] + BH[H + unit];          // (b_ih + b_hh) of the r and z gates
     bi_n = BI[2 * H + unit]; bh_n = BH[2 * H + unit];
   }
-  if (tid < H) hs[(tid >> 5) * HP + (tid & 31)] = 0.f;
+  if (tid < H) hs[0][(tid >> 5) * HP + (tid & 31)] = 0.f;
   __syncthreads();
   for (int step = 0; step < T; ++step) {
+    float* hsb = hs[step & 1]; float* gb = ghs[step & 1];
     const int t = dir ? (T - 1 - step) : step;
     float gr = 0.f, gz = 0.f, gn = 0.f;
     if (tid < HS) {
@@ -801,14 +808,14 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
           v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == (unsigned)step) break;
           if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(RVC_GRU_SLEEP);
         }
-        hs[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
+        hsb[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
       }
       __syncthreads();
     }
     {
-      const float4* hv = reinterpret_cast<const float4*>(hs + seg * HP);
+      const float4* hv = reinterpret_cast<const float4*>(hsb + seg * HP);
       float4 h4[8];
 #pragma unroll
       for (int c = 0; c < 8; ++c) h4[c] = hv[c];
@@ -823,24 +830,23 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
       a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
       a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
       a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xF, 0xF, true));   // row_half_mirror
-      if (seg == 0) ghs[lr] = a;
+      if (seg == 0) gb[lr] = a;
     }
     __syncthreads();
     if (tid < HS) {
       // gates on the hardware exp2 / reciprocal (1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1).
       // The library expf / tanhf were 770 of the 2550 cycles of a step, on the critical path of all 16 workgroups.
       constexpr float kL2E = 1.44269504088896340736f;
-      const float r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gr + ghs[tid])));
-      const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gz + ghs[HS + tid])));
-      const float xn = gn + r * (ghs[2 * HS + tid] + bh_n);
+      const float r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gr + gb[tid])));
+      const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gz + gb[HS + tid])));
+      const float xn = gn + r * (gb[2 * HS + tid] + bh_n);
       const float nn = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * kL2E * xn) + 1.f);
-      const float hprev = hs[(unit >> 5) * HP + (unit & 31)];
+      const float hprev = hsb[(unit >> 5) * HP + (unit & 31)];
       const float hnew = (1.f - zg) * nn + zg * hprev;
       const unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hnew);
       __hip_atomic_store(xb + (step & 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[(long long)(dir * H + unit) * T + t] = hnew;
     }
-    __syncthreads();
   }
 }
 // *err is a sticky device flag: set when a workgroup gave up waiting for its peers (they need co-residency: 16 workgroups of 768
