@@ -77,6 +77,7 @@ SIGNATURES = {
     "rvc_rmvpe_finalize": (c_int, [c_void_p]),
     "rvc_rmvpe_destroy": (c_int, [c_void_p]),
     "rvc_rmvpe_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, P(RmvpeTaps)]),
+    "rvc_f0_post": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, C.c_double, C.c_double, c_int, c_void_p, c_void_p]),
     "rvc_rmvpe_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rvc_rmvpe_status": (c_int, [c_void_p, c_void_p]),
     "rvc_rmvpe_debug_fault": (c_int, [c_void_p, c_int, C.c_uint]),

@@ -33,6 +33,7 @@ void feats_prepare(hipStream_t s, const float* f, const float* f0, const float* 
                    int do_protect);
 // x[c][t] += b[c] + sum_j w[c][j] src[t stride + j - pad] for k = 1 / 4 / 8 taps of one source channel (16-byte rows); false: not its shape
 bool noise_add(hipStream_t s, float* x, long long ld, int C, int T, const float* src, long long L, int k, int stride, int pad, const float* w, const float* b);
+void f0_post(hipStream_t s, const double* f0, long long n, double factor, double mel_min, double mel_max, int bins, long long* pitch, float* pitchf);
 void frames(hipStream_t s, const float* src, float* out, int L, int k, int stride, int pad, int Tout, int reflect);
 void magnitude(hipStream_t s, const float* ft, float* mag, int F, int T);
 void mel_to_unet(hipStream_t s, const float* mel, float* x, int n, int Tr, float a, float b);

@@ -691,6 +691,23 @@ bool noise_add(hipStream_t s, float* x, long long ld, int C, int T, const float*
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------- pitch post-processing at 100 frames per second
+// get_f0's tail (reference pitch_extraction.py / vc_infer_pipeline.py get_f0: f0 *= 2^(key / 12); mel = 2595 log10(1 + f0 / 700) scaled to 1 .. bins - 1,
+// rint) in float64 like the numpy original: pitchf (Hz, float32) and the coarse pitch (int64) the synthesizer takes, without a host round trip
+__global__ void f0_post_kernel(const double* __restrict__ f0, long long n, double factor, double mel_min, double mel_max, int bins,
+                               long long* __restrict__ pitch, float* __restrict__ pitchf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double f = f0[i] * factor;
+  double m = (2595.0 * log10(1.0 + f / 700.0) - mel_min) * (double)(bins - 2) / (mel_max - mel_min) + 1.0;
+  m = fmin(fmax(m, 1.0), (double)(bins - 1));
+  pitch[i] = (long long)rint(m);                            // (round half to even, as np.rint)
+  pitchf[i] = (float)f;
+}
+void f0_post(hipStream_t s, const double* f0, long long n, double factor, double mel_min, double mel_max, int bins, long long* pitch, float* pitchf) {
+  hipLaunchKernelGGL(f0_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, f0, n, factor, mel_min, mel_max, bins, pitch, pitchf);
+}
+
 // |STFT|: mag[f][t] = sqrt(re^2 + im^2) with re = ft[f][t], im = ft[f + F][t]   (reference lib/rmvpe.py:143-147)
 __global__ void magnitude_kernel(const float* __restrict__ ft, float* __restrict__ mag, int F, int T) {
   const long long n = (long long)F * T;

@@ -135,6 +135,13 @@ int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* sal, int64_t n, fl
   check_launch();
   RVC_CATCH
 }
+int rvc_f0_post(void* stream, const double* f0, int64_t n, double factor, double mel_min, double mel_max, int bins, int64_t* pitch, float* pitchf) {
+  RVC_TRY
+  RVC_REQUIRE(f0 && pitch && pitchf && n > 0 && bins > 2 && mel_max > mel_min, "bad argument");
+  f0_post((hipStream_t)stream, f0, n, factor, mel_min, mel_max, bins, reinterpret_cast<long long*>(pitch), pitchf);
+  check_launch();
+  RVC_CATCH
+}
 
 // ------------------------------------------------------------------------------------------------ crepe
 struct rvc_crepe { Crepe* m; rvc_ctx* ctx; };

@@ -270,11 +270,13 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
             # original, so nothing waits for the pitch on the host: the synthesizer is enqueued behind RMVPE.  The GRU scan's status word is
             # checked after the clip (below) instead of before the synthesizer.
             rm = self._rmvpe()
-            f0 = rm.infer(a_dev, 0.03)["f0"] * pow(2, f0_up_key / 12)
+            f0 = rm.infer(a_dev, 0.03)["f0"]
             mel_min, mel_max = 2595 * np.log10(1 + f0_min / 700), 2595 * np.log10(1 + f0_max / 700)      # lib/audio.py hz_to_mel
-            f0_mel = (2595 * torch.log10(1 + f0 / 700) - mel_min) * (self.f0_bins - 2) / (mel_max - mel_min) + 1
-            pitch_d = torch.round(torch.clamp(f0_mel, 1, self.f0_bins - 1)).to(torch.int64)      # (round half to even, as np.rint)
-            pitchf_d = f0.to(torch.float32)
+            pitch_d = torch.empty(f0.numel(), dtype=torch.int64, device=dev)
+            pitchf_d = torch.empty(f0.numel(), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib.rvc_f0_post(_lib.current_stream(), _lib.ptr(f0), f0.numel(), float(pow(2, f0_up_key / 12)), float(mel_min), float(mel_max),
+                                                int(self.f0_bins), _lib.ptr(pitch_d), _lib.ptr(pitchf_d)))
             deferred_status = rm
             _mark("f0 enqueued (rmvpe + device post)")
         else:

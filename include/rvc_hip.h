@@ -88,6 +88,9 @@ int rvc_rmvpe_status(rvc_rmvpe* r, void* stream);
 int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit);
 /* decode alone: salience_dev [n][360] row-major -> f0 float64 [n] */
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* salience_dev, int64_t n, float thred, double* f0_dev);
+/* Tail of get_f0 (reference pitch_extraction.py get_f0: transpose by `factor` = 2^(key / 12), mel-scale quantisation to 1 .. bins - 1 with np.rint), on the
+ * device in float64: pitch_dev int64 [n] (coarse), pitchf_dev float32 [n] (Hz).  mel_min / mel_max = hz_to_mel(f0_min / f0_max) = 2595 log10(1 + f / 700). */
+int rvc_f0_post(void* stream, const double* f0_dev, int64_t n, double factor, double mel_min, double mel_max, int bins, int64_t* pitch_dev, float* pitchf_dev);
 
 /* ------------------------------------------------------------------ CREPE (torchcrepe.Crepe "full" / "tiny") */
 /* Replaces the network inside torchcrepe.predict, which the reference calls for f0_method "crepe" / "mangio-crepe"
