@@ -1,7 +1,7 @@
 #!/bin/bash
 # scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence)
 cd "$GRAFT_REPO_ROOT" || exit 1
-bash tools/pmc_kernels.sh att attention_dma_kernel att64 2>&1 | tail -40
-bash tools/pmc_kernels.sh attrel attention_dma_kernel att96rel 2>&1 | tail -40
-bash tools/pmc_kernels.sh cbr16 cbr2_small cbr16 2>&1 | tail -40
-bash tools/pmc_kernels.sh cbr32 cbr2_small cbr32 2>&1 | tail -40
+mkdir -p gpurun_out
+timeout 1800 python -m pytest tests -m gpu -x -q > gpurun_out/final_pytest_gpu.txt 2>&1; tail -3 gpurun_out/final_pytest_gpu.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 600 python bench.py 2>/dev/null | cut -c1-400
