@@ -648,6 +648,22 @@ int rvc_op_layernorm_c(void* stream, const float* x, const float* res, const flo
   check_launch();
   RVC_CATCH
 }
+int rvc_op_layernorm_c_split(void* stream, const float* x, const float* gamma, const float* beta, float* y, float* y_img_f32, int C, int T) {
+  RVC_TRY
+  RVC_REQUIRE(x && gamma && beta && y_img_f32 && C > 0 && (C & 15) == 0 && T > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* img = nullptr;
+  try {
+    const long long tp = split_image_tp(T);
+    RVC_HIP_CHECK(hipMalloc(&img, split_image_bytes(C, T)));
+    layernorm_c_split(s, x, gamma, beta, y, img, tp, kSplitMargin, C, T, T, 1e-5f);
+    split_image_to_f32(s, img, tp, C, T, y_img_f32, T);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { (void)hipFree(img); throw; }
+  (void)hipFree(img);
+  RVC_CATCH
+}
 int rvc_op_sine_source(void* stream, const float* f0, const float* noise, float* har, float* sine, int T, int upp, float sr, float lw, float lb,
                        float* rad_out, float* tmp_out, float* phase_out) {
   RVC_TRY

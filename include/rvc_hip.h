@@ -293,6 +293,9 @@ int rvc_op_attention_split_rel(void* stream, const float* q_dev, const float* k_
  * y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2) + x; x, y device fp32 [C][H][W] (distinct), w host [C][C][3][3], C = 16 or 32. */
 int rvc_op_cbr2_small(void* stream, const float* x_dev, const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
                       float* y_dev, int C, int H, int W);
+/* LayerNorm over channels (column-wise on [C][T]) with the split-resident image as output (layernorm_c_split_kernel: HuBERT / text-encoder layers,
+ * modeling_hubert.py:291-477): y fp32 (optional) and the image read back as fp32; C a multiple of 16. */
+int rvc_op_layernorm_c_split(void* stream, const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, float* y_img_f32_dev, int C, int T);
 /* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
  * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
 int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);

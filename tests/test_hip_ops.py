@@ -470,6 +470,21 @@ def test_layernorm_channels(L):
     assert rel_err(y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("C,T", [(192, 333), (768, 1599), (512, 40), (1024, 77), (16, 5)])
+def test_layernorm_channels_with_image_output(L, C, T):
+    """layernorm_c_split_kernel: fp32 rows and the bf16 hi / lo image of the same values (the three register-caching variants: C <= 256, <= 768, any)."""
+    g = torch.Generator().manual_seed(23 + C)
+    x = torch.randn(C, T, generator=g) * 2.0 + 0.5
+    ga, be = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double().t(), (C,), ga.double(), be.double(), 1e-5).t()
+    y = torch.empty(C, T, device="cuda"); yi = torch.empty(C, T, device="cuda")
+    xd, gd, bd = dev(x), dev(ga), dev(be)
+    L.check(L.lib.rvc_op_layernorm_c_split(None, L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(y), L.ptr(yi), C, T))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().double(), ref) < 1e-5
+    assert (yi - y).abs().max().item() <= 2.0 ** -15 * ref.abs().max().item()      # hi + lo of the fp32 result
+
+
 def test_sine_source_phase_is_exact_on_a_long_segment(L):
     """41 s segment: the running phase (cycles) must equal torch's sample for sample.  The wrap detector of SineGen reacts to single
     ulps of the interpolated frame phase; with `scale * i - floor` contracted into an fma the device made ~8000 different (integer)
