@@ -132,6 +132,7 @@ SIGNATURES = {
     "rvc_op_attention_split_rel": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int]),
     "rvc_op_cbr2_small": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int]),
     "rvc_op_layernorm_c_split": (c_int, [c_void_p] * 6 + [c_int, c_int]),
+    "rvc_op_conv3_small": (c_int, [c_void_p] * 7 + [c_int] * 6),
     "rvc_op_gemm_split_swapped": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "rvc_op_attention_rel": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),

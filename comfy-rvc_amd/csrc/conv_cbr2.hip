@@ -283,4 +283,185 @@ void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, con
   if (c1.Co == 16) launch_cbr2<16, 8>(a, s); else launch_cbr2<32, 4>(a, s);
 }
 
+// ---------------------------------------------------------------------------------------------- one 3 x 3 convolution of few channels
+// The blocks of those levels that change the channel count (first block of a level: 1 x 1 shortcut beside the first convolution) and RMVPE's
+// 16 -> 3 output convolution, on the same structure: Y[co] = act(conv3x3(x)[co] + b[co]) [+ R[co]], CI = 16 / 32 input channels, up to 32 RB
+// output rows, weights in registers, input tile + halo 1 as the image in LDS, output through an fp32 LDS tile (16-byte accesses).  Rows below
+// `relu_rows` get the ReLU; rows >= `split_row` go to a second tensor Y2 (row - split_row) - so the first convolution and the 1 x 1 shortcut of a
+// block (its weights at the centre tap of a second group of rows) are ONE launch reading x once.
+struct Conv3SmallArgs {
+  const float* __restrict__ X; long long plane; int H, W;      // [CI][H W]
+  const unsigned char* Wimg; int CoPx; const float* bias;      // bf16x3 weight image (pack_x3, 9 taps), bias [Co]
+  float* __restrict__ Y; float* __restrict__ Y2; int Co, split_row, relu_rows;
+  const float* __restrict__ R;                                  // residual for the rows of Y (pitch plane) or null
+};
+
+template <int CI, int RB, int TH>
+__global__ __launch_bounds__(256, 2) void conv3_small_kernel(const Conv3SmallArgs p) {
+  constexpr int TW = 64, P = TW + 2, NCH = CI / 16, NU = NCH * 9;
+  constexpr int FRONT = 16, NP1 = (TH + 2) * P;
+  constexpr int N2 = TH * P, NB = (N2 + 31) / 32, NBW = (NB + 3) / 4;
+  constexpr int ENDM = P + 32 * NB + P + 2;
+  constexpr int SLACK = ENDM > NP1 ? ((ENDM - NP1 + 15) & ~15) : 16, NPOS = FRONT + NP1 + SLACK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_c3[];      // [chunk][plane 4][NPOS][16 B]; later the fp32 output tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int r0 = blockIdx.y * TH, c0 = blockIdx.x * TW;
+  const int H = p.H, W = p.W;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+  // ---- stage x: 8 channels x 4 consecutive columns per task, 16-byte loads over the aligned superset c0 - 4 .. c0 + TW + 3
+  {
+    constexpr int NQ = (TW + 8) / 4, NTASK = (CI / 8) * (TH + 2) * NQ, NIT = (NTASK + 255) / 256;
+    f32x4_t v[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int task = tid + 256 * it;
+      const int gr = task / NQ, k = task - gr * NQ, g = gr / (TH + 2), row = gr - g * (TH + 2);
+      const int ir = r0 - 1 + row, icq = c0 - 4 + 4 * k;
+      const bool ok = task < NTASK && ir >= 0 && ir < H && icq >= 0 && icq < W;
+      const float* src = p.X + (long long)(g * 8) * p.plane + (long long)ir * W + icq;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[it][j] = ok ? *reinterpret_cast<const f32x4_t*>(src + (long long)j * p.plane) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int task = tid + 256 * it;
+      const int gr = task / NQ, k = task - gr * NQ, g = gr / (TH + 2), row = gr - g * (TH + 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 4 * k + e - 3;                          // column of the pitch: image column c0 - 1 + col
+        u32x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { unsigned h_, l_; split2(v[it][2 * j][e], v[it][2 * j + 1][e], h_, l_); hi[j] = h_; lo[j] = l_; }
+        if (task < NTASK && col >= 0 && col < P) {
+          unsigned char* dst = smem_c3 + ((((g >> 1) * 4 + (g & 1)) * NPOS) + FRONT + row * P + col) * 16;
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + 2 * NPOS * 16) = lo;
+        }
+      }
+    }
+  }
+  for (int task = tid; task < (FRONT + SLACK) * NCH * 4; task += 256) {
+    const int pl = task / (FRONT + SLACK), q = task - pl * (FRONT + SLACK);
+    const int pos = q < FRONT ? q : NP1 + q;
+    *reinterpret_cast<u32x4*>(smem_c3 + (pl * NPOS + pos) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // ---- weights -> registers: unit u = chunk * 9 + tap, row block rb, lane (row li, half lh)
+  u32x4 wh[RB][NU], wl[RB][NU];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const unsigned char* a = p.Wimg + ((long long)(u * 4 + lh) * p.CoPx + 32 * rb + li) * 16;
+      wh[rb][u] = *reinterpret_cast<const u32x4*>(a);
+      wl[rb][u] = *reinterpret_cast<const u32x4*>(a + (long long)2 * p.CoPx * 16);
+    }
+  __syncthreads();
+
+  // ---- the convolution over rows 0 .. TH - 1 (LDS rows 1 .. TH), every column of the pitch; unit-outer over NBW x RB independent chains
+  f32x16 acc[NBW][RB];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][rb][r] = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int off = (t / 3 - 1) * P + (t % 3 - 1);
+      const int u = ch * 9 + t;
+      u32x4 bh[NBW], bl[NBW];
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) {
+        const unsigned char* b = smem_c3 + ((ch * 4 + lh) * NPOS + FRONT + P + 32 * min(wave + 4 * i, NB - 1) + li + off) * 16;
+        bh[i] = *reinterpret_cast<const u32x4*>(b); bl[i] = *reinterpret_cast<const u32x4*>(b + 2 * NPOS * 16);
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[rb][u]), __builtin_bit_cast(bf16x8, bl[i]), acc[i][rb], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl[rb][u]), __builtin_bit_cast(bf16x8, bh[i]), acc[i][rb], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) acc[i][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh[rb][u]), __builtin_bit_cast(bf16x8, bh[i]), acc[i][rb], 0, 0, 0);
+      }
+    }
+
+  // ---- epilogue through an fp32 LDS tile [row][TH][TW]: bias, ReLU for the rows below relu_rows, residual, 16-byte stores
+  constexpr int ROWS = 32 * RB;
+  __syncthreads();                                             // every wave's operand reads are done
+  float* ot = reinterpret_cast<float*>(smem_c3);
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int blk = wave + 4 * i;
+    const int q = P + 32 * blk + li, row = q / P - 1, col = q - (row + 1) * P - 1;
+    if (blk < NB && row < TH && col >= 0 && col < TW) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < p.Co) {
+            const float v = acc[i][rb][r] + p.bias[co];
+            ot[(co * TH + row) * TW + col] = co < p.relu_rows ? fmaxf(v, 0.f) : v;
+          }
+        }
+    }
+  }
+  __syncthreads();
+  for (int task = tid; task < p.Co * TH * (TW / 4); task += 256) {
+    const int kq = task % (TW / 4), cr = task / (TW / 4), row = cr % TH, co = cr / TH;
+    const int ir = r0 + row, ic = c0 + 4 * kq;
+    if (ir < H && ic < W) {
+      f32x4_t o = *reinterpret_cast<const f32x4_t*>(ot + (co * TH + row) * TW + 4 * kq);
+      const long long off = (long long)ir * W + ic;
+      if (co < p.split_row) {
+        if (p.R) o += *reinterpret_cast<const f32x4_t*>(p.R + (long long)co * p.plane + off);
+        *reinterpret_cast<f32x4_t*>(p.Y + (long long)co * p.plane + off) = o;
+      } else {
+        *reinterpret_cast<f32x4_t*>(p.Y2 + (long long)(co - p.split_row) * p.plane + off) = o;
+      }
+    }
+  }
+}
+
+constexpr size_t conv3_small_lds_bytes(int CI, int RB, int TH) {
+  const int P = 66, NP1 = (TH + 2) * P, NB = (TH * P + 31) / 32, ENDM = P + 32 * NB + P + 2;
+  const int SLACK = ENDM > NP1 ? ((ENDM - NP1 + 15) & ~15) : 16;
+  const size_t img = (size_t)(CI / 16) * 4 * (16 + NP1 + SLACK) * 16, tile = (size_t)32 * RB * TH * 64 * 4;
+  return img > tile ? img : tile;
+}
+template <int CI, int RB, int TH>
+static void launch_conv3_small(const Conv3SmallArgs& a, hipStream_t s) {
+  auto kern = conv3_small_kernel<CI, RB, TH>;
+  constexpr size_t lds = conv3_small_lds_bytes(CI, RB, TH);
+  static_assert(lds <= 80 * 1024, "two workgroups per CU");
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  hipLaunchKernelGGL(kern, dim3((a.W + 63) / 64, (a.H + TH - 1) / TH), dim3(256), lds, s, a);
+}
+
+bool conv3_small_eligible(const ConvLayer& L) {
+  return conv_x3_enabled() && L.mode == 2 && L.Wx_ != nullptr && L.ktaps == 9 && L.kh == 3 && L.kw == 3 && L.up2 == 0 && L.tconv_u == 0 && L.bd_ != nullptr &&
+         ((L.Ci == 16 && L.Co <= 64) || (L.Ci == 32 && L.Co <= 32)) && L.CoPx >= 64;      // (32 inputs x 64 rows of weights do not fit the registers)
+}
+// Y[co] = act(conv3x3(x)[co] + b[co]) [+ R[co]] for co < split_row, Y2[co - split_row] = the same without residual for the rest; ReLU on the rows below relu_rows
+void conv3_small_run(const ConvLayer& L, hipStream_t s, const float* x, int H, int W, float* Y, float* Y2, int split_row, int relu_rows, const float* R) {
+  RVC_REQUIRE(conv3_small_eligible(L), "conv3_small_run: a 3 x 3 convolution of 16 / 32 input and <= 64 output channels with a bf16x3 weight image");
+  RVC_REQUIRE(x != Y && x != Y2 && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+              (!Y2 || (reinterpret_cast<uintptr_t>(Y2) & 15) == 0) && (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0), "conv3_small_run: distinct, 16-byte aligned tensors, W a multiple of 4");
+  RVC_REQUIRE(split_row >= 0 && split_row <= L.Co && (split_row == L.Co || Y2 != nullptr), "conv3_small_run: row split");
+  Conv3SmallArgs a{};
+  a.X = x; a.plane = (long long)H * W; a.H = H; a.W = W;
+  a.Wimg = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.bias = L.bd_;
+  a.Y = Y; a.Y2 = Y2; a.Co = L.Co; a.split_row = split_row; a.relu_rows = relu_rows; a.R = R;
+  const int RB = L.Co > 32 ? 2 : 1;
+  if (L.Ci == 16 && RB == 1) launch_conv3_small<16, 1, 8>(a, s);
+  else if (L.Ci == 16) launch_conv3_small<16, 2, 4>(a, s);
+  else launch_conv3_small<32, 1, 4>(a, s);
+}
+
 }  // namespace rvc

@@ -8,6 +8,7 @@ namespace rvc {
 
 struct CBR {           // ConvBlockRes with BatchNorm folded into both convs
   ConvLayer c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0;
+  ConvLayer c1sc;        // shallow levels: first convolution and 1 x 1 shortcut as ONE layer of 2 cout rows (the shortcut's weights at the centre tap) for conv3_small_run
 };
 struct Rmvpe {
   Ctx* ctx = nullptr;
@@ -32,7 +33,7 @@ struct Rmvpe {
 Rmvpe* rmvpe_create(Ctx* ctx) { Rmvpe* R = new Rmvpe(); R->ctx = ctx; return R; }
 void rmvpe_set_tensor(Rmvpe* R, const char* name, const float* d, const long long* shape, int ndim) { R->ts.set(name, d, shape, ndim); }
 
-static void cbr_free(CBR& b) { conv_layer_free(b.c1); conv_layer_free(b.c2); conv_layer_free(b.sc); }
+static void cbr_free(CBR& b) { conv_layer_free(b.c1); conv_layer_free(b.c2); conv_layer_free(b.sc); conv_layer_free(b.c1sc); }
 static void rmvpe_free(Rmvpe& R) {
   conv_layer_free(R.stft); conv_layer_free(R.melproj);
   for (auto& l : R.enc) for (auto& b : l) cbr_free(b);
@@ -60,12 +61,13 @@ static void bn_fold(const TensorStore& ts, const std::string& bn, int C, std::ve
 
 static void make_cbr(CBR& B, const TensorStore& ts, const std::string& p, int cin, int cout) {
   B.cin = cin; B.cout = cout;
-  std::vector<float> sc, sh;
+  std::vector<float> sc, sh, w1f, b1f;
   {
     std::vector<float> w = ts.get(p + "conv.0.weight", {cout, cin, 3, 3}).data;
     bn_fold(ts, p + "conv.1", cout, sc, sh);
     for (int co = 0; co < cout; ++co) for (size_t i = 0; i < (size_t)cin * 9; ++i) w[(size_t)co * cin * 9 + i] *= sc[co];
     conv2d3x3_layer_init(B.c1, w.data(), sh.data(), cout, cin);
+    w1f = w; b1f = sh;
   }
   {
     std::vector<float> w = ts.get(p + "conv.3.weight", {cout, cout, 3, 3}).data;
@@ -74,7 +76,18 @@ static void make_cbr(CBR& B, const TensorStore& ts, const std::string& p, int ci
     conv2d3x3_layer_init(B.c2, w.data(), sh.data(), cout, cout);
   }
   B.has_sc = cin != cout;
-  if (B.has_sc) conv2d1x1_layer_init(B.sc, ts.get(p + "shortcut.weight", {cout, cin, 1, 1}).data.data(), ts.get(p + "shortcut.bias", {cout}).data.data(), cout, cin);
+  if (B.has_sc) {
+    const HostTensor& sw = ts.get(p + "shortcut.weight", {cout, cin, 1, 1}); const HostTensor& sb = ts.get(p + "shortcut.bias", {cout});
+    conv2d1x1_layer_init(B.sc, sw.data.data(), sb.data.data(), cout, cin);
+    if ((cin == 16 || cin == 32) && 2 * cout <= (cin == 16 ? 64 : 32)) {
+      // rows [0, cout): the first convolution; rows [cout, 2 cout): the shortcut, a 3 x 3 kernel that is zero except for its centre tap
+      std::vector<float> w((size_t)2 * cout * cin * 9, 0.f), b((size_t)2 * cout);
+      std::copy(w1f.begin(), w1f.end(), w.begin());
+      for (int co = 0; co < cout; ++co) for (int ci = 0; ci < cin; ++ci) w[((size_t)(cout + co) * cin + ci) * 9 + 4] = sw.data[(size_t)co * cin + ci];
+      std::copy(b1f.begin(), b1f.end(), b.begin()); std::copy(sb.data.begin(), sb.data.end(), b.begin() + cout);
+      conv2d3x3_layer_init(B.c1sc, w.data(), b.data(), 2 * cout, cin);
+    }
+  }
 }
 
 void rmvpe_finalize(Rmvpe* R) {
@@ -173,12 +186,22 @@ static void run_cbr(const CBR& B, hipStream_t s, Arena& A, const float* x, int H
   float* y1 = A.alloc<float>((size_t)B.cout * plane);
   float* scb = B.has_sc ? A.alloc<float>((size_t)B.cout * plane) : nullptr;
   if (!A.dry) {
-    ConvEpilogue E1; E1.act = ACT_RELU;
-    conv2d_run(B.c1, s, x, plane, H, W, y1, plane, E1);
+    const bool small = fuse_small && (W & 3) == 0 && W >= 64;      // the register-weight kernels of conv_cbr2.hip (levels of 16 / 32 channels)
     const float* res = x;
-    if (B.has_sc) { ConvEpilogue E0; conv1d_run(B.sc, s, x, plane, (int)plane, scb, plane, E0); res = scb; }
-    ConvEpilogue E2; E2.act = ACT_RELU; E2.act_before_res = 1; E2.R = res; E2.ldR = plane;
-    conv2d_run(B.c2, s, y1, plane, H, W, out, plane, E2);
+    if (small && B.has_sc && B.c1sc.Wx_ && conv3_small_eligible(B.c1sc)) {
+      conv3_small_run(B.c1sc, s, x, H, W, y1, scb, B.cout, B.cout, nullptr);      // relu(c1(x)) and sc(x) in one launch
+      res = scb;
+    } else {
+      ConvEpilogue E1; E1.act = ACT_RELU;
+      conv2d_run(B.c1, s, x, plane, H, W, y1, plane, E1);
+      if (B.has_sc) { ConvEpilogue E0; conv1d_run(B.sc, s, x, plane, (int)plane, scb, plane, E0); res = scb; }
+    }
+    if (small && conv3_small_eligible(B.c2) && out != y1 && out != res) {
+      conv3_small_run(B.c2, s, y1, H, W, out, nullptr, B.cout, B.cout, res);      // relu(c2(y1)) + res
+    } else {
+      ConvEpilogue E2; E2.act = ACT_RELU; E2.act_before_res = 1; E2.R = res; E2.ldR = plane;
+      conv2d_run(B.c2, s, y1, plane, H, W, out, plane, E2);
+    }
   }
   A.off = mark;
 }
@@ -373,7 +396,9 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
   float* hid = A.alloc<float>((size_t)512 * Tr);
   float* sal = A.alloc<float>((size_t)360 * Tr);
   if (!dry) {
-    conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
+    static const bool cnn_small = !(getenv("RVC_RMVPE_CBR2") && atoi(getenv("RVC_RMVPE_CBR2")) == 0);
+    if (cnn_small && conv3_small_eligible(R->cnn)) conv3_small_run(R->cnn, s, cur, Tr, 128, c3, nullptr, 3, 0, nullptr);      // 16 -> 3, no activation
+    else conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
     if (gi_x3s) {
       // gi[t][g] = sum_f W_ih[g][f] feat[f][t], f = c 128 + m: the frame features go straight from [c][t][m] into the image, the product is the
       // swapped split-resident GEMM writing fp32 rows [t][1536] (no transposition pass, no fp32-MFMA GEMM: 97 + 10 us -> ~25)

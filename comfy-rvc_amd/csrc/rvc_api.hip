@@ -485,6 +485,21 @@ int rvc_op_cbr2_small(void* stream, const float* x, const float* w1, const float
   conv_layer_free(c1); conv_layer_free(c2);
   RVC_CATCH
 }
+int rvc_op_conv3_small(void* stream, const float* x, const float* w, const float* b, const float* res, float* y, float* y2, int Ci, int Co, int H, int W, int split_row,
+                       int relu_rows) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && b && y && Ci > 0 && Co > 0 && H > 0 && W > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv2d3x3_layer_init(L, w, b, Co, Ci); }
+  try {
+    conv3_small_run(L, s, x, H, W, y, y2, split_row, relu_rows, res);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { conv_layer_free(L); throw; }
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_conv1d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, int Ci, int Co, int T, int k, int pad,
                         int dil, int groups, int act, int act_before_res) {
   RVC_TRY

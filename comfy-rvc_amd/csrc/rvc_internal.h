@@ -162,7 +162,10 @@ void split_image_from_tm(hipStream_t s, const float* x, int C, int T, int M, uns
 void conv_x3s_force(int ksplit, int am, int an);
 // one ConvBlockRes of 16 or 32 channels (3 x 3, 3 x 3, + x) in one launch (conv_cbr2.hip): x, out fp32 [C][H W], distinct
 bool cbr2_small_eligible(const ConvLayer& c1, const ConvLayer& c2);
-void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
+void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out);
+// one 3 x 3 convolution of 16 / 32 input and <= 64 output channels on the same structure: rows below relu_rows get the ReLU, rows >= split_row go to Y2, R added to Y's rows
+bool conv3_small_eligible(const ConvLayer& L);
+void conv3_small_run(const ConvLayer& L, hipStream_t s, const float* x, int H, int W, float* Y, float* Y2, int split_row, int relu_rows, const float* R);      // tests / benchmarks: K split and tile of the calling thread's next launches (0 = automatic)
 void split_image_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp);
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY);
 

@@ -296,6 +296,10 @@ int rvc_op_cbr2_small(void* stream, const float* x_dev, const float* w1_host, co
 /* LayerNorm over channels (column-wise on [C][T]) with the split-resident image as output (layernorm_c_split_kernel: HuBERT / text-encoder layers,
  * modeling_hubert.py:291-477): y fp32 (optional) and the image read back as fp32; C a multiple of 16. */
 int rvc_op_layernorm_c_split(void* stream, const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, float* y_img_f32_dev, int C, int T);
+/* one 3 x 3 convolution of RMVPE's shallow levels (conv_cbr2.hip conv3_small_kernel; Ci = 16 with Co <= 64, or Ci = 32 with Co <= 32): rows below relu_rows get
+ * the ReLU; rows < split_row go to y (+ res when given), the others to y2 (row - split_row): first convolution + 1 x 1 shortcut of a block in one launch. */
+int rvc_op_conv3_small(void* stream, const float* x_dev, const float* w_host, const float* b_host, const float* res_dev, float* y_dev, float* y2_dev, int Ci, int Co,
+                       int H, int W, int split_row, int relu_rows);
 /* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
  * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
 int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);

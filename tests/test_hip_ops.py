@@ -387,6 +387,36 @@ def test_conv_block_res_small_channels_fused(L, C, H, W):
     assert rel_err(y.cpu().double(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("Ci,C,H,W", [(32, 16, 40, 128), (16, 32, 19, 64), (16, 16, 33, 128), (32, 32, 9, 64), (16, 3, 50, 128), (16, 32, 7, 192)])
+def test_small_channel_conv3x3_with_merged_shortcut(L, Ci, C, H, W):
+    """conv3_small_kernel: relu(conv3x3(x) + b) and - as a second group of rows whose 3 x 3 kernel is zero except for the centre tap - the block's 1 x 1
+    shortcut, one launch, two outputs (RMVPE's channel-changing ConvBlockRes, lib/rmvpe.py:233-268); then the plain form with a residual.  float64 reference."""
+    g = torch.Generator().manual_seed(43 + H)
+    x = torch.randn(Ci, H, W, generator=g)
+    w1 = torch.randn(C, Ci, 3, 3, generator=g) / np.sqrt(9 * Ci); b1 = torch.randn(C, generator=g) * 0.2
+    xd = dev(x)
+    merged = 2 * C <= (64 if Ci == 16 else 32)
+    if merged:
+        ws = torch.randn(C, Ci, generator=g) / np.sqrt(Ci); bs = torch.randn(C, generator=g) * 0.2
+        wm = torch.zeros(2 * C, Ci, 3, 3); wm[:C] = w1; wm[C:, :, 1, 1] = ws
+        bm = torch.cat([b1, bs])
+        y = torch.full((C, H, W), 9.0, device="cuda"); y2 = torch.full((C, H, W), 9.0, device="cuda")
+        L.check(L.lib.rvc_op_conv3_small(None, L.ptr(xd), wm.contiguous().data_ptr(), bm.data_ptr(), None, L.ptr(y), L.ptr(y2), Ci, 2 * C, H, W, C, C))
+        torch.cuda.synchronize()
+        ref1 = F.relu(F.conv2d(x.double()[None], w1.double(), b1.double(), padding=1))[0]
+        ref2 = torch.einsum("oc,chw->ohw", ws.double(), x.double()) + bs.double()[:, None, None]
+        assert rel_err(y.cpu().double(), ref1) < 2e-5 and rel_err(y2.cpu().double(), ref2) < 2e-5
+    # plain: act(conv + b) + residual (C <= 3: no activation, no residual - the output convolution)
+    r = torch.randn(C, H, W, generator=g); rd = dev(r)
+    y = torch.full((C, H, W), 9.0, device="cuda")
+    act = C > 3
+    L.check(L.lib.rvc_op_conv3_small(None, L.ptr(xd), w1.contiguous().data_ptr(), b1.data_ptr(), L.ptr(rd) if act else None, L.ptr(y), None, Ci, C, H, W, C, C if act else 0))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double()[None], w1.double(), b1.double(), padding=1)[0]
+    ref = F.relu(ref) + r.double() if act else ref
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("Ci,Co,T,row0,rows", [(768, 2304, 1599, 1536, 768), (768, 2304, 100, 1536, 768), (64, 256, 333, 128, 128), (192, 192, 1000, 0, 192)])
 def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
     """out[t][j] = sum_c x[c][t] w[row0 + j][c] written as the image of the transposed tensor (the attention's V^T operand): rows t < T
