@@ -145,6 +145,10 @@ bool conv_x3_enabled();
 // software-pipelined kernel for stride-1 1-D convolutions on 2 x 2-wave tiles (conv_x3p.hip); `a` as conv_x3_try prepared it
 bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry);
 int conv_x3p_check_read();
+// persistent version of the above for the ResBlock convolutions: a workgroup per CU slot walks over its tiles, one continuous stream of
+// weight units / input chunks, residual added block by block inside the tile (conv_x3q.hip)
+bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry);
+int conv_x3q_check_read();
 // k = 1 (GEMM) on the pipelined kernel, fp32 [K][N] input (conv_x3p.hip)
 bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, bool dry);
 // fused ResBlock pair of the 32-channel stage on the pipelined kernel (conv_x3p.hip)

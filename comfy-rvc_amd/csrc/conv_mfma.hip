@@ -375,6 +375,7 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s) {
 void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
+void conv_x3q_timing_read(unsigned long long* out8, bool reset);
 void cbr2_timing_read(unsigned long long* out8, bool reset);
 void attention_dma_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
@@ -390,6 +391,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   cbr2_timing_read(x3, reset);          // (fused ConvBlockRes: [0] workgroups, [1] staging, [2] conv1, [3] y1 -> LDS, [4] conv2, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3p_timing_read(x3, reset);      // (pipelined kernel: [0] tiles, [1] prologue, [2] compute, [3] weight wait, [4] barrier, [5] epilogue, [6] total)
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  conv_x3q_timing_read(x3, reset);      // (persistent kernel: the same slots; [1] once per workgroup, [6] per workgroup)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
 }
 #else
@@ -773,8 +776,8 @@ int conv_prof_dump_csv(const char* path) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM)
-    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_x3u_kernel", "conv_x3_kernel", "conv_x3_kernel"};
+    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 6 persistent pipelined conv)
+    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_x3u_kernel", "conv_x3q_kernel", "conv_x3_kernel"};
     fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
             r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
             t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0);

@@ -566,6 +566,14 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
     const bool s2_up = a.stride == 2 && a.ktaps == 3 && a.Co >= 128 && !(t.AM == 2 && t.AN == 2) &&
                        (long long)((a.Co + 127) / 128) * ((a.Tout + 127) / 128) >= 150;
     const int pam = s2_up ? 2 : t.AM, pan = s2_up ? 2 : t.AN;
+    if (!s2_up && conv_x3q_try(a, t.AM, t.AN, s, g, true)) {
+      // the ResBlock convolutions: persistent workgroups (conv_x3q.hip)
+      if (dry) return true;
+      ProfTicket tk = conv_prof_begin(s);
+      conv_x3q_try(a, t.AM, t.AN, s, g, false);
+      conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 6 << 4);
+      return true;
+    }
     if (conv_x3p_try(a, pam, pan, s, g, true)) {
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);

@@ -716,7 +716,7 @@ int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) { RVC_T
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
-int rvc_debug_x3p_check(void) { return conv_x3p_check_read(); }
+int rvc_debug_x3p_check(void) { const int a = conv_x3p_check_read(), b = conv_x3q_check_read(); return a < 0 ? a : a + (b > 0 ? b : 0); }
 int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out, int w2d, int nlayers) {
   RVC_TRY
   RVC_REQUIRE(us_out && reps > 0 && Ci > 0 && Co > 0 && T > 0 && nlayers >= 1 && nlayers <= 64, "bad argument");

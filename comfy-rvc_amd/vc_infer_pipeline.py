@@ -192,6 +192,20 @@ class VC(FeatureExtractor):
         return audio_opt
 
 
+# the base implementations the device-side f0 path stands in for (captured at import: a later class-level patch no longer matches)
+_BASE_F0_METHODS = {name: FeatureExtractor.__dict__[name] for name in ("get_f0", "get_rmvpe", "_rmvpe")}
+
+
+def _is_base_method(obj, name):
+    """True when obj.<name> resolves to FeatureExtractor's own function: no instance attribute, no subclass override, no class-level patch."""
+    if name in getattr(obj, "__dict__", {}):
+        return False
+    for klass in type(obj).__mro__:
+        if name in klass.__dict__:
+            return klass.__dict__[name] is _BASE_F0_METHODS[name]
+    return False
+
+
 def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge_type, filter_radius, tgt_sr,
                      rms_mix_rate, version, protect, crepe_hop_length, f0_autotune, rmvpe_onnx, f0_min, f0_max, index=None, index_rate=0.0,
                      if_f0=True):
@@ -262,8 +276,12 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
     deferred_status = None
     if if_f0:
         m = f0_method[0] if isinstance(f0_method, (list, tuple)) and len(f0_method) == 1 else f0_method
-        plain_rmvpe = (m == "rmvpe" and not f0_autotune and self.device_f0_post and "get_f0" not in self.__dict__      # (an instance-level get_f0 override is honoured)
-                       and getattr(self.f0_method_dict.get("rmvpe"), "__func__", None) is type(self).get_rmvpe)
+        # the fused device path replaces get_f0 / get_rmvpe / _rmvpe only when all three ARE the base implementations: an instance attribute,
+        # a subclass override or a class-level patch (VC.get_f0 = ...) of any of them sends the clip through self.get_f0 like the reference
+        plain_rmvpe = (m == "rmvpe" and not f0_autotune and self.device_f0_post and _is_base_method(self, "get_f0")
+                       and _is_base_method(self, "_rmvpe") and _is_base_method(self, "get_rmvpe")
+                       and getattr(self.f0_method_dict.get("rmvpe"), "__func__", None) is _BASE_F0_METHODS["get_rmvpe"]
+                       and getattr(self.f0_method_dict.get("rmvpe"), "__self__", None) is self)
         if plain_rmvpe:
             # RMVPE with nothing spliced in (the default front end): the 100-fps post-processing of get_f0 (pitch_extraction.py:176-185, reference
             # vc_infer_pipeline.py / pitch_extraction.py: transpose, mel-scale quantisation to 1 .. 255) runs on the device in float64 like the numpy

@@ -223,3 +223,36 @@ def test_faiss_ivf_flat_reader_roundtrip(tmp_path):
         F.read_index_vectors(raw[:len(raw) // 2])
     with pytest.raises(ValueError, match="IwPQ"):
         F.read_index_vectors(b"IwPQ" + raw[4:])
+
+
+def test_device_f0_shortcut_honours_subclass_and_class_level_overrides():
+    """the fused rmvpe + device post-processing path may only replace get_f0 / get_rmvpe / _rmvpe when they ARE the base
+    implementations - an instance attribute, a subclass override or a class-level patch must send the clip through self.get_f0."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd import vc_infer_pipeline as V
+    vc = V.VC(40000, Config())
+    assert all(V._is_base_method(vc, n) for n in ("get_f0", "get_rmvpe", "_rmvpe"))
+
+    class Sub(V.VC):
+        def get_rmvpe(self, x, *a, **k):
+            return np.zeros(4)
+    sub = Sub(40000, Config())
+    assert not V._is_base_method(sub, "get_rmvpe") and V._is_base_method(sub, "get_f0")
+
+    class Sub2(V.VC):
+        def get_f0(self, *a, **k):
+            return None
+    assert not V._is_base_method(Sub2(40000, Config()), "get_f0")
+
+    vc.get_f0 = lambda *a, **k: None                     # instance attribute
+    assert not V._is_base_method(vc, "get_f0")
+    orig = V.VC.__dict__.get("get_f0")
+    V.VC.get_f0 = lambda self, *a, **k: None             # class-level patch
+    try:
+        assert not V._is_base_method(V.VC(40000, Config()), "get_f0")
+    finally:
+        if orig is None:
+            del V.VC.get_f0
+        else:
+            V.VC.get_f0 = orig
+    assert V._is_base_method(V.VC(40000, Config()), "get_f0")

@@ -2,7 +2,15 @@
 # scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_hip_pipeline.py tests/test_hip_ops.py -q -x -k "pipeline or postprocess or rms" 2>&1 | tail -3
-rm -rf gpurun_out/att_prof
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/att_prof -o att -- python3 bench.py --lanes 1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-grep "rms_mix" gpurun_out/att_prof/att_kernel_stats.csv | cut -d, -f11-13
+echo "== correctness (product lib, x3q on)"
+timeout 900 python -m pytest tests/test_hip_ops.py -q -x -k "split_resident_resblock_pair" 2>&1 | tail -5
+echo "== wait check build"
+RVC_HIP_LIB=$PWD/comfy-rvc_amd/csrc/variants/librvc_hip_check.so timeout 900 python -m pytest tests/test_hip_ops.py -q -x -k "split_resident_resblock_pair" 2>&1 | tail -5
+echo "== bench x3q=0"
+RVC_X3Q=0 timeout 300 python tools/bench_split.py 2>&1 | grep -v "^$\|amdgpu.ids"
+echo "== bench x3q=1"
+RVC_X3Q=1 timeout 300 python tools/bench_split.py 2>&1 | grep -v "^$\|amdgpu.ids"
+echo "== bench x3q=0 again"
+RVC_X3Q=0 timeout 300 python tools/bench_split.py 128 2>&1 | grep -v "^$\|amdgpu.ids"
+echo "== bench x3q=1 again"
+RVC_X3Q=1 timeout 300 python tools/bench_split.py 128 2>&1 | grep -v "^$\|amdgpu.ids"
