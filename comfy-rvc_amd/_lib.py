@@ -106,6 +106,8 @@ SIGNATURES = {
     "rvc_vc_segment_feats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p,
                                      c_void_p, c_void_p]),
     "rvc_index_create": (c_int, [c_void_p, c_void_p, c_int64, c_int, P(c_void_p)]),
+    "rvc_index_create_ivf": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int, P(c_void_p)]),
+    "rvc_index_nprobe": (c_int, [c_void_p]),
     "rvc_index_destroy": (c_int, [c_void_p]),
     "rvc_index_ntotal": (c_int64, [c_void_p]),
     "rvc_index_search": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -623,8 +623,7 @@ static void launch_att_ks(hipStream_t s, const float* Q, const float* K, long lo
   constexpr int KT = 32 * WK;
   const size_t lds = sizeof(float) * (32 * (D + 4) + KT * (D + 4) + D * (KT + 4) + WK * 32 * 36 + (REL ? 3 * 21 * 32 : 0));
   auto kern = attention_ks_kernel<D, WK, REL>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3((T + 31) / 32, heads), dim3(64 * WK), lds, s, Q, K, ldqk, V, ldv, bv, rel, pb, win, out, ldo, T, ek, ev);
 }
 

@@ -439,8 +439,7 @@ static void launch_att_dma(const AttnDmaArgs& a, int heads, hipStream_t s) {
   auto kern = attention_dma_kernel<D, NWQ, KS, REL>;
   constexpr size_t lds = (size_t)KS * 2 * (size_t)((D / 16) * 4 * 1024 + 16 * D * 16) + (REL ? (size_t)NWQ * KS * 4096 : 0);
   static_assert(lds <= 160 * 1024, "LDS");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   AttnDmaArgs b = a;
   b.nqt = (a.T + 32 * NWQ - 1) / (32 * NWQ); b.heads = heads;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;

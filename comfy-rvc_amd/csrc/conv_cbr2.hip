@@ -261,8 +261,7 @@ static void launch_cbr2(const Cbr2Args& a, hipStream_t s) {
   auto kern = cbr2_small_kernel<C, TH>;
   constexpr size_t lds = cbr2_lds_bytes(C, TH);
   static_assert(lds <= 160 * 1024, "LDS");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3((a.W + 63) / 64, (a.H + TH - 1) / TH), dim3(256), lds, s, a);
 }
 
@@ -439,8 +438,7 @@ static void launch_conv3_small(const Conv3SmallArgs& a, hipStream_t s) {
   auto kern = conv3_small_kernel<CI, RB, TH>;
   constexpr size_t lds = conv3_small_lds_bytes(CI, RB, TH);
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3((a.W + 63) / 64, (a.H + TH - 1) / TH), dim3(256), lds, s, a);
 }
 

@@ -464,9 +464,9 @@ void Arena::ensure(size_t bytes) {
   if (base) { RVC_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(base); base = nullptr; cap = 0; }
   size_t want = bytes + bytes / 8 + (1 << 20);
   RVC_HIP_CHECK(hipMalloc(&base, want));
-  cap = want;
+  cap = want; ++gen;
 }
-void Arena::release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+void Arena::release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; ++gen; }
 
 static int pick_ck(int V, int ktaps, int stride) {
   // k = 1 (GEMM): 64 channels per stage so that one stage of MFMA work outlasts the latency of the next stage's prefetch
@@ -702,8 +702,7 @@ __global__ void interleave2x2_kernel(const float* __restrict__ ph, float* __rest
 template <int WM, int WN, int AM, int AN, int MODE>
 static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_mfma_kernel<WM, WN, AM, AN, MODE>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 

@@ -487,8 +487,7 @@ bool conv_x3_enabled() {
 template <int WM, int WN, int AM, int AN, bool FUSE = false, bool XSPLIT = false, bool YSPLIT = false>
 static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE, XSPLIT, YSPLIT>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
 }
 

@@ -925,8 +925,7 @@ __global__ __launch_bounds__(256, WM == 1 ? 3 : 2) void conv_x3pf_kernel(const C
 template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool S2 = false>
 static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3p_kernel<AM, AN, KT, XSPLIT, YSPLIT, S2>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 template <int AM, int AN, int KT>
@@ -981,8 +980,7 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
 template <int AM, int AN, int C2D = 0>
 static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3g_kernel<AM, AN, C2D>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
@@ -1037,8 +1035,7 @@ bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, 
 template <int KT, int WM>
 static void launch_x3pf(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3pf_kernel<KT, WM>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 // a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32: 256 intermediate columns per tile; C = 64: 128).  false: not

@@ -66,12 +66,12 @@ typedef float f32x4q __attribute__((ext_vector_type(4)));
 
 // AM x AN accumulators per wave (2 x 2 waves), KT taps.  XSPLIT: split-resident input image (DMA) instead of fp32 rows (registers, converted);
 // YSPLIT: split-resident output image; RADD: residual (+ bias) added block by block during the tile (fp32 output, no activation after the sum).
-template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool RADD>
+template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD>
 __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(const ConvArgsX p) {
   static_assert(!(YSPLIT && RADD) && !(XSPLIT && YSPLIT), "one split side per launch");
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
-  constexpr int R = (AM == 2 && AN == 4) ? 4 : 3;           // weight slots in the ring
+  // R = weight slots in the ring (a unit is requested R - 2 units before the barrier that publishes it; as many as the LDS budget admits)
   constexpr int XS = 3;                                     // fp32 staging slots per wave (8 channels x 64 positions each): P <= 384
   constexpr int NPW = 2 * RB / NW;                          // weight pieces per unit and wave
   constexpr int NPX = (BN + 64) / 64;                       // split-resident input: pieces per chunk and wave
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smemq[];
   const int P = p.WROW;                                     // staged input positions: BN + (KT - 1) * dil
-  const int Pm = XSPLIT ? BN + 64 : P;
+  const int Pm = (P + 7) & ~7;                              // rows of a half-plane (split input: the last 64-row DMA piece is cut off there)
   const int xplane = Pm * 32, xhalf = xplane >> 1, xbuf = 2 * xplane;
   unsigned char* Xs = smemq;
   unsigned char* Ws = smemq + ((2 * xbuf + 1023) & ~1023);
@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
       const int hp = pi / pph, j = pi - hp * pph;
       const unsigned row = (unsigned)((chunk * 4 + hp) * (int)p.xsTp + (tl.bx + kSplitMargin) + j * 64);
       unsigned char* dst = Xs + xb * xbuf + hp * xhalf + j * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, (int)(row * 16u), 0, 0);
+      // (lanes past the half-plane's last row are switched off: the instruction still issues, so the counts below hold)
+      if (j * 64 + lane < Pm)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, (int)(row * 16u), 0, 0);
     }
     X3Q_ISSUED(NPX);
   };
@@ -500,69 +502,80 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
 
 
 // ============================================================================ host side
-template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool RADD>
+template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD>
 static void launch_x3q(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3q_kernel<AM, AN, KT, XSPLIT, YSPLIT, RADD>;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  auto kern = conv_x3q_kernel<AM, AN, KT, R, XSPLIT, YSPLIT, RADD>;
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
-template <int AM, int AN, int KT>
+template <int AM, int AN, int KT, int R>
 static void launch_x3q_io(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
-  if (mode == 0) launch_x3q<AM, AN, KT, false, true, false>(a, grid, lds, s);        // fp32 in, image out (c1 of a split pair)
-  else if (mode == 1) launch_x3q<AM, AN, KT, true, false, true>(a, grid, lds, s);    // image in, fp32 out + residual (c2 of a split pair)
-  else if (mode == 2) launch_x3q<AM, AN, KT, false, false, true>(a, grid, lds, s);   // fp32 in / out + residual
-  else launch_x3q<AM, AN, KT, false, false, false>(a, grid, lds, s);                 // fp32 in / out, generic epilogue
+  if (mode == 0) launch_x3q<AM, AN, KT, R, false, true, false>(a, grid, lds, s);        // fp32 in, image out (c1 of a split pair)
+  else launch_x3q<AM, AN, KT, R, true, false, true>(a, grid, lds, s);                  // image in, fp32 out + residual (c2 of a split pair)
+}
+template <int AM, int AN, int R>
+static void launch_x3q_k(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
+  if (a.ktaps == 3) launch_x3q_io<AM, AN, 3, R>(a, mode, grid, lds, s);
+  else if (a.ktaps == 7) launch_x3q_io<AM, AN, 7, R>(a, mode, grid, lds, s);
+  else launch_x3q_io<AM, AN, 11, R>(a, mode, grid, lds, s);
 }
 template <int AM, int AN>
-static void launch_x3q_k(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
-  if (a.ktaps == 3) launch_x3q_io<AM, AN, 3>(a, mode, grid, lds, s);
-  else if (a.ktaps == 7) launch_x3q_io<AM, AN, 7>(a, mode, grid, lds, s);
-  else launch_x3q_io<AM, AN, 11>(a, mode, grid, lds, s);
+static void launch_x3q_r(const ConvArgsX& a, int R, int mode, dim3 grid, size_t lds, hipStream_t s) {
+  if constexpr (AM == 2 && AN == 4) {
+    if (R >= 5) launch_x3q_k<AM, AN, 5>(a, mode, grid, lds, s); else launch_x3q_k<AM, AN, 4>(a, mode, grid, lds, s);
+  } else {
+    if (R >= 5) launch_x3q_k<AM, AN, 5>(a, mode, grid, lds, s); else if (R == 4) launch_x3q_k<AM, AN, 4>(a, mode, grid, lds, s); else launch_x3q_k<AM, AN, 3>(a, mode, grid, lds, s);
+  }
 }
 
-// a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the geometry is not this kernel's (the
-// per-tile pipelined kernel of conv_x3p.hip takes it): stride-1 Conv1d with 3 / 7 / 11 taps, whole row tiles, at least three 16-channel chunks.
+// a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the layer is not this kernel's (the
+// per-tile pipelined kernel of conv_x3p.hip takes it): the two halves of a split-resident ResBlock pair - stride-1 Conv1d with 3 / 7 / 11 taps,
+// whole row tiles, at least three 16-channel chunks, enough tiles for two rounds of resident workgroups.
 bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry) {
   static const int on = getenv("RVC_X3Q") ? atoi(getenv("RVC_X3Q")) : 1;
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
-  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || (xs && ys) || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
+  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || xs == ys || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
   if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
   const int BM = 64 * AM, BN = 64 * AN;
   if (a.Co % BM || a.Co > 1024) return false;
-  const bool radd = a.R != nullptr && a.act == ACT_NONE && !ys;
-  if (xs && !radd) return false;                                   // (image in without a residual: no caller)
+  if (xs && !(a.R != nullptr && a.act == ACT_NONE)) return false;     // image in: c2 of a pair (residual, nothing after the sum)
   if (ys && (a.R || a.accumulate)) return false;
-  if ((double)(a.Co / 16) * 4.0 * (double)a.ysTp * 16.0 >= 2147483648.0) return false;
-  const int mode = ys ? 0 : (xs ? 1 : (radd ? 2 : 3));
+  if ((double)(a.Co / 16) * 4.0 * (double)a.ysTp * 16.0 >= 2147483648.0 || (double)(a.Ci / 16) * 4.0 * (double)a.xsTp * 16.0 >= 2147483648.0) return false;
+  const int mode = ys ? 0 : 1;
   const int P = BN + (a.ktaps - 1) * a.dil;
   if (P > 384 || P > BN + 64) return false;
-  const int Pm = xs ? BN + 64 : P;
+  const int Pm = (P + 7) & ~7;
   const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
   const int wslot = 2 * BM * 32;
-  const int R = (AM == 2 && AN == 4) ? 4 : 3;
-  const size_t lds = (size_t)xbytes + (size_t)R * wslot + (size_t)((a.Co * 4 + 255) & ~255);
   const int per_cu = AM * AN >= 8 ? 2 : 3;
-  if (lds > (size_t)(160 * 1024 / per_cu)) return false;
+  const size_t budget = (size_t)(160 * 1024 / per_cu);
+  const size_t fixed = (size_t)xbytes + (size_t)((a.Co * 4 + 255) & ~255);
+  static const int r_env = getenv("RVC_X3Q_R") ? atoi(getenv("RVC_X3Q_R")) : 0;
+  const int rmin = (AM == 2 && AN == 4) ? 4 : 3;
+  int R = 5;
+  while (R > rmin && fixed + (size_t)R * wslot > budget) --R;
+  if (r_env >= rmin && r_env < R) R = r_env;
+  const size_t lds = fixed + (size_t)R * wslot;
+  if (lds > budget) return false;
   const long long ntiles = (long long)((a.Tout + BN - 1) / BN) * (a.Co / BM);
-  static const int min_tiles = getenv("RVC_X3Q_MINTILES") ? atoi(getenv("RVC_X3Q_MINTILES")) : 256;
-  if (ntiles < min_tiles) return false;
+  // a workgroup must own several tiles for the stream to hide anything: grids of less than two rounds stay on the per-tile kernel
+  static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
+  static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 2;
+  const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
+  if (ntiles < min_rounds * slots) return false;
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
-  static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-  static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
-  long long G = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
-  if (G > ntiles) G = ntiles;
-  G &= ~7LL;                                                      // a workgroup's tiles stay on its XCD
+  long long G = slots & ~7LL;                                      // a multiple of 8: a workgroup's tiles stay on its XCD
   dim3 grid((unsigned)G, 1, 1);
   grid_out = grid;
-  if (AM == 2 && AN == 4) launch_x3q_k<2, 4>(a, mode, grid, lds, s);
-  else if (AM == 1 && AN == 4) launch_x3q_k<1, 4>(a, mode, grid, lds, s);
-  else launch_x3q_k<2, 2>(a, mode, grid, lds, s);
+  if (AM == 2 && AN == 4) launch_x3q_r<2, 4>(a, R, mode, grid, lds, s);
+  else if (AM == 1 && AN == 4) launch_x3q_r<1, 4>(a, R, mode, grid, lds, s);
+  else launch_x3q_r<2, 2>(a, R, mode, grid, lds, s);
   return true;
 }
 

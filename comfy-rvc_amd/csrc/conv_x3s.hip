@@ -472,8 +472,7 @@ template <int AM, int AN, int RS>
 static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   auto kern = conv_x3s_kernel<AM, AN, RS>;
   constexpr size_t lds = (size_t)RS * (64 * AM + 64 * AN) * 64;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] { RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
 }
 

@@ -18,7 +18,7 @@ struct Hubert {
   Arena arena;
   TensorStore ts;
   bool ready = false;
-  const void* img_base = nullptr; size_t img_bytes = 0; int img_T = -1;   // image of the positional convolution's input: margins known to be zero
+  const void* img_base = nullptr; unsigned img_gen = 0; size_t img_bytes = 0; int img_T = -1;   // image of the positional convolution's input: margins known to be zero
   ConvLayer conv[7];
   DevVec gn_g, gn_b, fp_g, fp_b, enc_g, enc_b;
   DevVec w0;            // conv_layers.0 raw [512][10]: the fused conv0 + GroupNorm + GELU kernels evaluate it from the audio
@@ -44,7 +44,7 @@ static void hubert_free(Hubert& H) {
   conv_layer_free(H.proj); conv_layer_free(H.pos); conv_layer_free(H.final_proj);
   for (auto& l : H.layers) { conv_layer_free(l.qk); l.bv.free_(); conv_layer_free(l.o); conv_layer_free(l.ff1); conv_layer_free(l.ff2); l.g1.free_(); l.b1.free_(); l.g2.free_(); l.b2.free_(); }
   H.layers.clear();
-  H.img_base = nullptr; H.img_bytes = 0; H.img_T = -1;
+  H.img_base = nullptr; H.img_gen = 0; H.img_bytes = 0; H.img_T = -1;
 }
 void hubert_destroy(Hubert* H) { if (H) { hubert_free(*H); H->arena.release(); delete H; } }
 
@@ -135,9 +135,9 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
     const size_t img0 = A.off;
     hpos_s = A.alloc<unsigned char>(split_image_bytes(768, T));
     const size_t ib = A.off - img0;
-    if (!dry && (H->img_base != A.base + img0 || H->img_bytes != ib || H->img_T != T)) {
+    if (!dry && (H->img_base != A.base + img0 || H->img_gen != A.gen || H->img_bytes != ib || H->img_T != T)) {
       RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, ib, s));
-      H->img_base = A.base + img0; H->img_bytes = ib; H->img_T = T;
+      H->img_base = A.base + img0; H->img_gen = A.gen; H->img_bytes = ib; H->img_T = T;
     }
   }
   // ---- feature encoder

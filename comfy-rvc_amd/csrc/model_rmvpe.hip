@@ -21,7 +21,7 @@ struct Rmvpe {
   ConvLayer dect[5];
   ConvLayer dect_t[4];     // the same transposed convolutions as 2 x 2-tap phase convolutions for the split-resident kernel (input levels 5 .. 2)
   bool pad_ok = false;     // every layer of levels >= 2 has its bf16x3 image: those levels run on padded split-resident images (conv_x3s.hip)
-  const void* img_base = nullptr; size_t img_bytes = 0; int img_H1 = -1;   // image block whose margins are known to be zero (for this length)
+  const void* img_base = nullptr; unsigned img_gen = 0; size_t img_bytes = 0; int img_H1 = -1;   // image block whose margins are known to be zero (for this length)
   ConvLayer cnn;
   DevVec wihT, b_ih, w_hh, b_hh;
   ConvLayer fc;
@@ -41,7 +41,7 @@ static void rmvpe_free(Rmvpe& R) {
   for (auto& l : R.dec) for (auto& b : l) cbr_free(b);
   for (auto& c : R.dect) conv_layer_free(c);
   for (auto& c : R.dect_t) conv_layer_free(c);
-  R.pad_ok = false; R.img_base = nullptr; R.img_bytes = 0; R.img_H1 = -1;
+  R.pad_ok = false; R.img_base = nullptr; R.img_gen = 0; R.img_bytes = 0; R.img_H1 = -1;
   conv_layer_free(R.cnn); conv_layer_free(R.fc); conv_layer_free(R.wih);
   R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.b_hh.free_();
   dev_free(R.xbuf); dev_free(R.gru_err); R.xbuf = nullptr; R.gru_err = nullptr;
@@ -236,9 +236,9 @@ static void rmvpe_pad_plan(Rmvpe* R, hipStream_t s, Arena& A, int H1, PadPlan& P
   const size_t img_bytes = A.off - img0;
   static const bool rezero = getenv("RVC_RMVPE_REZERO") && atoi(getenv("RVC_RMVPE_REZERO")) != 0;      // debugging: zero the image block on every forward
   // (a shorter clip in the same allocation leaves the longer one's rows behind its end: the length is part of the layout)
-  if (!A.dry && (rezero || R->img_base != A.base + img0 || R->img_bytes != img_bytes || R->img_H1 != H1)) {
+  if (!A.dry && (rezero || R->img_base != A.base + img0 || R->img_gen != A.gen || R->img_bytes != img_bytes || R->img_H1 != H1)) {
     RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
-    R->img_base = A.base + img0; R->img_bytes = img_bytes; R->img_H1 = H1;
+    R->img_base = A.base + img0; R->img_gen = A.gen; R->img_bytes = img_bytes; R->img_H1 = H1;
   }
 }
 

@@ -65,7 +65,7 @@ struct Synth {
   DevVec dec_cond_w, dec_cond_b, conv_post_w;   // conv_post_w: raw [Ci][7] weights of the 1-channel output conv (ops.hip::conv_to1)
   std::vector<GenStage> stages;
   float lin_w = 1.f, lin_b = 0.f;
-  const void* img_base = nullptr; size_t img_bytes = 0; int img_T = -1;   // split-resident image block whose margins are known to be zero (synth_graph)
+  const void* img_base = nullptr; unsigned img_gen = 0; size_t img_bytes = 0; int img_T = -1;   // split-resident image block whose margins are known to be zero (synth_graph)
   bool f0 = true;        // false: the *_nono family (no pitch embedding, plain Generator: reference models.py:244-311,:812-1022)
 };
 
@@ -79,7 +79,7 @@ static void synth_free(Synth& S) {
   fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_(); S.conv_post_w.free_();
   for (auto& st : S.stages) { fl(st.up); fl(st.noise); st.noise_w.free_(); st.noise_b.free_(); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
   S.stages.clear();
-  S.img_base = nullptr; S.img_bytes = 0; S.img_T = -1;
+  S.img_base = nullptr; S.img_gen = 0; S.img_bytes = 0; S.img_T = -1;
 }
 
 Synth* synth_create(Ctx* ctx, const SynthConfig& c) {
@@ -253,9 +253,9 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     acts_s = A.alloc<unsigned char>(split_image_bytes(C, T)); z_s = A.alloc<unsigned char>(split_image_bytes(IC, T));
     const size_t img_bytes = A.off - img0;
     // (a shorter sequence in the same allocation leaves the longer one's rows behind its end: the length is part of the layout)
-    if (!dry && (S->img_base != A.base + img0 || S->img_bytes != img_bytes || S->img_T != T)) {
+    if (!dry && (S->img_base != A.base + img0 || S->img_gen != A.gen || S->img_bytes != img_bytes || S->img_T != T)) {
       RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
-      S->img_base = A.base + img0; S->img_bytes = img_bytes; S->img_T = T;
+      S->img_base = A.base + img0; S->img_gen = A.gen; S->img_bytes = img_bytes; S->img_T = T;
     }
   }
   // ---- speaker conditioning vectors

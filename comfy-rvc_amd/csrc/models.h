@@ -45,6 +45,9 @@ void rmvpe_forward(Rmvpe* R, hipStream_t s, const float* audio, long long L, flo
 // feature retrieval (index.hip): exact nearest neighbour over big_npy [N][D]
 struct FeatIndex;
 FeatIndex* index_create(Ctx* ctx, const float* big_npy, long long N, int D);
+// the reference's own index type (faiss IndexIVFFlat): nprobe nearest centroids, then the nearest vector inside those cells only
+FeatIndex* index_create_ivf(Ctx* ctx, const float* big_npy, long long N, int D, const float* centroids, int nlist, const int* list_of, int nprobe);
+int index_nprobe(const FeatIndex* I);   // 0: exact search
 void index_destroy(FeatIndex* I);
 long long index_size(const FeatIndex* I);
 int index_dim(const FeatIndex* I);

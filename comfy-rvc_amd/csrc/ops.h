@@ -44,6 +44,7 @@ void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long 
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,
                  int T, int upp, float sr, float lw, float lb, float* phase_out = nullptr);
 
+size_t preprocess_scratch_doubles(long long n, bool have_sos);   // doubles of scratch preprocess() needs for an input of n samples
 void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
                 double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch, const double* sos = nullptr,
                 const double* sos_zi = nullptr);      // sos [3][6] + sosfilt_zi [3][2]: block-propagated cascade evaluation (ops.hip)

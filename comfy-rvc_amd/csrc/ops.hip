@@ -1390,19 +1390,42 @@ __global__ __launch_bounds__(256) void rms_frames_f64_kernel(const double* __res
   if (threadIdx.x == 0) rms[blockIdx.x] = sqrt(red[0] / frame);
 }
 
+// Block length L and padded length Np of the filter pass for an input of n samples: ONE definition for the caller's scratch (2 Np doubles,
+// preprocess_scratch_doubles) and for the kernels (advisor, round 3: the scratch used to assume L <= 65536, which clips beyond ~2e8 samples
+// exceed, and an RVC_IIR_L that is not a power of two >= 32 silently dropped samples).
+static void iir_geometry(long long n, bool blocked, int& L, long long& Np) {
+  const long long N = n + 2 * 3 * (kIirOrder + 1);
+  if (!blocked) { L = 512; Np = (N + 7) & ~7LL; return; }
+  static const int blk_env = [] {
+    const int v = getenv("RVC_IIR_L") ? atoi(getenv("RVC_IIR_L")) : 256;      // block length of the propagated evaluation
+    RVC_REQUIRE(v >= 32 && v <= (1 << 20) && (v & (v - 1)) == 0, "RVC_IIR_L must be a power of two >= 32");
+    return v;
+  }();
+  long long l = blk_env;
+  while ((N + l - 1) / l > 3072) l *= 2;                     // the scan keeps all block states in LDS (6 doubles each)
+  RVC_REQUIRE(l <= (1LL << 30), "clip too long for the blocked filter");
+  L = (int)l; Np = ((N + l - 1) / l) * l;                    // whole blocks (zero-filled behind N)
+}
+static bool iir_blocked(bool have_sos) {
+  static const bool blocked_env = !(getenv("RVC_IIR_BLOCKED") && atoi(getenv("RVC_IIR_BLOCKED")) == 0);
+  return blocked_env && have_sos;
+}
+size_t preprocess_scratch_doubles(long long n, bool have_sos) {
+  int L; long long Np;
+  iir_geometry(n, iir_blocked(have_sos), L, Np);
+  return (size_t)(2 * Np);
+}
+
 void preprocess(hipStream_t s, const void* x, int is64, long long n, const double* b, const double* a, const double* zi, int t_pad,
-                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* 2 * (n + 2 padlen + 512) */,
+                double* filt, float* padded, double* rms1, int n1, int frame, int hop, double* scratch /* preprocess_scratch_doubles(n, sos) */,
                 const double* sos, const double* sos_zi) {
   IirArgs p{};
   for (int i = 0; i <= kIirOrder; ++i) { p.b[i] = b[i] / a[0]; p.a[i] = a[i] / a[0]; }
   for (int i = 0; i < kIirOrder; ++i) p.zi[i] = zi[i];
-  static const bool blocked_env = !(getenv("RVC_IIR_BLOCKED") && atoi(getenv("RVC_IIR_BLOCKED")) == 0);
-  const bool blocked = blocked_env && sos != nullptr && sos_zi != nullptr;
+  const bool blocked = iir_blocked(sos != nullptr && sos_zi != nullptr);
   p.x = x; p.is64 = is64; p.n = n; p.padlen = 3 * (kIirOrder + 1); p.N = n + 2 * p.padlen;
-  p.L = 512; p.W = 5120;
-  static const int blk_env = getenv("RVC_IIR_L") ? atoi(getenv("RVC_IIR_L")) : 256;      // block length of the propagated evaluation (power of two >= 32)
-  if (blocked) { p.L = blk_env; while ((p.N + p.L - 1) / p.L > 3072) p.L *= 2; }                  // the scan keeps all block states in LDS (6 doubles each)
-  p.Np = blocked ? ((p.N + p.L - 1) / p.L) * p.L : (p.N + 7) & ~7LL;          // whole blocks (zero-filled behind N)
+  p.W = 5120;
+  iir_geometry(n, blocked, p.L, p.Np);
   p.nchunks = (int)((p.Np + p.L - 1) / p.L); p.nb = p.nchunks;
   p.ext = scratch; p.yr = scratch + p.Np; p.filt = filt;
   hipLaunchKernelGGL(iir_extend_kernel, dim3((unsigned)((p.Np + 255) / 256)), dim3(256), 0, s, p);
@@ -1436,11 +1459,8 @@ void preprocess(hipStream_t s, const void* x, int is64, long long n, const doubl
     const dim3 g((unsigned)((p.nb + 63) / 64));
     hipLaunchKernelGGL((iir_block_kernel<0, false>), g, dim3(64), 0, s, p);
     const size_t scan_lds = ((size_t)64 * (gsz * 6 + 1) + 64 * 7) * sizeof(double);
-    static std::once_flag scan_once;
-    std::call_once(scan_once, [&] {
-      RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(iir_scan_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(iir_scan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    });
+    RVC_ALLOW_BIG_LDS(iir_scan_kernel<0>);
+    RVC_ALLOW_BIG_LDS(iir_scan_kernel<1>);
     hipLaunchKernelGGL((iir_scan_kernel<0>), dim3(1), dim3(256), scan_lds, s, p);
     hipLaunchKernelGGL((iir_block_kernel<0, true>), g, dim3(64), 0, s, p);
     hipLaunchKernelGGL((iir_block_kernel<1, false>), g, dim3(64), 0, s, p);

@@ -302,6 +302,16 @@ int rvc_index_create(rvc_ctx* ctx, const float* big_npy, int64_t N, int D, rvc_i
 }
 int rvc_index_destroy(rvc_index* h) { if (h) { index_destroy(h->m); delete h; } return 0; }
 int64_t rvc_index_ntotal(const rvc_index* h) { return h ? index_size(h->m) : 0; }
+int rvc_index_create_ivf(rvc_ctx* ctx, const float* big_npy, int64_t N, int D, const float* centroids, int nlist, const int32_t* list_of, int nprobe,
+                         rvc_index** out) {
+  RVC_TRY
+  RVC_REQUIRE(ctx && out, "null argument");
+  rvc_index* h = new rvc_index();
+  try { h->m = index_create_ivf(&ctx->c, big_npy, N, D, centroids, nlist, (const int*)list_of, nprobe); } catch (...) { delete h; throw; }
+  *out = h;
+  RVC_CATCH
+}
+int rvc_index_nprobe(const rvc_index* h) { return h && h->m ? index_nprobe(h->m) : 0; }
 int rvc_index_search(rvc_index* h, void* stream, const float* feats_cm, int64_t T, int64_t* idx, float* score) {
   RVC_TRY
   RVC_REQUIRE(h && feats_cm && idx && T > 0, "bad argument");
@@ -324,8 +334,8 @@ int rvc_preprocess(void* stream, const void* audio, int is_f64, int64_t n, const
   RVC_REQUIRE(a6[0] != 0.0, "a[0] must be non-zero");
   RVC_REQUIRE(rms1 == nullptr || n1 == (int)(n / 8000) + 1, "rms1 must hold n / 8000 + 1 frames");
   hipStream_t st = (hipStream_t)stream;
-  double* scratch = (double*)stream_scratch(st, 2, (size_t)(2 * (n + 36 + 65536)) * sizeof(double));      // ext | yr, each rounded up to whole blocks (512 samples; longer for clips beyond 98 s)
   RVC_REQUIRE((sos18 == nullptr) == (sos_zi6 == nullptr), "sos and its initial state come together");
+  double* scratch = (double*)stream_scratch(st, 2, preprocess_scratch_doubles(n, sos18 != nullptr) * sizeof(double));      // ext | yr, each rounded up to whole blocks
   preprocess(st, audio, is_f64, n, b6, a6, zi5, t_pad, filt, padded, rms1, n1, 16000, 8000, scratch, sos18, sos_zi6);
   check_launch();
   RVC_CATCH

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of librvc_hip.so (gfx950 only).
 // Public C ABI: include/rvc_hip.h.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -207,8 +208,24 @@ void* stream_scratch_zeroed(hipStream_t s, int slot, size_t bytes, bool* fresh =
 void stream_scratch_release(int device);                        // frees the scratch of one device (last context of the device destroyed)
 void dev_free(void* p);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a device's copy of the kernel: set it once per (call site = kernel instantiation, device),
+// not once per process - rvc_ctx_create takes a device id, and a second GPU driven from the same process would otherwise launch with the default
+// 64 KiB limit (advisor, round 3).  Two threads racing on the first launch both set it: harmless.
+#define RVC_ALLOW_BIG_LDS(kern)                                                                                                              \
+  do {                                                                                                                                       \
+    static std::atomic<unsigned long long> rvc_lds_mask_[4];                                                                                 \
+    int rvc_dev_ = 0; (void)hipGetDevice(&rvc_dev_);                                                                                         \
+    const unsigned long long rvc_bit_ = 1ull << (rvc_dev_ & 63);                                                                             \
+    std::atomic<unsigned long long>& rvc_m_ = rvc_lds_mask_[(rvc_dev_ >> 6) & 3];                                                            \
+    if (!(rvc_m_.load(std::memory_order_acquire) & rvc_bit_)) {                                                                              \
+      RVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+      rvc_m_.fetch_or(rvc_bit_, std::memory_order_release);                                                                                  \
+    }                                                                                                                                        \
+  } while (0)
+
 struct Arena {
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false;
+  unsigned gen = 0;   // bumped whenever the block is (re)allocated or released: a cached "these bytes are known to be zero" must not survive that
   void reset() { off = 0; }
   template <typename T> T* alloc(size_t n) {
     size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);

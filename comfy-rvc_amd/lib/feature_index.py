@@ -3,9 +3,15 @@
 The reference keeps a faiss IVF-Flat index over the training features `big_npy [N, D]` (built by
 custom_nodes/rvc_nodes.py:500-554, loaded by pitch_extraction.py:52-73) and calls `index.search(npy, k=1)` on the HuBERT
 frames of every segment (vc_infer_pipeline.py:60-75).  `DeviceIndex` offers that call surface - `search`, `ntotal`,
-`reconstruct_n` - over the same `big_npy`, as an exact L2 nearest-neighbour search on the GPU (rvc_index_*, csrc/index.hip).
-faiss's IVF probe (nprobe 1) is an approximation of this exact answer; faiss itself is not available offline, so parity of
-the retrieval is pinned against a brute-force restatement (oracle/pipeline.py::index_search), not against faiss.
+`reconstruct_n` - over the same `big_npy` on the GPU (rvc_index_*, csrc/index.hip), with the semantics of the object it stands for:
+
+* built from a faiss `IVF*,Flat` file (`ivf=(centroids, list_of, nprobe)`, what lib/faiss_io.py reads out of the file): faiss's
+  IndexIVFFlat search - the `nprobe` centroids nearest to the query pick the cells, the nearest vector INSIDE those cells is the answer
+  (nprobe 1 as train_index sets it: often not the global nearest neighbour), empty probed cells give label -1 / distance FLT_MAX;
+* built from a bare `big_npy` (`.npy` file, the reference's preloaded tuple): no cell structure exists, the search is the exact one.
+
+faiss itself is not available offline: both are pinned against restatements of faiss's published algorithm
+(oracle/pipeline.py::index_search_ivf / index_search), not against faiss.
 """
 import ctypes as C
 
@@ -16,16 +22,26 @@ from .. import _lib
 
 
 class DeviceIndex:
-    def __init__(self, big_npy, device="cuda:0"):
+    def __init__(self, big_npy, device="cuda:0", ivf=None):
         big_npy = np.ascontiguousarray(big_npy, dtype=np.float32)
         assert big_npy.ndim == 2, "big_npy must be [N, D]"
         self.device = torch.device(device)
         self.ntotal, self.d = int(big_npy.shape[0]), int(big_npy.shape[1])
         self._big = big_npy
         self._h = C.c_void_p()
+        self.nprobe = 0                                    # 0: exact search
         ctx = _lib.get_ctx(self.device.index or 0)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib.rvc_index_create(ctx, _lib.ptr(big_npy), self.ntotal, self.d, C.byref(self._h)))
+            if ivf is None:
+                _lib.check(_lib.lib.rvc_index_create(ctx, _lib.ptr(big_npy), self.ntotal, self.d, C.byref(self._h)))
+            else:
+                centroids, list_of, nprobe = ivf
+                centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+                list_of = np.ascontiguousarray(list_of, dtype=np.int32)
+                assert centroids.ndim == 2 and centroids.shape[1] == self.d and list_of.shape == (self.ntotal,)
+                _lib.check(_lib.lib.rvc_index_create_ivf(ctx, _lib.ptr(big_npy), self.ntotal, self.d, _lib.ptr(centroids), int(centroids.shape[0]),
+                                                         _lib.ptr(list_of), int(nprobe), C.byref(self._h)))
+                self.nprobe = int(_lib.lib.rvc_index_nprobe(self._h))
 
     def __del__(self):
         h = getattr(self, "_h", None)

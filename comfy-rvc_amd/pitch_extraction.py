@@ -61,7 +61,9 @@ class FeatureExtractor:
     def load_index(self, file_index):
         """(index, big_npy) for feature retrieval (reference :52-73).  Accepts the reference's preloaded tuple, "" (no index),
         a `.npy` file holding big_npy [N, D] (what `train_index` saves next to the faiss file as total_fea.npy), or a faiss
-        `.index` file (IVF*,Flat and Flat files are read natively, lib/faiss_io.py; other types need faiss); the search object is always a device-resident exact index (lib/feature_index.py).
+        `.index` file (IVF*,Flat and Flat files are read natively, lib/faiss_io.py; other types need faiss).  The search object is device
+        resident (lib/feature_index.py): an IVF file is searched the way faiss searches it - the file's nprobe nearest cells, the nearest vector
+        inside them (reference: index built with nprobe 1, custom_nodes/rvc_nodes.py:500-554) - a bare big_npy exactly.
         Errors are printed and turn into "no index", as in the reference."""
         index = big_npy = None
         try:
@@ -78,22 +80,25 @@ class FeatureExtractor:
                 # the `added_IVF*_Flat_*.index` files RVC users have: the stored vectors in id order are all the conversion needs (what
                 # faiss.read_index + reconstruct_n(0, ntotal) returns); read natively - faiss is optional (lib/faiss_io.py)
                 from .lib.faiss_io import read_index_vectors   # noqa: PLC0415
+                ivf = None
                 try:
-                    big_npy, _ = read_index_vectors(file_index)
+                    big_npy, info = read_index_vectors(file_index)
+                    if info.get("kind") == "ivf_flat" and info.get("metric", 1) == 1:
+                        ivf = (info["centroids"], info["list_of"], max(1, int(info["nprobe"])))
                 except ValueError:
                     import faiss   # noqa: PLC0415 - other index types (PQ ...): only faiss can decode them
                     fidx = faiss.read_index(file_index)
                     big_npy = fidx.reconstruct_n(0, fidx.ntotal)
-                index = self._device_index(big_npy)
+                index = self._device_index(big_npy, ivf)
         except Exception as e:   # noqa: BLE001 - reference behaviour
             print(f"Could not open Faiss index file for reading. {e}")
             index = big_npy = None
         return index, big_npy
 
-    def _device_index(self, big_npy):
+    def _device_index(self, big_npy, ivf=None):
         from .lib.feature_index import DeviceIndex   # noqa: PLC0415
         dev = self.device if str(self.device).startswith("cuda") else "cuda:0"
-        return DeviceIndex(big_npy, device=dev)
+        return DeviceIndex(big_npy, device=dev, ivf=ivf)
 
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):

@@ -193,11 +193,19 @@ int rvc_vc_segment_feats(rvc_synth* s, void* stream, const float* feats_cm_dev, 
 /* ------------------------------------------------------------------ feature retrieval (vc_infer_pipeline.py:60-75) */
 /* The reference looks every HuBERT frame up in a faiss IVF-Flat index over the training features big_npy [N][D]
  * (index.search(npy, k=1); pitch_extraction.py:52-73 loads it, custom_nodes/rvc_nodes.py:500-554 builds it) and blends the
- * neighbour in with weight index_rate.  rvc_index_* is the exact L2 nearest-neighbour search over the same big_npy, device
- * resident: search returns idx [T] (and optionally the squared distances faiss would report), blend writes
- * out = index_rate * big_npy[idx] + (1 - index_rate) * feats.  Features are channel-major [D][T]. */
+ * neighbour in with weight index_rate.  rvc_index_* is that search, device resident, over the same big_npy: search returns idx [T]
+ * (and optionally the squared distances faiss would report), blend writes out = index_rate * big_npy[idx] + (1 - index_rate) * feats.
+ * Features are channel-major [D][T].
+ * rvc_index_create: exact L2 nearest neighbour (for inputs without a cell structure: a big_npy array / the reference's preloaded tuple).
+ * rvc_index_create_ivf: the semantics of the reference's own index, faiss IndexIVFFlat as RVCTrainModelNode.train_index builds it
+ * ("IVF{n},Flat", nprobe 1): the nprobe centroids nearest to the query (coarse IndexFlatL2 quantiser) select the cells, only vectors of
+ * those cells compete (list_of[j] = the list row j was added to); probed cells without vectors give idx -1 / score FLT_MAX and - like the
+ * reference's weight arithmetic, :66-74 - a NaN frame in the blend.  nprobe <= 16, or >= nlist (= exact). */
 typedef struct rvc_index rvc_index;
 int rvc_index_create(rvc_ctx* ctx, const float* big_npy_host, int64_t N, int D, rvc_index** out);
+int rvc_index_create_ivf(rvc_ctx* ctx, const float* big_npy_host, int64_t N, int D, const float* centroids_host /* [nlist][D] */, int nlist,
+                         const int32_t* list_of_host /* [N] */, int nprobe, rvc_index** out);
+int rvc_index_nprobe(const rvc_index* h);   /* 0: exact search */
 int rvc_index_destroy(rvc_index* h);
 int64_t rvc_index_ntotal(const rvc_index* h);
 int rvc_index_search(rvc_index* h, void* stream, const float* feats_cm_dev, int64_t T, int64_t* idx_dev, float* score_dev /* may be NULL */);

@@ -118,17 +118,45 @@ def index_search(npy, big_npy):
     return d[np.arange(a.shape[0]), ix].astype(np.float32)[:, None], ix.astype(np.int64)[:, None]
 
 
+def index_search_ivf(npy, big_npy, centroids, list_of, nprobe=1):
+    """k = 1 search of a faiss `IndexIVFFlat` (L2), the index the reference builds and opens (custom_nodes/rvc_nodes.py:500-554:
+    `index_factory(dim, "IVF{n},Flat")`, `nprobe = 1`; pitch_extraction.py:52-73; searched at vc_infer_pipeline.py:65).  faiss (third
+    party, unpinned in requirements.txt, absent here) publishes the algorithm as: the coarse quantiser - an IndexFlatL2 over the
+    `nlist` centroids - returns the `nprobe` centroids nearest to the query; only the inverted lists of those cells are scanned, the
+    smallest squared L2 distance among THEIR vectors wins (IndexIVF::search -> search_preassigned -> IVFFlatScanner::scan_codes);
+    when the probed lists are empty the label is -1 and the distance is float32 max (HeapArray init of a min-distance heap).
+    `list_of[j]` = the list row j of big_npy was added to.  float64 distances, ties to the smaller index; returns
+    (score float32 [T, 1], ix int64 [T, 1])."""
+    a = np.asarray(npy, dtype=np.float64)
+    b = np.asarray(big_npy, dtype=np.float64)
+    cen = np.asarray(centroids, dtype=np.float64)
+    lo = np.asarray(list_of).astype(np.int64)
+    dc = (a * a).sum(1)[:, None] - 2.0 * (a @ cen.T) + (cen * cen).sum(1)[None, :]
+    cells = np.argsort(dc, axis=1, kind="stable")[:, :int(nprobe)]
+    d = (a * a).sum(1)[:, None] - 2.0 * (a @ b.T) + (b * b).sum(1)[None, :]
+    ok = (lo[None, None, :] == cells[:, :, None]).any(1)
+    d = np.where(ok, d, np.inf)
+    ix = d.argmin(1)
+    sc = d[np.arange(a.shape[0]), ix]
+    none = ~ok.any(1)
+    ix = np.where(none, -1, ix)
+    sc = np.where(none, np.finfo(np.float32).max, sc)
+    return sc.astype(np.float32)[:, None], ix.astype(np.int64)[:, None]
+
+
 def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf, protect, noise_fn, c,
-               n_hubert_layers=None, big_npy=None, index_rate=0.0):
-    """VC.vc (reference vc_infer_pipeline.py:25-114); index retrieval as an exact search over big_npy when given."""
+               n_hubert_layers=None, big_npy=None, index_rate=0.0, ivf=None):
+    """VC.vc (reference vc_infer_pipeline.py:25-114); index retrieval over big_npy when given: the IVF probe of the reference's faiss index
+    when `ivf = (centroids, list_of, nprobe)` describes one (index_search_ivf), an exact search otherwise."""
     feats = torch.from_numpy(audio0).float().view(1, -1)
     feats = nets.hubert_extract_features(hubert_sd, feats, version, n_layers=n_hubert_layers)
     feats0 = feats.clone()
     if big_npy is not None and index_rate > 0:
         npy = feats[0].numpy().astype("float32")
-        score, ix = index_search(npy, big_npy)
-        weight = np.square(1 / score)
-        weight /= weight.sum(axis=1, keepdims=True)
+        score, ix = index_search(npy, big_npy) if ivf is None else index_search_ivf(npy, big_npy, *ivf)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            weight = np.square(1 / score)
+            weight /= weight.sum(axis=1, keepdims=True)
         npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
         feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0) * index_rate + (1 - index_rate) * feats
     feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
@@ -155,8 +183,8 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
 def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up_key=0, f0_method="rmvpe",
              rms_mix_rate=0.25, protect=0.33, f0_autotune=False, noise_fn=None, f0_override=None,
              x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None, big_npy=None, index_rate=0.0,
-             if_f0=1):
-    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for resample_sr=0; optional exact index retrieval; if_f0=0 is the
+             if_f0=1, ivf=None):
+    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for resample_sr=0; optional index retrieval (exact, or the IVF probe when `ivf` is given); if_f0=0 is the
     no-pitch model family (*_nono): no f0 front-end, pitch None all the way (:151-152,:172-179).
 
     audio: 16 kHz mono float32 (already remixed).  Returns int16 [N] at tgt_sr (and the float waveform
@@ -186,13 +214,13 @@ def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up
         ps = pitch[:, s // c.window: (t + c.t_pad2) // c.window + 1] if if_f0 else None
         pfs = pitchf[:, s // c.window: (t + c.t_pad2) // c.window + 1] if if_f0 else None
         out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
-                              n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
+                              n_hubert_layers, big_npy, index_rate, ivf)[c.t_pad_tgt: -c.t_pad_tgt])
         s = t
     a = audio_pad[t:]
     ps = pitch[:, t // c.window:] if if_f0 and t is not None else pitch
     pfs = pitchf[:, t // c.window:] if if_f0 and t is not None else pitchf
     out.append(vc_segment(hubert_sd, synth_sd, config, version, sid, a, ps, pfs, protect, noise_fn, c,
-                          n_hubert_layers, big_npy, index_rate)[c.t_pad_tgt: -c.t_pad_tgt])
+                          n_hubert_layers, big_npy, index_rate, ivf)[c.t_pad_tgt: -c.t_pad_tgt])
     audio_opt = np.concatenate(out)
     if rms_mix_rate < 1:
         audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)

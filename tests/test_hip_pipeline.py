@@ -126,6 +126,60 @@ def test_device_index_search_and_blend_match_brute_force(models):
     assert list(i2[:, 0]) == [5, 39999] and np.all(np.abs(s2) < 1e-2)
 
 
+def test_device_index_ivf_probe_matches_faiss_semantics(models, tmp_path):
+    """The reference's index is faiss `IVF{n},Flat` with nprobe 1 (custom_nodes/rvc_nodes.py:500-554): the answer is the nearest vector INSIDE
+    the probed cell, which for a good share of the frames is not the global nearest neighbour.  The device search built from such a FILE must
+    give faiss's answer (restated in oracle.pipeline.index_search_ivf), for nprobe 1, nprobe 3 and with empty probed cells (label -1,
+    distance FLT_MAX, NaN frame in the blend - the reference's own arithmetic on that label)."""
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.lib.faiss_io import write_ivf_flat
+    from comfy_rvc_amd.lib.feature_index import DeviceIndex
+    from comfy_rvc_amd.pitch_extraction import FeatureExtractor
+    from oracle.pipeline import index_search, index_search_ivf
+    hub, _, _ = models
+    big = _big_npy(hub, n=40000)
+    q = hub.extract_features(torch.from_numpy(S.synth_audio(1.5, seed=9))[None], version="v2")[0].cpu().numpy()
+    rng = np.random.default_rng(5)
+    nlist = 64
+    cent = big[rng.choice(big.shape[0], nlist, replace=False)] + 0.01 * rng.standard_normal((nlist, big.shape[1])).astype(np.float32)
+    fe = FeatureExtractor(40000, Config())
+    _, ix_exact = index_search(q, big)
+    for nprobe in (1, 3):
+        path = str(tmp_path / f"added_IVF{nlist}_Flat_nprobe_{nprobe}_v2.index")
+        assign = write_ivf_flat(path, big, nlist, centroids=cent, nprobe=nprobe)
+        index, big2 = fe.load_index(path)
+        assert index.nprobe == nprobe and np.array_equal(big2, big)
+        score, ix = index.search(q, k=1)
+        rscore, rix = index_search_ivf(q, big, cent, assign, nprobe)
+        same = ix[:, 0] == rix[:, 0]
+        d_other = ((q[~same].astype(np.float64) - big[ix[~same, 0]].astype(np.float64)) ** 2).sum(1)
+        assert same.mean() > 0.99 and np.allclose(d_other, rscore[~same, 0], rtol=1e-5)       # (a different row only on a numerical tie)
+        assert np.allclose(score[:, 0], rscore[:, 0], rtol=2e-4, atol=1e-4)
+        differs = float((rix[:, 0] != ix_exact[:, 0]).mean())
+        assert differs > (0.05 if nprobe == 1 else 0.0), differs                             # the probe really is not the exact search
+        if nprobe == 1:
+            frac1 = differs
+        else:
+            assert differs < frac1                                                              # more cells: closer to exact
+        out = index.blend_device(torch.from_numpy(q).cuda().t().contiguous(), 0.75).t().cpu().numpy()
+        assert np.max(np.abs(out[same] - (big[rix[same, 0]] * 0.75 + 0.25 * q[same]))) < 1e-5
+    # empty probed cells: the cell nearest to these queries holds no vector
+    far = 50.0 + np.zeros((1, big.shape[1]), np.float32)
+    cent2 = np.concatenate([cent, far])
+    assign2 = np.concatenate([assign, [0]]).astype(np.int32)[:-1]                              # nobody is assigned to the far cell
+    idx2 = DeviceIndex(big, ivf=(cent2, assign2, 1))
+    qq = np.concatenate([q[:5], far + 0.01, far - 0.02]).astype(np.float32)
+    s2, i2 = idx2.search(qq, k=1)
+    rs2, ri2 = index_search_ivf(qq, big, cent2, assign2, 1)
+    assert list(i2[5:, 0]) == [-1, -1] and list(ri2[5:, 0]) == [-1, -1] and np.all(s2[5:, 0] == np.finfo(np.float32).max)
+    assert np.array_equal(i2[:5, 0], ri2[:5, 0])
+    o2 = idx2.blend_device(torch.from_numpy(qq).cuda().t().contiguous(), 0.75).t().cpu().numpy()
+    assert np.all(np.isnan(o2[5:])) and not np.any(np.isnan(o2[:5]))
+    # nprobe >= nlist is the exact search
+    idx3 = DeviceIndex(big, ivf=(cent, assign, nlist))
+    assert idx3.nprobe == 0 and np.array_equal(idx3.search(q, k=1)[1], DeviceIndex(big).search(q, k=1)[1])
+
+
 def test_pipeline_with_index_matches_oracle(models, noise_tape):
     """vc_single with a retrieval index (device path: search + blend on the side stream, feats0 into the protect blend) against
     the CPU oracle with its brute-force search; also the generic VC.vc path with the faiss-like search() surface."""
@@ -158,16 +212,22 @@ def test_pipeline_with_index_matches_oracle(models, noise_tape):
     out0 = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
                      file_index="", index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
     assert np.max(np.abs(out0[0].astype(np.int32) - ref.astype(np.int32))) > 10 * LSB
-    # the same index as the FILE users have (`added_IVF*_Flat_*.index`, faiss's on-disk layout): read natively, same audio as the tuple form
+    # the same vectors as the FILE users have (`added_IVF*_Flat_*.index`, faiss's on-disk layout, nprobe 1): read natively and searched the way
+    # faiss searches it - the nearest vector inside the ONE probed cell - against the oracle with the same cell structure
     import tempfile
     from comfy_rvc_amd.lib.faiss_io import write_ivf_flat
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "added_IVF16_Flat_nprobe_1_test_v2.index")
-        write_ivf_flat(path, big, 16)
+        assign = write_ivf_flat(path, big, 16)
+        cent = big[np.linspace(0, big.shape[0] - 1, 16).astype(np.int64)]
         it = iter(tape)
         out_f = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="pm",
                           file_index=path, index_rate=0.75, rms_mix_rate=0.25, protect=0.33)
-    assert out_f is not None and np.array_equal(out_f[0], out[0])
+    it = iter(tape)
+    ref_f = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 0), S.CONFIG_40K_V2, "v2", audio,
+                         rms_mix_rate=0.25, protect=0.33, noise_fn=lambda shape: next(it), f0_override=f0fn, big_npy=big, index_rate=0.75, ivf=(cent, assign, 1))
+    assert out_f is not None and np.max(np.abs(out_f[0].astype(np.int32) - ref_f.astype(np.int32))) <= LSB
+    assert np.max(np.abs(ref_f.astype(np.int32) - ref.astype(np.int32))) > 10 * LSB        # (the probe's answer is not the exact search's here)
 
 
 @pytest.mark.parametrize("variant", ["48k_v2", "40k_v1", "32k_v1", "48k_v1", "32k_v2"])

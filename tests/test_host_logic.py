@@ -256,3 +256,33 @@ def test_device_f0_shortcut_honours_subclass_and_class_level_overrides():
         else:
             V.VC.get_f0 = orig
     assert V._is_base_method(V.VC(40000, Config()), "get_f0")
+
+
+def test_oracle_ivf_probe_semantics():
+    """oracle.pipeline.index_search_ivf restates faiss IndexIVFFlat.search (the reference's index type, custom_nodes/rvc_nodes.py:500-554, searched at
+    vc_infer_pipeline.py:65): properties that pin the restatement - the answer lies in a probed cell, is the nearest vector of those cells, equals
+    the exact search when every cell is probed, differs from it for a share of the queries at nprobe 1, and is (-1, FLT_MAX) for empty cells."""
+    from oracle.pipeline import index_search, index_search_ivf
+    rng = np.random.default_rng(0)
+    big = rng.standard_normal((3000, 24)).astype(np.float32)
+    cen = big[rng.choice(3000, 20, replace=False)]
+    lo = (((big[:, None, :] - cen[None]) ** 2).sum(2)).argmin(1).astype(np.int32)
+    q = rng.standard_normal((400, 24)).astype(np.float32)
+    s0, i0 = index_search(q, big)
+    for nprobe in (1, 4, 20):
+        s, i = index_search_ivf(q, big, cen, lo, nprobe)
+        dc = ((q[:, None, :].astype(np.float64) - cen[None].astype(np.float64)) ** 2).sum(2)
+        cells = np.argsort(dc, axis=1, kind="stable")[:, :nprobe]
+        assert all(lo[i[t, 0]] in cells[t] for t in range(q.shape[0]))
+        for t in range(0, 400, 37):
+            rows = np.nonzero(np.isin(lo, cells[t]))[0]
+            d = ((big[rows].astype(np.float64) - q[t].astype(np.float64)) ** 2).sum(1)
+            assert rows[d.argmin()] == i[t, 0] and abs(d.min() - s[t, 0]) < 1e-4
+        assert np.all(s[:, 0] >= s0[:, 0] - 1e-5)
+        if nprobe == 20:
+            assert np.array_equal(i, i0)
+        if nprobe == 1:
+            assert 0.2 < float((i != i0).mean()) < 0.95
+    cen2 = np.concatenate([cen, np.full((1, 24), 40.0, np.float32)])
+    s, i = index_search_ivf(np.full((2, 24), 40.0, np.float32), big, cen2, lo, 1)
+    assert list(i[:, 0]) == [-1, -1] and np.all(s == np.finfo(np.float32).max)
