@@ -83,6 +83,20 @@ def cpu_model():
     return "unknown"
 
 
+def _set_affinity_all_threads(mask):
+    """sched_setaffinity for every thread of this process (the call with pid 0 only moves the calling thread; OpenMP / torch pool threads that
+    already exist keep the mask they were created under)."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for t in tids:
+        try:
+            os.sched_setaffinity(t, mask)
+        except OSError:
+            pass
+
+
 def cpu_baseline(config=None, seconds=CLIP_SECONDS, seed=100, budget_s=40.0):
     """The CPU oracle (validated restatement of the reference) timed on this box's host cores as BASELINE.md section 4 describes, on the
     SAME clip the GPU line converts (same length, same seed: rank 0's clip): 1 s warm-up clip + up to 3 timed runs inside budget_s of CPU
@@ -93,7 +107,7 @@ def cpu_baseline(config=None, seconds=CLIP_SECONDS, seed=100, budget_s=40.0):
     from comfy_rvc_amd import synthetic as S
     from oracle import nets, pipeline as opl
     ncpu = os.cpu_count() or 1
-    navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu      # the rank is pinned to its GPU's NUMA node
+    navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu      # (the caller has restored the process-wide mask)
     k = max(1, min(navail, 32))                # torch-CPU conv/GEMM on these sizes stops scaling well before 32 threads
     prev = torch.get_num_threads()
     torch.set_num_threads(k)
@@ -206,9 +220,14 @@ def main():
     # CPU affinity first: nothing in this process has touched HIP yet (importing torch / counting devices does not), so the runtime's helper
     # threads, the lane threads and the side-stream callbacks all inherit the mask.  One NUMA node's worth of CPUs per rank.
     bound = None
+    orig_affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     if not args.no_bind and not args.dry_run:
         from comfy_rvc_amd.parallel import bind_rank_to_numa
-        bound = bind_rank_to_numa(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        # gloo debug mode (RVC_BENCH_BACKEND != nccl: every rank runs on device 0 with LOCAL_RANK 0): the device's CPUs are split by RANK, not
+        # handed to all ranks at once (advisor, round 3)
+        shared_dev = world > 1 and os.environ.get("RVC_BENCH_BACKEND", "nccl") != "nccl"
+        bound = bind_rank_to_numa(local_rank, local_world, slot=rank if shared_dev else None, nslots=world if shared_dev else None)
 
     import numpy as np
     import torch
@@ -363,6 +382,10 @@ def main():
                                 "largest single kernel of this variant and has no FLOP / byte roofline; see profiles/*_kernel_stats_rmvpe60.csv")
     cpu = None
     if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
+        # the CPU baseline is "the reference's path on this box's host cores" (BASELINE.md section 4), not on the one NUMA node the rank was pinned
+        # to for the GPU run: every thread of the process (torch's intra-op pool included) gets the original mask back for this leg
+        if bound is not None and orig_affinity is not None:
+            _set_affinity_all_threads(orig_affinity)
         cpu = None if chain else (cpu_baseline_rmvpe(seconds=args.seconds) if pitch_only else cpu_baseline(config=SYN_CFG, seconds=args.seconds))      # (the CPU oracle of the separation net at full size takes minutes per chunk)
 
     if rank == 0:
@@ -397,6 +420,9 @@ def main():
 
 
 KERNEL_DESC = {
+    "conv_x3q_kernel": "rvc::conv_x3q_kernel<AM,AN,KT,R,XSPLIT,YSPLIT,RADD> - PERSISTENT software-pipelined bf16x3 implicit-GEMM Conv1d (the split-resident ResBlock pairs of "
+                       "the 128- / 64-channel generator stages): resident workgroups walk over their tiles in one stream of (tile, chunk, tap) units, residual added block "
+                       "by block inside the tile; 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
     "conv_x3p_kernel": "rvc::conv_x3p_kernel<AM,AN,KT,XSPLIT,YSPLIT,S2> - software-pipelined bf16x3 implicit-GEMM Conv1d (generator ResBlocks / up-samplers, "
                        "HuBERT stride-2 layers): 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
     "conv_x3pf_kernel": "rvc::conv_x3pf_kernel<KT,WM> - fused ResBlock pair (32- / 64-channel generator stages), bf16x3",

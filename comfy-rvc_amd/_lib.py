@@ -81,6 +81,7 @@ SIGNATURES = {
     "rvc_rmvpe_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "rvc_rmvpe_status": (c_int, [c_void_p, c_void_p]),
     "rvc_rmvpe_debug_fault": (c_int, [c_void_p, c_int, C.c_uint]),
+    "rvc_rmvpe_repaired": (c_int, [c_void_p, c_void_p]),
     "rvc_crepe_create": (c_int, [c_void_p, c_int, P(c_void_p)]),
     "rvc_crepe_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),
     "rvc_crepe_finalize": (c_int, [c_void_p]),

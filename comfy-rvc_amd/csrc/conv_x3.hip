@@ -538,7 +538,9 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       static const int wide_k3 = getenv("RVC_X3_WIDE_K3") ? atoi(getenv("RVC_X3_WIDE_K3")) : 2;      // the wide tile also for k = 3 (1: fp32 inputs, 2: split inputs too): on the pipelined kernel C128 k3 135 -> 129 us; not for the up-samplers (240 -> 250)
       if (w8_taps > 0 && a.Co > 64 && a.ktaps >= w8_taps && blocks(128, 512) >= w8_blk) t = TileCfg{2, 4, 2, 4};
       else
-      if (a.Co > 64 && blocks(128, 256) >= wide_blk && (a.ktaps > 3 || (wide_k3 >= 1 && a.ostride == 1)) && !(xs && a.ktaps <= 7 && !(a.ktaps <= 3 && wide_k3 >= 2))) t = TileCfg{2, 2, 2, 4};
+      static const int wide_xs7 = getenv("RVC_X3_WIDE_XS7") ? atoi(getenv("RVC_X3_WIDE_XS7")) : 0;   // the wide tile also for a split-input consumer with k = 7
+      if (a.Co > 64 && blocks(128, 256) >= wide_blk && (a.ktaps > 3 || (wide_k3 >= 1 && a.ostride == 1)) &&
+          !(xs && a.ktaps <= 7 && !(a.ktaps <= 3 && wide_k3 >= 2) && !(a.ktaps == 7 && wide_xs7))) t = TileCfg{2, 2, 2, 4};
       else if (wide64 && a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
   }

@@ -62,6 +62,16 @@ void conv_x3q_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 #endif
 
 struct QTile { int co0, n0, bx; bool edge, valid; };
+// One 32 x 32 x 16 product.  SWAP = false: D[channel][position], a lane holds ONE position (its column) and 16 channels - what the split-image
+// epilogue needs (8 channels of a position are one 16-byte row).  SWAP = true: the operands trade places, D[position][channel]: a lane holds ONE
+// channel and 4 x 4 consecutive positions, so residual loads and fp32 stores become 16-byte accesses without any transposition.  Measured
+// (round 4, profiles/r4b_x3q_steps.txt) and NOT used: a store instruction then writes 32 bytes per channel row instead of whole 128-byte lines,
+// the epilogue of a C128 k11 tile went from 10.4 k to 15.5 k cycles and every class got slower; the residual variant stages through LDS instead.
+template <bool SWAP>
+__device__ __forceinline__ f32x16 q_mfma(const u32x4& w, const u32x4& x, const f32x16& c) {
+  if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
 // AM x AN accumulators per wave (2 x 2 waves), KT taps.  XSPLIT: split-resident input image (DMA) instead of fp32 rows (registers, converted);
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
     static constexpr int w(int t) { int n = nD(t - (R - 2)) + nE(t - (R - 2)); for (int j = 1; j <= R - 3; ++j) n += tot(t - (R - 2) + j); return n + nA(t); }
   };
   // the epilogue's memory operations (a lower bound is what the waits need): stores only
-  constexpr int EP = YSPLIT ? 4 * AM * AN : 16 * AM * AN;
+  constexpr int EP = (YSPLIT || RADD) ? 4 * AM * AN : 16 * AM * AN;
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smemq[];
   const int P = p.WROW;                                     // staged input positions: BN + (KT - 1) * dil
@@ -100,6 +110,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
   unsigned char* Xs = smemq;
   unsigned char* Ws = smemq + ((2 * xbuf + 1023) & ~1023);
   float* Bs = reinterpret_cast<float*>(Ws + R * wslot);      // bias of every output row
+  unsigned char* Ss = reinterpret_cast<unsigned char*>(Bs) + ((p.Co * 4 + 255) & ~255);   // RADD: epilogue staging, 1 KiB per wave
 
   const int tid0 = threadIdx.x;
   int lane = tid0 & 63;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
-            acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bl[an]), acc[am][an], 0, 0, 0);
+            acc[am][an] = q_mfma<false>(ah[am], bl[an], acc[am][an]);
         {
           const unsigned char* wa = Ws + sl * wslot + BM * 32 + aoff;
 #pragma unroll
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
-            acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+            acc[am][an] = q_mfma<false>(ah[am], bh[an], acc[am][an]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- next unit: its weight slot (and, at a chunk boundary, its input buffer) published; the slot of unit u - 1 refilled
         {
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
-            acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[am]), __builtin_bit_cast(bf16x8, bh[an]), acc[am][an], 0, 0, 0);
+            acc[am][an] = q_mfma<false>(al[am], bh[an], acc[am][an]);
       };
       q_for<0, KT>(unit);
       xb ^= 1;
@@ -460,30 +471,47 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         }
       X3Q_ISSUED(4 * AM * AN);
     } else if constexpr (RADD) {
-      // residual and bias are inside the sum: v = acc * scale [+ previous output]
+      // residual and bias are inside the sum: v = acc * scale [+ previous output].  The MFMA layout gives a lane ONE column: stored directly
+      // that is 16 dword stores per accumulator (128 per tile) - and every store stands in the in-order vmcnt queue in front of the next tile's
+      // first waits, whose window then exceeds the counter's 6 bits (measured: 11 - 19 % of a tile spent waiting for stores to drain).  Through
+      // a 1-KiB staging area per wave a quarter block (8 channels x 32 positions) is re-read row-wise: a lane gets 4 consecutive positions,
+      // 8 lanes a whole 128-byte line, 4 stores per accumulator.  One wave's LDS operations execute in order: no barrier.
       const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)p.Co * (unsigned)p.ldY * 4u);
       const float oscale = p.out_scale;
       const bool has_acc = p.accumulate != 0;
+      float* stg = reinterpret_cast<float*>(Ss + wave * 1024);
+      const int rl = lane >> 3, cq = lane & 7;                  // read side: row rl of the quarter block, positions 4 cq .. 4 cq + 3
 #pragma unroll
       for (int am = 0; am < AM; ++am)
 #pragma unroll
         for (int an = 0; an < AN; ++an) {
-          const int n = cur.n0 + (wn * AN + an) * 32 + li;
-          const int mb = cur.co0 + (wm * AM + am) * 32 + 4 * lh;
-          const unsigned voff = n < p.Tout ? ((unsigned)mb * (unsigned)p.ldY + (unsigned)n) * 4u : kOOB;
-          float yv[16];
-          if (has_acc) {
+          const int n = cur.n0 + (wn * AN + an) * 32 + 4 * cq;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yv[r] = buf_load(yrs, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldY * 4u);
-          }
+          for (int g = 0; g < 4; ++g) {
+            // quarter block = the 8 channels 8 g + 4 lh + e of the accumulator's 32: staged row 4 lh + e
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[am][an][r] * oscale;
-            if (has_acc) v += yv[r];
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)voff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldY * 4u), 0);
+            for (int e = 0; e < 4; ++e) stg[(4 * lh + e) * 32 + li] = acc[am][an][4 * g + e] * oscale;
+            const int m = cur.co0 + (wm * AM + am) * 32 + 8 * g + rl;
+            const unsigned row = (unsigned)m * (unsigned)p.ldY;
+            f32x4q v = *reinterpret_cast<const f32x4q*>(stg + rl * 32 + 4 * cq);
+            if (has_acc) {
+              const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(n < p.Tout ? (row + (unsigned)n) * 4u : kOOB), 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += __uint_as_float(y[e]);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(v[e]);
+            // masked by an out-of-range offset (every tile issues the same operations); the group that straddles the end goes element-wise
+            __builtin_amdgcn_raw_buffer_store_b128(o, yrs, (int)(n + 3 < p.Tout ? (row + (unsigned)n) * 4u : kOOB), 0, 0);
+            if (n < p.Tout && n + 3 >= p.Tout) {
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (n + e < p.Tout) __builtin_amdgcn_raw_buffer_store_b32(o[e], yrs, (int)((row + (unsigned)(n + e)) * 4u), 0, 0);
+            }
           }
         }
-      X3Q_ISSUED(16 * AM * AN + (p.accumulate ? 16 * AM * AN : 0));
+      X3Q_ISSUED(4 * AM * AN + (p.accumulate ? 4 * AM * AN : 0));
     } else {
       dense_epilogue<WM, WN, AM, AN, 4>(p, acc, 0, cur.co0, cur.n0, wm, wn, li, lh);
       X3Q_ISSUED(EP);                                          // (a lower bound here: the check build only knows the stores)
@@ -551,7 +579,7 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   const int wslot = 2 * BM * 32;
   const int per_cu = AM * AN >= 8 ? 2 : 3;
   const size_t budget = (size_t)(160 * 1024 / per_cu);
-  const size_t fixed = (size_t)xbytes + (size_t)((a.Co * 4 + 255) & ~255);
+  const size_t fixed = (size_t)xbytes + (size_t)((a.Co * 4 + 255) & ~255) + (mode == 1 ? 4096 : 0);   // (mode 1: the epilogue's staging area)
   static const int r_env = getenv("RVC_X3Q_R") ? atoi(getenv("RVC_X3Q_R")) : 0;
   const int rmin = (AM == 2 && AN == 4) ? 4 : 3;
   int R = 5;

@@ -23,11 +23,11 @@ struct Rmvpe {
   bool pad_ok = false;     // every layer of levels >= 2 has its bf16x3 image: those levels run on padded split-resident images (conv_x3s.hip)
   const void* img_base = nullptr; unsigned img_gen = 0; size_t img_bytes = 0; int img_H1 = -1;   // image block whose margins are known to be zero (for this length)
   ConvLayer cnn;
-  DevVec wihT, b_ih, w_hh, b_hh;
+  DevVec wihT, b_ih, w_hh, w_hh_t, b_hh;
   ConvLayer fc;
   ConvLayer wih;           // GRU input projection [1536][384] (both directions) as a k = 1 layer: its weight image feeds the swapped split-resident product
   unsigned long long* xbuf = nullptr; int* gru_err = nullptr;
-  int gru_fault = 0; unsigned gru_spin_limit = 0;          // test hooks (rmvpe_debug_fault)
+  int gru_fault = 0; unsigned gru_spin_limit = 0; bool gru_no_repair = false;   // test hooks (rmvpe_debug_fault)
 };
 
 Rmvpe* rmvpe_create(Ctx* ctx) { Rmvpe* R = new Rmvpe(); R->ctx = ctx; return R; }
@@ -43,7 +43,7 @@ static void rmvpe_free(Rmvpe& R) {
   for (auto& c : R.dect_t) conv_layer_free(c);
   R.pad_ok = false; R.img_base = nullptr; R.img_gen = 0; R.img_bytes = 0; R.img_H1 = -1;
   conv_layer_free(R.cnn); conv_layer_free(R.fc); conv_layer_free(R.wih);
-  R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.b_hh.free_();
+  R.wihT.free_(); R.b_ih.free_(); R.w_hh.free_(); R.w_hh_t.free_(); R.b_hh.free_();
   dev_free(R.xbuf); dev_free(R.gru_err); R.xbuf = nullptr; R.gru_err = nullptr;
 }
 void rmvpe_destroy(Rmvpe* R) { if (R) { rmvpe_free(*R); R->arena.release(); delete R; } }
@@ -152,6 +152,11 @@ void rmvpe_finalize(Rmvpe* R) {
       std::copy(b2.data.begin(), b2.data.end(), bh.begin() + d * 768);
     }
     R->wihT.upload(wT); R->b_ih.upload(bi); R->w_hh.upload(wh); R->b_hh.upload(bh);
+    {
+      std::vector<float> wt((size_t)2 * 768 * 256);          // [dir][column][row]: the serial repair kernel reads a column across its 768 threads
+      for (int d = 0; d < 2; ++d) for (int r = 0; r < 768; ++r) for (int k = 0; k < 256; ++k) wt[((size_t)d * 256 + k) * 768 + r] = wh[((size_t)d * 768 + r) * 256 + k];
+      R->w_hh_t.upload(wt);
+    }
     std::vector<float> wrow((size_t)1536 * 384);            // [g][f] = wT[f][g]
     for (int g = 0; g < 1536; ++g) for (int k = 0; k < 384; ++k) wrow[(size_t)g * 384 + k] = wT[(size_t)k * 1536 + g];
     conv1d_layer_init(R->wih, wrow.data(), nullptr, 1536, 384, 1, 1, 0, 1, 1);
@@ -167,8 +172,8 @@ void rmvpe_finalize(Rmvpe* R) {
     R->pad_ok = ok;
   }
   RVC_HIP_CHECK(hipMalloc(&R->xbuf, sizeof(unsigned long long) * 2 * 2 * 256));
-  RVC_HIP_CHECK(hipMalloc(&R->gru_err, sizeof(int)));
-  RVC_HIP_CHECK(hipMemset(R->gru_err, 0, sizeof(int)));
+  RVC_HIP_CHECK(hipMalloc(&R->gru_err, 2 * sizeof(int)));      // [0] hand-off timed out, [1] directions repaired by the serial kernel
+  RVC_HIP_CHECK(hipMemset(R->gru_err, 0, 2 * sizeof(int)));
   R->ts.clear();
   R->ready = true;
 }
@@ -408,7 +413,7 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
       transpose(s, c3, feat, Tr, 128, 128, Tr, 3, (long long)Tr * 128, 128LL * Tr);           // [c][t][m] -> [c*128+m][t]
       gemm_tn_run(s, feat, Tr, 0, R->wihT.p, 1536, 0, gi, 1536, 0, Tr, 1536, 384, 1, nullptr, 0, E0);
     }
-    gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr, R->gru_spin_limit, R->gru_fault);
+    gru_scan(s, gi, R->b_ih.p, R->w_hh.p, R->gru_no_repair ? nullptr : R->w_hh_t.p, R->b_hh.p, hid, R->xbuf, R->gru_err, Tr, R->gru_spin_limit, R->gru_fault);
     if (taps && taps->gru) RVC_HIP_CHECK(hipMemcpyAsync(taps->gru, hid, (size_t)512 * Tr * sizeof(float), hipMemcpyDeviceToDevice, s));
     ConvEpilogue Es; Es.act = ACT_SIGMOID;
     conv1d_run(R->fc, s, hid, Tr, Tr, sal, Tr, Es);
@@ -440,13 +445,16 @@ void rmvpe_decode_rm(Rmvpe* R, hipStream_t s, const float* sal_rm, long long n, 
 
 size_t rmvpe_workspace(const Rmvpe* M) { return M->arena.cap; }
 
+// 0: the last forward's scan ran clean; 2: its hand-off timed out and the serial kernel repaired both directions (results valid);
+// 1: timed out and not repaired (f0 is NaN)
 int rmvpe_status(Rmvpe* R, hipStream_t s) {
-  int flag = 0;
+  int flag[2] = {0, 0};
   if (!R->gru_err) return 0;
-  RVC_HIP_CHECK(hipMemcpyAsync(&flag, R->gru_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  RVC_HIP_CHECK(hipMemcpyAsync(flag, R->gru_err, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   RVC_HIP_CHECK(hipStreamSynchronize(s));
-  return flag ? 1 : 0;
+  return flag[0] ? (flag[1] >= 2 ? 2 : 1) : 0;
 }
-void rmvpe_debug_fault(Rmvpe* R, int fault, unsigned spin_limit) { R->gru_fault = fault; R->gru_spin_limit = spin_limit; }
+// fault: 1 = one slice of the scan never publishes (its peers time out after spin_limit polls); | 2 = the repair kernel is not enqueued
+void rmvpe_debug_fault(Rmvpe* R, int fault, unsigned spin_limit) { R->gru_fault = fault & 1; R->gru_no_repair = (fault & 2) != 0; R->gru_spin_limit = spin_limit; }
 
 }  // namespace rvc

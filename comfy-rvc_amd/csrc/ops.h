@@ -38,7 +38,7 @@ void frames(hipStream_t s, const float* src, float* out, int L, int k, int strid
 void magnitude(hipStream_t s, const float* ft, float* mag, int F, int T);
 void mel_to_unet(hipStream_t s, const float* mel, float* x, int n, int Tr, float a, float b);
 void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long long ldx);
-void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* b_hh, float* out,
+void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* w_hh_t /* k-major copy for the repair kernel */, const float* b_hh, float* out,
               unsigned long long* xbuf, int* err, int T, unsigned spin_limit = 0, int fault = 0);
 void rmvpe_decode(hipStream_t s, const float* sal, double* f0, int n, long long ld, float thred, const int* err = nullptr);
 void sine_source(hipStream_t s, const float* f0, const float* noise, float* har, float* sine_out, float* rad, float* tmp, double* bsum,

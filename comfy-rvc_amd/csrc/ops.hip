@@ -866,18 +866,73 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
     }
   }
 }
+// Guaranteed outcome (round 4).  The scan above needs its 16 working workgroups resident at the same time; the bounded spin detects the case that
+// they are not, it cannot repair it.  This kernel can: ONE workgroup per direction computes the same recurrence with no inter-workgroup traffic at
+// all (768 threads = 768 rows of W_hh, read k-major from L2 - 768 KiB per step and direction, ~6 us per step instead of ~1), so it terminates
+// whatever else shares the GPU.  It is enqueued behind every scan and returns at once unless the scan raised its time-out flag (err[0]); then it
+// rewrites `out` completely and counts itself in err[1] (2 = both directions repaired: rmvpe_decode / rvc_rmvpe_status treat the forward as
+// good).  The products are summed in exactly the order of the fast kernel (eight 32-column segments: four FMA chains, (a0 + a1) + (a2 + a3), then
+// the pairwise tree of the DPP reduction), the gates use the same hardware exp2 / rcp forms: measured, the repaired hidden states agree with
+// a healthy run of the fast kernel to 2.4e-7 (rounding of the compiler's instruction selection; the f0 to 1e-6 relative).  No host round trip, no
+// re-exec: a fresh launch on the same stream.
+__global__ __launch_bounds__(768) void gru_serial_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih, const float* __restrict__ w_hh_t,
+                                                         const float* __restrict__ b_hh, float* __restrict__ out, int* err, int T) {
+  constexpr int H = 256;
+  if (*reinterpret_cast<volatile int*>(err) == 0) return;
+  __shared__ float hs[H];
+  __shared__ float ghs[3 * H];
+  const int dir = blockIdx.x, tid = threadIdx.x;
+  const float* WT = w_hh_t + (long long)dir * 3 * H * H;     // [column][row]: thread `tid` (= row) reads consecutive addresses across the wave
+  const float* BH = b_hh + dir * 3 * H;
+  const float* BI = b_ih + dir * 3 * H;
+  float c_r = 0.f, c_z = 0.f, bi_n = 0.f, bh_n = 0.f;
+  if (tid < H) { c_r = BI[tid] + BH[tid]; c_z = BI[H + tid] + BH[H + tid]; bi_n = BI[2 * H + tid]; bh_n = BH[2 * H + tid]; hs[tid] = 0.f; }
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    float sg[8];
+#pragma unroll
+    for (int seg = 0; seg < 8; ++seg) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int k = seg * 32 + 4 * c;
+        a0 = fmaf(WT[(long long)(k + 0) * (3 * H) + tid], hs[k + 0], a0); a1 = fmaf(WT[(long long)(k + 1) * (3 * H) + tid], hs[k + 1], a1);
+        a2 = fmaf(WT[(long long)(k + 2) * (3 * H) + tid], hs[k + 2], a2); a3 = fmaf(WT[(long long)(k + 3) * (3 * H) + tid], hs[k + 3], a3);
+      }
+      sg[seg] = (a0 + a1) + (a2 + a3);
+    }
+    ghs[tid] = ((sg[0] + sg[1]) + (sg[2] + sg[3])) + ((sg[7] + sg[6]) + (sg[5] + sg[4]));      // the DPP tree of gru_scan_kernel, lane 0's view
+    __syncthreads();
+    if (tid < H) {
+      constexpr float kL2E = 1.44269504088896340736f;
+      const float* g = gi + (long long)t * (6 * H) + dir * 3 * H + tid;
+      const float gr = g[0] + c_r, gz = g[H] + c_z, gn = g[2 * H] + bi_n;
+      const float r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gr + ghs[tid])));
+      const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gz + ghs[H + tid])));
+      const float xn = gn + r * (ghs[2 * H + tid] + bh_n);
+      const float nn = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * kL2E * xn) + 1.f);
+      const float hnew = (1.f - zg) * nn + zg * hs[tid];
+      out[(long long)(dir * H + tid) * T + t] = hnew;
+      hs[tid] = hnew;                                           // (every dot product of this step is done: nobody else reads hs before the barrier)
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { __threadfence(); atomicAdd(err + 1, 1); }
+}
+
 // *err is a sticky device flag: set when a workgroup gave up waiting for its peers (they need co-residency: 16 workgroups of 768
 // threads; a spin limit of 2^24 polls is ~10 s).  It is cleared here, consumed by rmvpe_decode (f0 becomes NaN) and reported by
 // rvc_rmvpe_status.
-void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* b_hh, float* out,
+void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_hh, const float* w_hh_t, const float* b_hh, float* out,
               unsigned long long* xbuf, int* err, int T, unsigned spin_limit, int fault) {
   (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
-  (void)hipMemsetAsync(err, 0, sizeof(int), s);
+  (void)hipMemsetAsync(err, 0, 2 * sizeof(int), s);
   // RVC_GRU_COOP=1: cooperative launch - the runtime checks that the whole grid (64 workgroups of 768 threads, 16 of which work) can be
   // resident at once and dispatches it as one unit.  Measured with three clips in flight (round 3, one gpurun call): 1793 -> 1621 xRT - a
   // cooperative dispatch waits until the grid is launchable as a whole, which idles the chip under the other lanes' kernels - so the plain
   // launch stays the default: its 16 working slices become resident as soon as ANY 16 CUs have 12 free waves (every other kernel of the path
-  // terminates without waiting for anything), and the bounded spin + status word report the case that they do not.
+  // terminates without waiting for anything); the bounded spin detects the case that they do not, and the serial kernel behind it repairs it.
   static const bool coop = getenv("RVC_GRU_COOP") && atoi(getenv("RVC_GRU_COOP")) != 0;
   unsigned sl = spin_limit ? spin_limit : (1u << 24);
   if (coop) {
@@ -886,6 +941,8 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
   } else {
     hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
   }
+  static const bool repair = !(getenv("RVC_GRU_REPAIR") && atoi(getenv("RVC_GRU_REPAIR")) == 0);
+  if (repair && w_hh_t) hipLaunchKernelGGL(gru_serial_kernel, dim3(2), dim3(768), 0, s, gi, b_ih, w_hh_t, b_hh, out, err, T);
 }
 
 // ---------------------------------------------------------------------------------------------- RMVPE decode
@@ -894,7 +951,7 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
 __global__ void rmvpe_decode_kernel(const float* __restrict__ sal, double* __restrict__ f0, int n, long long ld, float thred, const int* __restrict__ err) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  if (err && *err) { f0[t] = __longlong_as_double(0x7ff8000000000000LL); return; }     // the recurrence failed upstream: never hand out a plausible-looking pitch
+  if (err && err[0] && err[1] < 2) { f0[t] = __longlong_as_double(0x7ff8000000000000LL); return; }     // the recurrence failed upstream and was not repaired: never hand out a plausible-looking pitch
   float mx = -1.f; int am = 0;
   for (int c = 0; c < 360; ++c) { const float v = sal[(long long)c * ld + t]; if (v > mx) { mx = v; am = c; } }
   double ps = 0.0, ws = 0.0;

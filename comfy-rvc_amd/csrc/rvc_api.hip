@@ -123,10 +123,12 @@ int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio, int64_t L,
 int rvc_rmvpe_status(rvc_rmvpe* r, void* stream) {
   RVC_TRY
   RVC_REQUIRE(r, "null argument");
-  RVC_REQUIRE(rmvpe_status(r->m, (hipStream_t)stream) == 0,
-              "RMVPE: the GRU scan's workgroups timed out waiting for each other (they need to be co-resident); the f0 of the last forward is invalid (NaN)");
+  // (2 = the hand-off timed out and the serial kernel behind the scan repaired it: the forward is valid; rvc_rmvpe_repaired tells)
+  RVC_REQUIRE(rmvpe_status(r->m, (hipStream_t)stream) != 1,
+              "RMVPE: the GRU scan's workgroups timed out waiting for each other (they need to be co-resident) and the repair pass did not run; the f0 of the last forward is invalid (NaN)");
   RVC_CATCH
 }
+int rvc_rmvpe_repaired(rvc_rmvpe* r, void* stream) { return (r && r->m && rmvpe_status(r->m, (hipStream_t)stream) == 2) ? 1 : 0; }
 int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit) { RVC_TRY RVC_REQUIRE(r, "null argument"); rmvpe_debug_fault(r->m, fault, spin_limit); RVC_CATCH }
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* sal, int64_t n, float thred, double* f0) {
   RVC_TRY

@@ -65,12 +65,13 @@ def gpu_numa_cpus(local_rank, sysfs="/sys"):
         return None
 
 
-def bind_rank_to_numa(local_rank, local_world=1, sysfs="/sys"):
+def bind_rank_to_numa(local_rank, local_world=1, sysfs="/sys", slot=None, nslots=None):
     """Pins the calling process (and the lane / side-stream threads it starts later) to the CPUs next to its GPU.  MUST run before the first
     HIP call of the process: the runtime's own helper threads inherit the mask, and nothing is re-exec'ed (a process that has touched the
     GPU is never replaced; bench.py's ranks are started fresh by its launcher or by torch.distributed.run).  The ranks that share a NUMA
     node split its CPUs evenly so that N ranks x (lanes + side streams + HIP helper threads) do not sit on each other.  Returns the set of
-    CPUs bound to, or None when the topology is unknown (nothing is changed then)."""
+    CPUs bound to, or None when the topology is unknown (nothing is changed then).  slot / nslots: ranks that share one DEVICE (same
+    local_rank) split its CPUs by `slot` instead."""
     if not hasattr(os, "sched_setaffinity"):
         return None
     cpus = gpu_numa_cpus(local_rank, sysfs)
@@ -81,7 +82,12 @@ def bind_rank_to_numa(local_rank, local_world=1, sysfs="/sys"):
     if not mine:
         return None
     sharers = [r for r in range(max(local_world, 1)) if gpu_numa_cpus(r, sysfs) == cpus] or [local_rank]
-    if len(sharers) > 1 and len(mine) >= 2 * len(sharers):
+    if slot is not None and nslots:
+        # several ranks on ONE device (the gloo debug mode of bench.py: every rank has LOCAL_RANK 0): split that device's CPUs by rank
+        if nslots > 1 and len(mine) >= 2 * nslots:
+            per = len(mine) // nslots
+            mine = mine[(slot % nslots) * per:(slot % nslots + 1) * per]
+    elif len(sharers) > 1 and len(mine) >= 2 * len(sharers):
         k = sharers.index(local_rank) if local_rank in sharers else 0
         per = len(mine) // len(sharers)
         mine = mine[k * per:(k + 1) * per]

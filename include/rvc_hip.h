@@ -79,12 +79,16 @@ int rvc_rmvpe_destroy(rvc_rmvpe* r);
 /* n = L / 160 + 1 frames.  mel_dev [128][n], salience_dev [n][360], f0_dev float64 [n]; any may be NULL. */
 int rvc_rmvpe_forward(rvc_rmvpe* r, void* stream, const float* audio_dev, int64_t L, float thred, float* mel_dev,
                       float* salience_dev, double* f0_dev, const rvc_rmvpe_taps* taps);
-/* Waits for `stream` and reports the last forward of this handle: 0 = ok; non-zero (message via rvc_last_error) when the BiGRU scan's
- * workgroups timed out waiting for each other - its 16 workgroups exchange h_t through polled device memory and need co-residency -
- * in which case f0_dev of that forward holds NaN.  The reference has no counterpart (torch.nn.GRU, lib/rmvpe.py:420-428). */
+/* Waits for `stream` and reports the last forward of this handle: 0 = ok.  The BiGRU scan's 16 workgroups exchange h_t through polled
+ * device memory and need co-residency; when a hand-off times out (bounded spin) a serial, communication-free pass enqueued behind every scan
+ * recomputes the recurrence (same summation order: hidden states within 2.4e-7 of a healthy run, ~6 us per step instead of ~1), so the forward still ends with valid f0 and
+ * rvc_rmvpe_status stays 0 - rvc_rmvpe_repaired tells that it happened.  Non-zero (message via rvc_last_error) only when the time-out
+ * was not repaired (the repair pass switched off by RVC_GRU_REPAIR=0 or by the test hook): f0_dev of that forward holds NaN then.
+ * The reference has no counterpart (torch.nn.GRU, lib/rmvpe.py:420-428). */
 int rvc_rmvpe_status(rvc_rmvpe* r, void* stream);
-/* test hook: fault != 0 makes one workgroup of the following scans exit without publishing; spin_limit (0 = default 2^24 polls)
- * bounds how long its peers wait before they raise the flag */
+int rvc_rmvpe_repaired(rvc_rmvpe* r, void* stream);   /* 1: the last forward's scan timed out and was repaired by the serial pass */
+/* test hook: fault & 1 makes one workgroup of the following scans exit without publishing; fault & 2 keeps the repair pass from being
+ * enqueued; spin_limit (0 = default 2^24 polls) bounds how long the peers wait before they raise the flag */
 int rvc_rmvpe_debug_fault(rvc_rmvpe* r, int fault, unsigned spin_limit);
 /* decode alone: salience_dev [n][360] row-major -> f0 float64 [n] */
 int rvc_rmvpe_decode(rvc_rmvpe* r, void* stream, const float* salience_dev, int64_t n, float thred, double* f0_dev);

@@ -92,3 +92,23 @@ def record_parity(name, stats):
             json.dump(data, f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+def f0_frames_ok(f0, f0_ref, salience_ref, salience_err, rtol=1e-3):
+    """RMVPE's f0 passes through an arg-max over 360 salience bins (lib/rmvpe.py:661-685): a frame may legitimately land on another bin ONLY where
+    the reference's own two best bins are closer than the numerical noise between the two implementations.  Returns (n_differing, n_unexplained):
+    frames outside rtol, and those among them whose reference salience has a clear winner (top-2 gap > 4 x the measured salience error) - the
+    second number must be 0.  No percentile: every frame is either equal or an explained tie."""
+    import numpy as np
+    f0, f0_ref = np.asarray(f0, dtype=np.float64), np.asarray(f0_ref, dtype=np.float64)
+    bad = ~np.isclose(f0, f0_ref, rtol=rtol, atol=1e-6)
+    n_bad = int(bad.sum())
+    if n_bad == 0:
+        return 0, 0
+    sal = np.asarray(salience_ref)[: f0_ref.shape[0]]
+    top2 = np.sort(sal[bad], axis=1)[:, -2:]
+    gap = top2[:, 1] - top2[:, 0]
+    # a frame that sits at the voicing threshold (max salience ~ 0.03) may also switch between 0 Hz and voiced
+    near_thr = np.abs(top2[:, 1] - 0.03) <= 4 * salience_err
+    unexplained = int(((gap > 4 * salience_err) & ~near_thr).sum())
+    return n_bad, unexplained

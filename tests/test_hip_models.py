@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_err
+from conftest import f0_frames_ok, golden, record_parity, rel_err
 from comfy_rvc_amd import synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -83,11 +83,13 @@ def test_rmvpe_matches_oracle_other_length(rmvpe):
     taps = {}
     f0_ref = nets.rmvpe_infer_from_audio(S.rmvpe_state_dict(0), audio, taps=taps)
     r = rmvpe.infer(audio, want_salience=True)
-    assert np.max(np.abs(r["salience"].cpu().numpy() - taps["salience"])) < TOL
+    serr = float(np.max(np.abs(r["salience"].cpu().numpy() - taps["salience"])))
+    assert serr < TOL
     f0 = r["f0"].cpu().numpy()
-    # argmax flips between near-equal bins are legitimate discontinuities: require 99 % of frames within tolerance
-    ok = np.isclose(f0, f0_ref, rtol=TOL)
-    assert ok.mean() > 0.99
+    # every frame equal within tolerance, except genuine ties of the reference's own arg-max (conftest.f0_frames_ok): no percentile
+    n_bad, unexplained = f0_frames_ok(f0, f0_ref, taps["salience"], serr, rtol=TOL)
+    record_parity("rmvpe_3.21s", {"salience_max_err": serr, "f0_frames": int(f0.shape[0]), "f0_frames_differing": n_bad, "unexplained": unexplained})
+    assert unexplained == 0, (n_bad, unexplained)
 
 
 @pytest.mark.parametrize("name,config,version", [("synth_40k_v2.npz", S.CONFIG_40K_V2, "v2"), ("synth_48k_v2.npz", S.CONFIG_48K_V2, "v2"),

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import golden, record_parity
 from comfy_rvc_amd import synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -334,7 +334,10 @@ def test_pipeline_edge_inputs_match_oracle(models, case):
                     index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
     assert out is not None and out[0].shape == ref.shape
     d = np.abs(out[0].astype(np.int32) - ref.astype(np.int32))
-    assert np.mean(d <= LSB) > 0.995
+    record_parity(f"edge_{case}", {"max_lsb": int(d.max()), "n": int(d.size), "over_33": int((d > LSB).sum())})
+    # every sample within 1e-3 of full scale (33 LSB), like the full-size cases - no percentile that would let a tail of arbitrary errors through.
+    # (All-zero input included: both sides normalise their own peak, rvc_postprocess and the oracle divide by the same float32 maximum.)
+    assert int(d.max()) <= LSB, (case, int(d.max()), int((d > LSB).sum()))
 
 
 def test_two_lanes_in_flight_equal_sequential_conversion(models):
@@ -542,16 +545,41 @@ def test_c2_rmvpe_60s_matches_reference_golden(models):
     assert st["f0_max_rel_dev_voiced"] < 1e-3, st
 
 
-def test_gru_scan_failure_is_reported_not_silent(models):
-    """The BiGRU scan's 16 workgroups hand h_t to each other through polled device memory.  If one of them never publishes (fault
-    injected through rvc_rmvpe_debug_fault) its peers give up after the spin limit: the f0 is NaN, rvc_rmvpe_status returns an error
-    and infer_from_audio raises instead of handing out a plausible-looking pitch; the next healthy forward is clean again."""
+def test_gru_scan_timeout_is_repaired_and_never_silent(models):
+    """The BiGRU scan's 16 workgroups hand h_t to each other through polled device memory.  If one of them never publishes (fault injected
+    through rvc_rmvpe_debug_fault) its peers give up after the spin limit.  Guaranteed outcome (round 4): the serial pass enqueued behind every
+    scan recomputes the recurrence without any inter-workgroup traffic, in the fast kernel's summation order - the f0 equals a healthy run's
+    to rounding (1e-5 relative, voicing identical; hidden states 2.4e-7), the status is clean and rvc_rmvpe_repaired reports the event; a whole
+    vc_single through the faulty scan gives the healthy audio within 1 LSB.  With the repair pass switched off as well (fault | 2) the old contract holds: f0 is NaN, rvc_rmvpe_status returns an error and
+    infer_from_audio raises instead of handing out a plausible-looking pitch; the next healthy forward is clean again."""
     from comfy_rvc_amd import _lib as L
-    _, _, rm = models
+    from comfy_rvc_amd.config import Config
+    from comfy_rvc_amd.vc_infer_pipeline import VC, vc_single
+    hub, vcd, rm = models
     audio = S.synth_audio(1.0, seed=2)
     good = rm.infer_from_audio(audio)
+    assert L.lib.rvc_rmvpe_repaired(rm._h, None) == 0
+
+    def convert():
+        vc = VC(40000, Config())
+        vc.model_rmvpe = rm
+        g = torch.Generator().manual_seed(5)
+        vc.noise_fn = lambda shape: torch.randn(shape, generator=g)
+        return vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub, input_audio=(audio, 16000), sid=0, f0_up_key=0, f0_method="rmvpe",
+                         index_rate=0.0, rms_mix_rate=0.25, protect=0.33)
+    wav_good = convert()
     L.check(L.lib.rvc_rmvpe_debug_fault(rm._h, 1, 1 << 10))
     try:
+        with torch.cuda.device(rm.device):
+            f0 = rm.infer(audio)["f0"].cpu().numpy()
+            assert np.array_equal(f0 > 0, good > 0) and np.allclose(f0, good, rtol=1e-5, atol=0)      # repaired: every frame
+            rm.check_status()                                     # does not raise
+            assert L.lib.rvc_rmvpe_repaired(rm._h, L.current_stream()) == 1
+        assert np.allclose(rm.infer_from_audio(audio), good, rtol=1e-5, atol=0)
+        wav = convert()
+        assert wav is not None and np.max(np.abs(wav[0].astype(np.int32) - wav_good[0].astype(np.int32))) <= 1
+        # the repair pass switched off too: reported, never silent
+        L.check(L.lib.rvc_rmvpe_debug_fault(rm._h, 3, 1 << 10))
         f0 = rm.infer(audio)["f0"].cpu().numpy()
         assert np.isnan(f0).all()
         with pytest.raises(L.RvcHipError, match="GRU scan"):
@@ -561,6 +589,8 @@ def test_gru_scan_failure_is_reported_not_silent(models):
     finally:
         L.check(L.lib.rvc_rmvpe_debug_fault(rm._h, 0, 0))
     assert np.array_equal(rm.infer_from_audio(audio), good)
+    with torch.cuda.device(rm.device):
+        assert L.lib.rvc_rmvpe_repaired(rm._h, L.current_stream()) == 0
 
 
 def test_rmvpe_while_other_lanes_saturate_the_gpu(models):

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import f0_frames_ok, record_parity
 from comfy_rvc_amd import synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -36,12 +37,14 @@ def test_feature_input_dump_matches_oracle(tmp_path):
         ref = nets.hubert_extract_features(hsd, torch.from_numpy(x)[None], "v2")[0].numpy()
         assert feats.dtype == np.float32 and feats.shape == ref.shape
         assert np.abs(feats - ref).max() <= 1e-3 * np.abs(ref).max()
-        f0 = nets.rmvpe_infer_from_audio(rsd, x, thred=0.03)
+        taps = {}
+        f0 = nets.rmvpe_infer_from_audio(rsd, x, thred=0.03, taps=taps)
         assert coarse.dtype == np.int16 and nsf.dtype == np.float64 and nsf.shape == f0.shape
-        voiced = (f0 > 0) == (nsf > 0)
-        assert voiced.mean() > 0.99
-        ok = np.abs(nsf - f0) <= 1e-3 * np.maximum(f0, 1.0)
-        assert ok.mean() > 0.99                    # argmax front-end: gate on 99 % of frames like the RMVPE tests
+        # every frame equal (voicing included) unless the reference's own arg-max / voicing threshold is a tie within the salience noise between
+        # the two implementations (5e-5 measured by the RMVPE model tests; conftest.f0_frames_ok) - a maximum gate, not a percentile
+        n_bad, unexplained = f0_frames_ok(nsf, f0, taps["salience"], 5e-5, rtol=1e-3)
+        record_parity(f"feature_dump_f0_{i}", {"f0_frames": int(f0.shape[0]), "f0_frames_differing": n_bad, "unexplained": unexplained})
+        assert unexplained == 0, (i, n_bad, unexplained)
         mel = (hz_to_mel(nsf) - hz_to_mel(50.0)) * 254 / (hz_to_mel(1100.0) - hz_to_mel(50.0)) + 1   # training prep quantises with f0_max = 1100
         assert np.array_equal(coarse, np.rint(np.clip(mel, 1, 255)).astype(np.int16))
     assert os.path.exists(str(tmp_path / "extract_f0_feature.log"))
