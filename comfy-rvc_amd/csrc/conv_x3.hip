@@ -535,10 +535,10 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       // 8-wave workgroups (128 x 512 tile, one per CU): RVC_X3_W8 = minimum tap count that takes them (0 = never)
       static const int w8_taps = getenv("RVC_X3_W8") ? atoi(getenv("RVC_X3_W8")) : 0;
       static const int w8_blk = getenv("RVC_X3_W8_BLK") ? atoi(getenv("RVC_X3_W8_BLK")) : 400;
+      static const int wide_xs7 = getenv("RVC_X3_WIDE_XS7") ? atoi(getenv("RVC_X3_WIDE_XS7")) : 1;   // the wide tile also for a split-input consumer with k = 7 (persistent kernel: C128 k7 pair 399 -> 377 us; the per-tile kernel preferred 128 x 128 there)
       static const int wide_k3 = getenv("RVC_X3_WIDE_K3") ? atoi(getenv("RVC_X3_WIDE_K3")) : 2;      // the wide tile also for k = 3 (1: fp32 inputs, 2: split inputs too): on the pipelined kernel C128 k3 135 -> 129 us; not for the up-samplers (240 -> 250)
       if (w8_taps > 0 && a.Co > 64 && a.ktaps >= w8_taps && blocks(128, 512) >= w8_blk) t = TileCfg{2, 4, 2, 4};
       else
-      static const int wide_xs7 = getenv("RVC_X3_WIDE_XS7") ? atoi(getenv("RVC_X3_WIDE_XS7")) : 0;   // the wide tile also for a split-input consumer with k = 7
       if (a.Co > 64 && blocks(128, 256) >= wide_blk && (a.ktaps > 3 || (wide_k3 >= 1 && a.ostride == 1)) &&
           !(xs && a.ktaps <= 7 && !(a.ktaps <= 3 && wide_k3 >= 2) && !(a.ktaps == 7 && wide_xs7))) t = TileCfg{2, 2, 2, 4};
       else if (wide64 && a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};

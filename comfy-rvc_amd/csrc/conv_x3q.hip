@@ -578,7 +578,9 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
   const int wslot = 2 * BM * 32;
   const int per_cu = AM * AN >= 8 ? 2 : 3;
-  const size_t budget = (size_t)(160 * 1024 / per_cu);
+  // (LDS is allocated in granules: a footprint a few hundred bytes under a third of 160 KiB still admits only two workgroups per CU - measured,
+  // C64 k7: ring of 4 at 54 528 B 279 us, ring of 3 251 us - so the budget is cut to whole 2-KiB granules)
+  const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)2047;
   const size_t fixed = (size_t)xbytes + (size_t)((a.Co * 4 + 255) & ~255) + (mode == 1 ? 4096 : 0);   // (mode 1: the epilogue's staging area)
   static const int r_env = getenv("RVC_X3Q_R") ? atoi(getenv("RVC_X3Q_R")) : 0;
   const int rmin = (AM == 2 && AN == 4) ? 4 : 3;

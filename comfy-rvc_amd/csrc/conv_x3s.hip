@@ -64,14 +64,18 @@ template <int N> __device__ __forceinline__ void x3s_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int AM, int AN, int RS>
+// UC = (chunk, tap) units per ring slot = per barrier.  With one unit per barrier a 64 x 64 tile issues 3 MFMAs per wave between two barriers:
+// measured (round 4, 768 -> 768 at T = 1599) a unit costs ~600 cycles for 96 cycles of MFMA issue - the wait, the barrier, the DMA issue and the
+// operand reads ARE the kernel.  Two units per barrier halve that fixed cost per product; the slot is two units wide, everything else is unchanged.
+template <int AM, int AN, int RS, int UC = 1>
 __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(const GemmSArgs p) {
   constexpr int WN = 2, NW = 4;
   constexpr int BM = 64 * AM, BN = 64 * AN;
   constexpr int NPA = BM / 16, NPB = BN / 16, NPW = (NPA + NPB) / NW;      // 1-KiB pieces of a unit: weights, input, per wave
   static_assert((NPA % NW) == 0 && (NPB % NW) == 0, "every wave's i-th piece is of one kind");
-  constexpr int aslot = BM * 64, bslot = BN * 64, slot = aslot + bslot;    // [hi | lo][half][rows][16 B]
-  static_assert(RS >= 3 && (RS - 2) * NPW <= 63, "ring");
+  constexpr int aslot = BM * 64, bslot = BN * 64, uslot = aslot + bslot;   // one unit: [hi | lo][half][rows][16 B]
+  constexpr int slot = UC * uslot;                                        // one ring slot: UC units
+  static_assert(RS >= 3 && (RS - 2) * NPW * UC <= 63, "ring");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3s[];
 
   const int tid0 = threadIdx.x;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const int grp = tile_y / p.rows_pg;                       // (1 group: rows_pg = gy, grp = 0)
   const int co0 = (tile_y - grp * p.rows_pg) * BM, n0 = tile_x * BN;      // first row INSIDE the group
   const int row0 = grp * p.co_g, CoG = p.co_g;              // global row = row0 + m for m < CoG
-  const int U = p.nunits / S, u0 = ks * U;
+  const int U1 = p.nunits / S, u0 = ks * U1, U = U1 / UC;            // single units of this slice (a multiple of UC: host), ring steps
 
   // ---- accumulators: slice 0 starts from bias (+ residual unless an activation sits between the sum and the residual)
   const bool r_pre = p.R != nullptr && !(p.act_before_res && p.act != ACT_NONE);
@@ -144,22 +148,25 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   auto tap_off = [&](int t) { return arith ? t * p.tdil - p.tpad : p.toff[t & 15]; };
   int soff_a = (int)((unsigned)grp * p.wg_bytes) + u0 * wstep, soff_c = (grp * p.cig_chunks + u0 / KT) * cstep, soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
   int slw = 0, uw = 0;
-  auto issue = [&]() {                                       // next unit into slot slw; past the end the last unit is requested again
-    unsigned char* base = smem3s + slw * slot;
+  auto issue = [&]() {                                       // next UC units into slot slw; past the end the last unit is requested again
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-      if (i * NW < NPA) x3s_dma(ars, base + dsto[i], voff[i], soff_a);
-      else x3s_dma(brs, base + dsto[i], voff[i], soff_b);
-    }
-    ++uw;
-    if (uw < U) {
-      soff_a += wstep;
-      if (KT > 1) {
-        ++tap;
-        if (tap == KT) { tap = 0; soff_c += cstep; }
-        soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
-      } else {
-        soff_b += cstep;
+    for (int q = 0; q < UC; ++q) {
+      unsigned char* base = smem3s + slw * slot + q * uslot;
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        if (i * NW < NPA) x3s_dma(ars, base + dsto[i], voff[i], soff_a);
+        else x3s_dma(brs, base + dsto[i], voff[i], soff_b);
+      }
+      ++uw;
+      if (uw < U1) {
+        soff_a += wstep;
+        if (KT > 1) {
+          ++tap;
+          if (tap == KT) { tap = 0; soff_c += cstep; }
+          soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
+        } else {
+          soff_b += cstep;
+        }
       }
     }
     slw = slw + 1 == RS ? 0 : slw + 1;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   // ---- prologue: [bias / residual] units 0 .. RS - 2
 #pragma unroll
   for (int i = 0; i < RS - 1; ++i) issue();
-  x3s_wait_vmcnt<(RS - 2) * NPW>();                          // unit 0 (younger: units 1 .. RS - 2)
+  x3s_wait_vmcnt<(RS - 2) * NPW * UC>();                     // slot 0 (younger: slots 1 .. RS - 2)
 #pragma unroll
   for (int am = 0; am < AM; ++am)
 #pragma unroll
@@ -180,39 +187,45 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
 
   // Two operand register sets: the reads of unit u + 1 are issued right after the barrier that publishes its slot and land under the
   // twelve (AM AN 3) MFMAs of unit u - the only stall of a unit is that one wait + barrier.
-  struct Ops { u32x4 ah[AM], al[AM], bh[AN], bl[AN]; };
+  struct Ops { u32x4 ah[UC][AM], al[UC][AM], bh[UC][AN], bl[UC][AN]; };
   Ops o0, o1;
   auto read_ops = [&](Ops& o, int slot_i) {
-    const unsigned char* wa = smem3s + slot_i * slot + aoff;
-    const unsigned char* xa = smem3s + slot_i * slot + boff;
 #pragma unroll
-    for (int am = 0; am < AM; ++am) { o.ah[am] = *reinterpret_cast<const u32x4*>(wa + am * 512); o.al[am] = *reinterpret_cast<const u32x4*>(wa + BM * 32 + am * 512); }
+    for (int q = 0; q < UC; ++q) {
+      const unsigned char* wa = smem3s + slot_i * slot + q * uslot + aoff;
+      const unsigned char* xa = smem3s + slot_i * slot + q * uslot + boff;
 #pragma unroll
-    for (int an = 0; an < AN; ++an) { o.bh[an] = *reinterpret_cast<const u32x4*>(xa + an * 512); o.bl[an] = *reinterpret_cast<const u32x4*>(xa + BN * 32 + an * 512); }
+      for (int am = 0; am < AM; ++am) { o.ah[q][am] = *reinterpret_cast<const u32x4*>(wa + am * 512); o.al[q][am] = *reinterpret_cast<const u32x4*>(wa + BM * 32 + am * 512); }
+#pragma unroll
+      for (int an = 0; an < AN; ++an) { o.bh[q][an] = *reinterpret_cast<const u32x4*>(xa + an * 512); o.bl[q][an] = *reinterpret_cast<const u32x4*>(xa + BN * 32 + an * 512); }
+    }
   };
   auto mfmas = [&](const Ops& o) {
 #pragma unroll
-    for (int am = 0; am < AM; ++am)
+    for (int q = 0; q < UC; ++q) {
 #pragma unroll
-      for (int an = 0; an < AN; ++an)
-        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bl[an]), acc[am][an], 0, 0, 0);
+      for (int am = 0; am < AM; ++am)
 #pragma unroll
-    for (int am = 0; am < AM; ++am)
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[q][am]), __builtin_bit_cast(bf16x8, o.bl[q][an]), acc[am][an], 0, 0, 0);
 #pragma unroll
-      for (int an = 0; an < AN; ++an)
-        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.al[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+      for (int am = 0; am < AM; ++am)
 #pragma unroll
-    for (int am = 0; am < AM; ++am)
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.al[q][am]), __builtin_bit_cast(bf16x8, o.bh[q][an]), acc[am][an], 0, 0, 0);
 #pragma unroll
-      for (int an = 0; an < AN; ++an)
-        acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[q][am]), __builtin_bit_cast(bf16x8, o.bh[q][an]), acc[am][an], 0, 0, 0);
+    }
   };
   int sl = 0;
   auto body = [&](const Ops& cur, Ops& nxt) {
-    // unit u + 1 was requested RS - 2 units ago; younger: units u + 2 .. u + RS - 2
-    x3s_wait_vmcnt<(RS - 3) * NPW>();
+    // slot u + 1 was requested RS - 2 steps ago; younger: slots u + 2 .. u + RS - 2
+    x3s_wait_vmcnt<(RS - 3) * NPW * UC>();
     lds_barrier();
-    issue();                                                 // unit u + RS - 1 into the slot unit u - 1 was read from (those reads fed unit u - 1's MFMAs)
+    issue();                                                 // slot u + RS - 1 over the one step u - 1 was read from (those reads fed step u - 1's MFMAs)
     sl = sl + 1 == RS ? 0 : sl + 1;
     read_ops(nxt, sl);
     __builtin_amdgcn_sched_barrier(0);
@@ -468,16 +481,27 @@ void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, i
 }
 
 // ---------------------------------------------------------------------------- host side
-template <int AM, int AN, int RS>
+template <int AM, int AN, int RS, int UC = 1>
 static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
-  auto kern = conv_x3s_kernel<AM, AN, RS>;
-  constexpr size_t lds = (size_t)RS * (64 * AM + 64 * AN) * 64;
+  auto kern = conv_x3s_kernel<AM, AN, RS, UC>;
+  constexpr size_t lds = (size_t)RS * UC * (64 * AM + 64 * AN) * 64;
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
 }
 
 static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hipStream_t s) {
   static const int rs_env = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 4;      // ring depth (experiments: 3 / 4 / 6)
+  // units per barrier (RVC_X3S_UC=2: two, where the slice's unit count is even and the tile is small).  Measured in round 4 and NOT the default: the
+  // average launch stays at 20.0 us (20.3 with one unit per barrier) - the K loop of these 300 - 600-workgroup grids is bound by the L2 -> LDS
+  // latency per ring step, not by the barrier - and the doubled LDS footprint costs the three-lane bench 2.5 % (2095 -> 2040 xRT, same box).
+  static const int uc_env = getenv("RVC_X3S_UC") ? atoi(getenv("RVC_X3S_UC")) : 1;
+  const bool two = uc_env >= 2 && rs_env != 3 && rs_env < 6 && ((a.nunits / a.ksplit) & 1) == 0 && (a.nunits / a.ksplit) >= 8 && AM * AN <= 2;
+  if (two) {
+    if (AM == 2 && AN == 1) launch_x3s<2, 1, 4, 2>(a, blocks, s);
+    else if (AM == 1 && AN == 2) launch_x3s<1, 2, 4, 2>(a, blocks, s);
+    else launch_x3s<1, 1, 4, 2>(a, blocks, s);
+    return;
+  }
   if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 2, 6>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
   else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 1, 6>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
   else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }

@@ -766,10 +766,10 @@ void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long
 #ifndef RVC_GRU_SLEEP
 #define RVC_GRU_SLEEP 1      // back-off of the polling loop, in units of 64 cycles (measured: see DESIGN.md)
 #endif
-__global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
-                                                       const float* __restrict__ w_hh, const float* __restrict__ b_hh,
-                                                       float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
-                                                       unsigned spin_limit, int fault) {
+__global__ __launch_bounds__(768) void gru_scan_kernel_v1(const float* __restrict__ gi, const float* __restrict__ b_ih,
+                                                          const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                          float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
+                                                          unsigned spin_limit, int fault) {
   constexpr int H = 256, HS = 32;
   constexpr int HP = 36;                                   // padded pitch of one 32-value segment of h in LDS (float4 reads of the
                                                            // eight segments then fall on disjoint banks)
@@ -866,6 +866,95 @@ __global__ __launch_bounds__(768) void gru_scan_kernel(const float* __restrict__
     }
   }
 }
+// Round 4: the same scan with ONE barrier per step.  The three gate rows (r, z, n) of a hidden unit used to live in three different waves:
+// their dot products met in LDS (write, barrier, read) before 32 threads computed the gates.  Here a unit's eight lanes hold all three rows
+// (96 weights per thread, 256 threads = one wave per SIMD: the same 384 FMA issue cycles per SIMD as twelve waves of 32), the DPP tree leaves
+// the three sums in the unit's lane 0, which computes the gates at once - no second barrier, no LDS round trip.  Segments, FMA chains and the
+// reduction tree are those of gru_scan_kernel_v1: identical numerics.  (RVC_GRU_V=1 selects the old kernel.)
+__global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
+                                                       const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                       float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
+                                                       unsigned spin_limit, int fault) {
+  constexpr int H = 256, HS = 32, HP = 36;
+  __shared__ __attribute__((aligned(16))) float hs[2][8 * HP];
+  const int xcd = blockIdx.x & 7;
+  if (xcd != 0 && xcd != 4) return;
+  const int dir = xcd >> 2, sl = blockIdx.x >> 3;
+  if (fault && dir == 1 && sl == 5) return;                 // fault injection (tests): one slice never publishes, its peers must time out
+  const int tid = threadIdx.x;
+  bool failed = false;
+  const float* W = w_hh + (long long)dir * 3 * H * H;
+  const float* BH = b_hh + dir * 3 * H;
+  const float* BI = b_ih + dir * 3 * H;
+  unsigned long long* xb = xbuf + dir * 2 * H;
+  const int jj = tid >> 3, seg = tid & 7, unit = sl * HS + jj;
+  float w[3][32];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) w[g][c] = W[(long long)(g * H + unit) * H + seg * 32 + c];
+  float c_r = 0.f, c_z = 0.f, bi_n = 0.f, bh_n = 0.f;
+  if (seg == 0) { c_r = BI[unit] + BH[unit]; c_z = BI[H + unit] + BH[H + unit]; bi_n = BI[2 * H + unit]; bh_n = BH[2 * H + unit]; }
+  hs[0][(tid >> 5) * HP + (tid & 31)] = 0.f;
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    float* hsb = hs[step & 1];
+    const int t = dir ? (T - 1 - step) : step;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (seg == 0) {
+      const float* g = gi + (long long)t * (6 * H) + dir * 3 * H + unit;
+      gr = g[0] + c_r; gz = g[H] + c_z; gn = g[2 * H] + bi_n;
+    }
+    if (step > 0) {
+      // gather h_{step-1}: one granule per thread
+      const unsigned long long* gp = xb + ((step - 1) & 1) * H + tid;
+      unsigned long long v;
+      unsigned spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == (unsigned)step) break;
+        if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
+        __builtin_amdgcn_s_sleep(RVC_GRU_SLEEP);
+      }
+      hsb[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
+      __syncthreads();
+    }
+    float a[3];
+    {
+      const float4* hv = reinterpret_cast<const float4*>(hsb + seg * HP);
+      float4 h4[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) h4[c] = hv[c];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          a0 = fmaf(w[g][4 * c + 0], h4[c].x, a0); a1 = fmaf(w[g][4 * c + 1], h4[c].y, a1);
+          a2 = fmaf(w[g][4 * c + 2], h4[c].z, a2); a3 = fmaf(w[g][4 * c + 3], h4[c].w, a3);
+        }
+        float x = (a0 + a1) + (a2 + a3);
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+        a[g] = x;
+      }
+    }
+    if (seg == 0) {
+      constexpr float kL2E = 1.44269504088896340736f;
+      const float r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gr + a[0])));
+      const float zg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * (gz + a[1])));
+      const float xn = gn + r * (a[2] + bh_n);
+      const float nn = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * kL2E * xn) + 1.f);
+      const float hprev = hsb[(unit >> 5) * HP + (unit & 31)];
+      const float hnew = (1.f - zg) * nn + zg * hprev;
+      const unsigned long long gran = ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(hnew);
+      __hip_atomic_store(xb + (step & 1) * H + unit, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[(long long)(dir * H + unit) * T + t] = hnew;
+    }
+  }
+}
+
 // Guaranteed outcome (round 4).  The scan above needs its 16 working workgroups resident at the same time; the bounded spin detects the case that
 // they are not, it cannot repair it.  This kernel can: ONE workgroup per direction computes the same recurrence with no inter-workgroup traffic at
 // all (768 threads = 768 rows of W_hh, read k-major from L2 - 768 KiB per step and direction, ~6 us per step instead of ~1), so it terminates
@@ -935,11 +1024,15 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
   // terminates without waiting for anything); the bounded spin detects the case that they do not, and the serial kernel behind it repairs it.
   static const bool coop = getenv("RVC_GRU_COOP") && atoi(getenv("RVC_GRU_COOP")) != 0;
   unsigned sl = spin_limit ? spin_limit : (1u << 24);
+  static const int ver = getenv("RVC_GRU_V") ? atoi(getenv("RVC_GRU_V")) : 2;
   if (coop) {
     void* args[] = {(void*)&gi, (void*)&b_ih, (void*)&w_hh, (void*)&b_hh, (void*)&out, (void*)&xbuf, (void*)&err, (void*)&T, (void*)&sl, (void*)&fault};
-    RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel), dim3(64), dim3(768), args, 0, s));
+    if (ver == 1) RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel_v1), dim3(64), dim3(768), args, 0, s));
+    else RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel), dim3(64), dim3(256), args, 0, s));
+  } else if (ver == 1) {
+    hipLaunchKernelGGL(gru_scan_kernel_v1, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
   } else {
-    hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
   }
   static const bool repair = !(getenv("RVC_GRU_REPAIR") && atoi(getenv("RVC_GRU_REPAIR")) == 0);
   if (repair && w_hh_t) hipLaunchKernelGGL(gru_serial_kernel, dim3(2), dim3(768), 0, s, gi, b_ih, w_hh_t, b_hh, out, err, T);
