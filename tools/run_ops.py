@@ -1,5 +1,5 @@
 """Runs one free-standing op of the library a few times (for rocprofv3 counter passes: tools/pmc_kernels.sh):
-    python tools/run_ops.py att | attrel | cbr16 | cbr32"""
+    python tools/run_ops.py att | attrel | cbr16 | cbr32 | pair128k11 | pair128k3 | pair64k7   (pairNNNkK: one split-resident ResBlock pair = conv_x3q_kernel c1 + c2)"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -17,6 +17,18 @@ if what in ("att", "attrel"):
             L.check(L.lib.rvc_op_attention_split(None, q.data_ptr(), k.data_ptr(), v.data_ptr(), bv.data_ptr(), out.data_ptr(), None, heads, T))
         else:
             L.check(L.lib.rvc_op_attention_split_rel(None, q.data_ptr(), k.data_ptr(), v.data_ptr(), bv.data_ptr(), ek.data_ptr(), ev.data_ptr(), out.data_ptr(), None, heads, T, 0))
+elif what.startswith("pair"):
+    import ctypes as C
+    Cc, k = [int(v) for v in what[4:].split("k")]
+    T = 3198 * {256: 10, 128: 100, 64: 200}[Cc]
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    for dd in (1, 1):
+        w = (np.random.randn(Cc, Cc, k) / np.sqrt(Cc * k)).astype(np.float32); b = (np.random.randn(Cc) * 0.1).astype(np.float32)
+        pl = C.c_void_p(); L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w), L.ptr(b), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl))); plans.append(pl)
+    x = torch.randn(Cc, T, device="cuda"); y = torch.empty_like(x)
+    for _ in range(4):
+        L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(y), 1.0, 0))
 else:
     Cc, H, W = (16, 3232, 128) if what == "cbr16" else (32, 1616, 64)
     x = torch.randn(Cc, H, W, generator=g).cuda(); y = torch.empty_like(x)
