@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
             constexpr int s = decltype(sc)::value;
             if constexpr ((s * KT) / XS == T) {
               constexpr int NS = Q::sum() - 8;                 // younger than this slot's loads (issued in step A one chunk ago)
-              if (c0) { X3Q_CHECK(NS + EP, issued - mk_x[s]); q_wait<NS + EP>(); }
+              // (check build: waits whose target was issued in the prologue - first chunk of the first tile - are exempt: everything had landed there)
+              if (c0) { if (it > 0) X3Q_CHECK(NS + EP, issued - mk_x[s]); q_wait<NS + EP>(); }
               else { X3Q_CHECK(NS, issued - mk_x[s]); q_wait<NS>(); }
               store_slot(s, xb ^ 1);
               load_slot(s, t2, ch2);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
           const int exact = issued - mk_w[(uwc - (R - 2)) & 7];
 #endif
           [[maybe_unused]] const long long ta = XQTICK();
-          if (c0 && T < R - 2) { X3Q_CHECK(NWT + EP, exact); q_wait<NWT + EP>(); }
+          if (c0 && T < R - 2) { if (it > 0) X3Q_CHECK(NWT + EP, exact); q_wait<NWT + EP>(); }
           else { X3Q_CHECK(NWT, exact); q_wait<NWT>(); }
           [[maybe_unused]] const long long tb = XQTICK();
           lds_barrier();
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         // ---- step E: residual + bias of block c join the sum; block c + 1 (the next tile's block 0 in a tile's last chunk) requested
         if constexpr (RADD && T == TR) {
           constexpr int NR = Q::sum() - 16;
-          if (c0) { X3Q_CHECK(NR + EP, issued - mk_r); q_wait<NR + EP>(); }
+          if (c0) { if (it > 0) X3Q_CHECK(NR + EP, issued - mk_r); q_wait<NR + EP>(); }
           else { X3Q_CHECK(NR, issued - mk_r); q_wait<NR>(); }
           // The block that receives the residual is chosen at run time (block = chunk), its registers are not.  A branch the compiler can see
           // turns into copy-in / copy-out of the whole 16-register accumulator around every test (a phi of two 512-bit tuples: 256 v_mov per step
@@ -509,6 +510,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
               for (int e = 0; e < 3; ++e)
                 if (n + e < p.Tout) __builtin_amdgcn_raw_buffer_store_b32(o[e], yrs, (int)((row + (unsigned)(n + e)) * 4u), 0, 0);
             }
+#ifdef RVC_X3P_CHECK
+#pragma unroll
+            for (int e = 0; e < 3; ++e) if (__ballot(n < p.Tout && n + 3 >= p.Tout && n + e < p.Tout)) X3Q_ISSUED(1);      // (an instruction issues when any lane is active)
+#endif
           }
         }
       X3Q_ISSUED(4 * AM * AN + (p.accumulate ? 4 * AM * AN : 0));
@@ -595,12 +600,13 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
   static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 2;
   const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
-  if (ntiles < min_rounds * slots) return false;
+  if (ntiles < min_rounds * slots || ntiles < 8) return false;
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
-  long long G = slots & ~7LL;                                      // a multiple of 8: a workgroup's tiles stay on its XCD
+  long long G = (slots < ntiles ? slots : ntiles) & ~7LL;          // a multiple of 8 (a workgroup's tiles stay on its XCD), every workgroup owns a tile
+  if (G < 8) return false;
   dim3 grid((unsigned)G, 1, 1);
   grid_out = grid;
   if (AM == 2 && AN == 4) launch_x3q_r<2, 4>(a, R, mode, grid, lds, s);

@@ -43,6 +43,7 @@ struct GemmSArgs {
   int xcd_remap;
   int ymargin;                              // output image: position n lives at row ymargin + n (= margin except for the swapped product)
   int zero_tail;                            // rows >= Co of the last stored 16-row chunk are written as zeros (swapped product: keys past the end)
+  int row_fast;                             // tile numbering inside an XCD's run: 1 = row tiles fastest (the XCD owns a column range), 0 = column tiles fastest
 };
 
 // exact-erf GELU (torch F.gelu default), branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. ~1e-7 of the
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const unsigned bid = p.xcd_remap ? xcd_tile(blockIdx.x, total) : blockIdx.x;
   const int S = p.ksplit;
   const int tile = (int)(bid / (unsigned)S), ks = (int)(bid - (unsigned)tile * (unsigned)S);
-  const int tile_y = tile / p.gx, tile_x = tile - tile_y * p.gx;
+  // An XCD works on one contiguous run of tiles.  Column tiles fastest: the run is a few rows of tiles - the XCD's L2 keeps ITS weight rows and streams the whole
+  // activation image (fabric traffic ~ W + 8 X over the eight L2s).  Row tiles fastest: the run is a column range - it keeps its slice of the activations and streams
+  // the whole weight image (8 W + X).  The host picks the smaller (row_fast = rows < columns: the 768 -> 768 and 3072 -> 768 layers of HuBERT at T = 1599).
+  const int tile_y = p.row_fast ? tile % p.gy : tile / p.gx, tile_x = p.row_fast ? tile / p.gy : tile - tile_y * p.gx;
   const int grp = tile_y / p.rows_pg;                       // (1 group: rows_pg = gy, grp = 0)
   const int co0 = (tile_y - grp * p.rows_pg) * BM, n0 = tile_x * BN;      // first row INSIDE the group
   const int row0 = grp * p.co_g, CoG = p.co_g;              // global row = row0 + m for m < CoG
@@ -599,6 +603,8 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.gx = (T + BN - 1) / BN; a.gy = a.rows_pg * G; a.ksplit = S;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
+  static const int rf_env = getenv("RVC_X3S_ROWFAST") ? atoi(getenv("RVC_X3S_ROWFAST")) : 0;      // 0: column tiles fastest always, 1: by operand size, 2: row tiles fastest always
+  a.row_fast = (G == 1 && xcd_env && (rf_env == 2 || (rf_env == 1 && (long long)L.Co < (long long)T))) ? 1 : 0;
   const unsigned blocks = (unsigned)((long long)a.gx * a.gy * S);
   if (S > 1) {
     // slabs + one ticket word per tile (zeroed when the scratch is first handed out and by every launch's last arriver)

@@ -673,6 +673,69 @@ def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
+@pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(128, 11, 5, 274489, 1.0 / 3, True), (128, 7, 3, 270001, 1.0, False), (128, 3, 1, 262144 + 256 * 3 + 5, 1.0, True),
+                                                  (64, 11, 1, 400003, 1.0, False), (64, 7, 5, 393216 + 77, 1.0 / 3, True)])
+def test_persistent_resblock_pair(L, tmp_path, Cc, k, d, T, scale, accum):
+    """The split-resident ResBlock pair at lengths where the PERSISTENT kernel takes it (conv_x3q.hip: at least two rounds of resident
+    workgroups - the sizes of the generator's 128- / 64-channel stages): every workgroup walks over several tiles in one stream of units, the
+    residual joins the sum block by block, stores go through the LDS staging area.  The launch profile must name conv_x3q_kernel for both
+    halves; values are checked against fp64 torch on windows at both ends of the sequence, at tile seams and in the middle (the whole tensor in
+    fp64 on the CPU would take minutes), the -DRVC_X3P_CHECK build's wait bookkeeping must stay clean."""
+    g = torch.Generator().manual_seed(4000 + 37 * k + d + Cc)
+    x = torch.randn(Cc, T, generator=g)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
+    y0 = torch.randn(Cc, T, generator=g)
+    y, xg = dev(y0), dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    csv_path = str(tmp_path / "launches.csv")
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
+        torch.cuda.synchronize()
+        L.check(L.lib.rvc_prof_dump_csv(csv_path.encode()))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+    kernels = [ln.split(",")[1] for ln in open(csv_path).read().strip().split("\n")[1:]]
+    assert kernels == ["conv_x3q_kernel", "conv_x3q_kernel"], kernels
+    yc = y.cpu().double()
+    halo = (k - 1) // 2 * (d + 1) + 8
+    BN = 256
+    wins = [(0, 1500), (T - 1500, T), (T // 2 - 700, T // 2 + 700)]
+    for seam in (BN * 3, BN * 517, (T // BN) * BN):                 # tile seams: an early one, one deep inside a later round, the last (ragged) tile
+        wins.append((max(seam - 300, 0), min(seam + 300, T)))
+    worst = 0.0
+    for lo, hi in wins:
+        a0, a1 = max(lo - halo, 0), min(hi + halo, T)
+        xd = x[:, a0:a1].double()
+        h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+        # (positions outside the sequence are the second convolution's zero padding; inside the window's margin they are simply not compared)
+        ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+        o = lo - a0
+        # trim the part of the window whose halo was cut by the slice (not by the true sequence ends)
+        tl = 0 if a0 == 0 else halo
+        tr = 0 if a1 == T else halo
+        ref = ref[:, o + (tl if lo - a0 < tl else 0): o + (hi - lo)]
+        got = yc[:, lo + (tl if lo - a0 < tl else 0): hi]
+        if accum:
+            ref = ref + y0[:, lo + (tl if lo - a0 < tl else 0): hi].double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < 2e-5, (lo, hi, err)
+    bad = L.lib.rvc_debug_x3p_check()
+    assert bad <= 0, f"{bad} waits of the persistent kernel with a too large compile-time count"
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
 @pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(32, 11, 5, 140003, 1.0 / 3, True), (32, 7, 3, 131072, 1.0, False), (32, 3, 1, 200001, 1.0, False),
                                                   (32, 3, 5, 136100, 1.0 / 3, True), (32, 11, 1, 150000, 1.0, False),
                                                   (32, 11, 5, 140004, 1.0 / 3, True), (32, 11, 3, 131076, 1.0, False), (32, 7, 5, 128000, 1.0 / 3, True), (32, 7, 1, 130052, 1.0, False), (32, 3, 3, 160000, 1.0, False),

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_hip_mdx23c.py -x -q 2>&1 | tail -3
-timeout 600 python3 bench.py --variant uvr_48k_v2 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
-timeout 600 python3 bench.py --variant uvr_48k_v2 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
+echo "== persistent pair test, product lib"
+timeout 1200 python -m pytest tests/test_hip_ops.py -q -x -k "persistent_resblock_pair" 2>&1 | tail -8
+echo "== persistent pair test, wait-check build"
+RVC_HIP_LIB=$PWD/comfy-rvc_amd/csrc/variants/librvc_hip_check.so timeout 1200 python -m pytest tests/test_hip_ops.py -q -x -k "persistent_resblock_pair" 2>&1 | tail -8
