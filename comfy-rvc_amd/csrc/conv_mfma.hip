@@ -376,6 +376,7 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
 void conv_x3q_timing_read(unsigned long long* out8, bool reset);
+void conv_x3s_timing_read(unsigned long long* out8, bool reset);
 void cbr2_timing_read(unsigned long long* out8, bool reset);
 void attention_dma_timing_read(unsigned long long* out8, bool reset);
 void conv_timing_read(unsigned long long* out8, bool reset) {
@@ -393,6 +394,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   conv_x3p_timing_read(x3, reset);      // (pipelined kernel: [0] tiles, [1] prologue, [2] compute, [3] weight wait, [4] barrier, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3q_timing_read(x3, reset);      // (persistent kernel: the same slots; [1] once per workgroup, [6] per workgroup)
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  conv_x3s_timing_read(x3, reset);      // (split-resident GEMM: [0] workgroups, [1] prologue, [2] reads + MFMA issue, [3] DMA wait, [4] barrier, [5] split-K + epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
 }
 #else

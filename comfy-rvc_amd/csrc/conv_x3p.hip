@@ -1048,7 +1048,8 @@ bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry)
   // 64 channels: the narrow wave tile (32 rows: one operand read per MFMA) only wins where the pair is HBM-bound - k = 3: 220 -> 151 us;
   // k = 7: 284 -> 296, k = 11: 393 -> 507 against the two split-resident launches (RVC_X3PF64=2 forces it)
   // (128 channels, 4 waves on top of each other on 64-column tiles, was tried for k = 3: 307 vs 294 us - no gain, not kept)
-  if (C == 64 && a.ktaps != 3 && on64 < 2) return false;
+  // (RVC_X3PF64=3: k = 3 and k = 7 fused, k = 11 split - round 4: with clips in flight the bytes a fused pair keeps off the HBM count)
+  if (C == 64 && a.ktaps != 3 && !(on64 == 2 || (on64 == 3 && a.ktaps == 7))) return false;
   const int P = BN + (a.ktaps - 1) * a.dil;
   if (P > BN + 64) return false;
   const int NO = BN - (a.ktaps - 1);

@@ -65,6 +65,21 @@ template <int N> __device__ __forceinline__ void x3s_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef RVC_CONV_TIMING
+__device__ unsigned long long g_x3s_timing[8];   // [0] workgroups, [1] prologue (to the first barrier), [2] between barriers (operand reads + MFMA issue), [3] DMA wait, [4] barrier, [5] split-K + epilogue, [6] total
+void conv_x3s_timing_read(unsigned long long* out8, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_x3s_timing), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_x3s_timing), z, sizeof(z)); }
+}
+#define XSTICK() ((long long)__builtin_readcyclecounter())
+#define XSACC(i, v) do { xst[i] += (v); } while (0)
+#else
+void conv_x3s_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 8; ++i) out8[i] = 0; }
+#define XSTICK() 0ll
+#define XSACC(i, v) do {} while (0)
+#endif
+
 // UC = (chunk, tap) units per ring slot = per barrier.  With one unit per barrier a 64 x 64 tile issues 3 MFMAs per wave between two barriers:
 // measured (round 4, 768 -> 768 at T = 1599) a unit costs ~600 cycles for 96 cycles of MFMA issue - the wait, the barrier, the DMA issue and the
 // operand reads ARE the kernel.  Two units per barrier halve that fixed cost per product; the slot is two units wide, everything else is unchanged.
@@ -98,6 +113,11 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const int co0 = (tile_y - grp * p.rows_pg) * BM, n0 = tile_x * BN;      // first row INSIDE the group
   const int row0 = grp * p.co_g, CoG = p.co_g;              // global row = row0 + m for m < CoG
   const int U1 = p.nunits / S, u0 = ks * U1, U = U1 / UC;            // single units of this slice (a multiple of UC: host), ring steps
+#ifdef RVC_CONV_TIMING
+  long long xst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  [[maybe_unused]] const long long xs_begin = XSTICK();
+  [[maybe_unused]] long long xs_last = xs_begin;
 
   // ---- accumulators: slice 0 starts from bias (+ residual unless an activation sits between the sum and the residual)
   const bool r_pre = p.R != nullptr && !(p.act_before_res && p.act != ACT_NONE);
@@ -227,8 +247,12 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   int sl = 0;
   auto body = [&](const Ops& cur, Ops& nxt) {
     // slot u + 1 was requested RS - 2 steps ago; younger: slots u + 2 .. u + RS - 2
+    [[maybe_unused]] const long long ta = XSTICK();
     x3s_wait_vmcnt<(RS - 3) * NPW * UC>();
+    [[maybe_unused]] const long long tb = XSTICK();
     lds_barrier();
+    [[maybe_unused]] const long long tc = XSTICK();
+    XSACC(2, ta - xs_last); XSACC(3, tb - ta); XSACC(4, tc - tb); xs_last = tc;
     issue();                                                 // slot u + RS - 1 over the one step u - 1 was read from (those reads fed step u - 1's MFMAs)
     sl = sl + 1 == RS ? 0 : sl + 1;
     read_ops(nxt, sl);
@@ -237,9 +261,12 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
     __builtin_amdgcn_sched_barrier(0);
   };
   read_ops(o0, 0);
+  xs_last = XSTICK(); XSACC(1, xs_last - xs_begin);
   int u = 0;
   for (; u + 1 < U; u += 2) { body(o0, o1); body(o1, o0); }
   if (u < U) body(o0, o1);
+  [[maybe_unused]] const long long xs_epi = XSTICK();
+  XSACC(2, xs_epi - xs_last);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the requests past the end: nothing may land in LDS after the workgroup has gone)
 
   // ---- K split: slabs in register order, write-through; the last slice to arrive sums them in slice order
@@ -271,7 +298,13 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       *flag = t;
     }
     __syncthreads();
-    if (*flag != (unsigned)S - 1u) return;
+    if (*flag != (unsigned)S - 1u) {
+#ifdef RVC_CONV_TIMING
+    { const long long te = XSTICK(); XSACC(5, te - xs_epi); XSACC(6, te - xs_begin); XSACC(0, 1);
+      if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_x3s_timing[i], (unsigned long long)xst[i]); }
+#endif
+      return;
+    }
 #pragma unroll
     for (int am = 0; am < AM; ++am)
 #pragma unroll
@@ -412,6 +445,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
         }
       }
   }
+#ifdef RVC_CONV_TIMING
+  { const long long te = XSTICK(); XSACC(5, te - xs_epi); XSACC(6, te - xs_begin); XSACC(0, 1);
+    if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_x3s_timing[i], (unsigned long long)xst[i]); }
+#endif
 }
 
 // ---------------------------------------------------------------------------- fp32 [C][T] <-> split image (producers without an image epilogue, tests)
@@ -533,9 +570,10 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int grou
   if (t_force_an == 1 || t_force_an == 2) AN = t_force_an;
   S = 1;
   const long long nt = tiles(AM, AN);
-  for (int c : {2, 3, 4, 6, 8}) {
+  static const int min_units = getenv("RVC_X3S_MINUNITS") ? atoi(getenv("RVC_X3S_MINUNITS")) : 32;
+  for (int c : {2, 3, 4, 6, 8, 12, 16}) {
     if (nt * S >= target) break;
-    if (units % c == 0 && units / c >= 32) S = c;             // (a slice shorter than K = 512 does not pay for its slab round trip)
+    if (units % c == 0 && units / c >= min_units) S = c;      // (a slice shorter than K = 512 does not pay for its slab round trip)
   }
   if (f_s) S = (units % f_s == 0) ? f_s : 1;
   if (t_force_s > 0) S = (units % t_force_s == 0 && units / t_force_s >= 4) ? t_force_s : 1;
