@@ -563,7 +563,7 @@ static void launch_x3q_r(const ConvArgsX& a, int R, int mode, dim3 grid, size_t 
 
 // a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the layer is not this kernel's (the
 // per-tile pipelined kernel of conv_x3p.hip takes it): the two halves of a split-resident ResBlock pair - stride-1 Conv1d with 3 / 7 / 11 taps,
-// whole row tiles, at least three 16-channel chunks, enough tiles for two rounds of resident workgroups.
+// whole row tiles, at least three 16-channel chunks, at least 8 tiles.
 bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry) {
   static const int on = getenv("RVC_X3Q") ? atoi(getenv("RVC_X3Q")) : 1;
   if (!on) return false;
@@ -595,17 +595,20 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   const size_t lds = fixed + (size_t)R * wslot;
   if (lds > budget) return false;
   const long long ntiles = (long long)((a.Tout + BN - 1) / BN) * (a.Co / BM);
-  // a workgroup must own several tiles for the stream to hide anything: grids of less than two rounds stay on the per-tile kernel
+  // (RVC_X3Q_MINROUNDS: grids of fewer rounds of resident workgroups stay on the per-tile kernel)
   static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
   static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
-  static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 2;
+  // (default 0: every eligible pair, also where a workgroup owns a single tile - the 256-channel stage, short clips: measured neutral there against the per-tile
+  // kernel (C256 pairs 1018 -> 1008 us), one kernel for every ResBlock pair of the three wide stages)
+  static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 0;
   const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
   if (ntiles < min_rounds * slots || ntiles < 8) return false;
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
-  long long G = (slots < ntiles ? slots : ntiles) & ~7LL;          // a multiple of 8 (a workgroup's tiles stay on its XCD), every workgroup owns a tile
+  // a multiple of 8 (a workgroup's later tiles stay on its XCD) unless every workgroup owns exactly one tile
+  long long G = ntiles <= slots ? ntiles : (slots & ~7LL);
   if (G < 8) return false;
   dim3 grid((unsigned)G, 1, 1);
   grid_out = grid;

@@ -634,7 +634,7 @@ def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
                                                   (192, 7, 1, 60000, 1.0, False), (256, 11, 3, 32000, 1.0, True), (256, 3, 5, 30001, 1.0, False)])
 def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
     """One ResBlock1 pair as the wide generator stages run it: conv1 writes its output as the bf16 hi / lo image (split-resident), conv2
-    stages that image by DMA - both on the software-pipelined kernel (conv_x3p.hip; channel counts from three chunks up, every kernel size
+    stages that image by DMA - both on the persistent software-pipelined kernel (conv_x3q.hip; conv_x3p.hip with RVC_X3Q=0; channel counts from three chunks up, every kernel size
     of the generator, sequence ends inside / at tile borders) - against fp64 torch."""
     g = torch.Generator().manual_seed(2000 + 37 * k + d + Cc)
     x = torch.randn(Cc, T, generator=g)

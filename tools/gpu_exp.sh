@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-for cfg in "RVC_X3S_BLK=440" "RVC_X3S_BLK=220" "RVC_X3S_BLK=120" "RVC_X3S_BLK=60" "RVC_X3S_BLK=440" "RVC_X3S_BLK=220" "RVC_X3S_BLK=120"; do
-echo "== $cfg"
-env $cfg timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"
-done
+echo "== pair tests, wait-check build"
+RVC_HIP_LIB=$PWD/comfy-rvc_amd/csrc/variants/librvc_hip_check.so timeout 1200 python -m pytest tests/test_hip_ops.py -q -x -k "resblock_pair" 2>&1 | tail -4
+echo "== full GPU suite, product"
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
