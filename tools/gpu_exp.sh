@@ -1,7 +1,8 @@
 #!/bin/bash
+# scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence):
+#   gpurun --timeout 1800 -- 'bash tools/gpu_exp.sh > gpurun_out/expN.txt 2>&1; cat gpurun_out/expN.txt'
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-echo "== pair tests, wait-check build"
-RVC_HIP_LIB=$PWD/comfy-rvc_amd/csrc/variants/librvc_hip_check.so timeout 1200 python -m pytest tests/test_hip_ops.py -q -x -k "resblock_pair" 2>&1 | tail -4
-echo "== full GPU suite, product"
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+run() { env $@ timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"; }
+run RVC_X3Q=1
+run RVC_X3Q=0
