@@ -675,11 +675,12 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
 // after the attention: softmax rows sum to 1); rows >= T of the last chunk are written as zeros.  Yrm (optional): the same product as fp32 rows
 // out[t][j] with pitch ldYrm - a time-major result without a transposition pass (RMVPE's GRU input projection).
 void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp,
-                          float* Yrm, long long ldYrm) {
+                          float* Yrm, long long ldYrm, const float* Rrm, long long ldRrm) {
   RVC_REQUIRE(L.Wx_ != nullptr && L.mode == 1 && L.k == 1 && L.groups == 1 && (L.Ci & 15) == 0, "conv_x3s_run_swapped: a k = 1 projection with a bf16x3 weight image");
   RVC_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= L.Co && (row0 & 15) == 0, "conv_x3s_run_swapped: row range");
   RVC_REQUIRE(Xs != nullptr && xsTp >= kSplitMargin + T + 704 && (Ys != nullptr || Yrm != nullptr) && (!Ys || ysTp >= kSplitMargin + rows), "conv_x3s_run_swapped: images missing or too short");
   RVC_REQUIRE(!Yrm || (ldYrm >= rows && (double)T * (double)ldYrm * 4.0 < 2147483648.0), "conv_x3s_run_swapped: row-major output pitch");
+  RVC_REQUIRE(!Rrm || (Yrm && ldRrm >= rows && (double)T * (double)ldRrm * 4.0 < 2147483648.0), "conv_x3s_run_swapped: the residual goes with the row-major output");
   const double xs_bytes = (double)(L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)(L.Ci / 16) * 4.0 * (double)L.CoPx * 16.0;
   RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
   GemmSArgs a{};
@@ -689,6 +690,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   a.groups = 1; a.co_g = T; a.cig_chunks = L.Ci / 16; a.tdil = 1;
   a.Ys = Ys; a.ysTp = ysTp; a.act = ACT_NONE; a.out_scale = 1.f;
   a.Y = Yrm; a.ldY = ldYrm;                                    // fp32 out[t][j], row-major (the GRU's input projection)
+  a.R = Rrm; a.ldR = ldRrm;
   int AM, AN, S;
   x3s_plan(T, rows, a.nunits, AM, AN, S, 1);
   S = 1;                                                       // (48-unit reductions: never split)
@@ -703,7 +705,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   if (tk.on) {
     ConvArgsX pa{};
     pa.Ci = L.Ci; pa.Co = rows; pa.ktaps = 1; pa.kreal = 1; pa.dil = 1; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.ksplit = 1;
-    const double bytes = 4.0 * ((double)L.Ci * T + (double)rows * T + (double)rows * L.Ci);
+    const double bytes = 4.0 * ((double)L.Ci * T + (double)rows * T * (Rrm ? 2.0 : 1.0) + (double)rows * L.Ci);
     const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
     conv_prof_end(tk, s, 2.0 * (double)rows * T * L.Ci, 14 + id, bytes, &pa, (long long)blocks, 4 << 4);
   }

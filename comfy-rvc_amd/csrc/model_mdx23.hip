@@ -9,6 +9,13 @@
 //                               transposed to [f][C * T] in front of them and back (with the residual add) behind them
 //   2x2 stride-2 conv / deconv  space-to-depth / depth-to-space re-arrangement around a k = 1 GEMM
 //   STFT / inverse STFT         framing + GEMM against windowed DFT matrices (built on the host in float64), overlap-add kernel
+// Round 4: when every 3x3 / 2x2 layer has its bf16x3 weight image the U-Net runs on PADDED planes [C][H][W + 2] (one zero column on either side
+// of a row, as RMVPE's deep levels: split2d.hip) and the split-resident GEMM kernel (conv_x3s.hip): InstanceNorm + GELU writes the bf16 hi / lo
+// image the next product stages by DMA, the 3x3 convolutions are 9 row offsets into that image, the TDF linears take the image of the
+// TRANSPOSED plane ([W / 16 chunks][c H positions]: 16 neighbouring bins of a row are one image row) and the second linear runs as the swapped
+// product straight into the plane layout with the residual - no transposition passes - and the 2x2 stride-2 (de)convolutions read / write
+// the padded layout.  `mdx23_graph_plain` (fp32 planes, staged kernels) remains for networks without the images (fp32 precision, odd channel counts).
+#include "conv_x3_dev.h"
 #include "model_common.h"
 #include "models.h"
 
@@ -34,6 +41,8 @@ struct Mdx23 {
   DevVec window;
   std::vector<MdxScale> enc, dec;
   MdxScale bott;
+  bool pad_ok = false;                       // every 3x3 / 2x2 layer has its bf16x3 image: the padded split-resident graph (mdx23_graph_padded)
+  const char* img_base = nullptr; size_t img_bytes = 0; unsigned img_gen = 0;      // the conv-input images' margins were zeroed for this layout
 };
 
 Mdx23* mdx23_create(Ctx* ctx, const rvc_mdx23_config& c) {
@@ -116,6 +125,15 @@ void mdx23_finalize(Mdx23* M) {
   }
   conv1d_layer_init(M->fin0, ts.get("final_conv.0.weight", {ch, ch + dim_c, 1, 1}).data.data(), nullptr, ch, ch + dim_c, 1, 1, 0, 1, 1);
   conv1d_layer_init(M->fin2, ts.get("final_conv.2.weight", {c.num_targets * dim_c, ch, 1, 1}).data.data(), nullptr, c.num_targets * dim_c, ch, 1, 1, 0, 1, 1);
+  {
+    static const bool off = getenv("RVC_MDX_X3S") && atoi(getenv("RVC_MDX_X3S")) == 0;
+    bool ok = !off && conv_x3_enabled();
+    auto blocks_ok = [&](const std::vector<TfcBlock>& bs) { for (const TfcBlock& B : bs) ok = ok && conv_x3s_eligible(B.tfc1) && conv_x3s_eligible(B.tfc2); };
+    for (auto& S : M->enc) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
+    for (auto& S : M->dec) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
+    blocks_ok(M->bott.blocks);
+    M->pad_ok = ok; M->img_base = nullptr;
+  }
   M->ts.clear();
   M->ready = true;
 }
@@ -235,6 +253,171 @@ __global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict
   out[i] = s / e;
 }
 
+
+// ---------------------------------------------------------------------------------------------- padded split-resident graph (round 4)
+// branch-free exact-erf GELU, the form conv_x3s.hip's epilogue evaluates (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 absolute): the image producers
+// below run at HBM rate only if the activation stays under ~20 VALU instructions per value (ocml's erff: two divergent paths)
+__device__ __forceinline__ float gelu_as(float v) {
+  const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+  return 0.5f * v * (1.f + copysignf(fmaf(-poly, e, 1.f), x));
+}
+// 8 values of one position -> one 16-byte row of the hi and of the lo plane; g = group of 8 rows = chunk * 2 + half, row = margin + position
+__device__ __forceinline__ void split8_store(const float (&v)[8], unsigned char* __restrict__ img, long long tp, long long row, int g) {
+  u32x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { unsigned h_, l_; split2(v[2 * j], v[2 * j + 1], h_, l_); hi[j] = h_; lo[j] = l_; }
+  unsigned char* r = img + (((long long)(g >> 1) * 4 + (g & 1)) * tp + row) * 16;
+  *reinterpret_cast<u32x4*>(r) = hi;
+  *reinterpret_cast<u32x4*>(r + tp * 32) = lo;
+}
+// InstanceNorm statistics, stage 1, over ROWS: channel c = blockIdx.x owns `rows` rows of Wv contiguous values, value (j, w) at x[c cs + j rs + w] -
+// padded planes [C][H][W + 2] (x + 1, cs = H (W + 2), rs = W + 2: the pad columns are never read, whatever they hold) and the first TDF linear's
+// output [f / bn][C][H] (cs = H, rs = C H).  Part q = blockIdx.y takes a run of whole rows; four independent loads per thread and trip.
+__global__ __launch_bounds__(256) void inorm_part_rows_kernel(const float* __restrict__ x, long long cs, long long rs, int rows, int Wv, int wshift, int P,
+                                                              double* __restrict__ part) {
+  const int c = blockIdx.x, q = blockIdx.y;
+  const int rpp = (rows + P - 1) / P, j0 = q * rpp, j1 = j0 + rpp < rows ? j0 + rpp : rows;
+  const long long n = j1 > j0 ? (long long)(j1 - j0) * Wv : 0;
+  const float* xc = x + (long long)c * cs + (long long)j0 * rs;
+  auto at = [&](long long i) -> float { const long long j = wshift >= 0 ? (i >> wshift) : (i / Wv); return xc[j * rs + (i - j * Wv)]; };
+  double s = 0.0, qq = 0.0;
+  long long i = threadIdx.x;
+  for (; i + 768 < n; i += 1024) {
+    const float v0 = at(i), v1 = at(i + 256), v2 = at(i + 512), v3 = at(i + 768);
+    s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    qq += ((double)v0 * v0 + (double)v1 * v1) + ((double)v2 * v2 + (double)v3 * v3);
+  }
+  for (; i < n; i += 256) { const float v = at(i); s += v; qq += (double)v * v; }
+  __shared__ double ss[256], sq[256];
+  ss[threadIdx.x] = s; sq[threadIdx.x] = qq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sq[threadIdx.x] += sq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[((long long)c * P + q) * 2] = ss[0]; part[((long long)c * P + q) * 2 + 1] = sq[0]; }
+}
+// gelu(x a + b) written as the split image (one thread = one position x 8 rows, consecutive threads consecutive positions).
+// COLCH false: the norm channel is the ROW - planes [rows][T], padded rows of padw positions whose two pad columns are written as zeros (the 3x3
+// convolution's horizontal zero padding).  COLCH true: the norm channel is the column group t / chdiv (the first TDF linear's output [f / bn][c H]).
+template <bool COLCH>
+__global__ __launch_bounds__(256) void inorm_apply_split_kernel(const float* __restrict__ x, long long ld, int rows, long long T, const float* __restrict__ sc,
+                                                                const float* __restrict__ sh, int chdiv, int padw, unsigned char* __restrict__ img, long long tp,
+                                                                int margin) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (t >= T) return;
+  bool pad = false;
+  if (padw > 0) { const unsigned w = (unsigned)t % (unsigned)padw; pad = (w == 0u || w == (unsigned)padw - 1u); }
+  float a = 0.f, b = 0.f;
+  if (COLCH) { const int c = (int)((unsigned)t / (unsigned)chdiv); a = sc[c]; b = sh[c]; }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = g * 8 + j;
+    v[j] = 0.f;
+    if (!pad && row < rows) {
+      if (!COLCH) { a = sc[row]; b = sh[row]; }
+      v[j] = gelu_as(fmaf(x[(long long)row * ld + t], a, b));
+    }
+  }
+  split8_store(v, img, tp, margin + t, g);
+}
+// The first TDF linear contracts over the bins of a row: it takes the image of the TRANSPOSED plane - chunk = 16 neighbouring bins, position = row
+// r = c H + h.  32 rows x 64 bins per workgroup: coalesced reads along the rows, turned through LDS, 16-byte image rows written along r.
+__global__ __launch_bounds__(256) void inorm_apply_tm_kernel(const float* __restrict__ x, int Wp, int W, int R, int H, int hshift, const float* __restrict__ sc,
+                                                             const float* __restrict__ sh, unsigned char* __restrict__ img, long long tp) {
+  __shared__ float tile[32][65];
+  const int w0 = blockIdx.x * 64, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ri = i * 4 + (threadIdx.x >> 6), wi = threadIdx.x & 63, r = r0 + ri;
+    float v = 0.f;
+    if (r < R && w0 + wi < W) { const int c = hshift >= 0 ? (r >> hshift) : (r / H); v = gelu_as(fmaf(x[(long long)r * Wp + 1 + w0 + wi], sc[c], sh[c])); }
+    tile[ri][wi] = v;
+  }
+  __syncthreads();
+  const int ri = threadIdx.x & 31, g8 = threadIdx.x >> 5, r = r0 + ri;
+  if (r < R && w0 + g8 * 8 < W) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[ri][g8 * 8 + j];
+    split8_store(v, img, tp, (long long)kSplitMargin + r, (w0 >> 3) + g8);
+  }
+}
+// InstanceNorm + GELU + space-to-depth in front of the 2x2 stride-2 convolution: the image of the [4 C][H / 2][W / 2 + 2] tensor whose row
+// ci * 4 + dy * 2 + dx is the (dy, dx) phase of channel ci (the weight's own memory order); one thread = one half-resolution position x 2 channels
+__global__ __launch_bounds__(256) void inorm_apply_s2d_split_kernel(const float* __restrict__ x, long long TPin, int Wp, int C, int Ho, int Wo,
+                                                                    const float* __restrict__ sc, const float* __restrict__ sh, unsigned char* __restrict__ img,
+                                                                    long long tp, int margin) {
+  const int Wpo = Wo + 2;
+  const long long P = (long long)Ho * Wpo, p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (p >= P) return;
+  const int y = (int)(p / Wpo), xq = (int)(p - (long long)y * Wpo);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (xq != 0 && xq != Wpo - 1) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int ch = 2 * g + cc;
+      if (ch < C) {
+        const float a = sc[ch], b = sh[ch];
+        const float* src = x + (long long)ch * TPin + (long long)(2 * y) * Wp + 1 + 2 * (xq - 1);
+        v[cc * 4 + 0] = gelu_as(fmaf(src[0], a, b)); v[cc * 4 + 1] = gelu_as(fmaf(src[1], a, b));
+        v[cc * 4 + 2] = gelu_as(fmaf(src[Wp], a, b)); v[cc * 4 + 3] = gelu_as(fmaf(src[Wp + 1], a, b));
+      }
+    }
+  }
+  split8_store(v, img, tp, margin + p, g);
+}
+// depth-to-space behind the 2x2 stride-2 transposed convolution, padded in and out: out[co][2 y + dy][1 + 2 x + dx] = in[co * 4 + dy * 2 + dx][y][1 + x]
+__global__ void d2s_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int Co, int H, int W) {
+  const int Wpi = W + 2, Wpo = 2 * W + 2, Ho = 2 * H;
+  const long long n = (long long)Co * Ho * Wpo, st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+    const int xq = (int)(i % Wpo); long long r = i / Wpo;
+    const int yo = (int)(r % Ho); const int co = (int)(r / Ho);
+    float v = 0.f;
+    if (xq != 0 && xq != Wpo - 1) {
+      const int xo = xq - 1;
+      v = in[(((long long)co * 4 + (yo & 1) * 2 + (xo & 1)) * H + (yo >> 1)) * Wpi + 1 + (xo >> 1)];
+    }
+    out[i] = v;
+  }
+}
+// small levels (linears without a weight image): padded plane -> [W][R] with InstanceNorm + GELU, and [W][R] -> padded plane with the residual
+__global__ void tr2d_in_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int W, int Wp, int H, const float* __restrict__ sc, const float* __restrict__ sh) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    float v = 0.f;
+    if (r < R && c < W) { const int ch = r / H; v = gelu_as(fmaf(in[(long long)r * Wp + 1 + c], sc[ch], sh[ch])); }
+    tile[j][threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < W && r < R) out[(long long)c * R + r] = tile[threadIdx.x][j];
+  }
+}
+__global__ void tr2d_out_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ res, int W, int R, int Wp) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;      // in [W rows][R columns]: c = column of in = plane row
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (r < W && c < R) ? in[(long long)r * R + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < R && r < W) { const long long o = (long long)c * Wp + 1 + r; out[o] = tile[threadIdx.x][j] + res[o]; }
+  }
+}
+
 static int gridn(long long n) { long long g = (n + 255) / 256; return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g)); }
 static void norm_gelu(hipStream_t s, const float* x, float* y, int A, int C, long long B, const float* g, const float* b, float* sc, float* sh) {
   const long long n = (long long)A * C * B, per_c = (long long)A * B;
@@ -279,7 +462,7 @@ static void run_tfc(const std::vector<TfcBlock>& blocks, hipStream_t s, const Md
   }
 }
 
-static void mdx23_graph(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out) {
+static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out) {
   const rvc_mdx23_config& c = M->cfg;
   const bool dry = A.dry;
   const int T = c.dim_t, k = c.num_subbands, f0 = c.dim_f / k, n = c.num_scales, g = c.growth, S = c.num_targets;
@@ -357,13 +540,182 @@ static void mdx23_graph(Mdx23* M, hipStream_t s, Arena& A, const float* audio, l
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- the padded graph
+static int ilog2_exact(int v) { if (v <= 0 || (v & (v - 1))) return -1; int k = 0; while ((1 << k) < v) ++k; return k; }
+// statistics + fold: value (j, w) of channel c at x[c cs + j rs + w], j < rows, w < Wv
+static void stats_fold(hipStream_t s, const float* x, long long cs, long long rs, int C, int rows, int Wv, const float* g, const float* b, float* sc, float* sh) {
+  const long long per_c = (long long)rows * Wv;
+  int P = std::max(1, 2048 / C);
+  if (P > rows) P = rows;
+  while (P > 1 && per_c / P < 4096) --P;
+  double* part = (double*)stream_scratch(s, 12, (size_t)C * P * 2 * sizeof(double));
+  hipLaunchKernelGGL(inorm_part_rows_kernel, dim3((unsigned)C, (unsigned)P), dim3(256), 0, s, x, cs, rs, rows, Wv, ilog2_exact(Wv), P, part);
+  hipLaunchKernelGGL(inorm_fold_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, s, part, C, P, (double)per_c, g, b, 1e-5f, sc, sh);
+}
+struct PadLv { int C = 0, H = 0, W = 0, Wp = 0; long long TP = 0, tp = 0; SplitGeom g, g1; unsigned char* ia = nullptr; };
+// plane [rows][H (W + 2)] -> the conv-input image of the level (pad columns zero)
+static void apply_plane(hipStream_t s, const float* x, int rows, const PadLv& L, const float* sc, const float* sh) {
+  hipLaunchKernelGGL(inorm_apply_split_kernel<false>, dim3((unsigned)((L.TP + 255) / 256), (unsigned)((rows + 7) / 8)), dim3(256), 0, s, x, L.TP, rows, L.TP, sc, sh, 1, L.Wp,
+                     L.ia, L.tp, L.g.margin);
+}
+
+// TFC_TDF.forward (tfc_tdf.py:137-144) over padded planes [c][H][W + 2]; the last block writes to `out`.  il / im: images of the two linears' inputs.
+static void run_tfc_padded(const std::vector<TfcBlock>& blocks, hipStream_t s, const MdxScratch& K, const PadLv& L, unsigned char* il, unsigned char* im, const float* x,
+                           float* out, float* mid) {
+  const int H = L.H, W = L.W, Wp = L.Wp;
+  const long long TP = L.TP;
+  ConvEpilogue E0;
+  const float* cur = x;
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const TfcBlock& B = blocks[i];
+    float* dst = (i + 1 == blocks.size()) ? out : mid;
+    conv1d_run(B.shortcut, s, cur, TP, (int)TP, K.sbuf, TP, E0);                                // s = shortcut(x) (pad columns: whatever, zeroed with tfc2's)
+    stats_fold(s, cur + 1, TP, Wp, B.in_c, H, W, B.n1g.p, B.n1b.p, K.sc, K.sh);
+    apply_plane(s, cur, B.in_c, L, K.sc, K.sh);
+    conv_x3s_run(B.tfc1, s, L.ia, L.tp, (int)TP, K.t2, TP, E0, &L.g);                           // x1 = tfc1(x)
+    // x2 = x1 + tdf(x1)
+    const int R = B.c * H, fb = B.lin1.Co;
+    stats_fold(s, K.t2 + 1, TP, Wp, B.c, H, W, B.t0g.p, B.t0b.p, K.sc, K.sh);
+    float* x2;
+    if (il && conv_x3s_eligible(B.lin1) && conv_x3s_eligible(B.lin2) && (W & 15) == 0 && (fb & 15) == 0) {
+      const long long tpl = split_image_tp(R);
+      hipLaunchKernelGGL(inorm_apply_tm_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)((R + 31) / 32)), dim3(256), 0, s, K.t2, Wp, W, R, H, ilog2_exact(H), K.sc, K.sh, il, tpl);
+      conv_x3s_run(B.lin1, s, il, tpl, R, K.t1, R, E0);                                         // [W / bn][R]
+      stats_fold(s, K.t1, H, R, B.c, fb, H, B.t3g.p, B.t3b.p, K.sc, K.sh);                      // channel c owns the columns [c H, (c + 1) H) of every row
+      hipLaunchKernelGGL(inorm_apply_split_kernel<true>, dim3((unsigned)((R + 255) / 256), (unsigned)((fb + 7) / 8)), dim3(256), 0, s, K.t1, (long long)R, fb, (long long)R,
+                         K.sc, K.sh, H, 0, im, tpl, kSplitMargin);
+      conv_x3s_run_swapped(B.lin2, 0, W, s, im, tpl, R, nullptr, 0, K.t3 + 1, Wp, K.t2 + 1, Wp);  // the swapped product lands in the plane layout, + x1
+      x2 = K.t3;
+    } else {
+      hipLaunchKernelGGL(tr2d_in_kernel, dim3((unsigned)((W + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, s, K.t2, K.t3, R, W, Wp, H, K.sc, K.sh);   // [W][R]
+      conv1d_run(B.lin1, s, K.t3, R, R, K.t1, R, E0);
+      norm_gelu(s, K.t1, K.t1, fb, B.c, H, B.t3g.p, B.t3b.p, K.sc, K.sh);
+      conv1d_run(B.lin2, s, K.t1, R, R, K.t3, R, E0);                                           // [W][R]
+      hipLaunchKernelGGL(tr2d_out_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((W + 31) / 32)), dim3(32, 8), 0, s, K.t3, K.t1, K.t2, W, R, Wp);
+      x2 = K.t1;
+    }
+    stats_fold(s, x2 + 1, TP, Wp, B.c, H, W, B.n2g.p, B.n2b.p, K.sc, K.sh);
+    apply_plane(s, x2, B.c, L, K.sc, K.sh);
+    ConvEpilogue Er; Er.R = K.sbuf; Er.ldR = TP;
+    conv_x3s_run(B.tfc2, s, L.ia, L.tp, (int)TP, dst, TP, Er, &L.g);                            // tfc2(x2) + s, pad columns zero
+    cur = dst;
+  }
+}
+
+static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out) {
+  const rvc_mdx23_config& c = M->cfg;
+  const bool dry = A.dry;
+  const int T = c.dim_t, k = c.num_subbands, f0 = c.dim_f / k, n = c.num_scales, g = c.growth, S = c.num_targets, bn = c.bottleneck;
+  const int dim_c = k * 4, c0 = c.num_channels;
+  ConvEpilogue E0;
+  const long long FT = (long long)f0 * T;
+  std::vector<PadLv> lv((size_t)n + 1);
+  for (int i = 0; i <= n; ++i) {
+    PadLv& P = lv[(size_t)i];
+    P.C = c0 + i * g; P.H = T >> i; P.W = f0 >> i; P.Wp = P.W + 2; P.TP = (long long)P.H * P.Wp;
+    P.g = split_geom_2d(P.W); P.g1 = P.g; P.g1.ktaps = 1; P.g1.toff[0] = 0;
+    P.tp = ((long long)P.g.margin + P.TP + std::max(704, P.g.margin) + 63) & ~63LL;            // rows per plane: both vertical paddings inside the plane
+  }
+  // ---- the conv-input images: a block of their own, margins (= the vertical zero padding) zeroed once per layout - nothing else ever writes there
+  const size_t img0 = A.off;
+  for (int i = 0; i <= n; ++i) {
+    int chans = i < n ? 2 * lv[(size_t)i].C : lv[(size_t)i].C;                                  // decoder input [up-sampled | skip]
+    if (i > 0) chans = std::max(chans, 4 * lv[(size_t)i - 1].C);                                // space-to-depth rows of the level above
+    lv[(size_t)i].ia = A.alloc<unsigned char>((size_t)((chans + 15) / 16) * 4 * (size_t)lv[(size_t)i].tp * 16);
+  }
+  const size_t img_bytes = A.off - img0;
+  if (!dry && (M->img_base != A.base + img0 || M->img_gen != A.gen || M->img_bytes != img_bytes)) {
+    RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
+    M->img_base = A.base + img0; M->img_gen = A.gen; M->img_bytes = img_bytes;
+  }
+  // ---- images of the TDF linears' inputs (k = 1 products: no taps, margins never multiplied into a kept column)
+  size_t il_bytes = 0, im_bytes = 0;
+  for (int i = 0; i <= n; ++i) {
+    const PadLv& P = lv[(size_t)i];
+    if ((P.W & 15) || ((P.W / bn) & 15)) continue;
+    const long long tpl = split_image_tp((long long)P.C * P.H);
+    il_bytes = std::max(il_bytes, (size_t)(P.W / 16) * 4 * (size_t)tpl * 16);
+    im_bytes = std::max(im_bytes, (size_t)(P.W / bn / 16) * 4 * (size_t)tpl * 16);
+  }
+  unsigned char* il = il_bytes ? A.alloc<unsigned char>(il_bytes) : nullptr;
+  unsigned char* im = im_bytes ? A.alloc<unsigned char>(im_bytes) : nullptr;
+  float* fr = A.alloc<float>((size_t)c.n_fft * T);
+  float* spec = A.alloc<float>((size_t)4 * c.dim_f * T);          // [ch][re | im][dim_f][T] = cac2cws view [16][f0][T]
+  float* first = A.alloc<float>((size_t)c0 * FT);
+  size_t big = 0, curmax = 0;
+  for (int i = 0; i <= n; ++i) { big = std::max(big, (size_t)2 * lv[(size_t)i].C * (size_t)lv[(size_t)i].TP); curmax = std::max(curmax, (size_t)lv[(size_t)i].C * (size_t)lv[(size_t)i].TP); }
+  for (int i = 0; i < n; ++i) big = std::max(big, (size_t)4 * lv[(size_t)i].C * (size_t)lv[(size_t)i + 1].TP);     // phase rows of the transposed convolution
+  big = std::max(big, (size_t)((long long)(c0 + dim_c) * FT));
+  big = std::max(big, (size_t)((long long)S * dim_c * FT));        // the mask head's output [S dim_c][f0][T] lands in t1 as well
+  MdxScratch K;
+  K.t1 = A.alloc<float>(big + 64); K.t2 = A.alloc<float>(big + 64); K.t3 = A.alloc<float>(big + 64); K.sbuf = A.alloc<float>(big + 64);
+  K.sc = A.alloc<float>((size_t)2 * lv[(size_t)n].C + 64); K.sh = A.alloc<float>((size_t)2 * lv[(size_t)n].C + 64);
+  float* mid = A.alloc<float>(big + 64);
+  std::vector<float*> cat((size_t)n);                             // decoder inputs [2 c_i][H_i][W_i + 2]: [up-sampled | encoder skip]
+  for (int i = 0; i < n; ++i) cat[(size_t)i] = A.alloc<float>((size_t)2 * lv[(size_t)i].C * (size_t)lv[(size_t)i].TP + 64);
+  float* x0 = A.alloc<float>((size_t)c0 * (size_t)lv[0].TP + 64);
+  float* cur = A.alloc<float>(curmax + 64);
+  float* cur2 = A.alloc<float>(curmax + 64);
+  if (dry) return;
+  // ---- STFT of both channels: frames (reflect-padded by n_fft / 2) x windowed DFT matrix
+  for (int a = 0; a < 2; ++a) {
+    frames(s, audio + (long long)a * L, fr, (int)L, c.n_fft, c.hop, c.n_fft / 2, T, 1);
+    conv1d_run(M->stft, s, fr, T, T, spec + (size_t)a * 2 * c.dim_f * T, T, E0);
+  }
+  conv1d_run(M->first, s, spec, FT, (int)FT, first, FT, E0);                                   // [c0][f0][T]
+  transpose(s, first, x0 + 1, f0, T, T, lv[0].Wp, c0, FT, lv[0].TP);                            // [c0][T][f0 + 2]
+  // ---- encoder
+  const float* h = x0;
+  for (int i = 0; i < n; ++i) {
+    const PadLv& P = lv[(size_t)i]; const PadLv& Q = lv[(size_t)i + 1];
+    float* skip = cat[(size_t)i] + (size_t)P.C * (size_t)P.TP;
+    run_tfc_padded(M->enc[(size_t)i].blocks, s, K, P, il, im, h, skip, mid);
+    stats_fold(s, skip + 1, P.TP, P.Wp, P.C, P.H, P.W, M->enc[(size_t)i].ng.p, M->enc[(size_t)i].nb.p, K.sc, K.sh);
+    hipLaunchKernelGGL(inorm_apply_s2d_split_kernel, dim3((unsigned)((Q.TP + 255) / 256), (unsigned)((4 * P.C + 7) / 8)), dim3(256), 0, s, skip, P.TP, P.Wp, P.C, Q.H, Q.W, K.sc,
+                       K.sh, Q.ia, Q.tp, Q.g.margin);
+    conv_x3s_run(M->enc[(size_t)i].rs, s, Q.ia, Q.tp, (int)Q.TP, cur, Q.TP, E0, &Q.g1);          // [C + g][H / 2][W / 2 + 2]
+    h = cur; std::swap(cur, cur2);
+  }
+  {
+    float* o = cur;
+    run_tfc_padded(M->bott.blocks, s, K, lv[(size_t)n], il, im, h, o, mid);
+    h = o; std::swap(cur, cur2);
+  }
+  // ---- decoder
+  for (int i = 0; i < n; ++i) {
+    const int lo = n - 1 - i;                                       // output level
+    const PadLv& Pi = lv[(size_t)lo + 1]; const PadLv& Po = lv[(size_t)lo];
+    stats_fold(s, h + 1, Pi.TP, Pi.Wp, Pi.C, Pi.H, Pi.W, M->dec[(size_t)i].ng.p, M->dec[(size_t)i].nb.p, K.sc, K.sh);
+    apply_plane(s, h, Pi.C, Pi, K.sc, K.sh);
+    conv_x3s_run(M->dec[(size_t)i].rs, s, Pi.ia, Pi.tp, (int)Pi.TP, K.t2, Pi.TP, E0, &Pi.g1);   // [(co, dy, dx)][H][W + 2]
+    hipLaunchKernelGGL(d2s_pad_kernel, dim3(gridn((long long)Po.C * Po.TP)), dim3(256), 0, s, K.t2, cat[(size_t)lo], Po.C, Pi.H, Pi.W);
+    float* o = cur;
+    run_tfc_padded(M->dec[(size_t)i].blocks, s, K, Po, il, im, cat[(size_t)lo], o, mid);
+    h = o; std::swap(cur, cur2);
+  }
+  // ---- mask head: x^T * first_conv_out, cat(mix, x), 1x1 -> GELU -> 1x1
+  float* hc = K.t3;                                                 // [dim_c + c0][f0][T]
+  RVC_HIP_CHECK(hipMemcpyAsync(hc, spec, (size_t)dim_c * FT * sizeof(float), hipMemcpyDeviceToDevice, s));
+  transpose(s, h + 1, K.t1, T, f0, lv[0].Wp, T, c0, lv[0].TP, FT);                             // [c0][f0][T]
+  hipLaunchKernelGGL(mul_kernel, dim3(gridn((long long)c0 * FT)), dim3(256), 0, s, K.t1, first, hc + (size_t)dim_c * FT, (long long)c0 * FT);
+  ConvEpilogue Eg; Eg.act = ACT_GELU;
+  conv1d_run(M->fin0, s, hc, FT, (int)FT, K.t2, FT, Eg);
+  conv1d_run(M->fin2, s, K.t2, FT, (int)FT, K.t1, FT, E0);                                     // [S * 16][f0][T] = [S][ch][re | im][dim_f][T]
+  // ---- inverse STFT per source and channel
+  for (int q = 0; q < S * 2; ++q) {
+    conv1d_run(M->istft, s, K.t1 + (size_t)q * 2 * c.dim_f * T, T, T, fr, T, E0);              // [n_fft][T] windowed inverse FFT frames
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L);
+  }
+}
+
 void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out) {
   RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
   RVC_REQUIRE(L == (long long)M->cfg.hop * (M->cfg.dim_t - 1), "a chunk is hop * (dim_t - 1) samples per channel");
   Arena& A = M->arena;
   for (int pass = 0; pass < 2; ++pass) {
     A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
-    mdx23_graph(M, s, A, audio, L, out);
+    if (M->pad_ok) mdx23_graph_padded(M, s, A, audio, L, out); else mdx23_graph_plain(M, s, A, audio, L, out);
     if (pass == 0) A.ensure(A.peak);
   }
   A.dry = false;

@@ -158,7 +158,8 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
                   const SplitGeom* geom = nullptr);
 // the swapped product: out[t][j] = sum_c X[c][t] W[row0 + j][c], written as the image of the transposed tensor (V^T for attention_split)
 void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, unsigned char* Ys, long long ysTp,
-                          float* Yrm = nullptr, long long ldYrm = 0);      // Yrm: also / instead fp32 out[t][j] with pitch ldYrm
+                          float* Yrm = nullptr, long long ldYrm = 0,      // Yrm: also / instead fp32 out[t][j] with pitch ldYrm
+                          const float* Rrm = nullptr, long long ldRrm = 0);  // Rrm: residual added to the product, laid out like Yrm (MDX23C's x + tdf(x))
 void split_image_from_tm(hipStream_t s, const float* x, int C, int T, int M, unsigned char* img, long long tp);      // x [C][T][M] -> image of the (C M) x T tensor
 void conv_x3s_force(int ksplit, int am, int an);
 // one ConvBlockRes of 16 or 32 channels (3 x 3, 3 x 3, + x) in one launch (conv_cbr2.hip): x, out fp32 [C][H W], distinct

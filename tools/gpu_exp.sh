@@ -1,8 +1,18 @@
 #!/bin/bash
-# scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence):
-#   gpurun --timeout 1800 -- 'bash tools/gpu_exp.sh > gpurun_out/expN.txt 2>&1; cat gpurun_out/expN.txt'
+# scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-run() { env $@ timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"; }
-run RVC_X3Q=1
-run RVC_X3Q=0
+echo "== mfmabench"
+timeout 300 tools/micro/mfmabench
+echo "== mdx tests"
+timeout 1200 python -m pytest tests/test_hip_mdx23c.py -x -q 2>&1 | tail -15
+echo "== uvr bench"
+timeout 900 python bench.py --variant uvr_48k_v2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-900
+echo "== uvr profile"
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_uvr -o uvr -- python3 $GRAFT_REPO_ROOT/bench.py --variant uvr_48k_v2 --steps 2 --warmup 1 --lanes 1 --clips 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/prof_uvr -name "*kernel_stats.csv" | head -1)
+cp "$f" gpurun_out/uvr_kernel_stats.csv
+head -32 gpurun_out/uvr_kernel_stats.csv | cut -c1-200
+rm -rf gpurun_out/prof_uvr

@@ -1,0 +1,111 @@
+// What does the matrix pipe deliver under sustained load?  Bare v_mfma_f32_32x32x16_bf16 chains (no memory), W waves per SIMD, for a short (~0.3 ms) and a long (~20 ms)
+// launch; then the same with the operand traffic of the generator's kernel (12 ds_read_b128 per 24 MFMAs).  Prints dense bf16 TFLOP/s and the bf16x3-algorithmic equivalent (/ 3).
+//   hipcc --offload-arch=gfx950 -O3 -o mfmabench tools/micro/mfmabench.hip && ./mfmabench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int NACC, int MODE>
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned long long* clk) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[MODE ? 32768 : 16];
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  u32x4 a = {0x3f803f80u + threadIdx.x, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  constexpr bool LDS = MODE != 0;
+  if (LDS) { for (int i = threadIdx.x; i < 32768 / 4; i += 256) reinterpret_cast<unsigned*>(sm)[i] = 0x3f803f80u; __syncthreads(); }
+  const unsigned char* base = sm + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 4096;
+  u32x4 cur[12];
+  for (int q = 0; q < 12; ++q) cur[q] = a;
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 1) {
+      // 12 operand reads for 24 MFMAs (conv_x3q_kernel's 2 x 4 wave tile: ah, al x 2 rows, bh, bl x 4 columns), all reads first
+      u32x4 o[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) o[q] = *reinterpret_cast<const u32x4*>(base + ((q * 1024 + it * 16) & 16383));
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[(g + i) % 4]), __builtin_bit_cast(bf16x8, o[4 + (g * 3 + i) % 8]), acc[i % NACC], 0, 0, 0);
+    } else if (MODE == 2 || MODE == 3) {
+      // software-pipelined: the reads of iteration it + 1 are issued between the MFMAs of iteration it (one read every 2 (MODE 2) / 3 (MODE 3) MFMAs), waited for at the end
+      constexpr int NR = MODE == 2 ? 12 : 8, EVERY = 24 / NR;
+      static u32x4 dummy;
+      u32x4 nx[12];
+      if (it == 0) for (int q = 0; q < 12; ++q) cur[q] = *reinterpret_cast<const u32x4*>(base + q * 1024);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        if (i % EVERY == 0) { const int q = i / EVERY; asm volatile("ds_read_b128 %0, %1" : "=v"(nx[q]) : "v"((unsigned)(size_t)(base - sm) + ((q * 1024 + (it + 1) * 16) & 16383))); }
+        acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[i % 4]), __builtin_bit_cast(bf16x8, cur[4 + (i % (NR - 4))]), acc[i % NACC], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < NR; ++q) { asm volatile("" : "+v"(nx[q])); cur[q] = nx[q]; }
+    } else if (MODE == 4) {
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      u32x4 o[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const u32x2 lo2 = *reinterpret_cast<const u32x2*>(base + ((q * 1024 + it * 16) & 16383)), hi2 = *reinterpret_cast<const u32x2*>(base + ((q * 1024 + it * 16) & 16383) + 8);
+        o[q] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o[(g + i) % 4]), __builtin_bit_cast(bf16x8, o[4 + (g * 3 + i) % 8]), acc[i % NACC], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[i % NACC], 0, 0, 0);
+    }
+  }
+  const long long t1 = (long long)__builtin_readcyclecounter();
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
+}
+
+template <int NACC, int MODE>
+static int run(const char* name, int wgs_per_cu, int iters) {
+  float* out; unsigned long long* clk; CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256 * wgs_per_cu;
+  hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, 64, clk);
+  float best = 1e9f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+  }
+  unsigned long long c = 0; CK(hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost));
+  const double flops = (double)grid * 4 * (double)iters * 24 * 2.0 * 32 * 32 * 16;
+  // s_memtime counts at a constant 100 MHz: cycles of the shader clock per MFMA of one wave = (time / MFMAs per wave per SIMD)
+  printf("%-44s %d WG/CU  %9.1f us  %7.0f TFLOP/s dense bf16 = %5.0f as bf16x3 (%.3f of 2500)   refclk ticks of workgroup 0: %llu\n", name, wgs_per_cu, best * 1e3, flops / best / 1e9,
+         flops / best / 1e9 / 3, flops / best / 1e9 / 2500.0, c);
+  hipFree(out); hipFree(clk);
+  return 0;
+}
+int main() {
+  // iters: 24 MFMAs x 32 cycles = 768 cycles per iteration per wave at one wave per SIMD
+  for (int w = 1; w <= 3; ++w) {
+    run<4, 0>("bare MFMA, 4 accumulators, short", w, 1000 / w);
+    run<4, 0>("bare MFMA, 4 accumulators, long (20 ms)", w, 60000 / w);
+  }
+  run<8, 0>("bare MFMA, 8 accumulators, long", 2, 30000);
+  for (int w = 1; w <= 3; ++w) {
+    run<8, 1>("12 ds_read_b128 then 24 MFMA, short", w, 1000 / w);
+    run<8, 1>("12 ds_read_b128 then 24 MFMA, long", w, 60000 / w);
+  }
+  for (int w = 1; w <= 2; ++w) {
+    run<8, 2>("12 ds_read_b128 between 24 MFMA (pipelined)", w, 20000 / w);
+    run<8, 3>("8 ds_read_b128 between 24 MFMA (pipelined)", w, 20000 / w);
+    run<8, 4>("24 ds_read_b64 then 24 MFMA", w, 20000 / w);
+  }
+  return 0;
+}
