@@ -540,6 +540,18 @@ static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
   RVC_HIP_CHECK(hipMemcpy(L.Wx_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 }
 
+void conv_layer_append_x3(ConvLayer& dst, const ConvLayer& extra) {
+  RVC_REQUIRE(dst.Wx_ && extra.Wx_ && dst.CoPx == extra.CoPx && dst.Co == extra.Co && dst.groups == 1 && extra.groups == 1 && extra.mode == 1 && extra.k == 1 &&
+              (extra.Ci & 15) == 0 && dst.seg2_chunks == 0 && !dst.bd_ == !extra.bd_, "conv_layer_append_x3: layers do not combine");
+  RVC_REQUIRE(!dst.bd_, "conv_layer_append_x3: bias-free layers only");
+  uint16_t* W2 = nullptr;
+  RVC_HIP_CHECK(hipMalloc(&W2, (size_t)(dst.wxBatch + extra.wxBatch) * sizeof(uint16_t)));
+  RVC_HIP_CHECK(hipMemcpy(W2, dst.Wx_, (size_t)dst.wxBatch * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+  RVC_HIP_CHECK(hipMemcpy(W2 + dst.wxBatch, extra.Wx_, (size_t)extra.wxBatch * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+  dev_free(dst.Wx_);
+  dst.Wx_ = W2; dst.seg2_chunks = extra.Ci / 16;
+}
+
 void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, int Ci, int k, int stride, int pad,
                        int dil, int groups) {
   RVC_REQUIRE(Co % groups == 0 && Ci % groups == 0, "groups must divide channels");

@@ -44,6 +44,8 @@ struct GemmSArgs {
   int ymargin;                              // output image: position n lives at row ymargin + n (= margin except for the swapped product)
   int zero_tail;                            // rows >= Co of the last stored 16-row chunk are written as zeros (swapped product: keys past the end)
   int row_fast;                             // tile numbering inside an XCD's run: 1 = row tiles fastest (the XCD owns a column range), 0 = column tiles fastest
+  int seg2_u, seg2_soff;                    // units >= seg2_u read a SECOND image (same rows per plane, same margin) at byte offset seg2_soff of Xs, one tap of offset 0 per
+                                            // chunk: two products over one accumulator; INT_MAX: none
 };
 
 // exact-erf GELU (torch F.gelu default), branch-free: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. ~1e-7 of the
@@ -168,9 +170,12 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
   const int KT = p.ktaps;
   const int wstep = p.CoPx * 64, cstep = (int)(p.xsTp * 64);
   int tap = u0 % KT;
+  bool seg2 = false;
   const bool arith = KT > 16;                                // long 1-D kernels: offsets by formula instead of the table
   auto tap_off = [&](int t) { return arith ? t * p.tdil - p.tpad : p.toff[t & 15]; };
   int soff_a = (int)((unsigned)grp * p.wg_bytes) + u0 * wstep, soff_c = (grp * p.cig_chunks + u0 / KT) * cstep, soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
+  if (u0 >= p.seg2_u) { seg2 = true; soff_b = p.seg2_soff + (u0 - p.seg2_u) * cstep + p.margin * 16; }     // (a K slice that starts inside the second image)
+  const int seg2_at = p.seg2_u - u0;                         // unit of this slice at which the second image starts
   int slw = 0, uw = 0;
   auto issue = [&]() {                                       // next UC units into slot slw; past the end the last unit is requested again
 #pragma unroll
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(c
       ++uw;
       if (uw < U1) {
         soff_a += wstep;
-        if (KT > 1) {
+        if (uw == seg2_at) { seg2 = true; soff_b = p.seg2_soff + p.margin * 16; }
+        else if (KT > 1 && !seg2) {
           ++tap;
           if (tap == KT) { tap = 0; soff_c += cstep; }
           soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
@@ -619,13 +625,16 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   RVC_REQUIRE(!e.ys_out || (e.ys_tp >= geom->margin + T + 704 && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
   RVC_REQUIRE((double)L.groups * L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.groups * L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
   const int G = L.mode == 1 ? L.groups : 1;
-  const double xs_bytes = (double)G * (L.Ci / 16) * 4.0 * (double)xsTp * 16.0, wx_bytes = (double)G * (L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0;
+  RVC_REQUIRE(L.seg2_chunks == 0 || (G == 1 && geom->seg2_off > 0), "conv_x3s_run: a layer with an appended product needs its second image");
+  const double xs_bytes = std::max((double)G * (L.Ci / 16) * 4.0 * (double)xsTp * 16.0, L.seg2_chunks ? (double)geom->seg2_off + (double)L.seg2_chunks * 4.0 * (double)xsTp * 16.0 : 0.0);
+  const double wx_bytes = (double)G * (L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0 + (double)L.seg2_chunks * 4.0 * (double)L.CoPx * 16.0;
   RVC_REQUIRE(G == 1 || (!e.ys_out || (L.Co & 15) == 0), "grouped layer: rows per group must be a multiple of 16 for the image output");
   RVC_REQUIRE(xs_bytes < 2147483648.0 && wx_bytes < 2147483648.0, "operand image exceeds 32-bit buffer addressing");
   GemmSArgs a{};
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.Xs = Xs; a.xsTp = xsTp;
   a.wx_bytes = (unsigned)wx_bytes; a.xs_bytes = (unsigned)xs_bytes;
-  a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps;
+  a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps + L.seg2_chunks;
+  a.seg2_u = L.seg2_chunks ? L.Ci / 16 * geom->ktaps : 0x7fffffff; a.seg2_soff = (int)geom->seg2_off;
   a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw;
   a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
   for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
@@ -664,7 +673,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
     // algorithmic bytes: the input image (4 B per element, like fp32), the outputs that are written, the residual, the weights
     const double bytes = 4.0 * ((double)L.Ci * T + (double)L.Co * T * ((Y ? 1.0 : 0.0) + (e.ys_out ? 1.0 : 0.0) + (e.R ? 1.0 : 0.0)) + (double)L.Co * L.Ci * geom->ktaps);
     const int id = AM == 2 ? (AN == 2 ? 3 : 5) : (AN == 2 ? 5 : 6);
-    conv_prof_end(tk, s, 2.0 * (double)G * L.Co * T * L.Ci * geom->ktaps, 14 + id, bytes * (G > 1 ? (double)G : 1.0), &pa, (long long)blocks, 4 << 4);
+    conv_prof_end(tk, s, 2.0 * (double)G * L.Co * T * (L.Ci * geom->ktaps + 16 * L.seg2_chunks), 14 + id, bytes * (G > 1 ? (double)G : 1.0), &pa, (long long)blocks, 4 << 4);
   }
 }
 
@@ -686,7 +695,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   GemmSArgs a{};
   a.Wx = Xs + (size_t)kSplitMargin * 16; a.CoPx = (int)xsTp; a.wx_bytes = (unsigned)xs_bytes - (unsigned)kSplitMargin * 16u;
   a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_) + (size_t)row0 * 16; a.xsTp = L.CoPx; a.xs_bytes = (unsigned)wx_bytes - (unsigned)row0 * 16u;
-  a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1;
+  a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1; a.seg2_u = 0x7fffffff;
   a.groups = 1; a.co_g = T; a.cig_chunks = L.Ci / 16; a.tdil = 1;
   a.Ys = Ys; a.ysTp = ysTp; a.act = ACT_NONE; a.out_scale = 1.f;
   a.Y = Yrm; a.ldY = ldYrm;                                    // fp32 out[t][j], row-major (the GRU's input projection)

@@ -25,6 +25,7 @@ struct TfcBlock {
   int in_c = 0, c = 0, f = 0;
   DevVec n1g, n1b, t0g, t0b, t3g, t3b, n2g, n2b;
   ConvLayer tfc1, tfc2, shortcut, lin1, lin2;
+  bool fused_sc = false;    // padded graph: the shortcut's weight image is appended to tfc2's - tfc2(x2) + shortcut(x) is ONE product over two images
 };
 struct MdxScale {
   std::vector<TfcBlock> blocks;
@@ -133,6 +134,16 @@ void mdx23_finalize(Mdx23* M) {
     for (auto& S : M->dec) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
     blocks_ok(M->bott.blocks);
     M->pad_ok = ok; M->img_base = nullptr;
+    static const bool fuse = !(getenv("RVC_MDX_FUSE_SC") && atoi(getenv("RVC_MDX_FUSE_SC")) == 0);
+    auto fuse_blocks = [&](std::vector<TfcBlock>& bs) {
+      for (TfcBlock& B : bs)
+        if (conv_x3s_eligible(B.shortcut) && B.shortcut.CoPx == B.tfc2.CoPx) { conv_layer_append_x3(B.tfc2, B.shortcut); B.fused_sc = true; }
+    };
+    if (ok && fuse) {
+      for (auto& S : M->enc) fuse_blocks(S.blocks);
+      for (auto& S : M->dec) fuse_blocks(S.blocks);
+      fuse_blocks(M->bott.blocks);
+    }
   }
   M->ts.clear();
   M->ready = true;
@@ -238,7 +249,7 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
 }
 // overlap-add of windowed inverse-FFT frames fr [n_fft][T] over the squared-window envelope, centre-trimmed (torch.istft, center=True):
 // out[i] = sum_m fr[i + n_fft / 2 - m * hop][m] / sum_m w^2[i + n_fft / 2 - m * hop]
-__global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict__ w, float* __restrict__ out, int n_fft, int hop, int T, long long L) {
+__global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict__ w, float* __restrict__ out, int n_fft, int hop, int T, long long L, long long ldf) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
   const long long p = i + n_fft / 2;
@@ -248,7 +259,7 @@ __global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict
   for (long long m = m0; m <= m1; ++m) {
     const long long j = p - m * hop;
     if (j < 0 || j >= n_fft) continue;
-    s += fr[j * T + m]; const float ww = w[j]; e = fmaf(ww, ww, e);
+    s += fr[j * ldf + m]; const float ww = w[j]; e = fmaf(ww, ww, e);
   }
   out[i] = s / e;
 }
@@ -300,27 +311,61 @@ __global__ __launch_bounds__(256) void inorm_part_rows_kernel(const float* __res
   }
   if (threadIdx.x == 0) { part[((long long)c * P + q) * 2] = ss[0]; part[((long long)c * P + q) * 2 + 1] = sq[0]; }
 }
+// The fold of inorm_fold_kernel inside the consumer (same order, same arithmetic: bit-identical): scale / shift of the channels [c0, c0 + nch) from the partial sums
+// into LDS - 4700 launches of a 5-us kernel per clip were 3 % of the separation.  Ends with a barrier.
+struct NormStat { const double* part; int P; double n; const float* gamma; const float* beta; int C; };
+constexpr int kNormParts = 16;                                // most parts per channel (stats_part)
+__device__ __forceinline__ void fold_to_lds(const NormStat& st, int c0, int nch, float* __restrict__ s_a, float* __restrict__ s_b) {
+  __shared__ double s_part[8 * kNormParts * 2];
+  const bool par = nch <= 8 && blockDim.x >= 8 * kNormParts;   // the loads of 8 channels' parts in one go; the sums below keep the part order
+  if (par) {
+    const int i = (int)threadIdx.x / st.P, q = (int)threadIdx.x - i * st.P;
+    if (i < nch && c0 + i < st.C) {
+      const double2 v = *reinterpret_cast<const double2*>(st.part + ((long long)(c0 + i) * st.P + q) * 2);
+      s_part[(i * kNormParts + q) * 2] = v.x; s_part[(i * kNormParts + q) * 2 + 1] = v.y;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nch; i += blockDim.x) {
+    const int c = c0 + i;
+    float a = 0.f, b = 0.f;
+    if (c < st.C) {
+      double s = 0.0, q = 0.0;
+      if (par) for (int p = 0; p < st.P; ++p) { s += s_part[(i * kNormParts + p) * 2]; q += s_part[(i * kNormParts + p) * 2 + 1]; }
+      else for (int p = 0; p < st.P; ++p) { s += st.part[((long long)c * st.P + p) * 2]; q += st.part[((long long)c * st.P + p) * 2 + 1]; }
+      const double m = s / st.n, var = q / st.n - m * m;
+      a = st.gamma[c] * (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)1e-5f));
+      b = st.beta[c] - (float)m * a;
+    }
+    s_a[i] = a; s_b[i] = b;
+  }
+  __syncthreads();
+}
 // gelu(x a + b) written as the split image (one thread = one position x 8 rows, consecutive threads consecutive positions).
 // COLCH false: the norm channel is the ROW - planes [rows][T], padded rows of padw positions whose two pad columns are written as zeros (the 3x3
 // convolution's horizontal zero padding).  COLCH true: the norm channel is the column group t / chdiv (the first TDF linear's output [f / bn][c H]).
-template <bool COLCH>
-__global__ __launch_bounds__(256) void inorm_apply_split_kernel(const float* __restrict__ x, long long ld, int rows, long long T, const float* __restrict__ sc,
-                                                                const float* __restrict__ sh, int chdiv, int padw, unsigned char* __restrict__ img, long long tp,
-                                                                int margin) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+// RAW: the plane as it is (no norm, no activation: the shortcut's input).
+template <bool COLCH, bool RAW = false>
+__global__ __launch_bounds__(256) void inorm_apply_split_kernel(const float* __restrict__ x, long long ld, int rows, long long T, const NormStat st, int chdiv, int padw,
+                                                                unsigned char* __restrict__ img, long long tp, int margin) {
+  __shared__ float s_a[COLCH ? 72 : 8], s_b[COLCH ? 72 : 8];
+  const long long t0 = (long long)blockIdx.x * 256, t = t0 + threadIdx.x;
   const int g = blockIdx.y;
+  const int cfirst = COLCH ? (int)((unsigned)t0 / (unsigned)chdiv) : g * 8;
+  if (!RAW) fold_to_lds(st, cfirst, COLCH ? (int)((unsigned)(t0 + 255) / (unsigned)chdiv) - cfirst + 1 : 8, s_a, s_b);      // (host: 256 / chdiv + 2 <= 72)
   if (t >= T) return;
   bool pad = false;
   if (padw > 0) { const unsigned w = (unsigned)t % (unsigned)padw; pad = (w == 0u || w == (unsigned)padw - 1u); }
   float a = 0.f, b = 0.f;
-  if (COLCH) { const int c = (int)((unsigned)t / (unsigned)chdiv); a = sc[c]; b = sh[c]; }
+  if (COLCH) { const int c = (int)((unsigned)t / (unsigned)chdiv) - cfirst; a = s_a[c]; b = s_b[c]; }
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int row = g * 8 + j;
     v[j] = 0.f;
     if (!pad && row < rows) {
-      if (!COLCH) { a = sc[row]; b = sh[row]; }
+      if (RAW) { v[j] = x[(long long)row * ld + t]; continue; }
+      if (!COLCH) { a = s_a[j]; b = s_b[j]; }
       v[j] = gelu_as(fmaf(x[(long long)row * ld + t], a, b));
     }
   }
@@ -328,15 +373,18 @@ __global__ __launch_bounds__(256) void inorm_apply_split_kernel(const float* __r
 }
 // The first TDF linear contracts over the bins of a row: it takes the image of the TRANSPOSED plane - chunk = 16 neighbouring bins, position = row
 // r = c H + h.  32 rows x 64 bins per workgroup: coalesced reads along the rows, turned through LDS, 16-byte image rows written along r.
-__global__ __launch_bounds__(256) void inorm_apply_tm_kernel(const float* __restrict__ x, int Wp, int W, int R, int H, int hshift, const float* __restrict__ sc,
-                                                             const float* __restrict__ sh, unsigned char* __restrict__ img, long long tp) {
+__global__ __launch_bounds__(256) void inorm_apply_tm_kernel(const float* __restrict__ x, int Wp, int W, int R, int H, int hshift, const NormStat st,
+                                                             unsigned char* __restrict__ img, long long tp) {
   __shared__ float tile[32][65];
+  __shared__ float s_a[32], s_b[32];
   const int w0 = blockIdx.x * 64, r0 = blockIdx.y * 32;
+  const int cfirst = r0 / H;
+  fold_to_lds(st, cfirst, (r0 + 31) / H - cfirst + 1, s_a, s_b);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int ri = i * 4 + (threadIdx.x >> 6), wi = threadIdx.x & 63, r = r0 + ri;
     float v = 0.f;
-    if (r < R && w0 + wi < W) { const int c = hshift >= 0 ? (r >> hshift) : (r / H); v = gelu_as(fmaf(x[(long long)r * Wp + 1 + w0 + wi], sc[c], sh[c])); }
+    if (r < R && w0 + wi < W) { const int c = (hshift >= 0 ? (r >> hshift) : (r / H)) - cfirst; v = gelu_as(fmaf(x[(long long)r * Wp + 1 + w0 + wi], s_a[c], s_b[c])); }
     tile[ri][wi] = v;
   }
   __syncthreads();
@@ -350,12 +398,13 @@ __global__ __launch_bounds__(256) void inorm_apply_tm_kernel(const float* __rest
 }
 // InstanceNorm + GELU + space-to-depth in front of the 2x2 stride-2 convolution: the image of the [4 C][H / 2][W / 2 + 2] tensor whose row
 // ci * 4 + dy * 2 + dx is the (dy, dx) phase of channel ci (the weight's own memory order); one thread = one half-resolution position x 2 channels
-__global__ __launch_bounds__(256) void inorm_apply_s2d_split_kernel(const float* __restrict__ x, long long TPin, int Wp, int C, int Ho, int Wo,
-                                                                    const float* __restrict__ sc, const float* __restrict__ sh, unsigned char* __restrict__ img,
-                                                                    long long tp, int margin) {
+__global__ __launch_bounds__(256) void inorm_apply_s2d_split_kernel(const float* __restrict__ x, long long TPin, int Wp, int C, int Ho, int Wo, const NormStat st,
+                                                                    unsigned char* __restrict__ img, long long tp, int margin) {
+  __shared__ float s_a[2], s_b[2];
   const int Wpo = Wo + 2;
   const long long P = (long long)Ho * Wpo, p = (long long)blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y;
+  fold_to_lds(st, 2 * g, 2, s_a, s_b);
   if (p >= P) return;
   const int y = (int)(p / Wpo), xq = (int)(p - (long long)y * Wpo);
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -364,7 +413,7 @@ __global__ __launch_bounds__(256) void inorm_apply_s2d_split_kernel(const float*
     for (int cc = 0; cc < 2; ++cc) {
       const int ch = 2 * g + cc;
       if (ch < C) {
-        const float a = sc[ch], b = sh[ch];
+        const float a = s_a[cc], b = s_b[cc];
         const float* src = x + (long long)ch * TPin + (long long)(2 * y) * Wp + 1 + 2 * (xq - 1);
         v[cc * 4 + 0] = gelu_as(fmaf(src[0], a, b)); v[cc * 4 + 1] = gelu_as(fmaf(src[1], a, b));
         v[cc * 4 + 2] = gelu_as(fmaf(src[Wp], a, b)); v[cc * 4 + 3] = gelu_as(fmaf(src[Wp + 1], a, b));
@@ -373,20 +422,27 @@ __global__ __launch_bounds__(256) void inorm_apply_s2d_split_kernel(const float*
   }
   split8_store(v, img, tp, margin + p, g);
 }
-// depth-to-space behind the 2x2 stride-2 transposed convolution, padded in and out: out[co][2 y + dy][1 + 2 x + dx] = in[co * 4 + dy * 2 + dx][y][1 + x]
-__global__ void d2s_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int Co, int H, int W) {
+// depth-to-space behind the 2x2 stride-2 transposed convolution, padded in and out: out[co][2 y + dy][1 + 2 x + dx] = in[co * 4 + dy * 2 + dx][y][1 + x],
+// as the fp32 plane and (img != null) as its raw image - the first half of the decoder block's concatenated input.  One thread = one position x 8 channels.
+__global__ __launch_bounds__(256) void d2s_pad_split_kernel(const float* __restrict__ in, float* __restrict__ out, int Co, int H, int W, unsigned char* __restrict__ img,
+                                                            long long tp, int margin) {
   const int Wpi = W + 2, Wpo = 2 * W + 2, Ho = 2 * H;
-  const long long n = (long long)Co * Ho * Wpo, st = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
-    const int xq = (int)(i % Wpo); long long r = i / Wpo;
-    const int yo = (int)(r % Ho); const int co = (int)(r / Ho);
-    float v = 0.f;
-    if (xq != 0 && xq != Wpo - 1) {
-      const int xo = xq - 1;
-      v = in[(((long long)co * 4 + (yo & 1) * 2 + (xo & 1)) * H + (yo >> 1)) * Wpi + 1 + (xo >> 1)];
+  const long long TPo = (long long)Ho * Wpo, p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (p >= TPo) return;
+  const int yo = (int)(p / Wpo), xq = (int)(p - (long long)yo * Wpo);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (xq != 0 && xq != Wpo - 1) {
+    const int xo = xq - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = g * 8 + j;
+      if (co < Co) v[j] = in[(((long long)co * 4 + (yo & 1) * 2 + (xo & 1)) * H + (yo >> 1)) * Wpi + 1 + (xo >> 1)];
     }
-    out[i] = v;
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (g * 8 + j < Co) out[(long long)(g * 8 + j) * TPo + p] = v[j];
+  if (img) split8_store(v, img, tp, margin + p, g);
 }
 // small levels (linears without a weight image): padded plane -> [W][R] with InstanceNorm + GELU, and [W][R] -> padded plane with the residual
 __global__ void tr2d_in_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int W, int Wp, int H, const float* __restrict__ sc, const float* __restrict__ sh) {
@@ -415,6 +471,36 @@ __global__ void tr2d_out_kernel(const float* __restrict__ in, float* __restrict_
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int c = c0 + j, r = r0 + threadIdx.x;
     if (c < R && r < W) { const long long o = (long long)c * Wp + 1 + r; out[o] = tile[threadIdx.x][j] + res[o]; }
+  }
+}
+
+// The DFT products read an 8192 x 8192 basis (268 MB as the bf16 hi / lo image) for T = 256 columns: one product over BOTH channels' frames (and one over the
+// four separated signals' spectra) reads it once instead of 2 (4) times.  frames2: out[j][a T + t] = reflect-padded audio[a][t hop + j - n_fft / 2];
+// cols_unbatch: out[b][r][t] = in[r][b T + t]; cols_batch: out[r][b T + t] = in[b][r][t]
+__global__ void frames2_kernel(const float* __restrict__ audio, float* __restrict__ out, long long L, int n_fft, int hop, int T) {
+  const long long n = (long long)n_fft * 2 * T, st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+    const int j = (int)(i / (2 * T)), at = (int)(i - (long long)j * 2 * T), a = at / T, t = at - a * T;
+    long long x = (long long)t * hop + j - n_fft / 2;
+    if (x < 0) x = -x;
+    if (x >= L) x = 2 * (L - 1) - x;
+    out[i] = audio[(long long)a * L + x];
+  }
+}
+__global__ void cols_unbatch_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int B, int T) {
+  const long long n = (long long)rows * B * T, st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+    const int t = (int)(i % T); long long q = i / T;
+    const int r = (int)(q % rows), b = (int)(q / rows);
+    out[i] = in[((long long)r * B + b) * T + t];
+  }
+}
+__global__ void cols_batch_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int B, int T) {
+  const long long n = (long long)rows * B * T, st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+    const int t = (int)(i % T); long long q = i / T;
+    const int b = (int)(q % B), r = (int)(q / B);
+    out[i] = in[((long long)b * rows + r) * T + t];
   }
 }
 
@@ -536,58 +622,70 @@ static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* au
   // ---- inverse STFT per source and channel
   for (int q = 0; q < S * 2; ++q) {
     conv1d_run(M->istft, s, K.t1 + (size_t)q * 2 * c.dim_f * T, T, T, fr, T, E0);              // [n_fft][T] windowed inverse FFT frames
-    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L);
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L, (long long)T);
   }
 }
 
 
 // ---------------------------------------------------------------------------------------------- the padded graph
 static int ilog2_exact(int v) { if (v <= 0 || (v & (v - 1))) return -1; int k = 0; while ((1 << k) < v) ++k; return k; }
-// statistics + fold: value (j, w) of channel c at x[c cs + j rs + w], j < rows, w < Wv
-static void stats_fold(hipStream_t s, const float* x, long long cs, long long rs, int C, int rows, int Wv, const float* g, const float* b, float* sc, float* sh) {
+// statistics, stage 1: value (j, w) of channel c at x[c cs + j rs + w], j < rows, w < Wv.  The consumer folds the parts itself (fold_to_lds); the parts live
+// in the stream's scratch until the next call.
+static NormStat stats_part(hipStream_t s, const float* x, long long cs, long long rs, int C, int rows, int Wv, const float* g, const float* b) {
   const long long per_c = (long long)rows * Wv;
-  int P = std::max(1, 2048 / C);
+  int P = std::min(kNormParts, std::max(1, 2048 / C));
   if (P > rows) P = rows;
   while (P > 1 && per_c / P < 4096) --P;
   double* part = (double*)stream_scratch(s, 12, (size_t)C * P * 2 * sizeof(double));
   hipLaunchKernelGGL(inorm_part_rows_kernel, dim3((unsigned)C, (unsigned)P), dim3(256), 0, s, x, cs, rs, rows, Wv, ilog2_exact(Wv), P, part);
-  hipLaunchKernelGGL(inorm_fold_kernel, dim3((unsigned)((C + 127) / 128)), dim3(128), 0, s, part, C, P, (double)per_c, g, b, 1e-5f, sc, sh);
+  return NormStat{part, P, (double)per_c, g, b, C};
 }
-struct PadLv { int C = 0, H = 0, W = 0, Wp = 0; long long TP = 0, tp = 0; SplitGeom g, g1; unsigned char* ia = nullptr; };
+static void stats_fold(hipStream_t s, const NormStat& st, float* sc, float* sh) {      // (the fp32 consumers of the small levels take folded vectors)
+  hipLaunchKernelGGL(inorm_fold_kernel, dim3((unsigned)((st.C + 127) / 128)), dim3(128), 0, s, st.part, st.C, st.P, st.n, st.gamma, st.beta, 1e-5f, sc, sh);
+}
+// ia: the conv-input image (norm + GELU applied); rin / rmid: raw images of a block's input / output (the fused shortcut's operand), ir: raw image of the
+// decoder's concatenated input [up-sampled | skip].  All four are neighbours in one allocation: the fused product addresses the raw image as an offset of ia.
+struct PadLv { int C = 0, H = 0, W = 0, Wp = 0; long long TP = 0, tp = 0; SplitGeom g, g1; unsigned char *ia = nullptr, *rin = nullptr, *rmid = nullptr, *ir = nullptr; };
+static size_t pad_img_bytes(int chans, const PadLv& L) { return (size_t)((chans + 15) / 16) * 4 * (size_t)L.tp * 16; }
 // plane [rows][H (W + 2)] -> the conv-input image of the level (pad columns zero)
-static void apply_plane(hipStream_t s, const float* x, int rows, const PadLv& L, const float* sc, const float* sh) {
-  hipLaunchKernelGGL(inorm_apply_split_kernel<false>, dim3((unsigned)((L.TP + 255) / 256), (unsigned)((rows + 7) / 8)), dim3(256), 0, s, x, L.TP, rows, L.TP, sc, sh, 1, L.Wp,
+static void apply_plane(hipStream_t s, const float* x, int rows, const PadLv& L, const NormStat& st) {
+  hipLaunchKernelGGL(inorm_apply_split_kernel<false>, dim3((unsigned)((L.TP + 255) / 256), (unsigned)((rows + 7) / 8)), dim3(256), 0, s, x, L.TP, rows, L.TP, st, 1, L.Wp,
                      L.ia, L.tp, L.g.margin);
 }
 
 // TFC_TDF.forward (tfc_tdf.py:137-144) over padded planes [c][H][W + 2]; the last block writes to `out`.  il / im: images of the two linears' inputs.
+// raw_in: raw image of x (null: none - the shortcuts run as launches of their own); raw_out: where the last block leaves the raw image of its output (or null).
 static void run_tfc_padded(const std::vector<TfcBlock>& blocks, hipStream_t s, const MdxScratch& K, const PadLv& L, unsigned char* il, unsigned char* im, const float* x,
-                           float* out, float* mid) {
+                           const unsigned char* raw_in, float* out, unsigned char* raw_out, float* mid) {
   const int H = L.H, W = L.W, Wp = L.Wp;
   const long long TP = L.TP;
   ConvEpilogue E0;
   const float* cur = x;
+  const unsigned char* raw_cur = raw_in;
   for (size_t i = 0; i < blocks.size(); ++i) {
     const TfcBlock& B = blocks[i];
-    float* dst = (i + 1 == blocks.size()) ? out : mid;
-    conv1d_run(B.shortcut, s, cur, TP, (int)TP, K.sbuf, TP, E0);                                // s = shortcut(x) (pad columns: whatever, zeroed with tfc2's)
-    stats_fold(s, cur + 1, TP, Wp, B.in_c, H, W, B.n1g.p, B.n1b.p, K.sc, K.sh);
-    apply_plane(s, cur, B.in_c, L, K.sc, K.sh);
+    const bool last = i + 1 == blocks.size();
+    float* dst = last ? out : mid;
+    const bool fused = B.fused_sc && raw_cur != nullptr;
+    RVC_REQUIRE(fused || !B.fused_sc, "run_tfc_padded: a block with a fused shortcut needs the raw image of its input");
+    if (!fused) conv1d_run(B.shortcut, s, cur, TP, (int)TP, K.sbuf, TP, E0);                    // s = shortcut(x) (pad columns: whatever, zeroed with tfc2's)
+    apply_plane(s, cur, B.in_c, L, stats_part(s, cur + 1, TP, Wp, B.in_c, H, W, B.n1g.p, B.n1b.p));
     conv_x3s_run(B.tfc1, s, L.ia, L.tp, (int)TP, K.t2, TP, E0, &L.g);                           // x1 = tfc1(x)
     // x2 = x1 + tdf(x1)
     const int R = B.c * H, fb = B.lin1.Co;
-    stats_fold(s, K.t2 + 1, TP, Wp, B.c, H, W, B.t0g.p, B.t0b.p, K.sc, K.sh);
+    const NormStat st0 = stats_part(s, K.t2 + 1, TP, Wp, B.c, H, W, B.t0g.p, B.t0b.p);
     float* x2;
-    if (il && conv_x3s_eligible(B.lin1) && conv_x3s_eligible(B.lin2) && (W & 15) == 0 && (fb & 15) == 0) {
+    if (il && conv_x3s_eligible(B.lin1) && conv_x3s_eligible(B.lin2) && (W & 15) == 0 && (fb & 15) == 0 && H >= 4) {
       const long long tpl = split_image_tp(R);
-      hipLaunchKernelGGL(inorm_apply_tm_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)((R + 31) / 32)), dim3(256), 0, s, K.t2, Wp, W, R, H, ilog2_exact(H), K.sc, K.sh, il, tpl);
+      hipLaunchKernelGGL(inorm_apply_tm_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)((R + 31) / 32)), dim3(256), 0, s, K.t2, Wp, W, R, H, ilog2_exact(H), st0, il, tpl);
       conv_x3s_run(B.lin1, s, il, tpl, R, K.t1, R, E0);                                         // [W / bn][R]
-      stats_fold(s, K.t1, H, R, B.c, fb, H, B.t3g.p, B.t3b.p, K.sc, K.sh);                      // channel c owns the columns [c H, (c + 1) H) of every row
+      const NormStat st3 = stats_part(s, K.t1, H, R, B.c, fb, H, B.t3g.p, B.t3b.p);             // channel c owns the columns [c H, (c + 1) H) of every row
       hipLaunchKernelGGL(inorm_apply_split_kernel<true>, dim3((unsigned)((R + 255) / 256), (unsigned)((fb + 7) / 8)), dim3(256), 0, s, K.t1, (long long)R, fb, (long long)R,
-                         K.sc, K.sh, H, 0, im, tpl, kSplitMargin);
+                         st3, H, 0, im, tpl, kSplitMargin);
       conv_x3s_run_swapped(B.lin2, 0, W, s, im, tpl, R, nullptr, 0, K.t3 + 1, Wp, K.t2 + 1, Wp);  // the swapped product lands in the plane layout, + x1
       x2 = K.t3;
     } else {
+      stats_fold(s, st0, K.sc, K.sh);
       hipLaunchKernelGGL(tr2d_in_kernel, dim3((unsigned)((W + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, s, K.t2, K.t3, R, W, Wp, H, K.sc, K.sh);   // [W][R]
       conv1d_run(B.lin1, s, K.t3, R, R, K.t1, R, E0);
       norm_gelu(s, K.t1, K.t1, fb, B.c, H, B.t3g.p, B.t3b.p, K.sc, K.sh);
@@ -595,11 +693,14 @@ static void run_tfc_padded(const std::vector<TfcBlock>& blocks, hipStream_t s, c
       hipLaunchKernelGGL(tr2d_out_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((W + 31) / 32)), dim3(32, 8), 0, s, K.t3, K.t1, K.t2, W, R, Wp);
       x2 = K.t1;
     }
-    stats_fold(s, x2 + 1, TP, Wp, B.c, H, W, B.n2g.p, B.n2b.p, K.sc, K.sh);
-    apply_plane(s, x2, B.c, L, K.sc, K.sh);
-    ConvEpilogue Er; Er.R = K.sbuf; Er.ldR = TP;
-    conv_x3s_run(B.tfc2, s, L.ia, L.tp, (int)TP, dst, TP, Er, &L.g);                            // tfc2(x2) + s, pad columns zero
-    cur = dst;
+    apply_plane(s, x2, B.c, L, stats_part(s, x2 + 1, TP, Wp, B.c, H, W, B.n2g.p, B.n2b.p));
+    ConvEpilogue Er;
+    SplitGeom g2 = L.g;
+    if (fused) g2.seg2_off = (long long)(raw_cur - L.ia); else { Er.R = K.sbuf; Er.ldR = TP; }
+    unsigned char* raw_dst = last ? raw_out : (raw_in ? ((i & 1) ? L.rin : L.rmid) : nullptr);  // (rin is free once block 0 has read it; the decoder's raw_in is ir)
+    if (raw_dst) { Er.ys_out = raw_dst; Er.ys_tp = L.tp; }
+    conv_x3s_run(B.tfc2, s, L.ia, L.tp, (int)TP, dst, TP, Er, &g2);                             // tfc2(x2) + shortcut(x), pad columns zero
+    cur = dst; raw_cur = raw_dst;
   }
 }
 
@@ -622,7 +723,12 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   for (int i = 0; i <= n; ++i) {
     int chans = i < n ? 2 * lv[(size_t)i].C : lv[(size_t)i].C;                                  // decoder input [up-sampled | skip]
     if (i > 0) chans = std::max(chans, 4 * lv[(size_t)i - 1].C);                                // space-to-depth rows of the level above
-    lv[(size_t)i].ia = A.alloc<unsigned char>((size_t)((chans + 15) / 16) * 4 * (size_t)lv[(size_t)i].tp * 16);
+    PadLv& P = lv[(size_t)i];
+    P.ia = A.alloc<unsigned char>(pad_img_bytes(chans, P));
+    P.rin = A.alloc<unsigned char>(pad_img_bytes(P.C, P));
+    P.rmid = A.alloc<unsigned char>(pad_img_bytes(P.C, P));
+    P.ir = i < n ? A.alloc<unsigned char>(pad_img_bytes(2 * P.C, P)) : nullptr;
+    RVC_REQUIRE((double)pad_img_bytes(chans, P) + 2.0 * (double)pad_img_bytes(P.C, P) + (double)pad_img_bytes(2 * P.C, P) < 2147483648.0, "a level's images exceed 32-bit buffer addressing");
   }
   const size_t img_bytes = A.off - img0;
   if (!dry && (M->img_base != A.base + img0 || M->img_gen != A.gen || M->img_bytes != img_bytes)) {
@@ -640,7 +746,7 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   }
   unsigned char* il = il_bytes ? A.alloc<unsigned char>(il_bytes) : nullptr;
   unsigned char* im = im_bytes ? A.alloc<unsigned char>(im_bytes) : nullptr;
-  float* fr = A.alloc<float>((size_t)c.n_fft * T);
+  float* fr = A.alloc<float>((size_t)c.n_fft * T * (size_t)std::max(2, 2 * S));      // frames of both channels / of every separated signal
   float* spec = A.alloc<float>((size_t)4 * c.dim_f * T);          // [ch][re | im][dim_f][T] = cac2cws view [16][f0][T]
   float* first = A.alloc<float>((size_t)c0 * FT);
   size_t big = 0, curmax = 0;
@@ -658,40 +764,42 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   float* cur = A.alloc<float>(curmax + 64);
   float* cur2 = A.alloc<float>(curmax + 64);
   if (dry) return;
-  // ---- STFT of both channels: frames (reflect-padded by n_fft / 2) x windowed DFT matrix
-  for (int a = 0; a < 2; ++a) {
-    frames(s, audio + (long long)a * L, fr, (int)L, c.n_fft, c.hop, c.n_fft / 2, T, 1);
-    conv1d_run(M->stft, s, fr, T, T, spec + (size_t)a * 2 * c.dim_f * T, T, E0);
-  }
+  // ---- STFT of both channels in one product: frames (reflect-padded by n_fft / 2) x windowed DFT matrix
+  hipLaunchKernelGGL(frames2_kernel, dim3(gridn((long long)c.n_fft * 2 * T)), dim3(256), 0, s, audio, fr, L, c.n_fft, c.hop, T);
+  conv1d_run(M->stft, s, fr, 2 * T, 2 * T, K.t1, 2 * T, E0);                                    // [2 dim_f][(a, t)]
+  hipLaunchKernelGGL(cols_unbatch_kernel, dim3(gridn((long long)4 * c.dim_f * T)), dim3(256), 0, s, K.t1, spec, 2 * c.dim_f, 2, T);
   conv1d_run(M->first, s, spec, FT, (int)FT, first, FT, E0);                                   // [c0][f0][T]
   transpose(s, first, x0 + 1, f0, T, T, lv[0].Wp, c0, FT, lv[0].TP);                            // [c0][T][f0 + 2]
+  hipLaunchKernelGGL((inorm_apply_split_kernel<false, true>), dim3((unsigned)((lv[0].TP + 255) / 256), (unsigned)((c0 + 7) / 8)), dim3(256), 0, s, x0, lv[0].TP, c0, lv[0].TP,
+                     NormStat{}, 1, lv[0].Wp, lv[0].rin, lv[0].tp, lv[0].g.margin);
   // ---- encoder
   const float* h = x0;
   for (int i = 0; i < n; ++i) {
     const PadLv& P = lv[(size_t)i]; const PadLv& Q = lv[(size_t)i + 1];
     float* skip = cat[(size_t)i] + (size_t)P.C * (size_t)P.TP;
-    run_tfc_padded(M->enc[(size_t)i].blocks, s, K, P, il, im, h, skip, mid);
-    stats_fold(s, skip + 1, P.TP, P.Wp, P.C, P.H, P.W, M->enc[(size_t)i].ng.p, M->enc[(size_t)i].nb.p, K.sc, K.sh);
-    hipLaunchKernelGGL(inorm_apply_s2d_split_kernel, dim3((unsigned)((Q.TP + 255) / 256), (unsigned)((4 * P.C + 7) / 8)), dim3(256), 0, s, skip, P.TP, P.Wp, P.C, Q.H, Q.W, K.sc,
-                       K.sh, Q.ia, Q.tp, Q.g.margin);
-    conv_x3s_run(M->enc[(size_t)i].rs, s, Q.ia, Q.tp, (int)Q.TP, cur, Q.TP, E0, &Q.g1);          // [C + g][H / 2][W / 2 + 2]
+    run_tfc_padded(M->enc[(size_t)i].blocks, s, K, P, il, im, h, P.rin, skip, P.ir + pad_img_bytes(P.C, P), mid);
+    const NormStat std_ = stats_part(s, skip + 1, P.TP, P.Wp, P.C, P.H, P.W, M->enc[(size_t)i].ng.p, M->enc[(size_t)i].nb.p);
+    hipLaunchKernelGGL(inorm_apply_s2d_split_kernel, dim3((unsigned)((Q.TP + 255) / 256), (unsigned)((4 * P.C + 7) / 8)), dim3(256), 0, s, skip, P.TP, P.Wp, P.C, Q.H, Q.W, std_,
+                       Q.ia, Q.tp, Q.g.margin);
+    ConvEpilogue Ed; Ed.ys_out = Q.rin; Ed.ys_tp = Q.tp;
+    conv_x3s_run(M->enc[(size_t)i].rs, s, Q.ia, Q.tp, (int)Q.TP, cur, Q.TP, Ed, &Q.g1);          // [C + g][H / 2][W / 2 + 2], plane + raw image
     h = cur; std::swap(cur, cur2);
   }
   {
     float* o = cur;
-    run_tfc_padded(M->bott.blocks, s, K, lv[(size_t)n], il, im, h, o, mid);
+    run_tfc_padded(M->bott.blocks, s, K, lv[(size_t)n], il, im, h, lv[(size_t)n].rin, o, nullptr, mid);
     h = o; std::swap(cur, cur2);
   }
   // ---- decoder
   for (int i = 0; i < n; ++i) {
     const int lo = n - 1 - i;                                       // output level
     const PadLv& Pi = lv[(size_t)lo + 1]; const PadLv& Po = lv[(size_t)lo];
-    stats_fold(s, h + 1, Pi.TP, Pi.Wp, Pi.C, Pi.H, Pi.W, M->dec[(size_t)i].ng.p, M->dec[(size_t)i].nb.p, K.sc, K.sh);
-    apply_plane(s, h, Pi.C, Pi, K.sc, K.sh);
+    apply_plane(s, h, Pi.C, Pi, stats_part(s, h + 1, Pi.TP, Pi.Wp, Pi.C, Pi.H, Pi.W, M->dec[(size_t)i].ng.p, M->dec[(size_t)i].nb.p));
     conv_x3s_run(M->dec[(size_t)i].rs, s, Pi.ia, Pi.tp, (int)Pi.TP, K.t2, Pi.TP, E0, &Pi.g1);   // [(co, dy, dx)][H][W + 2]
-    hipLaunchKernelGGL(d2s_pad_kernel, dim3(gridn((long long)Po.C * Po.TP)), dim3(256), 0, s, K.t2, cat[(size_t)lo], Po.C, Pi.H, Pi.W);
+    hipLaunchKernelGGL(d2s_pad_split_kernel, dim3((unsigned)((Po.TP + 255) / 256), (unsigned)((Po.C + 7) / 8)), dim3(256), 0, s, K.t2, cat[(size_t)lo], Po.C, Pi.H, Pi.W, Po.ir,
+                       Po.tp, Po.g.margin);
     float* o = cur;
-    run_tfc_padded(M->dec[(size_t)i].blocks, s, K, Po, il, im, cat[(size_t)lo], o, mid);
+    run_tfc_padded(M->dec[(size_t)i].blocks, s, K, Po, il, im, cat[(size_t)lo], Po.ir, o, nullptr, mid);
     h = o; std::swap(cur, cur2);
   }
   // ---- mask head: x^T * first_conv_out, cat(mix, x), 1x1 -> GELU -> 1x1
@@ -702,11 +810,12 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   ConvEpilogue Eg; Eg.act = ACT_GELU;
   conv1d_run(M->fin0, s, hc, FT, (int)FT, K.t2, FT, Eg);
   conv1d_run(M->fin2, s, K.t2, FT, (int)FT, K.t1, FT, E0);                                     // [S * 16][f0][T] = [S][ch][re | im][dim_f][T]
-  // ---- inverse STFT per source and channel
-  for (int q = 0; q < S * 2; ++q) {
-    conv1d_run(M->istft, s, K.t1 + (size_t)q * 2 * c.dim_f * T, T, T, fr, T, E0);              // [n_fft][T] windowed inverse FFT frames
-    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L);
-  }
+  // ---- inverse STFT of every source and channel in one product
+  const int Q = S * 2;
+  hipLaunchKernelGGL(cols_batch_kernel, dim3(gridn((long long)Q * 2 * c.dim_f * T)), dim3(256), 0, s, K.t1, K.t2, 2 * c.dim_f, Q, T);      // [2 dim_f][(q, t)]
+  conv1d_run(M->istft, s, K.t2, Q * T, Q * T, fr, Q * T, E0);                                    // [n_fft][(q, t)] windowed inverse FFT frames
+  for (int q = 0; q < Q; ++q)
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr + (size_t)q * T, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L, (long long)Q * T);
 }
 
 void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out) {

@@ -80,6 +80,8 @@ struct ConvLayer {
   int kh = 3, kw = 3, ph = 1, pwl = 1;   // 2-D window (conv2d_kx_layer_init; the 3 x 3 layers keep the defaults)
   uint16_t* Wx_ = nullptr; // bf16x3 split image (conv_x3.hip), null when the layer only runs on the fp32 kernel
   int CoPx = 0; long long wxBatch = 0;
+  int seg2_chunks = 0;     // conv_x3s only: 16-channel chunks of a SECOND input image appended to the reduction with tap offset 0 (conv_layer_append_x3:
+                           // MDX23C's tfc2(x2) + shortcut(x) as one product); the caller names that image in SplitGeom::seg2_off
 };
 
 struct ConvEpilogue {
@@ -151,7 +153,10 @@ bool conv_x3_enabled();                       // bf16x3 kernels not switched off
 // (im2col by address).  1-D "same" convolutions need nothing else (rows in front of position 0 / behind position T - 1 are the zero padding:
 // producers keep the margins zero).  2-D convolutions run over PADDED images: row pitch W + 2 with a zero column on either side, position
 // p = h (W + 2) + w + 1, T = H (W + 2); the kernel writes zeros into the pad columns of its outputs (SplitGeom from split_geom_2d).
-struct SplitGeom { int ktaps = 1; int toff[16] = {0}; int padw = 0; int margin = kSplitMargin; };
+struct SplitGeom { int ktaps = 1; int toff[16] = {0}; int padw = 0; int margin = kSplitMargin;
+                   long long seg2_off = 0; };   // byte offset (from the first image, < 2 GiB, same rows per plane and margin) of the second image of a layer with seg2_chunks
+// dst (a conv_x3s-eligible layer) += the k = 1 layer `extra` over a second input: the weight image of `extra` is appended as further units of dst's reduction
+void conv_layer_append_x3(ConvLayer& dst, const ConvLayer& extra);
 SplitGeom split_geom_2d(int Wd, int KH = 3, int KW = 3, int PH = 1, int PWL = 1);
 bool conv_x3s_eligible(const ConvLayer& L);
 void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
