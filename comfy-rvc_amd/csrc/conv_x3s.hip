@@ -567,8 +567,11 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int grou
   // measured on MI355X at N = 1599 (tools/bench_gemm.py, profiles/r3b_bench_gemm.txt): 768 -> 3072 128 x 64 35 us (64 x 128 the same, 128 x 128 38),
   // 768 -> 2304 128 x 64 28 us, 768 -> 768 64 x 64 16.3 us un-split (17.6 split in two), 3072 -> 768 64 x 64 split in two 37.8 us (128 x 64 in three 39.0)
   AM = 2; AN = 2;
-  if (tiles(AM, AN) < target) AN = 1;
-  if (tiles(AM, AN) < target) AM = 1;
+  // (deep reductions - MDX23C's 3 x 3 layers at 384+ channels, 216+ units - keep the 128 x 128 tile from one tile per CU on: 384 -> 384 over 64 x 258 positions
+  //  143 us on 387 tiles against 168 on 774 of 128 x 64; the transformer projections above have fewer tiles or shorter reductions and are not touched)
+  const bool deep = units >= 128 && groups == 1 && tiles(2, 2) >= 256;
+  if (!deep && tiles(AM, AN) < target) AN = 1;
+  if (!deep && tiles(AM, AN) < target) AM = 1;
   if (groups > 1) AM = 1;                                    // (a group's rows fit one 64-row tile: pack_x3_grouped)
   if (f_am && groups == 1) AM = f_am;
   if (f_an) AN = f_an;

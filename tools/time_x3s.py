@@ -8,7 +8,8 @@ from comfy_rvc_amd import _lib as L
 L.get_ctx(0)
 SHAPES = [("hubert ffn1 768->3072", 768, 3072, 1599, 0), ("hubert ffn2 3072->768", 3072, 768, 1599, 0), ("hubert qkv 768->2304", 768, 2304, 1599, 0),
           ("hubert out 768->768", 768, 768, 1599, 0), ("flow 192->192", 192, 192, 3198, 0),
-          ("rmvpe L5 512 3x3", 512, 512, 101 * 6, 4), ("rmvpe L4 256 3x3", 256, 256, 202 * 10, 8), ("rmvpe L3 128 3x3", 128, 128, 404 * 18, 16)]
+          ("rmvpe L5 512 3x3", 512, 512, 101 * 6, 4), ("rmvpe L4 256 3x3", 256, 256, 202 * 10, 8), ("rmvpe L3 128 3x3", 128, 128, 404 * 18, 16),
+          ("mdx L0 128 3x3", 128, 128, 256 * 1026, 1024), ("mdx L1 256 3x3", 256, 256, 128 * 514, 512), ("mdx L2 384 3x3", 384, 384, 64 * 258, 256)]
 sel = sys.argv[1:]
 NL = int(os.environ.get("BENCH_NLAYERS", "12"))
 for name, Ci, Co, T, w2d in SHAPES:
