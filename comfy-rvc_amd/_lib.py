@@ -137,6 +137,8 @@ SIGNATURES = {
     "rvc_op_layernorm_c_split": (c_int, [c_void_p] * 6 + [c_int, c_int]),
     "rvc_op_conv3_small": (c_int, [c_void_p] * 7 + [c_int] * 6),
     "rvc_op_gemm_split_swapped": (c_int, [c_void_p] * 4 + [c_int] * 5),
+    "rvc_op_conv2d3x3_plus_1x1": (c_int, [c_void_p] * 7 + [c_int] * 6),
+    "rvc_op_gemm_split_swapped_res": (c_int, [c_void_p] * 5 + [c_int] * 5),
     "rvc_op_attention_rel": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p]),
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),
     "rvc_resample": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),

@@ -421,6 +421,63 @@ int rvc_op_gemm_split_swapped(void* stream, const float* x, const float* w, floa
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_conv2d3x3_plus_1x1(void* stream, const float* x1, const float* w1, const float* x2, const float* w2, float* y, float* y_img_f32, int Ci1, int Ci2, int Co, int H, int W,
+                              int ksplit) {
+  RVC_TRY
+  RVC_REQUIRE(x1 && w1 && x2 && w2 && y && Ci1 > 0 && Ci2 > 0 && Co > 0 && H > 0 && W > 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L1, L2;
+  { ConvBuildScope scope(2); conv2d3x3_layer_init(L1, w1, nullptr, Co, Ci1); conv1d_layer_init(L2, w2, nullptr, Co, Ci2, 1, 1, 0, 1, 1); }
+  unsigned char* img = nullptr; unsigned char* yimg = nullptr; float* yp = nullptr;
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L1) && conv_x3s_eligible(L2), "layers not eligible for the split-resident GEMM (channels % 16, Co >= 32)");
+    conv_layer_append_x3(L1, L2);
+    SplitGeom g = split_geom_2d(W);
+    const long long TP = (long long)H * (W + 2), tp = ((long long)g.margin + TP + std::max(704, g.margin) + 63) & ~63LL;
+    const size_t b1 = (size_t)(Ci1 / 16) * 4 * (size_t)tp * 16, b2 = (size_t)(Ci2 / 16) * 4 * (size_t)tp * 16, bo = (size_t)((Co + 15) / 16) * 4 * (size_t)tp * 16;
+    RVC_HIP_CHECK(hipMalloc(&img, b1 + b2)); RVC_HIP_CHECK(hipMemsetAsync(img, 0, b1 + b2, s));      // zero margins: the vertical zero padding
+    RVC_HIP_CHECK(hipMalloc(&yp, (size_t)Co * TP * sizeof(float)));
+    if (y_img_f32) { RVC_HIP_CHECK(hipMalloc(&yimg, bo)); RVC_HIP_CHECK(hipMemsetAsync(yimg, 0xff, bo, s)); }
+    pad2d_split(s, x1, (long long)H * W, Ci1, H, W, nullptr, 0, img, tp, g.margin);
+    pad2d_split(s, x2, (long long)H * W, Ci2, H, W, nullptr, 0, img + b1, tp, g.margin);
+    g.seg2_off = (long long)b1;
+    ConvEpilogue e;
+    if (yimg) { e.ys_out = yimg; e.ys_tp = tp; }
+    conv_x3s_force(ksplit, 0, 0);
+    try { conv_x3s_run(L1, s, img, tp, (int)TP, yp, TP, e, &g); } catch (...) { conv_x3s_force(0, 0, 0); throw; }
+    conv_x3s_force(0, 0, 0);
+    unpad2d(s, yp, TP, Co, H, W, y, (long long)H * W);
+    if (yimg) {                                                 // the raw image of the output, read back through the padded layout
+      split_image_to_f32(s, yimg + (size_t)(g.margin - kSplitMargin) * 16, tp, Co, (int)TP, yp, TP);
+      unpad2d(s, yp, TP, Co, H, W, y_img_f32, (long long)H * W);
+    }
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (img) (void)hipFree(img); if (yimg) (void)hipFree(yimg); if (yp) (void)hipFree(yp); conv_layer_free(L1); conv_layer_free(L2); throw; }
+  (void)hipFree(img); if (yimg) (void)hipFree(yimg); (void)hipFree(yp);
+  conv_layer_free(L1); conv_layer_free(L2);
+  RVC_CATCH
+}
+int rvc_op_gemm_split_swapped_res(void* stream, const float* x, const float* w, const float* res, float* y, int Ci, int Co, int T, int ld, int off) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && res && y && Ci > 0 && Co > 0 && T > 0 && ld >= Co + off && off >= 0, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, nullptr, Co, Ci, 1, 1, 0, 1, 1); }
+  unsigned char* xs = nullptr;
+  try {
+    const long long tp = split_image_tp(T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0, split_image_bytes(Ci, T), s));
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    conv_x3s_run_swapped(L, 0, Co, s, xs, tp, T, nullptr, 0, y + off, ld, res + off, ld);      // y[t][off + j] = sum_c x[c][t] w[j][c] + res[t][off + j]
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); conv_layer_free(L); throw; }
+  (void)hipFree(xs);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_attention_split(void* stream, const float* q, const float* k, const float* v, const float* bv, float* out, float* out_img_f32, int heads, int T) {
   RVC_TRY
   RVC_REQUIRE(q && k && v && (out || out_img_f32) && heads > 0 && T > 0, "bad argument");

@@ -315,6 +315,13 @@ int rvc_op_conv3_small(void* stream, const float* x_dev, const float* w_host, co
 /* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
  * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
 int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);
+/* Test ops of the two-image split-resident product (MDX23C, csrc/model_mdx23.hip: reference lib/karafan/tfc_tdf.py:137-144, `s = shortcut(x) ... x = tfc2(x) + s`):
+ * y = conv3x3(x1, w1 [Co][Ci1][3][3], zero padding) + conv1x1(x2, w2 [Co][Ci2]) as ONE launch over the padded images of x1 and x2 (plain [C][H][W] tensors in
+ * and out; y_img_f32: the raw output image written beside it, read back as fp32, or null); and the swapped product with a residual in the row-major layout,
+ * y[t][off + j] = sum_c x[c][t] w[j][c] + res[t][off + j] with row pitch ld (tfc_tdf.py:142, `x = x + self.tdf(x)`). */
+int rvc_op_conv2d3x3_plus_1x1(void* stream, const float* x1_dev, const float* w1_host, const float* x2_dev, const float* w2_host, float* y_dev, float* y_img_f32_dev,
+                              int Ci1, int Ci2, int Co, int H, int W, int ksplit);
+int rvc_op_gemm_split_swapped_res(void* stream, const float* x_dev, const float* w_host, const float* res_dev, float* y_dev, int Ci, int Co, int T, int ld, int off);
 int rvc_op_attention_rel(void* stream, const float* q_dev, const float* k_dev, const float* v_rm_dev, const float* bv_dev, const float* rel_dev,
                          float* pb_dev, float* out_dev, int heads, int T, const float* ek_dev, const float* ev_dev);
 int rvc_op_layernorm_c(void* stream, const float* x_dev, const float* res_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,

@@ -434,6 +434,40 @@ def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
     assert torch.equal(y[T:], torch.zeros(T64 - T, rows, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("Ci,Co,T,ld,off", [(256, 1024, 700, 1026, 1), (32, 128, 333, 130, 1), (64, 192, 129, 192, 0)])
+def test_gemm_split_swapped_product_with_residual(L, Ci, Co, T, ld, off):
+    """y[t][off + j] = sum_c x[c][t] w[j][c] + res[t][off + j], rows of pitch ld (MDX23C's second TDF linear lands in the padded plane layout with
+    x1 added: tfc_tdf.py:142): against float64; the columns outside [off, off + Co) keep what they held."""
+    g = torch.Generator().manual_seed(9 + T)
+    x = torch.randn(Ci, T, generator=g); w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci); r = torch.randn(T, ld, generator=g)
+    y = torch.full((T, ld), 7.0, device="cuda")
+    xd = dev(x); rd = dev(r); wh = w.contiguous()
+    L.check(L.lib.rvc_op_gemm_split_swapped_res(None, L.ptr(xd), wh.data_ptr(), L.ptr(rd), L.ptr(y), Ci, Co, T, ld, off))
+    torch.cuda.synchronize()
+    got = y.cpu().double()
+    ref = x.double().t() @ w.double().t() + r.double()[:, off:off + Co]
+    assert rel_err(got[:, off:off + Co], ref) < 2e-5
+    keep = torch.ones(ld, dtype=torch.bool); keep[off:off + Co] = False
+    assert torch.equal(got[:, keep], torch.full((T, int(keep.sum())), 7.0, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("Ci1,Ci2,Co,H,W,ksplit", [(128, 128, 128, 12, 64, 0), (64, 128, 64, 9, 30, 0), (48, 96, 48, 5, 16, 0), (256, 256, 256, 4, 16, 4), (256, 512, 256, 4, 16, 8), (256, 512, 256, 4, 16, 11)])
+def test_two_image_product_conv3x3_plus_1x1(L, Ci1, Ci2, Co, H, W, ksplit):
+    """conv3x3(x1) + conv1x1(x2) as ONE split-resident product over two padded images (MDX23C's tfc2(x) + shortcut(x0), tfc_tdf.py:137-144): the second
+    image's chunks are further units of the reduction with tap offset 0 - also when a K slice starts inside the second image (ksplit) - and the raw
+    image written beside the fp32 output holds the same values (bf16 hi + lo: 2^-16 relative)."""
+    g = torch.Generator().manual_seed(Ci1 + W)
+    x1 = torch.randn(Ci1, H, W, generator=g); x2 = torch.randn(Ci2, H, W, generator=g)
+    w1 = torch.randn(Co, Ci1, 3, 3, generator=g) / np.sqrt(Ci1 * 9); w2 = torch.randn(Co, Ci2, generator=g) / np.sqrt(Ci2)
+    y = torch.full((Co, H, W), 5.0, device="cuda"); yi = torch.full((Co, H, W), 5.0, device="cuda")
+    x1d = dev(x1); x2d = dev(x2)
+    L.check(L.lib.rvc_op_conv2d3x3_plus_1x1(None, L.ptr(x1d), w1.contiguous().data_ptr(), L.ptr(x2d), w2.contiguous().data_ptr(), L.ptr(y), L.ptr(yi), Ci1, Ci2, Co, H, W, ksplit))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x1.double()[None], w1.double(), padding=1)[0] + torch.einsum("oc,chw->ohw", w2.double(), x2.double())
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+    assert rel_err(yi.cpu().double(), y.cpu().double()) < 4e-5
+
+
 @pytest.mark.parametrize("heads,T", [(2, 3001), (2, 150), (2, 20), (3, 129), (2, 5)])
 def test_fused_relative_attention(L, heads, T):
     """The text encoder's windowed relative-position attention in one kernel (reference attentions.py:230-267): scores of keys within
