@@ -1,5 +1,4 @@
 #!/bin/bash
-# scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_hip_ops.py -x -q -k "two_image or swapped" 2>&1 | tail -8
+timeout 600 python tools/gpu_exp.py 2>&1 | grep -v amdgpu.ids
