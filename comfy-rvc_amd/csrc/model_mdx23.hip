@@ -249,7 +249,8 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
 }
 // overlap-add of windowed inverse-FFT frames fr [n_fft][T] over the squared-window envelope, centre-trimmed (torch.istft, center=True):
 // out[i] = sum_m fr[i + n_fft / 2 - m * hop][m] / sum_m w^2[i + n_fft / 2 - m * hop]
-__global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict__ w, float* __restrict__ out, int n_fft, int hop, int T, long long L, long long ldf) {
+__global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict__ w, float* __restrict__ out, int n_fft, int hop, int T, long long L, long long ldf,
+                           int accumulate) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
   const long long p = i + n_fft / 2;
@@ -261,7 +262,9 @@ __global__ void ola_kernel(const float* __restrict__ fr, const float* __restrict
     if (j < 0 || j >= n_fft) continue;
     s += fr[j * ldf + m]; const float ww = w[j]; e = fmaf(ww, ww, e);
   }
-  out[i] = s / e;
+  float v = s / e;
+  if (accumulate) { if (v != v) v = 0.f; v += out[i]; }      // demix_mdxv3: X[..., window] += nan_to_num(chunk), chunks in stream order
+  out[i] = v;
 }
 
 
@@ -477,14 +480,14 @@ __global__ void tr2d_out_kernel(const float* __restrict__ in, float* __restrict_
 // The DFT products read an 8192 x 8192 basis (268 MB as the bf16 hi / lo image) for T = 256 columns: one product over BOTH channels' frames (and one over the
 // four separated signals' spectra) reads it once instead of 2 (4) times.  frames2: out[j][a T + t] = reflect-padded audio[a][t hop + j - n_fft / 2];
 // cols_unbatch: out[b][r][t] = in[r][b T + t]; cols_batch: out[r][b T + t] = in[b][r][t]
-__global__ void frames2_kernel(const float* __restrict__ audio, float* __restrict__ out, long long L, int n_fft, int hop, int T) {
+__global__ void frames2_kernel(const float* __restrict__ audio, long long ld, float* __restrict__ out, long long L, int n_fft, int hop, int T) {
   const long long n = (long long)n_fft * 2 * T, st = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
     const int j = (int)(i / (2 * T)), at = (int)(i - (long long)j * 2 * T), a = at / T, t = at - a * T;
     long long x = (long long)t * hop + j - n_fft / 2;
     if (x < 0) x = -x;
     if (x >= L) x = 2 * (L - 1) - x;
-    out[i] = audio[(long long)a * L + x];
+    out[i] = audio[(long long)a * ld + x];
   }
 }
 __global__ void cols_unbatch_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int B, int T) {
@@ -519,6 +522,9 @@ static void tr2d(hipStream_t s, const float* in, float* out, const float* res, i
   hipLaunchKernelGGL(tr2d_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, s, in, out, res, R, C);
 }
 
+// where a chunk comes from and goes to: rows of pitch ld_in / ld_out (a window of the whole padded mix / of the accumulator of demix_mdxv3's overlap-add,
+// or a free-standing chunk); accumulate: out += result with NaN as zero (upstream's nan_to_num in front of the accumulation)
+struct MdxIO { long long ld_in, ld_out; int accumulate; };
 // scratch planes shared by every block (sized for the largest scale)
 struct MdxScratch { float *t1, *t2, *t3, *sbuf, *sc, *sh; };
 
@@ -548,7 +554,7 @@ static void run_tfc(const std::vector<TfcBlock>& blocks, hipStream_t s, const Md
   }
 }
 
-static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out) {
+static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out, const MdxIO& io) {
   const rvc_mdx23_config& c = M->cfg;
   const bool dry = A.dry;
   const int T = c.dim_t, k = c.num_subbands, f0 = c.dim_f / k, n = c.num_scales, g = c.growth, S = c.num_targets;
@@ -577,7 +583,7 @@ static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* au
   if (dry) return;
   // ---- STFT of both channels: frames (reflect-padded by n_fft / 2) x windowed DFT matrix
   for (int a = 0; a < 2; ++a) {
-    frames(s, audio + (long long)a * L, fr, (int)L, c.n_fft, c.hop, c.n_fft / 2, T, 1);
+    frames(s, audio + (long long)a * io.ld_in, fr, (int)L, c.n_fft, c.hop, c.n_fft / 2, T, 1);
     conv1d_run(M->stft, s, fr, T, T, spec + (size_t)a * 2 * c.dim_f * T, T, E0);
   }
   conv1d_run(M->first, s, spec, FT, (int)FT, first, FT, E0);                                   // [c0][f0][T]
@@ -622,7 +628,7 @@ static void mdx23_graph_plain(Mdx23* M, hipStream_t s, Arena& A, const float* au
   // ---- inverse STFT per source and channel
   for (int q = 0; q < S * 2; ++q) {
     conv1d_run(M->istft, s, K.t1 + (size_t)q * 2 * c.dim_f * T, T, T, fr, T, E0);              // [n_fft][T] windowed inverse FFT frames
-    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L, (long long)T);
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr, M->window.p, out + (long long)q * io.ld_out, c.n_fft, c.hop, T, L, (long long)T, io.accumulate);
   }
 }
 
@@ -704,7 +710,7 @@ static void run_tfc_padded(const std::vector<TfcBlock>& blocks, hipStream_t s, c
   }
 }
 
-static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out) {
+static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out, const MdxIO& io) {
   const rvc_mdx23_config& c = M->cfg;
   const bool dry = A.dry;
   const int T = c.dim_t, k = c.num_subbands, f0 = c.dim_f / k, n = c.num_scales, g = c.growth, S = c.num_targets, bn = c.bottleneck;
@@ -765,7 +771,7 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   float* cur2 = A.alloc<float>(curmax + 64);
   if (dry) return;
   // ---- STFT of both channels in one product: frames (reflect-padded by n_fft / 2) x windowed DFT matrix
-  hipLaunchKernelGGL(frames2_kernel, dim3(gridn((long long)c.n_fft * 2 * T)), dim3(256), 0, s, audio, fr, L, c.n_fft, c.hop, T);
+  hipLaunchKernelGGL(frames2_kernel, dim3(gridn((long long)c.n_fft * 2 * T)), dim3(256), 0, s, audio, io.ld_in, fr, L, c.n_fft, c.hop, T);
   conv1d_run(M->stft, s, fr, 2 * T, 2 * T, K.t1, 2 * T, E0);                                    // [2 dim_f][(a, t)]
   hipLaunchKernelGGL(cols_unbatch_kernel, dim3(gridn((long long)4 * c.dim_f * T)), dim3(256), 0, s, K.t1, spec, 2 * c.dim_f, 2, T);
   conv1d_run(M->first, s, spec, FT, (int)FT, first, FT, E0);                                   // [c0][f0][T]
@@ -815,19 +821,38 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
   hipLaunchKernelGGL(cols_batch_kernel, dim3(gridn((long long)Q * 2 * c.dim_f * T)), dim3(256), 0, s, K.t1, K.t2, 2 * c.dim_f, Q, T);      // [2 dim_f][(q, t)]
   conv1d_run(M->istft, s, K.t2, Q * T, Q * T, fr, Q * T, E0);                                    // [n_fft][(q, t)] windowed inverse FFT frames
   for (int q = 0; q < Q; ++q)
-    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr + (size_t)q * T, M->window.p, out + (long long)q * L, c.n_fft, c.hop, T, L, (long long)Q * T);
+    hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr + (size_t)q * T, M->window.p, out + (long long)q * io.ld_out, c.n_fft, c.hop, T, L, (long long)Q * T, io.accumulate);
 }
 
-void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out) {
-  RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
-  RVC_REQUIRE(L == (long long)M->cfg.hop * (M->cfg.dim_t - 1), "a chunk is hop * (dim_t - 1) samples per channel");
+static void mdx23_chunk(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out, const MdxIO& io) {
   Arena& A = M->arena;
   for (int pass = 0; pass < 2; ++pass) {
     A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
-    if (M->pad_ok) mdx23_graph_padded(M, s, A, audio, L, out); else mdx23_graph_plain(M, s, A, audio, L, out);
+    if (M->pad_ok) mdx23_graph_padded(M, s, A, audio, L, out, io); else mdx23_graph_plain(M, s, A, audio, L, out, io);
     if (pass == 0) A.ensure(A.peak);
   }
   A.dry = false;
+}
+void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out) {
+  RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
+  RVC_REQUIRE(L == (long long)M->cfg.hop * (M->cfg.dim_t - 1), "a chunk is hop * (dim_t - 1) samples per channel");
+  mdx23_chunk(M, s, audio, L, out, MdxIO{L, L, 0});
+}
+__global__ void div_kernel(float* __restrict__ x, long long n, float d) {
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) x[i] = x[i] / d;
+}
+// demix_mdxv3's chunk loop on the device (reference lib/karafan/inference.py:52-66): chunks of C = hop (dim_t - 1) samples every `step` samples of the zero-padded mix
+// [2][Lp]; every chunk's separated signals are added into acc [S][2][Lp] at the chunk's offset (NaN as zero) in chunk order - the reference's own order of fp32
+// additions - and the sum is divided by `overlap` at the end.  The network reads its window of the mix in place and its inverse STFT adds into acc: no chunk copies.
+void mdx23_demix(Mdx23* M, hipStream_t s, const float* mix, long long Lp, long long step, long long n_chunks, float overlap, float* acc) {
+  RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
+  const long long C = (long long)M->cfg.hop * (M->cfg.dim_t - 1);
+  RVC_REQUIRE(step > 0 && n_chunks > 0 && (n_chunks - 1) * step + C <= Lp && overlap > 0.f, "demix: the last chunk must end inside the padded mix");
+  const long long n = (long long)M->cfg.num_targets * 2 * Lp;
+  RVC_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)n * sizeof(float), s));
+  for (long long c = 0; c < n_chunks; ++c) mdx23_chunk(M, s, mix + c * step, C, acc + c * step, MdxIO{Lp, Lp, 1});
+  hipLaunchKernelGGL(div_kernel, dim3(gridn(n)), dim3(256), 0, s, acc, n, overlap);
 }
 size_t mdx23_workspace(const Mdx23* M) { return M->arena.cap; }
 

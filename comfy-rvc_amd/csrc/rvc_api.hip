@@ -207,6 +207,13 @@ int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk, int64_t L,
   check_launch();
   RVC_CATCH
 }
+int rvc_mdx23_demix(rvc_mdx23* m, void* stream, const float* mix, int64_t Lp, int64_t step, int64_t n_chunks, float overlap, float* acc) {
+  RVC_TRY
+  RVC_REQUIRE(m && mix && acc, "null argument");
+  mdx23_demix(m->m, (hipStream_t)stream, mix, Lp, step, n_chunks, overlap, acc);
+  check_launch();
+  RVC_CATCH
+}
 
 // ------------------------------------------------------------------------------------------------ synth
 int rvc_synth_create(rvc_ctx* ctx, const rvc_synth_config* cfg, rvc_synth** out) {

@@ -91,3 +91,14 @@ class TFC_TDF_net:
             for b in range(x.shape[0]):
                 _lib.check(_lib.lib.rvc_mdx23_forward(self._h, _lib.current_stream(), _lib.ptr(x[b]), self.chunk_size, _lib.ptr(out[b])))
         return out if S > 1 else out[:, 0]
+
+    def demix_device(self, mix, step, n_chunks, overlap):
+        """The chunk loop of demix_mdxv3 (reference lib/karafan/inference.py:52-66) behind one C call: mix [2, Lp] device tensor (already zero-padded) ->
+        [S, 2, Lp] = sum over chunks (every `step` samples, in order, NaN as zero) of the separated chunk at its offset, divided by `overlap`."""
+        assert self._ready, "load_state_dict first"
+        mix = mix.to(self.device, torch.float32).contiguous()
+        assert mix.dim() == 2 and mix.shape[0] == 2
+        acc = torch.empty(self.num_target_instruments, 2, mix.shape[1], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.rvc_mdx23_demix(self._h, _lib.current_stream(), _lib.ptr(mix), int(mix.shape[1]), int(step), int(n_chunks), float(overlap), _lib.ptr(acc)))
+        return acc

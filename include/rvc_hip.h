@@ -140,6 +140,10 @@ int rvc_mdx23_finalize(rvc_mdx23* m);
 int rvc_mdx23_destroy(rvc_mdx23* m);
 /* chunk_dev float32 [2][L] with L = hop * (dim_t - 1) -> out_dev [num_targets][2][L] */
 int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk_dev, int64_t L, float* out_dev);
+/* The chunk loop of demix_mdxv3 (reference lib/karafan/inference.py:52-66) in one call: n_chunks chunks of C = hop (dim_t - 1) samples every `step` samples of the
+ * zero-padded stereo mix mix_dev [2][Lp] ((n_chunks - 1) step + C <= Lp); each chunk's separated signals are added (NaN as zero) into acc_dev [S][2][Lp] at the
+ * chunk's offset, in chunk order, and the sum is divided by `overlap`.  acc_dev is overwritten.  The caller pads the mix and trims the result as the reference does. */
+int rvc_mdx23_demix(rvc_mdx23* m, void* stream, const float* mix_dev, int64_t Lp, int64_t step, int64_t n_chunks, float overlap, float* acc_dev);
 
 /* ------------------------------------------------------------------ synthesizer */
 typedef struct rvc_synth_config {   /* the fields of cpt["config"] that the inference graph needs */
