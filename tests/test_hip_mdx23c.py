@@ -57,6 +57,34 @@ def test_mdx23c_other_geometry_matches_oracle():
     assert rel_err(net(x[None])[0].cpu().numpy(), ref) < 1e-3
 
 
+_ALT_GRAPH = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from conftest import golden, rel_err
+from comfy_rvc_amd import synthetic as S
+from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
+cfg = S.mdx23c_config(**S.MDX23C_SMALL)
+net = TFC_TDF_net(cfg); net.load_state_dict(S.mdx23c_state_dict(cfg, 0))
+g = golden("mdx23c_small.npz")
+e1 = rel_err(net(g["x"][None])[0].cpu().numpy(), g["out"])
+est = demix_mdxv3(g["clip"], net, net.device, cfg, int(g["overlap"]))
+e2 = rel_err(np.stack([est["Vocals"], est["Instrumental"]]), g["demix"])
+print("ERR", e1, e2)
+assert e1 < 1e-3 and e2 < 1e-3
+"""
+
+
+@pytest.mark.parametrize("env", [{"RVC_MDX_X3S": "0"}, {"RVC_MDX_FUSE_SC": "0"}])
+def test_mdx23c_alternative_graphs_match_reference_golden(env):
+    """The graphs behind the switches - fp32 planes on the staged kernels (RVC_MDX_X3S=0: what a network without bf16x3 weight images runs) and the padded graph
+    with the shortcuts as launches of their own (RVC_MDX_FUSE_SC=0) - against the same golden chunk and demix (the switches are read once per process)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-c", _ALT_GRAPH, os.path.dirname(here), here], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ERR" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_full_mdx23c_recipe_runs_at_size():
     """The shipped recipe (n_fft 8192, dim_f 4096, dim_t 256, 128 channels + 128 per scale, 5 scales: 112 M parameters) on one 5.9 s
     chunk - too large for the CPU oracle inside the suite, so size-independent properties: shape, finiteness, bit-identical repeats,
