@@ -86,7 +86,7 @@ void conv_x3s_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 // measured (round 4, 768 -> 768 at T = 1599) a unit costs ~600 cycles for 96 cycles of MFMA issue - the wait, the barrier, the DMA issue and the
 // operand reads ARE the kernel.  Two units per barrier halve that fixed cost per product; the slot is two units wide, everything else is unchanged.
 template <int AM, int AN, int RS, int UC = 1>
-__global__ __launch_bounds__(256, (AM * AN >= 4) ? 2 : 3) void conv_x3s_kernel(const GemmSArgs p) {
+__global__ __launch_bounds__(256, (AM * AN >= 4 && RS != 3) ? 2 : 3) void conv_x3s_kernel(const GemmSArgs p) {
   constexpr int WN = 2, NW = 4;
   constexpr int BM = 64 * AM, BN = 64 * AN;
   constexpr int NPA = BM / 16, NPB = BN / 16, NPW = (NPA + NPB) / NW;      // 1-KiB pieces of a unit: weights, input, per wave
@@ -537,7 +537,11 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
 }
 
 static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hipStream_t s) {
-  static const int rs_env = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 4;      // ring depth (experiments: 3 / 4 / 6)
+  // ring depth: RVC_X3S_RS = 3 / 4 / 6 for every launch; default 4, and 3 for the 128 x 128 tile on grids of three workgroups per CU and deep reductions - a ring of
+  // three slots is 48 KiB and the kernel then fits 168 VGPRs, so THREE workgroups share a CU (MDX23C's 3x3 layers at 128 / 256 channels: 263 -> 235, 250 -> 217,
+  // 526 -> 451 us in one call; smaller grids and the transformer projections lose 5 - 10 % with three slots and keep four)
+  static const int rs_force = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 0;
+  const int rs_env = rs_force ? rs_force : ((AM == 2 && AN == 2 && blocks >= 768u && a.nunits / a.ksplit >= 64) ? 3 : 4);
   // units per barrier (RVC_X3S_UC=2: two, where the slice's unit count is even and the tile is small).  Measured in round 4 and NOT the default: the
   // average launch stays at 20.0 us (20.3 with one unit per barrier) - the K loop of these 300 - 600-workgroup grids is bound by the L2 -> LDS
   // latency per ring step, not by the barrier - and the doubled LDS footprint costs the three-lane bench 2.5 % (2095 -> 2040 xRT, same box).
