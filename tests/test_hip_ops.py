@@ -451,11 +451,12 @@ def test_gemm_split_swapped_product_with_residual(L, Ci, Co, T, ld, off):
     assert torch.equal(got[:, keep], torch.full((T, int(keep.sum())), 7.0, dtype=torch.float64))
 
 
-@pytest.mark.parametrize("Ci1,Ci2,Co,H,W,ksplit", [(128, 128, 128, 12, 64, 0), (64, 128, 64, 9, 30, 0), (48, 96, 48, 5, 16, 0), (256, 256, 256, 4, 16, 4), (256, 512, 256, 4, 16, 8), (256, 512, 256, 4, 16, 11)])
+@pytest.mark.parametrize("Ci1,Ci2,Co,H,W,ksplit", [(128, 128, 128, 96, 1024, 0), (128, 128, 128, 12, 64, 0), (64, 128, 64, 9, 30, 0), (48, 96, 48, 5, 16, 0), (256, 256, 256, 4, 16, 4), (256, 512, 256, 4, 16, 8), (256, 512, 256, 4, 16, 11)])
 def test_two_image_product_conv3x3_plus_1x1(L, Ci1, Ci2, Co, H, W, ksplit):
     """conv3x3(x1) + conv1x1(x2) as ONE split-resident product over two padded images (MDX23C's tfc2(x) + shortcut(x0), tfc_tdf.py:137-144): the second
     image's chunks are further units of the reduction with tap offset 0 - also when a K slice starts inside the second image (ksplit) - and the raw
-    image written beside the fp32 output holds the same values (bf16 hi + lo: 2^-16 relative)."""
+    image written beside the fp32 output holds the same values (bf16 hi + lo: 2^-16 relative).  The first case is a grid of 770 tiles of 128 x 128: the
+    three-slot ring with three workgroups per CU."""
     g = torch.Generator().manual_seed(Ci1 + W)
     x1 = torch.randn(Ci1, H, W, generator=g); x2 = torch.randn(Ci2, H, W, generator=g)
     w1 = torch.randn(Co, Ci1, 3, 3, generator=g) / np.sqrt(Ci1 * 9); w2 = torch.randn(Co, Ci2, generator=g) / np.sqrt(Ci2)
