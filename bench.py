@@ -289,7 +289,8 @@ def main():
                 return f0
             return convert, None
 
-        def make_lane():
+        convert_mdx = []
+        def make_lane():   # (one model set per lane; the MDX23C networks are kept for the single-clip measurement below)
             if pitch_only:
                 return make_pitch_lane()
             hub = HubertModelWithFinalProj(hub_sd, S.HUBERT_CONFIG, device=dev)
@@ -305,6 +306,7 @@ def main():
                 from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
                 mdx = TFC_TDF_net(MDX23C_CONFIG, device=dev)
                 mdx.load_state_dict(mdx_sd)
+                convert_mdx.append(mdx)
 
             def convert(clip, i=0):
                 sr_in = 16000
@@ -323,6 +325,7 @@ def main():
         def stub(clip, i=0):                    # --dry-run: the documented output length, no compute
             time.sleep(0.002)
             return np.zeros(clip.shape[0] // 160 + 1, dtype=np.float64) if pitch_only else np.zeros(n_out, dtype=np.int16)
+        convert_mdx = []
         lanes = [(stub, None) for _ in range(n_lanes)]
         pool = ClipLanes([fn for fn, _ in lanes], device=None)
 
@@ -372,6 +375,15 @@ def main():
             torch.cuda.synchronize()
         alone.append(time.perf_counter() - t1)
     alone_ms = sorted(alone)[len(alone) // 2] * 1e3          # median of 9
+    alone3_ms = None
+    if use_gpu and convert_mdx:            # the UVR node's setting for a single conversion: a clip's chunks over three streams (UVR5Node: load_mdx23c)
+        convert_mdx[0].set_streams(3)
+        a3 = []
+        for _ in range(6):
+            t1 = time.perf_counter(); step(); torch.cuda.synchronize(); a3.append(time.perf_counter() - t1)
+        alone3_ms = sorted(a3[1:])[2] * 1e3          # median of 5 after one pass that allocates the extra arenas
+        if os.environ.get("RVC_BENCH_DEBUG"): print("alone", [round(x * 1e3) for x in alone], "alone3", [round(x * 1e3) for x in a3], file=sys.stderr)
+        convert_mdx[0].set_streams(1)
     sync()
 
     roofline = None
@@ -409,6 +421,7 @@ def main():
                        "gathers_per_step": 1 if collective else 0,
                        "audio_seconds_delivered_per_clip": round(delivered, 3),
                        "one_clip_alone_ms": round(alone_ms, 2), "one_clip_alone_xrt": round(delivered / alone_ms * 1e3, 1),
+                       **({"one_clip_alone_ms_3_chunk_streams": round(alone3_ms, 2)} if alone3_ms is not None else {}),
                        "weights": "procedural (comfy-rvc_amd/synthetic.py)", "noise": "device generator",
                        "parallelism": f"clip-per-GPU x{world} ({n_lanes} lanes each), one RCCL gather of the step's int16 waveforms"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rvc_mdx23_finalize": (c_int, [c_void_p]),
     "rvc_mdx23_destroy": (c_int, [c_void_p]),
     "rvc_mdx23_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rvc_mdx23_set_streams": (c_int, [c_void_p, c_int]),
     "rvc_mdx23_demix": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "rvc_synth_create": (c_int, [c_void_p, P(SynthConfig), P(c_void_p)]),
     "rvc_synth_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int]),

@@ -34,7 +34,13 @@ struct MdxScale {
 };
 struct Mdx23 {
   Ctx* ctx = nullptr;
-  Arena arena;
+  // activations: one arena (+ the "images are zeroed" record) per chunk stream.  Lane 0 runs on the caller's stream; demix may alternate a clip's chunks over further
+  // lanes with streams of their own (they are independent until the overlap-add): the small launches of the deep levels of one chunk run beside the chip-filling ones of another
+  static constexpr int kMaxLanes = 4;
+  struct Lane { Arena arena; const char* img_base = nullptr; size_t img_bytes = 0; unsigned img_gen = 0; hipStream_t st = nullptr; hipEvent_t done = nullptr; float* acc = nullptr; size_t acc_n = 0; };
+  Lane lane[kMaxLanes];
+  hipEvent_t ev_start = nullptr;
+  int streams = 0;                           // chunk streams of demix (0: RVC_MDX_STREAMS or 1), mdx23_set_streams
   TensorStore ts;
   bool ready = false;
   rvc_mdx23_config cfg{};
@@ -43,7 +49,6 @@ struct Mdx23 {
   std::vector<MdxScale> enc, dec;
   MdxScale bott;
   bool pad_ok = false;                       // every 3x3 / 2x2 layer has its bf16x3 image: the padded split-resident graph (mdx23_graph_padded)
-  const char* img_base = nullptr; size_t img_bytes = 0; unsigned img_gen = 0;      // the conv-input images' margins were zeroed for this layout
 };
 
 Mdx23* mdx23_create(Ctx* ctx, const rvc_mdx23_config& c) {
@@ -69,7 +74,18 @@ static void mdx23_free(Mdx23& M) {
   scale_free(M.bott);
   M.enc.clear(); M.dec.clear();
 }
-void mdx23_destroy(Mdx23* M) { if (M) { mdx23_free(*M); M->arena.release(); delete M; } }
+void mdx23_destroy(Mdx23* M) {
+  if (!M) return;
+  mdx23_free(*M);
+  for (auto& Ln : M->lane) {
+    if (Ln.st) { (void)hipStreamSynchronize(Ln.st); (void)hipStreamDestroy(Ln.st); }
+    if (Ln.done) (void)hipEventDestroy(Ln.done);
+    if (Ln.acc) (void)hipFree(Ln.acc);
+    Ln.arena.release();
+  }
+  if (M->ev_start) (void)hipEventDestroy(M->ev_start);
+  delete M;
+}
 
 static void make_tfc(std::vector<TfcBlock>& out, const TensorStore& ts, const std::string& prefix, int in_c, int c, int f, int l, int bn) {
   out.resize((size_t)l);
@@ -133,7 +149,7 @@ void mdx23_finalize(Mdx23* M) {
     for (auto& S : M->enc) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
     for (auto& S : M->dec) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
     blocks_ok(M->bott.blocks);
-    M->pad_ok = ok; M->img_base = nullptr;
+    M->pad_ok = ok; for (auto& Ln : M->lane) Ln.img_base = nullptr;
     static const bool fuse = !(getenv("RVC_MDX_FUSE_SC") && atoi(getenv("RVC_MDX_FUSE_SC")) == 0);
     auto fuse_blocks = [&](std::vector<TfcBlock>& bs) {
       for (TfcBlock& B : bs)
@@ -710,7 +726,7 @@ static void run_tfc_padded(const std::vector<TfcBlock>& blocks, hipStream_t s, c
   }
 }
 
-static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* audio, long long L, float* out, const MdxIO& io) {
+static void mdx23_graph_padded(Mdx23* M, Mdx23::Lane& Ln, hipStream_t s, Arena& A, const float* audio, long long L, float* out, const MdxIO& io) {
   const rvc_mdx23_config& c = M->cfg;
   const bool dry = A.dry;
   const int T = c.dim_t, k = c.num_subbands, f0 = c.dim_f / k, n = c.num_scales, g = c.growth, S = c.num_targets, bn = c.bottleneck;
@@ -737,9 +753,9 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
     RVC_REQUIRE((double)pad_img_bytes(chans, P) + 2.0 * (double)pad_img_bytes(P.C, P) + (double)pad_img_bytes(2 * P.C, P) < 2147483648.0, "a level's images exceed 32-bit buffer addressing");
   }
   const size_t img_bytes = A.off - img0;
-  if (!dry && (M->img_base != A.base + img0 || M->img_gen != A.gen || M->img_bytes != img_bytes)) {
+  if (!dry && (Ln.img_base != A.base + img0 || Ln.img_gen != A.gen || Ln.img_bytes != img_bytes)) {
     RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
-    M->img_base = A.base + img0; M->img_gen = A.gen; M->img_bytes = img_bytes;
+    Ln.img_base = A.base + img0; Ln.img_gen = A.gen; Ln.img_bytes = img_bytes;
   }
   // ---- images of the TDF linears' inputs (k = 1 products: no taps, margins never multiplied into a kept column)
   size_t il_bytes = 0, im_bytes = 0;
@@ -824,11 +840,12 @@ static void mdx23_graph_padded(Mdx23* M, hipStream_t s, Arena& A, const float* a
     hipLaunchKernelGGL(ola_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, fr + (size_t)q * T, M->window.p, out + (long long)q * io.ld_out, c.n_fft, c.hop, T, L, (long long)Q * T, io.accumulate);
 }
 
-static void mdx23_chunk(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out, const MdxIO& io) {
-  Arena& A = M->arena;
+static void mdx23_chunk(Mdx23* M, int lane, hipStream_t s, const float* audio, long long L, float* out, const MdxIO& io) {
+  Mdx23::Lane& Ln = M->lane[lane];
+  Arena& A = Ln.arena;
   for (int pass = 0; pass < 2; ++pass) {
     A.dry = (pass == 0); A.reset(); if (pass == 0) A.peak = 0;
-    if (M->pad_ok) mdx23_graph_padded(M, s, A, audio, L, out, io); else mdx23_graph_plain(M, s, A, audio, L, out, io);
+    if (M->pad_ok) mdx23_graph_padded(M, Ln, s, A, audio, L, out, io); else mdx23_graph_plain(M, s, A, audio, L, out, io);
     if (pass == 0) A.ensure(A.peak);
   }
   A.dry = false;
@@ -836,24 +853,54 @@ static void mdx23_chunk(Mdx23* M, hipStream_t s, const float* audio, long long L
 void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out) {
   RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
   RVC_REQUIRE(L == (long long)M->cfg.hop * (M->cfg.dim_t - 1), "a chunk is hop * (dim_t - 1) samples per channel");
-  mdx23_chunk(M, s, audio, L, out, MdxIO{L, L, 0});
+  mdx23_chunk(M, 0, s, audio, L, out, MdxIO{L, L, 0});
 }
 __global__ void div_kernel(float* __restrict__ x, long long n, float d) {
   const long long st = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) x[i] = x[i] / d;
 }
+__global__ void add_kernel(float* __restrict__ x, const float* __restrict__ y, long long n) {
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) x[i] += y[i];
+}
 // demix_mdxv3's chunk loop on the device (reference lib/karafan/inference.py:52-66): chunks of C = hop (dim_t - 1) samples every `step` samples of the zero-padded mix
-// [2][Lp]; every chunk's separated signals are added into acc [S][2][Lp] at the chunk's offset (NaN as zero) in chunk order - the reference's own order of fp32
-// additions - and the sum is divided by `overlap` at the end.  The network reads its window of the mix in place and its inverse STFT adds into acc: no chunk copies.
+// [2][Lp]; every chunk's separated signals are added into acc [S][2][Lp] at the chunk's offset (NaN as zero) and the sum is divided by `overlap` at the end.  The
+// network reads its window of the mix in place and its inverse STFT adds into the accumulator: no chunk copies.
+// One chunk stream (the default; what a server with several clips in flight wants - bench.py's lanes): chunks in order = the reference's own order of fp32 additions.
+// mdx23_set_streams(K) / RVC_MDX_STREAMS=K (a single conversion alone on the GPU - the ComfyUI node sets 3: one clip 860 -> 700 ms; with three clips in flight it costs 4 - 6 %):
+// K chunk streams: chunk c runs on stream c mod K with that stream's arena and accumulator, the K accumulators are added in stream order at the end - the same
+// result on every run, an ulp-level re-association of the reference's sum.
 void mdx23_demix(Mdx23* M, hipStream_t s, const float* mix, long long Lp, long long step, long long n_chunks, float overlap, float* acc) {
   RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
   const long long C = (long long)M->cfg.hop * (M->cfg.dim_t - 1);
   RVC_REQUIRE(step > 0 && n_chunks > 0 && (n_chunks - 1) * step + C <= Lp && overlap > 0.f, "demix: the last chunk must end inside the padded mix");
-  const long long n = (long long)M->cfg.num_targets * 2 * Lp;
-  RVC_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)n * sizeof(float), s));
-  for (long long c = 0; c < n_chunks; ++c) mdx23_chunk(M, s, mix + c * step, C, acc + c * step, MdxIO{Lp, Lp, 1});
-  hipLaunchKernelGGL(div_kernel, dim3(gridn(n)), dim3(256), 0, s, acc, n, overlap);
+  static const int k_env = getenv("RVC_MDX_STREAMS") ? atoi(getenv("RVC_MDX_STREAMS")) : 0;
+  const int k_want = k_env > 0 ? k_env : (M->streams > 0 ? M->streams : 1);
+  const int K = (int)std::min<long long>(std::max(1, std::min(k_want, (int)Mdx23::kMaxLanes)), n_chunks);
+  const size_t n = (size_t)M->cfg.num_targets * 2 * (size_t)Lp;
+  RVC_HIP_CHECK(hipMemsetAsync(acc, 0, n * sizeof(float), s));
+  if (K > 1) {
+    if (!M->ev_start) RVC_HIP_CHECK(hipEventCreateWithFlags(&M->ev_start, hipEventDisableTiming));
+    RVC_HIP_CHECK(hipEventRecord(M->ev_start, s));
+    for (int k = 1; k < K; ++k) {
+      Mdx23::Lane& Ln = M->lane[k];
+      if (!Ln.st) { RVC_HIP_CHECK(hipStreamCreateWithFlags(&Ln.st, hipStreamNonBlocking)); RVC_HIP_CHECK(hipEventCreateWithFlags(&Ln.done, hipEventDisableTiming)); }
+      if (Ln.acc_n < n) { if (Ln.acc) (void)hipFree(Ln.acc); Ln.acc = nullptr; RVC_HIP_CHECK(hipMalloc(&Ln.acc, n * sizeof(float))); Ln.acc_n = n; }
+      RVC_HIP_CHECK(hipStreamWaitEvent(Ln.st, M->ev_start, 0));          // (the mix is ready, the previous call's reads of this lane's accumulator are behind us)
+      RVC_HIP_CHECK(hipMemsetAsync(Ln.acc, 0, n * sizeof(float), Ln.st));
+    }
+  }
+  for (long long c = 0; c < n_chunks; ++c) {
+    const int k = (int)(c % K);
+    mdx23_chunk(M, k, k == 0 ? s : M->lane[k].st, mix + c * step, C, (k == 0 ? acc : M->lane[k].acc) + c * step, MdxIO{Lp, Lp, 1});
+  }
+  for (int k = 1; k < K; ++k) {
+    RVC_HIP_CHECK(hipEventRecord(M->lane[k].done, M->lane[k].st)); RVC_HIP_CHECK(hipStreamWaitEvent(s, M->lane[k].done, 0));
+    hipLaunchKernelGGL(add_kernel, dim3(gridn((long long)n)), dim3(256), 0, s, acc, M->lane[k].acc, (long long)n);
+  }
+  hipLaunchKernelGGL(div_kernel, dim3(gridn((long long)n)), dim3(256), 0, s, acc, (long long)n, overlap);
 }
-size_t mdx23_workspace(const Mdx23* M) { return M->arena.cap; }
+void mdx23_set_streams(Mdx23* M, int k) { M->streams = k < 0 ? 0 : (k > Mdx23::kMaxLanes ? Mdx23::kMaxLanes : k); }
+size_t mdx23_workspace(const Mdx23* M) { size_t b = 0; for (const auto& Ln : M->lane) b += Ln.arena.cap; return b; }
 
 }  // namespace rvc

@@ -69,6 +69,7 @@ void mdx23_set_tensor(Mdx23* M, const char* name, const float* d, const long lon
 void mdx23_finalize(Mdx23* M);
 void mdx23_forward(Mdx23* M, hipStream_t s, const float* audio, long long L, float* out);
 void mdx23_demix(Mdx23* M, hipStream_t s, const float* mix, long long Lp, long long step, long long n_chunks, float overlap, float* acc);
+void mdx23_set_streams(Mdx23* M, int k);
 size_t mdx23_workspace(const Mdx23* M);
 
 // CREPE pitch network (model_crepe.hip): probabilities [360][n] for n = crepe_num_frames(L, hop, pad) frames

@@ -207,6 +207,7 @@ int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk, int64_t L,
   check_launch();
   RVC_CATCH
 }
+int rvc_mdx23_set_streams(rvc_mdx23* m, int k) { RVC_TRY RVC_REQUIRE(m, "null argument"); mdx23_set_streams(m->m, k); RVC_CATCH }
 int rvc_mdx23_demix(rvc_mdx23* m, void* stream, const float* mix, int64_t Lp, int64_t step, int64_t n_chunks, float overlap, float* acc) {
   RVC_TRY
   RVC_REQUIRE(m && mix && acc, "null argument");

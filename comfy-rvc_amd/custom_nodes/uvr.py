@@ -30,6 +30,7 @@ def load_mdx23c(model_path, config=None):
         cfg = yaml.safe_load(open(side)) if os.path.isfile(side) else MDX23C_CONFIG
     net = TFC_TDF_net(cfg)
     net.load_state_dict(torch.load(model_path, map_location="cpu"))
+    net.set_streams(3)          # the node converts one clip at a time: its chunks alternate over three streams (one clip 0.86 -> 0.70 s)
     return net, cfg
 
 

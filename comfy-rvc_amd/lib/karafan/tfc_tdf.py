@@ -92,6 +92,11 @@ class TFC_TDF_net:
                 _lib.check(_lib.lib.rvc_mdx23_forward(self._h, _lib.current_stream(), _lib.ptr(x[b]), self.chunk_size, _lib.ptr(out[b])))
         return out if S > 1 else out[:, 0]
 
+    def set_streams(self, k):
+        """Chunk streams of demix_device (rvc_mdx23_set_streams): 1 = the reference's order of additions (default), 3 = a single conversion alone on the GPU."""
+        _lib.check(_lib.lib.rvc_mdx23_set_streams(self._h, int(k)))
+        return self
+
     def demix_device(self, mix, step, n_chunks, overlap):
         """The chunk loop of demix_mdxv3 (reference lib/karafan/inference.py:52-66) behind one C call: mix [2, Lp] device tensor (already zero-padded) ->
         [S, 2, Lp] = sum over chunks (every `step` samples, in order, NaN as zero) of the separated chunk at its offset, divided by `overlap`."""

@@ -144,6 +144,10 @@ int rvc_mdx23_forward(rvc_mdx23* m, void* stream, const float* chunk_dev, int64_
  * zero-padded stereo mix mix_dev [2][Lp] ((n_chunks - 1) step + C <= Lp); each chunk's separated signals are added (NaN as zero) into acc_dev [S][2][Lp] at the
  * chunk's offset, in chunk order, and the sum is divided by `overlap`.  acc_dev is overwritten.  The caller pads the mix and trims the result as the reference does. */
 int rvc_mdx23_demix(rvc_mdx23* m, void* stream, const float* mix_dev, int64_t Lp, int64_t step, int64_t n_chunks, float overlap, float* acc_dev);
+/* Chunk streams of rvc_mdx23_demix: 1 (default) = chunks in order on the caller's stream, the reference's order of additions; k = 2 .. 4: chunk c runs on stream
+ * c mod k (streams, arenas and accumulators of the model's own, ordered against the caller's stream by events), the k accumulators are added in stream order -
+ * reproducible, an ulp-level re-association.  For a single conversion alone on the GPU (the node); costs throughput when several clips are in flight. */
+int rvc_mdx23_set_streams(rvc_mdx23* m, int k);
 
 /* ------------------------------------------------------------------ synthesizer */
 typedef struct rvc_synth_config {   /* the fields of cpt["config"] that the inference graph needs */

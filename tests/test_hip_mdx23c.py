@@ -33,7 +33,8 @@ def test_mdx23c_chunk_matches_reference_golden(small):
 
 
 def test_demix_mdxv3_matches_reference_golden(small):
-    """demix_mdxv3: zero padding, chunks every C / overlap samples, overlap-add, 1 / overlap - on a clip of 2.6 chunks, overlap 4."""
+    """demix_mdxv3: zero padding, chunks every C / overlap samples, overlap-add, 1 / overlap - on a clip of 2.6 chunks, overlap 4; then the same
+    clip with its chunks over three streams (`set_streams(3)`): the golden again, bit-identical repeats, within re-association of the one-stream sum."""
     from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
     cfg, net = small
     g = golden("mdx23c_small.npz")
@@ -41,6 +42,14 @@ def test_demix_mdxv3_matches_reference_golden(small):
     assert list(est) == ["Vocals", "Instrumental"]
     got = np.stack([est["Vocals"], est["Instrumental"]])
     assert got.shape == g["demix"].shape and rel_err(got, g["demix"]) < 1e-3
+    net.set_streams(3)
+    try:
+        e3 = [demix_mdxv3(g["clip"], net, net.device, cfg, int(g["overlap"])) for _ in range(2)]
+    finally:
+        net.set_streams(1)
+    got3 = np.stack([e3[0]["Vocals"], e3[0]["Instrumental"]])
+    assert rel_err(got3, g["demix"]) < 1e-3 and rel_err(got3, got) < 1e-5
+    assert np.array_equal(got3, np.stack([e3[1]["Vocals"], e3[1]["Instrumental"]]))
 
 
 def test_mdx23c_other_geometry_matches_oracle():
@@ -75,10 +84,11 @@ assert e1 < 1e-3 and e2 < 1e-3
 """
 
 
-@pytest.mark.parametrize("env", [{"RVC_MDX_X3S": "0"}, {"RVC_MDX_FUSE_SC": "0"}])
+@pytest.mark.parametrize("env", [{"RVC_MDX_X3S": "0"}, {"RVC_MDX_FUSE_SC": "0"}, {"RVC_MDX_STREAMS": "3"}])
 def test_mdx23c_alternative_graphs_match_reference_golden(env):
     """The graphs behind the switches - fp32 planes on the staged kernels (RVC_MDX_X3S=0: what a network without bf16x3 weight images runs) and the padded graph
-    with the shortcuts as launches of their own (RVC_MDX_FUSE_SC=0) - against the same golden chunk and demix (the switches are read once per process)."""
+    with the shortcuts as launches of their own (RVC_MDX_FUSE_SC=0) - and demix with a clip's chunks over three streams (RVC_MDX_STREAMS=3 = `set_streams(3)`, the node's
+    setting) against the same golden chunk and demix (the switches are read once per process)."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-c", _ALT_GRAPH, os.path.dirname(here), here], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
