@@ -9,8 +9,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 template <int NACC, int MODE>
-__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned long long* clk) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[MODE ? 32768 : 16];
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned long long* clk, const unsigned char* src) {
+  __shared__ __attribute__((aligned(1024))) unsigned char sm[MODE ? (MODE >= 5 ? 65536 : 32768) : 16];
   f32x16 acc[NACC];
   for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   u32x4 a = {0x3f803f80u + threadIdx.x, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
   const unsigned char* base = sm + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 4096;
   u32x4 cur[12];
   for (int q = 0; q < 12; ++q) cur[q] = a;
+  float vx[8], vy = 0.999f + 1e-9f * threadIdx.x;
+  for (int q = 0; q < 8; ++q) vx[q] = (float)q;
   const long long t0 = (long long)__builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (MODE == 1) {
@@ -45,6 +47,30 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int q = 0; q < NR; ++q) { asm volatile("" : "+v"(nx[q])); cur[q] = nx[q]; }
+    } else if (MODE >= 5) {
+      constexpr int NP = MODE == 5 ? 2 : (MODE == 7 ? 8 : 4), NR = 12, EVERY = 2;      // MODE 8 / 9: 4 pieces and one s_barrier per 24 / 12 MFMAs
+      u32x4 nx[12];
+      if (it == 0) for (int q = 0; q < 12; ++q) cur[q] = *reinterpret_cast<const u32x4*>(base + q * 1024);
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(src), 0, 262144, 0x00020000);
+      unsigned char* dst = sm + 32768 + (threadIdx.x >> 6) * 8192;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        if (i % EVERY == 0) { const int q = i / EVERY; asm volatile("ds_read_b128 %0, %1" : "=v"(nx[q]) : "v"((unsigned)(size_t)(base - sm) + ((q * 1024 + (it + 1) * 16) & 16383))); }
+        if (i % (24 / NP) == 1) {
+          const int pc = i / (24 / NP);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, (int)((threadIdx.x & 63) * 16), (int)(((it * NP + pc) * 1024 + blockIdx.x * 4096) & 262143), 0, 0);
+        }
+        acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[i % 4]), __builtin_bit_cast(bf16x8, cur[4 + (i % (NR - 4))]), acc[i % NACC], 0, 0, 0);
+        if ((MODE == 9 && i == 11) || (MODE >= 8 && i == 23)) asm volatile("s_barrier" ::: "memory");
+        if (MODE >= 10) {                                         // MODE 10 / 11: 1 / 2 independent VALU instructions per MFMA (conversion / address work of the real kernels: 2.1 per MFMA)
+          asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[i % 8]) : "v"(vy));
+          if (MODE >= 11) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[(i + 4) % 8]) : "v"(vy));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (NP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // one iteration's pieces stay in flight
+#pragma unroll
+      for (int q = 0; q < NR; ++q) { asm volatile("" : "+v"(nx[q])); cur[q] = nx[q]; }
     } else if (MODE == 4) {
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       u32x4 o[12];
@@ -66,6 +92,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
   const long long t1 = (long long)__builtin_readcyclecounter();
   float s = 0.f;
   for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  for (int q = 0; q < 8; ++q) s += vx[q];
   if (s == 12345.678f) out[0] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
 }
@@ -75,11 +102,12 @@ static int run(const char* name, int wgs_per_cu, int iters) {
   float* out; unsigned long long* clk; CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = 256 * wgs_per_cu;
-  hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, 64, clk);
+  unsigned char* src; CK(hipMalloc(&src, 262144 + 4096)); CK(hipMemset(src, 0x3f, 262144 + 4096));
+  hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, 64, clk, src);
   float best = 1e9f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, iters, clk);
+    hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, iters, clk, src);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
@@ -88,7 +116,7 @@ static int run(const char* name, int wgs_per_cu, int iters) {
   // s_memtime counts at a constant 100 MHz: cycles of the shader clock per MFMA of one wave = (time / MFMAs per wave per SIMD)
   printf("%-44s %d WG/CU  %9.1f us  %7.0f TFLOP/s dense bf16 = %5.0f as bf16x3 (%.3f of 2500)   refclk ticks of workgroup 0: %llu\n", name, wgs_per_cu, best * 1e3, flops / best / 1e9,
          flops / best / 1e9 / 3, flops / best / 1e9 / 2500.0, c);
-  hipFree(out); hipFree(clk);
+  hipFree(out); hipFree(clk); hipFree(src);
   return 0;
 }
 int main() {
@@ -106,6 +134,17 @@ int main() {
     run<8, 2>("12 ds_read_b128 between 24 MFMA (pipelined)", w, 20000 / w);
     run<8, 3>("8 ds_read_b128 between 24 MFMA (pipelined)", w, 20000 / w);
     run<8, 4>("24 ds_read_b64 then 24 MFMA", w, 20000 / w);
+  }
+  // the same pipelined loop plus LDS-DMA pieces (1 KiB per wave-instruction, L2-resident source): the generator kernel issues ~2.5 per wave and 24 MFMAs,
+  // the split-resident GEMM kernel 8 (128 x 128 tile: 4 per 12)
+  for (int w = 1; w <= 2; ++w) {
+    run<8, 5>("12 reads + 2 LDS-DMA pieces between 24 MFMA", w, 20000 / w);
+    run<8, 6>("12 reads + 4 LDS-DMA pieces between 24 MFMA", w, 20000 / w);
+    run<8, 7>("12 reads + 8 LDS-DMA pieces between 24 MFMA", w, 20000 / w);
+    run<8, 8>("12 reads + 4 pieces + 1 s_barrier per 24 MFMA", w, 20000 / w);
+    run<8, 9>("12 reads + 4 pieces + 2 s_barrier per 24 MFMA", w, 20000 / w);
+    run<8, 10>("... + 1 barrier + 1 VALU per MFMA", w, 20000 / w);
+    run<8, 11>("... + 1 barrier + 2 VALU per MFMA", w, 20000 / w);
   }
   return 0;
 }
