@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
   const unsigned char* base = sm + (threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 4096;
   u32x4 cur[12];
   for (int q = 0; q < 12; ++q) cur[q] = a;
+  unsigned sx = 0;
   float vx[8], vy = 0.999f + 1e-9f * threadIdx.x;
   for (int q = 0; q < 8; ++q) vx[q] = (float)q;
   const long long t0 = (long long)__builtin_readcyclecounter();
@@ -62,10 +63,13 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
         }
         acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[i % 4]), __builtin_bit_cast(bf16x8, cur[4 + (i % (NR - 4))]), acc[i % NACC], 0, 0, 0);
         if ((MODE == 9 && i == 11) || (MODE >= 8 && i == 23)) asm volatile("s_barrier" ::: "memory");
-        if (MODE >= 10) {                                         // MODE 10 / 11: 1 / 2 independent VALU instructions per MFMA (conversion / address work of the real kernels: 2.1 per MFMA)
+        // MODE 10 / 11: 1 / 2 independent VALU instructions per MFMA; 12 / 13: one per 2 / per 4 MFMAs (the generator kernel's loops: 0.7 per MFMA where it converts its
+        // fp32 input, 0.2 where it reads an image); 14: one SALU instruction per MFMA and no VALU (the kernels run ~1 per MFMA: offsets of the DMA pieces, counters)
+        if (MODE == 10 || MODE == 11 || (MODE == 12 && (i & 1) == 0) || (MODE == 13 && (i & 3) == 0)) {
           asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[i % 8]) : "v"(vy));
-          if (MODE >= 11) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[(i + 4) % 8]) : "v"(vy));
+          if (MODE == 11) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[(i + 4) % 8]) : "v"(vy));
         }
+        if (MODE == 14) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx) : : "scc");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (NP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // one iteration's pieces stay in flight
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
   float s = 0.f;
   for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
   for (int q = 0; q < 8; ++q) s += vx[q];
+  s += (float)sx;
   if (s == 12345.678f) out[0] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
 }
@@ -145,6 +150,9 @@ int main() {
     run<8, 9>("12 reads + 4 pieces + 2 s_barrier per 24 MFMA", w, 20000 / w);
     run<8, 10>("... + 1 barrier + 1 VALU per MFMA", w, 20000 / w);
     run<8, 11>("... + 1 barrier + 2 VALU per MFMA", w, 20000 / w);
+    run<8, 12>("... + 1 barrier + 1 VALU per 2 MFMA", w, 20000 / w);
+    run<8, 13>("... + 1 barrier + 1 VALU per 4 MFMA", w, 20000 / w);
+    run<8, 14>("... + 1 barrier + 1 SALU per MFMA", w, 20000 / w);
   }
   return 0;
 }
