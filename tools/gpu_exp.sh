@@ -2,8 +2,8 @@
 # scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence):  gpurun --timeout 900 -- 'bash tools/gpu_exp.sh > gpurun_out/expN.txt 2>&1'
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-rm -rf gpurun_out/prof_busy
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_busy -o b -- python3 bench.py --lanes 3 --steps 16 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-f=$(find gpurun_out/prof_busy -name "*kernel_trace.csv" | head -1)
-echo "lanes 3: $(python tools/busy_fraction.py $f 20)"
-rm -rf gpurun_out/prof_busy
+for rep in 1 2 3; do
+for v in 1 3; do
+echo "== RVC_X3PF64=$v rep $rep: $(RVC_X3PF64=$v timeout 600 python bench.py --steps 20 --warmup 2 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["config"]["one_clip_alone_ms"], d["roofline"]["frac"], d["roofline"].get("kernel_ms_per_clip"))')"
+done
+done
