@@ -13,6 +13,8 @@ tot = 0.0
 for Cc in sel:
     T = T0 * {256: 10, 128: 100, 64: 200, 32: 400}[Cc]
     for k, d in ((3, 1), (3, 5), (7, 1), (7, 3), (11, 1), (11, 5)):
+        if os.environ.get('BENCH_K') and int(os.environ['BENCH_K']) != k:
+            continue
         plans = []
         for dd in (d, 1):
             w = (np.random.randn(Cc, Cc, k) / np.sqrt(Cc * k)).astype(np.float32); b = (np.random.randn(Cc) * 0.1).astype(np.float32)
