@@ -514,6 +514,8 @@ def roofline_pass(_lib, vc, step, torch):
                   "kernel": KERNEL_DESC.get(name, "rvc::" + name),
                   "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product" if x3 else "fp32 MFMA peak") +
                                f"; bound chosen by this kernel's arithmetic intensity ({gf * 1e3 / mb if mb > 0 else 0:.0f} FLOP/B) against the ridge {ridge:.0f} FLOP/B (8 TB/s)",
+                  "clock_note": "peak is at the nominal 2.4 GHz; measured beside this workload (profiles/r4zz_power_clocks.txt): the board sits at its 1400 W limit with the shader clock at "
+                                "1.72 GHz under the persistent generator kernel alone, 2.0 GHz / ~1290 W with three clips in flight",
                   "launches_per_clip": n, "avg_launch_us": round(us / n, 2),
                   "algorithmic_gflop_per_launch": round(gf / n, 3), "algorithmic_mbytes_per_launch": round(mb / n, 2),
                   "kernel_ms_per_clip": round(us / 1e3, 3), "algorithmic_tflop_per_clip": round(gf / 1e3, 3),
