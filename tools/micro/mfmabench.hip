@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned
   if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = (unsigned long long)(t1 - t0);
 }
 
+static double g_sustain_s = 0.0;      // > 0: repeat the launch for this many seconds (clock / power of the mix: poll rocm-smi beside it)
 template <int NACC, int MODE>
 static int run(const char* name, int wgs_per_cu, int iters) {
   float* out; unsigned long long* clk; CK(hipMalloc(&out, 64)); CK(hipMalloc(&clk, 64));
@@ -110,7 +111,8 @@ static int run(const char* name, int wgs_per_cu, int iters) {
   unsigned char* src; CK(hipMalloc(&src, 262144 + 4096)); CK(hipMemset(src, 0x3f, 262144 + 4096));
   hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, 64, clk, src);
   float best = 1e9f;
-  for (int rep = 0; rep < 3; ++rep) {
+  const int nrep = g_sustain_s > 0 ? (int)(g_sustain_s / 0.009) : 3;
+  for (int rep = 0; rep < nrep; ++rep) {
     hipEventRecord(e0);
     hipLaunchKernelGGL((mfma_loop<NACC, MODE>), dim3(grid), dim3(256), 0, 0, out, iters, clk, src);
     hipEventRecord(e1); hipEventSynchronize(e1);
@@ -124,7 +126,21 @@ static int run(const char* name, int wgs_per_cu, int iters) {
   hipFree(out); hipFree(clk); hipFree(src);
   return 0;
 }
-int main() {
+#include <cstdlib>
+#include <cstring>
+int main(int argc, char** argv) {
+  if (argc >= 4 && !strcmp(argv[1], "sustain")) {
+    g_sustain_s = atof(argv[3]);
+    switch (atoi(argv[2])) {
+      case 0: return run<8, 0>("bare MFMA (sustained)", 2, 30000);
+      case 2: return run<8, 2>("12 reads between 24 MFMA (sustained)", 2, 10000);
+      case 6: return run<8, 6>("12 reads + 4 LDS-DMA pieces (sustained)", 2, 10000);
+      case 8: return run<8, 8>("12 reads + 4 pieces + barrier (sustained)", 2, 10000);
+      case 10: return run<8, 10>("... + 1 VALU per MFMA (sustained)", 2, 10000);
+      case 12: return run<8, 12>("... + 1 VALU per 2 MFMA (sustained)", 2, 10000);
+      default: return 1;
+    }
+  }
   // iters: 24 MFMAs x 32 cycles = 768 cycles per iteration per wave at one wave per SIMD
   for (int w = 1; w <= 3; ++w) {
     run<4, 0>("bare MFMA, 4 accumulators, short", w, 1000 / w);
