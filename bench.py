@@ -37,6 +37,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Pea
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
 PMC_TRAFFIC_FILE = os.path.join("profiles", "r4zz_pmc_traffic.json")
+MAX_LINE_BYTES = 6144              # the driver parses ONE JSON line from stdout; round 4's 17.9 KB line was not parsed
 
 
 def launch_ranks(n):
@@ -154,9 +155,8 @@ def cpu_baseline(config=None, seconds=CLIP_SECONDS, seed=100, budget_s=40.0):
     return {"value": round(delivered / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(k), "kind": "port", "cpu": cpu_model(),
             "host_logical_cpus": int(ncpu), "cpus_in_affinity_mask": int(navail), "n_runs": len(runs), "wall_s_median": round(dt, 2),
             "stage_seconds": {n: round(v, 2) for n, v in sorted(st.items())},
-            "sample": f"1 x {seconds:g} s clip = the clip of the GPU line (synthetic.synth_audio seed {seed}), 1 s warm-up clip + median of {len(runs)} run(s), same procedural weights, "
-                      f"oracle.pipeline = torch-CPU fp32 restatement of the reference validated against reference goldens, "
-                      f"torch.set_num_threads({k})"}
+            "sample": f"1 x {seconds:g} s clip (the GPU line's clip, seed {seed}), 1 s warm-up + median of {len(runs)} run(s), oracle.pipeline (torch-CPU fp32 "
+                      f"restatement pinned to reference goldens), {k} threads"}
 
 
 def cpu_baseline_rmvpe(seconds=60.0, seed=100, budget_s=30.0):
@@ -185,8 +185,8 @@ def cpu_baseline_rmvpe(seconds=60.0, seed=100, budget_s=30.0):
     dt = runs[len(runs) // 2]
     return {"value": round(seconds / dt, 4), "unit": "audio-sec/wall-sec", "cores": int(k), "kind": "port", "cpu": cpu_model(), "n_runs": len(runs),
             "wall_s_median": round(dt, 2),
-            "sample": f"1 x {seconds:g} s clip = the clip of the GPU line (synthetic.synth_audio seed {seed}), 1 s warm-up + median of {len(runs)} run(s), "
-                      f"oracle.nets.rmvpe_infer_from_audio (torch-CPU fp32 restatement validated against reference goldens), torch.set_num_threads({k})"}
+            "sample": f"1 x {seconds:g} s clip (the GPU line's clip, seed {seed}), 1 s warm-up + median of {len(runs)} run(s), oracle.nets.rmvpe_infer_from_audio "
+                      f"(torch-CPU fp32 restatement pinned to reference goldens), {k} threads"}
 
 
 def main():
@@ -386,12 +386,11 @@ def main():
         convert_mdx[0].set_streams(1)
     sync()
 
-    roofline = None
+    roofline, detail = None, None
     if rank == 0 and use_gpu and not args.no_roofline:
-        roofline = roofline_pass(_lib, vc, step, torch)
+        roofline, detail = roofline_pass(_lib, vc, step, torch)
         if roofline is not None and pitch_only:
-            roofline["note"] = ("conv-kernel launches only: the BiGRU recurrence (rvc::gru_scan_kernel, latency-bound serial scan on 16 workgroups) is the "
-                                "largest single kernel of this variant and has no FLOP / byte roofline; see profiles/*_kernel_stats_rmvpe60.csv")
+            roofline["note"] = "conv kernels only; rvc::gru_scan_kernel (serial, latency-bound) is the largest single kernel of this variant"
     cpu = None
     if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
         # the CPU baseline is "the reference's path on this box's host cores" (BASELINE.md section 4), not on the one NUMA node the rank was pinned
@@ -408,15 +407,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if use_gpu else "dry-run (stub conversion, NO GPU work: launcher / collective check only)",
-            "dtype_note": "fp32 tensors end to end; eligible convolutions multiply on the bf16 matrix cores as a 3-term hi/lo split with fp32 accumulation (error ~1e-5, parity tolerance 1e-3), the rest on the fp32 matrix cores",
+            "dtype_note": "fp32 tensors; convolutions as a 3-term bf16 hi/lo split on the MFMA units with fp32 accumulation (fp32-equivalent), rest fp32 MFMA",
             "ranks": world, "backend": (backend if collective else None), "nccl_ranks": (world if (collective and backend == "nccl") else None),
             "cpu_affinity": (f"{len(bound)} CPUs of the GPU's NUMA node" if bound else "unbound (topology unknown or --no-bind)"),
             "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
-            "config": {"workload": (f"lib/rmvpe.RMVPE pitch extraction alone (log-mel -> Deep U-Net -> BiGRU -> Linear -> decode), {args.seconds:g} s 16 kHz clips, {n_clips} per GPU per step "
-                                    f"({n_lanes} in flight concurrently), host audio in -> float64 f0 on the host (BASELINE.json configs[1])") if pitch_only else
+            "config": {"workload": (f"RMVPE pitch extraction alone, {args.seconds:g} s 16 kHz clips, {n_clips} per GPU per step ({n_lanes} in flight), host audio in -> "
+                                    f"float64 f0 out (BASELINE.json configs[1])") if pitch_only else
                                    ("MDX23C vocal split (stereo 44.1 kHz, overlap 8) -> " if chain else "") +
                                    f"Full VC {args.variant} (HuBERT -> RMVPE -> SynthesizerTrnMs768NSFsid), {args.seconds:g} s {'44.1 kHz stereo' if chain else '16 kHz'} clips, {n_clips} per GPU "
-                                   f"per step ({n_lanes} in flight concurrently), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
+                                   f"per step ({n_lanes} in flight), vc_single host array in -> int16 host array out (BASELINE.json configs[{cfg_idx}])",
                        "clips_per_step": world * n_clips, "clips_per_gpu_per_step": n_clips, "clips_in_flight_per_gpu": n_lanes,
                        "gathers_per_step": 1 if collective else 0,
                        "audio_seconds_delivered_per_clip": round(delivered, 3),
@@ -426,7 +425,12 @@ def main():
                        "parallelism": f"clip-per-GPU x{world} ({n_lanes} lanes each), one RCCL gather of the step's int16 waveforms"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        text = json.dumps(line, separators=(",", ":"))
+        assert len(text) < MAX_LINE_BYTES, f"bench line grew to {len(text)} bytes: the driver parses one short JSON line; move detail to write_detail()"
+        if detail is not None:
+            detail["line"] = line
+            write_detail(detail)
+        print(text, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -448,9 +452,11 @@ KERNEL_DESC = {
 
 def roofline_pass(_lib, vc, step, torch):
     """One extra, untimed-for-the-headline clip with every conv-kernel launch bracketed by HIP events on the stream it is launched on
-    (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes.  The per-launch table is grouped by KERNEL:
-    `roofline` is the kernel with the most time per clip (the same kernel tops profiles/*_kernel_stats_lanes1.csv), priced against its own
-    bound (arithmetic intensity of ITS launches against the ridge) with ITS PMC traffic; the other kernels follow in `other_kernels`."""
+    (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes.  The per-launch table is grouped by KERNEL.
+    Returns (roofline, detail): `roofline` is the COMPACT object of the kernel with the most time per clip (the same kernel tops
+    profiles/*_kernel_stats_lanes1.csv), priced against its own bound (arithmetic intensity of ITS launches against the ridge) with ITS PMC
+    traffic - it goes on the JSON line, which the driver parses and which therefore stays small; `detail` (every kernel, launch classes, the
+    long notes) goes to gpurun_out/bench_detail.json and stderr."""
     import csv
     import tempfile
     _lib.check(_lib.lib.rvc_prof_enable(1))
@@ -476,9 +482,15 @@ def roofline_pass(_lib, vc, step, torch):
     try:
         with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
             doc = json.load(f)
-        traffic, traffic_src = doc["kernels"], f"from file {PMC_TRAFFIC_FILE} (commit {doc.get('commit', '?')}), not measured in this run"
+        traffic, traffic_src = doc["kernels"], f"{PMC_TRAFFIC_FILE} (tree {str(doc.get('commit', '?')).split(' ')[0]})"
     except (OSError, ValueError, KeyError):
         pass
+    return roofline_from_rows(rows, traffic, traffic_src)
+
+
+def roofline_from_rows(rows, traffic, traffic_src):
+    """Formatter shared by the live pass and tests/test_parallel_gloo.py (which feeds it a synthetic full-size launch table and checks the
+    size of the resulting line)."""
     x3_peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
     kernels = {}
     for r in rows:
@@ -501,39 +513,54 @@ def roofline_pass(_lib, vc, step, torch):
         else:
             e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)})
         tr = traffic.get("rvc::" + name)
-        # the launch classes of this kernel (shape -> launches, us, TFLOP/s), largest first
+        e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
+                  "traffic_src": None if tr is None else traffic_src,
+                  "kernel": "rvc::" + name,
+                  "launches_per_clip": n, "avg_launch_us": round(us / n, 2),
+                  "algorithmic_gflop_per_launch": round(gf / n, 3), "algorithmic_mbytes_per_launch": round(mb / n, 2),
+                  "kernel_ms_per_clip": round(us / 1e3, 3), "algorithmic_tflop_per_clip": round(gf / 1e3, 3),
+                  "algorithmic_tflops": round(tf, 2), "algorithmic_gbps": round(gbs, 1),
+                  "intensity_flop_per_byte": round(gf * 1e3 / mb, 1) if mb > 0 else None, "ridge_flop_per_byte": round(ridge, 1)})
+        # detail only: the launch classes of this kernel (shape -> launches, us, TFLOP/s), largest first, and the prose
         cls = {}
         for r in rs:
             k = (r["tile"], r["Ci"], r["Co"], r["k"], r["dil"], r["stride"], r["Tout"], r["Wd"], r["fused_pair"], r["ksplit"])
             c = cls.setdefault(k, [0, 0.0, 0.0, 0.0])
             c[0] += 1; c[1] += float(r["us"]); c[2] += float(r["alg_gflop"]); c[3] += float(r["alg_mbytes"])
         top = sorted(cls.items(), key=lambda kv: -kv[1][1])[:8]
-        e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
-                  "traffic_note": None if tr is None else "HBM bytes per launch of THIS kernel (mean over its launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
-                                                          "WRITE_SIZE, separate passes (tools/pmc_traffic.py); " + traffic_src,
-                  "kernel": KERNEL_DESC.get(name, "rvc::" + name),
-                  "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product" if x3 else "fp32 MFMA peak") +
-                               f"; bound chosen by this kernel's arithmetic intensity ({gf * 1e3 / mb if mb > 0 else 0:.0f} FLOP/B) against the ridge {ridge:.0f} FLOP/B (8 TB/s)",
-                  "clock_note": "peak is at the nominal 2.4 GHz; measured beside this workload (profiles/r4zz_power_clocks.txt): the board sits at its 1400 W limit with the shader clock at "
-                                "1.72 GHz under the persistent generator kernel alone, 2.0 GHz / ~1290 W with three clips in flight",
-                  "launches_per_clip": n, "avg_launch_us": round(us / n, 2),
-                  "algorithmic_gflop_per_launch": round(gf / n, 3), "algorithmic_mbytes_per_launch": round(mb / n, 2),
-                  "kernel_ms_per_clip": round(us / 1e3, 3), "algorithmic_tflop_per_clip": round(gf / 1e3, 3),
-                  "algorithmic_gbps": round(gbs, 1),
+        d = dict(e)
+        d.update({"description": KERNEL_DESC.get(name, "rvc::" + name),
+                  "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product" if x3 else "fp32 MFMA peak") + " at the nominal 2.4 GHz clock",
+                  "traffic_note": "HBM bytes per launch of THIS kernel (mean over its launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
+                                  "(tools/pmc_traffic.py); read from the committed file named in traffic_src, not measured in this run",
                   "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / x3_peak, 4),
-                                    "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "hbm_8TBps": round(gbs / (HBM_PEAK_BPS / 1e9), 4),
-                                    "algorithmic_tflops": round(tf, 2)},
+                                    "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "hbm_8TBps": round(gbs / (HBM_PEAK_BPS / 1e9), 4)},
                   "top_classes": [{"tile": k[0], "Ci": int(k[1]), "Co": int(k[2]), "k": int(k[3]), "dil": int(k[4]), "stride": int(k[5]), "Tout": int(k[6]), "Wd": int(k[7]),
                                    "pair": int(k[8]), "ksplit": int(k[9]), "launches": c[0], "us": round(c[1] / c[0], 1),
                                    "tflops": round(c[2] / c[1] / 1e-3, 1) if c[1] > 0 else 0.0, "alg_gbps": round(c[3] / c[1] * 1e3, 0) if c[1] > 0 else 0.0}
                                   for k, c in top]})
-        return e
-    ents = sorted((entry(n, rs) for n, rs in kernels.items()), key=lambda e: -e["kernel_ms_per_clip"])
+        return e, d
+    ents = sorted((entry(n, rs) for n, rs in kernels.items()), key=lambda ed: -ed[0]["kernel_ms_per_clip"])
     if not ents:
-        return None
-    roofline = ents[0]
-    roofline["other_kernels"] = ents[1:]
-    return roofline
+        return None, None
+    roofline = ents[0][0]
+    # a one-line table of the rest (name, ms per clip, fraction of its own bound) so that the line still shows where the other time goes
+    roofline["others"] = [[e["kernel"].replace("rvc::", "").replace("_kernel", ""), e["kernel_ms_per_clip"], e["bound"], e["frac"]] for e, _ in ents[1:8]]
+    roofline["all_conv_kernels_ms_per_clip"] = round(sum(e["kernel_ms_per_clip"] for e, _ in ents), 3)
+    roofline["all_conv_kernels_tflops"] = round(sum(e["algorithmic_tflop_per_clip"] for e, _ in ents) / max(roofline["all_conv_kernels_ms_per_clip"], 1e-9) * 1e3, 1)
+    return roofline, {"kernels": [d for _, d in ents]}
+
+
+def write_detail(detail):
+    """gpurun_out/bench_detail.json (merged back from the GPU box) + one stderr line; never stdout."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail.json"), "w") as f:
+            json.dump(detail, f, indent=1)
+    except OSError:
+        pass
+    print("bench detail: " + json.dumps(detail), file=sys.stderr, flush=True)
 
 
 if __name__ == "__main__":

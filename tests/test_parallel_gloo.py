@@ -65,3 +65,31 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
     e = dict(os.environ, RVC_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2"], env=e, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in p.stderr
+
+
+def test_bench_line_stays_small_enough_for_the_driver():
+    """The driver parses ONE JSON line from bench.py's stdout; round 4's line grew to 17.9 KB and was not parsed.  The dry-run line and a full-size
+    `roofline` (the committed launch table of a real 30 s clip through the same formatter, every kernel present) plus a full `cpu_baseline`
+    object must stay far below 8 KB together; the per-kernel detail goes to gpurun_out/bench_detail.json / stderr instead."""
+    import csv
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    import bench
+    r = _bench("--gpus", "1")
+    base = len(json.dumps(r, separators=(",", ":")))
+    with open(os.path.join(root, "profiles", "r4zz_launches.csv")) as f:
+        rows = list(csv.DictReader(f))
+    with open(os.path.join(root, bench.PMC_TRAFFIC_FILE)) as f:
+        doc = json.load(f)
+    roof, detail = bench.roofline_from_rows(rows, doc["kernels"], "profiles/x_pmc_traffic.json (tree 0123456)")
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_clip", "avg_launch_us"):
+        assert key in roof
+    assert roof["kernel"] == "rvc::conv_x3q_kernel" and roof["bound"] == "mfma" and roof["peak"] == 833.3 and roof["launches_per_clip"] == 48
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] == round(doc["kernels"]["rvc::conv_x3q_kernel"]["hbm_bytes_per_launch"])
+    assert "top_classes" not in roof and "other_kernels" not in roof and len(detail["kernels"]) >= 6 and "top_classes" in detail["kernels"][0]
+    cpu = {"value": 2.6543, "unit": "audio-sec/wall-sec", "cores": 32, "kind": "port", "cpu": "AMD EPYC 9575F 64-Core Processor", "host_logical_cpus": 256,
+           "cpus_in_affinity_mask": 256, "n_runs": 2, "wall_s_median": 11.12, "stage_seconds": {"host_dsp": 0.11, "hubert": 2.22, "rmvpe": 1.33, "synthesizer": 7.46},
+           "sample": "1 x 30 s clip (the GPU line's clip, seed 100), 1 s warm-up + median of 2 run(s), oracle.pipeline (torch-CPU fp32 restatement pinned to reference goldens), 32 threads"}
+    total = base + len(json.dumps(roof, separators=(",", ":"))) + len(json.dumps(cpu, separators=(",", ":")))
+    assert total < bench.MAX_LINE_BYTES < 8192, total
+    assert total < 4096, total          # (today ~2.6 KB; a regression that doubles it should be looked at)
