@@ -8,7 +8,9 @@ Noise:   torch.randn_like is patched to draw from torch.Generator(cpu).manual_se
     python -m oracle.gen_golden            # writes tests/golden/*.npz (a few MB)
 """
 import os
+import shutil
 import sys
+import tempfile
 import types
 
 import numpy as np
@@ -202,9 +204,12 @@ def run_ref_pipeline(ns, hub, vcd, audio, seed, cfg=None, designed_f0=None, **kw
                 filter_radius=3, resample_sr=0, rms_mix_rate=0.25, protect=0.33, crepe_hop_length=160,
                 f0_autotune=False)
     args.update(kw)
-    with ref_shim.chdir_ws(), patched_randn_like(tape), torch.no_grad():
-        out = ns.vc_infer_pipeline.vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub,
-                                             input_audio=(audio, 16000), config=cfg, **args)
+    try:
+        with ref_shim.chdir_ws(), patched_randn_like(tape), torch.no_grad():
+            out = ns.vc_infer_pipeline.vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=vc, hubert_model=hub,
+                                                 input_audio=(audio, 16000), config=cfg, **args)
+    finally:
+        vc.get_f0 = orig_get_f0          # (a second call on the same VC must not write into this call's `captured` through a nested wrapper)
     assert out is not None, "reference vc_single swallowed an exception"
     return out[0], out[1], captured, tape.shapes
 
@@ -261,6 +266,103 @@ def gen_hostdsp(ns):
     np.savez_compressed(os.path.join(OUT, "hostdsp.npz"), audio=audio, filtfilt=filt, f0_in=f0, rms_d1=d1, rms_d2=d2,
                         rms_out=mixed, remix_in=st, remix_out=rem, **res)
     print("hostdsp ok")
+
+
+class StubIndex:
+    """The `.search(x, k)` surface of a faiss L2 index (the only member VC.vc touches, reference vc_infer_pipeline.py:65) over `big`: exact
+    squared-L2 k = 1 search in float64, ties to the smaller row.  faiss itself is absent from the container; what this pins is everything the
+    REFERENCE does around the search - score -> weight, the gather from big_npy, the index_rate blend, the x2 up-sampling, the protect blend."""
+
+    def __init__(self, big):
+        self.big = np.asarray(big, dtype=np.float64)
+        self.calls = []
+
+    def search(self, x, k=1):
+        assert k == 1
+        x = np.asarray(x, dtype=np.float64)
+        d = (x * x).sum(1)[:, None] - 2.0 * x @ self.big.T + (self.big * self.big).sum(1)[None]
+        ix = d.argmin(1)
+        score = np.maximum(d[np.arange(x.shape[0]), ix], 0).astype(np.float32)[:, None]
+        self.calls.append(ix.astype(np.int64))
+        return score, ix.astype(np.int64)[:, None]
+
+
+def gen_pinned(ns, which):
+    """Branches of the hot path that the first goldens left to the restated oracle alone, now through the real
+    reference:
+      pipeline_2s_index      vc_single with file_index = (index, big_npy) - the "preloaded file index" form load_index accepts
+                             (pitch_extraction.py:55-57) - index_rate 0.75, protect 0.33: vc_infer_pipeline.py:58-95
+      pipeline_2s_rmvpeplus  f0_method = "rmvpe+" through vc_single (pitch_extraction.py:197-201 -> lib/rmvpe.py:636-659: the clip turns
+                             unvoiced frames into 50 Hz)
+      pipeline_2s_f0file     f0_file = object with .name -> "time,f0" lines spliced over the extracted pitch (vc_infer_pipeline.py:146-151,
+                             pitch_extraction.py:281-291)
+      featinput              FeatureInput.go (preprocessing_utils.py:155-193) over two clips with load_input_audio stubbed: the three .npy
+                             files per clip (dtype, shape, values)"""
+    hub, vcd = build_models(ns, S.CONFIG_40K_V2, "v2")
+
+    def dz(x):
+        n = x.shape[0] // 160 + 1
+        return S.designed_f0(n, seed=0).astype(np.float64)
+    audio = S.synth_audio(2.0, seed=7)
+    if "index" in which:
+        # the bank: reference-HuBERT features of three other clips plus jitter, stored as float16 (0.6 MB) and used as float32 on both sides
+        rng = np.random.default_rng(3)
+        with torch.no_grad():
+            base = np.concatenate([np_(hub.extract_features(torch.from_numpy(S.synth_audio(2.0, seed=50 + i)).view(1, -1), version="v2"))[0] for i in range(3)], 0)
+        big = (base[rng.integers(0, base.shape[0], 768)] + 0.05 * rng.standard_normal((768, base.shape[1]))).astype(np.float16).astype(np.float32)
+        idx = StubIndex(big)
+        i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=111, designed_f0=dz, f0_method="pm", file_index=(idx, big), index_rate=0.75, protect=0.33)
+        assert len(idx.calls) == 1
+        i16n, _, _, _ = run_ref_pipeline(ns, hub, vcd, audio, seed=111, designed_f0=dz, f0_method="pm", file_index="", index_rate=0.75, protect=0.33)
+        np.savez_compressed(os.path.join(OUT, "pipeline_2s_index.npz"), audio=audio, big_f16=big.astype(np.float16), ix=idx.calls[0].astype(np.int32), out_i16=i16,
+                            out_i16_noindex=i16n, sr=np.int64(sr), pitch=cap["pitch"], pitchf=cap["pitchf"], noise_seed=np.int64(111), index_rate=np.float64(0.75),
+                            protect=np.float64(0.33))
+        print("pipeline_2s_index", i16.shape, "distinct rows hit", len(set(idx.calls[0].tolist())), "max |with - without| =", int(np.abs(i16.astype(np.int32) - i16n).max()))
+    if "rmvpeplus" in which:
+        i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=112, f0_method="rmvpe+", f0_up_key=-2)
+        np.savez_compressed(os.path.join(OUT, "pipeline_2s_rmvpeplus.npz"), audio=audio, out_i16=i16, sr=np.int64(sr), pitch=cap["pitch"], pitchf=cap["pitchf"],
+                            noise_seed=np.int64(112), f0_up_key=np.int64(-2))
+        print("pipeline_2s_rmvpeplus", i16.shape, "min f0", float(cap["pitchf"].min()), "frames at the 50 Hz floor (x 2^(-2/12))", int((np.abs(cap["pitchf"] - 50 * 2 ** (-2 / 12)) < 1e-3).sum()))
+    if "f0file" in which:
+        # a hand-drawn contour over 0.3 .. 1.5 s: a glide, an unvoiced gap (0 Hz points) and a jump; 4 digits after the point like a text editor would save
+        pts = [(0.30, 220.0), (0.55, 330.0), (0.70, 330.0), (0.71, 0.0), (0.90, 0.0), (0.91, 440.0), (1.20, 392.5), (1.50, 261.63)]
+        text = "\n".join(f"{t:.4f},{f:.4f}" for t, f in pts) + "\n"
+        path = os.path.join(ns.ws, "f0_curve.csv")
+        with open(path, "w") as f:
+            f.write(text)
+        fobj = types.SimpleNamespace(name=path)
+        i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=113, designed_f0=dz, f0_method="pm", f0_file=fobj, f0_up_key=2)
+        i16n, _, capn, _ = run_ref_pipeline(ns, hub, vcd, audio, seed=113, designed_f0=dz, f0_method="pm", f0_up_key=2)
+        np.savez_compressed(os.path.join(OUT, "pipeline_2s_f0file.npz"), audio=audio, f0_text=np.frombuffer(text.encode(), dtype=np.uint8), out_i16=i16, sr=np.int64(sr),
+                            pitch=cap["pitch"], pitchf=cap["pitchf"], pitchf_nofile=capn["pitchf"], noise_seed=np.int64(113), f0_up_key=np.int64(2))
+        print("pipeline_2s_f0file", i16.shape, "frames changed by the splice", int((cap["pitchf"] != capn["pitchf"]).sum()))
+    if "featinput" in which:
+        pu = ref_shim.load_preprocessing_utils()
+        exp = tempfile.mkdtemp(prefix="rvc_featinput_")
+        clips = {"0_0.wav": S.synth_audio(1.7, seed=61), "0_1.wav": S.synth_audio(2.3, seed=62)}
+        pu.load_input_audio = lambda path, sr: (clips[os.path.basename(path)].copy(), sr)       # (the wav reader needs soundfile / ffmpeg)
+        out = {}
+        for version, D in (("v2", 768), ("v1", 256)):
+            d = os.path.join(exp, version)
+            for sub in ("2a_f0", "2b-f0nsf", f"3_feature{D}"):
+                os.makedirs(os.path.join(d, sub))
+            fi = pu.FeatureInput(hub, "rmvpe", d, samplerate=16000, hop_size=160, device="cpu", version=version, if_f0=True)
+            paths = [(os.path.join(d, n), os.path.join(d, "2a_f0", n), os.path.join(d, "2b-f0nsf", n), os.path.join(d, f"3_feature{D}", n)) for n in clips]
+            with ref_shim.chdir_ws(), torch.no_grad():
+                fi.go(paths)
+            for n in clips:
+                key = n.replace(".wav", "")
+                coarse, nsf, feat = (np.load(os.path.join(d, sub, n + ".npy")) for sub in ("2a_f0", "2b-f0nsf", f"3_feature{D}"))
+                out[f"{version}_{key}_coarse"], out[f"{version}_{key}_nsf"], out[f"{version}_{key}_feat"] = coarse, nsf, feat
+                print("featinput", version, key, coarse.dtype, coarse.shape, nsf.dtype, nsf.shape, feat.dtype, feat.shape, "coarse max", int(coarse.max()))
+            # second go(): everything present -> nothing rewritten (skip rule, :167-172)
+            before = {n: os.path.getmtime(os.path.join(d, f"3_feature{D}", n + ".npy")) for n in clips}
+            with ref_shim.chdir_ws(), torch.no_grad():
+                fi.go(paths)
+            assert before == {n: os.path.getmtime(os.path.join(d, f"3_feature{D}", n + ".npy")) for n in clips}
+            out[f"{version}_log"] = np.frombuffer(open(os.path.join(d, "extract_f0_feature.log")).read().encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "featinput.npz"), seconds=np.array([1.7, 2.3]), seeds=np.array([61, 62]), **out)
+        shutil.rmtree(exp)
 
 
 def _audio_digest(a):
@@ -443,6 +545,8 @@ def main():
         gen_synth_nono(ns, S.CONFIG_40K_V1, "v1", "40k_v1_nono")
     if "pipeline" in which:
         gen_pipeline(ns)
+    if {"index", "rmvpeplus", "f0file", "featinput"} & set(which):      # round 5: branches pinned through the real reference (see gen_pinned)
+        gen_pinned(ns, which)
     if "mdx23c" in which:
         gen_mdx23c()
     if "mdx23c_full" in which:       # one chunk at the shipped recipe (minutes of CPU)

@@ -61,12 +61,21 @@ def autotune_f0(f0):
     return np.array(out, dtype="float32")
 
 
-def f0_postprocess(f0, f0_up_key=0, f0_autotune=False, f0_min=50, f0_max=1600, f0_bins=256):
-    """get_f0 tail (reference pitch_extraction.py:280-303): autotune, transpose, coarse mel quantisation."""
+def f0_postprocess(f0, f0_up_key=0, f0_autotune=False, f0_min=50, f0_max=1600, f0_bins=256, inp_f0=None, x_pad=1):
+    """get_f0 tail (reference pitch_extraction.py:276-303): autotune, transpose, the f0-file splice, coarse mel quantisation.
+    inp_f0: float32 [m, 2] rows of (seconds, Hz) read from the user's f0 file (vc_infer_pipeline.py:146-151); the curve is resampled to 100 fps
+    over its own time span and written over the extracted pitch from the first frame of the un-padded clip on (:281-291) - AFTER the
+    transposition, so a spliced curve is not transposed."""
     f0 = np.array(f0, copy=True)
     if f0_autotune:
         f0 = autotune_f0(f0)
     f0 *= pow(2, f0_up_key / 12)
+    if inp_f0 is not None:
+        tf0 = 100
+        delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+        replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+        n = f0[x_pad * tf0: x_pad * tf0 + len(replace_f0)].shape[0]
+        f0[x_pad * tf0: x_pad * tf0 + len(replace_f0)] = replace_f0[:n]
     f0_mel_min, f0_mel_max = hz_to_mel(f0_min), hz_to_mel(f0_max)
     f0_mel = hz_to_mel(f0)
     f0_mel = (f0_mel - f0_mel_min) * (f0_bins - 2) / (f0_mel_max - f0_mel_min) + 1
@@ -183,8 +192,8 @@ def vc_segment(hubert_sd, synth_sd, config, version, sid, audio0, pitch, pitchf,
 def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up_key=0, f0_method="rmvpe",
              rms_mix_rate=0.25, protect=0.33, f0_autotune=False, noise_fn=None, f0_override=None,
              x_pad=1, x_query=6, x_center=38, x_max=41, return_float=False, n_hubert_layers=None, big_npy=None, index_rate=0.0,
-             if_f0=1, ivf=None):
-    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for resample_sr=0; optional index retrieval (exact, or the IVF probe when `ivf` is given); if_f0=0 is the
+             if_f0=1, ivf=None, inp_f0=None):
+    """VC.pipeline (reference vc_infer_pipeline.py:116-196) for resample_sr=0; inp_f0 = the parsed f0 file (see f0_postprocess); optional index retrieval (exact, or the IVF probe when `ivf` is given); if_f0=0 is the
     no-pitch model family (*_nono): no f0 front-end, pitch None all the way (:151-152,:172-179).
 
     audio: 16 kHz mono float32 (already remixed).  Returns int16 [N] at tgt_sr (and the float waveform
@@ -203,7 +212,7 @@ def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up
             f0 = nets.rmvpe_infer_from_audio(rmvpe_sd, audio_pad, thred=0.03)
             if f0_method == "rmvpe+":
                 f0 = np.clip(f0, a_min=50, a_max=1600)   # infer_from_audio_with_pitch (lib/rmvpe.py:649-659)
-        pitch, pitchf = f0_postprocess(f0, f0_up_key, f0_autotune)
+        pitch, pitchf = f0_postprocess(f0, f0_up_key, f0_autotune, inp_f0=inp_f0, x_pad=x_pad)
         p_len = min(pitch.shape[0], pitchf.shape[0])
         pitch = torch.from_numpy(pitch[:p_len].astype(np.int64)).unsqueeze(0)
         pitchf = torch.from_numpy(pitchf[:p_len].astype(np.float32)).unsqueeze(0)
@@ -228,3 +237,19 @@ def pipeline(hubert_sd, rmvpe_sd, synth_sd, config, version, audio, sid=0, f0_up
     audio_max = np.abs(audio_opt).max() / 0.99
     audio_i16 = (audio_opt * MAX_INT16 / audio_max).astype(np.int16)
     return (audio_i16, audio_f) if return_float else audio_i16
+
+
+def parse_f0_file(text):
+    """The f0 file of `vc_single(f0_file=...)`: one "seconds,Hz" pair per line (reference vc_infer_pipeline.py:146-151)."""
+    return np.array([list(map(float, line.split(","))) for line in text.strip("\n").split("\n")], dtype="float32")
+
+
+def feature_input(hubert_sd, rmvpe_sd, x, version="v2"):
+    """FeatureInput.go's three arrays for one 16 kHz clip (reference preprocessing_utils.py:129-193): HuBERT features float32 [T_h, 768 | 256]
+    (compute_feats, all 12 layers run, layer 12 / final_proj(layer 9) taken), and compute_f0 = get_f0(x, 0, "rmvpe") with get_f0's OWN defaults
+    f0_min 50 / f0_max 1100 (pitch_extraction.py:261-262; inference passes 1600) -> coarse int16 [n], f0 float64 [n].  The clip is NOT padded."""
+    feats = nets.hubert_extract_features(hubert_sd, torch.from_numpy(np.asarray(x)).float().view(1, -1), version)
+    feats = feats.squeeze(0).float().numpy()
+    f0 = nets.rmvpe_infer_from_audio(rmvpe_sd, np.asarray(x), thred=0.03)
+    coarse, nsf = f0_postprocess(f0, 0, False, f0_min=50, f0_max=1100)
+    return coarse, nsf, feats

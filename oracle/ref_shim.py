@@ -188,6 +188,23 @@ def load_reference():
     return ns
 
 
+def load_preprocessing_utils():
+    """The reference's preprocessing_utils (FeatureInput), imported on demand: it pulls lib/slicer2 and lib/audio's
+    AudioProcessor, which the inference goldens never need."""
+    ns = load_reference()
+    if not hasattr(ns, "preprocessing_utils"):
+        link = os.path.join(ns.ws, PKG, "preprocessing_utils.py")
+        if not os.path.exists(link):
+            os.symlink(os.path.join(REF_ROOT, "preprocessing_utils.py"), link)
+        old = os.getcwd()
+        os.chdir(ns.ws)
+        try:
+            ns.preprocessing_utils = importlib.import_module(f"{PKG}.preprocessing_utils")
+        finally:
+            os.chdir(old)
+    return ns.preprocessing_utils
+
+
 class chdir_ws:
     """Context manager: run reference code with CWD = the scratch workspace (models/, configs/)."""
 

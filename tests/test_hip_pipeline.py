@@ -67,6 +67,70 @@ def test_pipeline_rmvpe_matches_reference_golden(models, noise_tape):
     assert st["max"] <= LSB, st
 
 
+def test_pipeline_index_blend_matches_reference_golden(models, noise_tape):
+    """Retrieval + protect blend against the REAL reference (golden from vc_single with a preloaded (index, big_npy) pair, reference
+    vc_infer_pipeline.py:58-95): the device search picks the rows the reference's index returned on every frame, and the waveform follows -
+    on the device path (DeviceIndex.blend_device on the side stream) and on the generic VC.vc path with a plain `.search` object."""
+    from scipy import signal
+    from comfy_rvc_amd.lib.feature_index import DeviceIndex
+    from comfy_rvc_amd.vc_infer_pipeline import ah, bh
+    hub = models[0]
+    g0 = golden("pipeline_2s_index.npz")
+    big = g0["big_f16"].astype(np.float32)
+    idx = DeviceIndex(big)
+    padded = np.pad(signal.filtfilt(bh, ah, g0["audio"]), (16000, 16000), mode="reflect")
+    q = hub.extract_features(torch.from_numpy(padded.copy()).float()[None], version="v2")[0].cpu().numpy()
+    _, ix = idx.search(q, k=1)
+    assert np.array_equal(ix[:, 0], g0["ix"])
+    kw = dict(designed=True, f0_method="pm", index_rate=float(g0["index_rate"]), protect=float(g0["protect"]))
+    g, wav, sr, _ = _run(models, "pipeline_2s_index.npz", noise_tape, file_index=(idx, big), **kw)
+    assert wav.shape == g["out_i16"].shape and np.max(np.abs(wav.astype(np.int32) - g["out_i16"].astype(np.int32))) <= LSB
+
+    class HostIndex:          # no blend_device: VC.pipeline takes the host loop and VC.vc the generic branch (reference arithmetic in numpy)
+        search_device = None  # (load_index swaps foreign index objects for a DeviceIndex unless they carry this attribute)
+
+        def search(self, x, k=1):
+            return idx.search(x, k=k)
+    _, wav2, _, _ = _run(models, "pipeline_2s_index.npz", noise_tape, file_index=(HostIndex(), big), **kw)
+    assert np.max(np.abs(wav2.astype(np.int32) - g["out_i16"].astype(np.int32))) <= LSB
+    _, wav0, _, _ = _run(models, "pipeline_2s_index.npz", noise_tape, file_index="", **kw)
+    assert np.max(np.abs(wav0.astype(np.int32) - g["out_i16_noindex"].astype(np.int32))) <= LSB
+
+
+def test_pipeline_rmvpe_plus_matches_reference_golden(models, noise_tape):
+    """f0_method "rmvpe+" (the example graphs' default) through vc_single against the reference (pitch_extraction.py:197-201): every frame's
+    pitch - the 50 Hz floor of the unvoiced frames included - the coarse pitch and the waveform."""
+    from comfy_rvc_amd.vc_infer_pipeline import VC
+    cap = {}
+    orig = VC.get_f0
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        cap["pitch"], cap["pitchf"] = np.array(r[0]), np.array(r[1])
+        return r
+    VC.get_f0 = spy
+    try:
+        g, wav, sr, vc = _run(models, "pipeline_2s_rmvpeplus.npz", noise_tape, f0_method="rmvpe+", f0_up_key=-2)
+    finally:
+        VC.get_f0 = orig
+    assert cap["pitchf"].shape == g["pitchf"].shape and np.allclose(cap["pitchf"], g["pitchf"], rtol=1e-3, atol=1e-3)
+    assert np.array_equal(cap["pitchf"] < 45, g["pitchf"] < 45) and np.max(np.abs(cap["pitch"].astype(int) - g["pitch"].astype(int))) == 0
+    assert wav.shape == g["out_i16"].shape and np.max(np.abs(wav.astype(np.int32) - g["out_i16"].astype(np.int32))) <= LSB
+
+
+def test_pipeline_f0_file_matches_reference_golden(models, noise_tape, tmp_path):
+    """vc_single(f0_file=<object with .name>) against the reference (vc_infer_pipeline.py:146-151, pitch_extraction.py:281-291)."""
+    import types
+    g0 = golden("pipeline_2s_f0file.npz")
+    path = tmp_path / "curve.csv"
+    path.write_bytes(bytes(g0["f0_text"]))
+    g, wav, sr, vc = _run(models, "pipeline_2s_f0file.npz", noise_tape, designed=True, f0_method="pm", f0_up_key=int(g0["f0_up_key"]),
+                          f0_file=types.SimpleNamespace(name=str(path)))
+    assert wav.shape == g["out_i16"].shape and np.max(np.abs(wav.astype(np.int32) - g["out_i16"].astype(np.int32))) <= LSB
+    _, wav0, _, _ = _run(models, "pipeline_2s_f0file.npz", noise_tape, designed=True, f0_method="pm", f0_up_key=int(g0["f0_up_key"]))
+    assert np.max(np.abs(wav0.astype(np.int32) - g["out_i16"].astype(np.int32))) > 10 * LSB            # (the splice is audible in this fixture)
+
+
 def test_generic_callee_path_equals_fused_path(models, noise_tape):
     """VC.vc through the duck-typed protocol (extract_features / infer) gives the same audio as the fused entry point."""
     from comfy_rvc_amd.config import Config
