@@ -40,6 +40,14 @@ PMC_TRAFFIC_FILE = os.path.join("profiles", "r4zz_pmc_traffic.json")
 MAX_LINE_BYTES = 6144              # the driver parses ONE JSON line from stdout; round 4's 17.9 KB line was not parsed
 
 
+class Delivered:
+    """One converted clip: the host array vc_single returned and the device tensor the same samples still occupy (for the gather)."""
+    __slots__ = ("host", "dev")
+
+    def __init__(self, host, dev):
+        self.host, self.dev = host, dev
+
+
 def launch_ranks(n):
     """Parent of a self-launched N-rank run: starts one child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and waits.
     Runs before anything in this process has touched HIP (importing torch does not); the children are ordinary subprocesses, nothing
@@ -205,6 +213,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the process group and run every step's gather (exercises RCCL on a 1-GPU box)")
+    ap.add_argument("--ragged", action="store_true", help="--dry-run only: stub outputs of clip- and rank-dependent lengths (the gather's padded path)")
     ap.add_argument("--no-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     args = ap.parse_args()
     if args.seconds <= 0:
@@ -314,6 +323,8 @@ def main():
                     clip, sr_in = demix_mdxv3(clip, mdx, dev, MDX23C_CONFIG, MDX23C_CONFIG["inference"]["num_overlap"])["Vocals"], 44100
                 out = vc_single(cpt=vcd["cpt"], net_g=vcd["net_g"], vc=lvc, hubert_model=hub, input_audio=(clip, sr_in), config=cfg, **params)
                 assert out is not None, "vc_single failed"
+                if collective and backend == "nccl":      # the gather takes the int16 result where rvc_postprocess left it (HBM): no host re-upload
+                    return Delivered(out[0], lvc.last_i16)
                 return out[0]
             return convert, lvc
         lanes = [make_lane() for _ in range(n_lanes)]
@@ -322,9 +333,10 @@ def main():
     else:
         n_out = int((2 * ((int(args.seconds * 16000) + 32000 - 400) // 320 + 1)) * (SYN_CFG[-1] // 100) - 2 * SYN_CFG[-1])
 
-        def stub(clip, i=0):                    # --dry-run: the documented output length, no compute
+        def stub(clip, i=0):                    # --dry-run: the documented output length (minus a clip-dependent tail with --ragged), no compute
             time.sleep(0.002)
-            return np.zeros(clip.shape[0] // 160 + 1, dtype=np.float64) if pitch_only else np.zeros(n_out, dtype=np.int16)
+            cut = (7 * rank + i) % 13 * 48 if args.ragged else 0
+            return np.zeros(clip.shape[0] // 160 + 1, dtype=np.float64) if pitch_only else np.full(n_out - cut, rank, dtype=np.int16)
         convert_mdx = []
         lanes = [(stub, None) for _ in range(n_lanes)]
         pool = ClipLanes([fn for fn, _ in lanes], device=None)
@@ -336,11 +348,16 @@ def main():
         """k steps = k * CLIPS clips of this rank through the lanes (a free lane pulls the next clip while the previous step is gathered);
         the waveforms of a step are handed to ONE gather (the path's only exchange) in clip order."""
         wav, batch = None, []
-        for wav in pool.imap([audio] * (k * n_clips)):
-            batch.append(wav)
+        for res in pool.imap([audio] * (k * n_clips)):
+            wav = res.host if isinstance(res, Delivered) else res
+            batch.append(res)
             if len(batch) == n_clips:
                 if collective:   # every rank already holds ITS clips on the host (vc_single delivered them); rank 0 keeps the gathered copy in HBM
-                    gather_waveforms(np.concatenate(batch).view(np.int16), coll_dev, to_host=False, force_collective=True)     # (f0 vectors travel as their bytes)
+                    if isinstance(batch[0], Delivered):
+                        step_wav = torch.cat([b.dev for b in batch])                 # device-resident int16, concatenated on the device
+                    else:
+                        step_wav = np.concatenate(batch).view(np.int16)            # gloo / dry run / f0 vectors (which travel as their bytes)
+                    gather_waveforms(step_wav, coll_dev, to_host=False, force_collective=True)
                 batch = []
         return wav
 

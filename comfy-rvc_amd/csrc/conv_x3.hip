@@ -571,14 +571,14 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       // the ResBlock convolutions: persistent workgroups (conv_x3q.hip)
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
-      conv_x3q_try(a, t.AM, t.AN, s, g, false);
+      RVC_REQUIRE(conv_x3q_try(a, t.AM, t.AN, s, g, false), "conv_x3q_try accepted the layer in its dry run and declined the launch");
       conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 6 << 4);
       return true;
     }
     if (conv_x3p_try(a, pam, pan, s, g, true)) {
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
-      conv_x3p_try(a, pam, pan, s, g, false);
+      RVC_REQUIRE(conv_x3p_try(a, pam, pan, s, g, false), "conv_x3p_try accepted the layer in its dry run and declined the launch");
       conv_prof_end(tk, s, flops, 14 + (s2_up ? 3 : id), conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 1 << 4);
       return true;
     }

@@ -596,20 +596,27 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   if (lds > budget) return false;
   const long long ntiles = (long long)((a.Tout + BN - 1) / BN) * (a.Co / BM);
   // (RVC_X3Q_MINROUNDS: grids of fewer rounds of resident workgroups stay on the per-tile kernel)
-  static const int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+  // (per device: one process may drive several GPUs, and the persistent grid is sized by the CURRENT device's CU count)
+  static int ncu_of[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (ncu_of[dev] == 0) { int n = 256; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); ncu_of[dev] = n > 0 ? n : 256; }
+  const int ncu = ncu_of[dev];
   static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
   // (default 0: every eligible pair, also where a workgroup owns a single tile - the 256-channel stage, short clips: measured neutral there against the per-tile
   // kernel (C256 pairs 1018 -> 1008 us), one kernel for every ResBlock pair of the three wide stages)
   static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 0;
   const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
   if (ntiles < min_rounds * slots || ntiles < 8) return false;
+  // a multiple of 8 (a workgroup's later tiles stay on its XCD) unless every workgroup owns exactly one tile; decided before the dry-run answer and
+  // before `a` is touched, so that "yes" in the dry run is "launched" in the real call
+  const long long G = ntiles <= slots ? ntiles : (slots & ~7LL);
+  if (G < 8) return false;
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
   static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
   a.xcd_remap = xcd_env;
-  // a multiple of 8 (a workgroup's later tiles stay on its XCD) unless every workgroup owns exactly one tile
-  long long G = ntiles <= slots ? ntiles : (slots & ~7LL);
-  if (G < 8) return false;
   dim3 grid((unsigned)G, 1, 1);
   grid_out = grid;
   if (AM == 2 && AN == 4) launch_x3q_r<2, 4>(a, R, mode, grid, lds, s);

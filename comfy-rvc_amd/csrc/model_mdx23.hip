@@ -885,14 +885,22 @@ void mdx23_demix(Mdx23* M, hipStream_t s, const float* mix, long long Lp, long l
     for (int k = 1; k < K; ++k) {
       Mdx23::Lane& Ln = M->lane[k];
       if (!Ln.st) { RVC_HIP_CHECK(hipStreamCreateWithFlags(&Ln.st, hipStreamNonBlocking)); RVC_HIP_CHECK(hipEventCreateWithFlags(&Ln.done, hipEventDisableTiming)); }
-      if (Ln.acc_n < n) { if (Ln.acc) (void)hipFree(Ln.acc); Ln.acc = nullptr; RVC_HIP_CHECK(hipMalloc(&Ln.acc, n * sizeof(float))); Ln.acc_n = n; }
+      if (Ln.acc_n < n) { if (Ln.acc) (void)hipFree(Ln.acc); Ln.acc = nullptr; Ln.acc_n = 0; RVC_HIP_CHECK(hipMalloc(&Ln.acc, n * sizeof(float))); Ln.acc_n = n; }
       RVC_HIP_CHECK(hipStreamWaitEvent(Ln.st, M->ev_start, 0));          // (the mix is ready, the previous call's reads of this lane's accumulator are behind us)
       RVC_HIP_CHECK(hipMemsetAsync(Ln.acc, 0, n * sizeof(float), Ln.st));
     }
   }
-  for (long long c = 0; c < n_chunks; ++c) {
-    const int k = (int)(c % K);
-    mdx23_chunk(M, k, k == 0 ? s : M->lane[k].st, mix + c * step, C, (k == 0 ? acc : M->lane[k].acc) + c * step, MdxIO{Lp, Lp, 1});
+  try {
+    for (long long c = 0; c < n_chunks; ++c) {
+      const int k = (int)(c % K);
+      mdx23_chunk(M, k, k == 0 ? s : M->lane[k].st, mix + c * step, C, (k == 0 ? acc : M->lane[k].acc) + c * step, MdxIO{Lp, Lp, 1});
+    }
+  } catch (...) {
+    // a chunk failed to enqueue: the lane streams may still be reading `mix` / writing their accumulators - the caller's stream waits for them before the
+    // error reaches Python (which then hands both buffers back to torch's caching allocator)
+    for (int k = 1; k < K; ++k)
+      if (M->lane[k].st && M->lane[k].done && hipEventRecord(M->lane[k].done, M->lane[k].st) == hipSuccess) (void)hipStreamWaitEvent(s, M->lane[k].done, 0);
+    throw;
   }
   for (int k = 1; k < K; ++k) {
     RVC_HIP_CHECK(hipEventRecord(M->lane[k].done, M->lane[k].st)); RVC_HIP_CHECK(hipStreamWaitEvent(s, M->lane[k].done, 0));

@@ -84,7 +84,17 @@ class FeatureExtractor:
                 try:
                     big_npy, info = read_index_vectors(file_index)
                     if info.get("kind") == "ivf_flat" and info.get("metric", 1) == 1:
-                        ivf = (info["centroids"], info["list_of"], max(1, int(info["nprobe"])))
+                        nprobe, nlist = max(1, int(info["nprobe"])), int(info["nlist"])
+                        if 16 < nprobe < nlist:
+                            # the device probe handles up to 16 cells per query; a file saved with more (none of the reference's: train_index sets 1)
+                            # is searched exactly instead of being dropped - the exact answer is what faiss converges to as nprobe grows
+                            print(f"{file_index}: nprobe {nprobe} of {nlist} cells exceeds the device probe (16): using the exact search")
+                        else:
+                            ivf = (info["centroids"], info["list_of"], nprobe)
+                            if nprobe < nlist and not getattr(FeatureExtractor, "_warned_empty_cells", False):
+                                FeatureExtractor._warned_empty_cells = True
+                                print("IVF index: a frame whose probed cells are all empty gets faiss's label -1 and, through the reference's "
+                                      "1 / score^2 weights, a NaN feature frame (reference behaviour, kept)")
                 except ValueError:
                     import faiss   # noqa: PLC0415 - other index types (PQ ...): only faiss can decode them
                     fidx = faiss.read_index(file_index)

@@ -330,6 +330,7 @@ def _pipeline_device(self, model, net_g, sid, audio, f0_up_key, f0_method, merge
         _lib.check(_lib.lib.rvc_postprocess(_lib.current_stream(), _lib.ptr(wav), N, _lib.ptr(rms1), 0 if rms1 is None else rms1.numel(),
                                             int(tgt_sr), float(rms_mix_rate), _lib.ptr(i16)))
     self.last_float = wav          # device tensor: waveform after change_rms, before the int16 normalisation
+    self.last_i16 = i16            # device tensor: the int16 result (what a multi-GPU caller hands to the gather without a host round trip)
     _mark("post enqueued")
     res = i16.cpu().numpy()
     _mark("result on host")

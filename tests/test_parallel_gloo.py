@@ -93,3 +93,31 @@ def test_bench_line_stays_small_enough_for_the_driver():
     total = base + len(json.dumps(roof, separators=(",", ":"))) + len(json.dumps(cpu, separators=(",", ":")))
     assert total < bench.MAX_LINE_BYTES < 8192, total
     assert total < 4096, total          # (today ~2.6 KB; a regression that doubles it should be looked at)
+
+
+def test_c4_shape_world8(tmp_path):
+    """BASELINE.json configs[3] on CPU: 8 ranks (gloo), 64 clips, 8 per rank through three lanes each, ragged outputs; every clip comes back on
+    rank 0 in clip order, and the per-step gather bench.py performs (a rank's 8 clips as one vector) delivers 8 vectors of the right lengths.
+    No 8-GPU node has been available to any round: this is the only execution of the N = 8 path so far (unmeasured on hardware)."""
+    sys.path.insert(0, HERE)
+    from gloo_worker_c4 import out_len
+    out = str(tmp_path / "c4.json")
+    port = _free_port()
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "gloo_worker_c4.py"), out], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r = json.load(open(out))
+    assert r["ok"] is True
+    assert r["lens"] == [sum(out_len(i) for i in range(k, 64, 8)) for k in range(8)]
+    assert r["heads"] == [[k, 56 + k] for k in range(8)]
+
+
+def test_bench_dry_run_world8_c4_shape():
+    """bench.py --gpus 8 --variant 48k_v2 (64 clips per step, 8 per GPU) with the stub conversion and ragged outputs: launcher, process group of
+    eight, one gather per step, one line."""
+    r = _bench("--gpus", "8", "--variant", "48k_v2", "--ragged", env={"OMP_NUM_THREADS": "1"})
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["config"]["clips_per_step"] == 64 and r["config"]["clips_per_gpu_per_step"] == 8
+    assert r["config"]["gathers_per_step"] == 1 and r["scaling"] == "weak" and r["data"].startswith("dry-run") and r["value"] > 0
