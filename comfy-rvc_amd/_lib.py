@@ -152,6 +152,7 @@ SIGNATURES = {
     "rvc_prof_cfg_name": (c_char_p, [c_int]),
     "rvc_debug_conv_timing": (c_int, [P(C.c_uint64), c_int]),
     "rvc_debug_x3p_check": (c_int, []),
+    "rvc_debug_set_x3s_mode": (c_int, [c_int]),
     "rvc_debug_gemm_split_bench": (c_int, [c_void_p] + [c_int] * 8 + [P(c_float), c_int, c_int]),
     "rvc_op_sine_source": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 3),
 }

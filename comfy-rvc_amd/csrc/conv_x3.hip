@@ -554,7 +554,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   const int NW = t.WM * t.WN;
   if (id < 0) return false;
   if ((xs || a0.Ys) && !(id == 3 || id == 4 || id == 7 || id == 8 || id == 9)) return false;   // tiles instantiated with the split-resident paths
-  if (xs && a0.Ys) return false;                                                    // (one side at a time so far)
+  static const int both_ok = getenv("RVC_X3Q_BOTH") ? atoi(getenv("RVC_X3Q_BOTH")) : 0;
+  if (xs && a0.Ys && !both_ok) return false;                                        // (one side at a time; both: the persistent kernel's experiment mode only)
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
   static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;

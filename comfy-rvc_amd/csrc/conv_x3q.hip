@@ -78,7 +78,7 @@ typedef float f32x4q __attribute__((ext_vector_type(4)));
 // YSPLIT: split-resident output image; RADD: residual (+ bias) added block by block during the tile (fp32 output, no activation after the sum).
 template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD>
 __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(const ConvArgsX p) {
-  static_assert(!(YSPLIT && RADD) && !(XSPLIT && YSPLIT), "one split side per launch");
+  static_assert(!(YSPLIT && RADD), "an image output has no residual");
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
   // R = weight slots in the ring (a unit is requested R - 2 units before the barrier that publishes it; as many as the LDS budget admits)
@@ -544,6 +544,7 @@ static void launch_x3q(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s)
 template <int AM, int AN, int KT, int R>
 static void launch_x3q_io(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
   if (mode == 0) launch_x3q<AM, AN, KT, R, false, true, false>(a, grid, lds, s);        // fp32 in, image out (c1 of a split pair)
+  else if (mode == 2) launch_x3q<AM, AN, KT, R, true, true, false>(a, grid, lds, s);   // image in, image out (round-5 experiment: c1 fed by a producer's image)
   else launch_x3q<AM, AN, KT, R, true, false, true>(a, grid, lds, s);                  // image in, fp32 out + residual (c2 of a split pair)
 }
 template <int AM, int AN, int R>
@@ -568,15 +569,16 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   static const int on = getenv("RVC_X3Q") ? atoi(getenv("RVC_X3Q")) : 1;
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
-  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || xs == ys || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
+  static const int both_ok = getenv("RVC_X3Q_BOTH") ? atoi(getenv("RVC_X3Q_BOTH")) : 0;      // image in AND image out (experiment, profiles/r5_x3q_image_in.txt)
+  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || (xs == ys && !(xs && ys && both_ok)) || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
   if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
   const int BM = 64 * AM, BN = 64 * AN;
   if (a.Co % BM || a.Co > 1024) return false;
-  if (xs && !(a.R != nullptr && a.act == ACT_NONE)) return false;     // image in: c2 of a pair (residual, nothing after the sum)
+  if (xs && !ys && !(a.R != nullptr && a.act == ACT_NONE)) return false;     // image in: c2 of a pair (residual, nothing after the sum)
   if (ys && (a.R || a.accumulate)) return false;
   if ((double)(a.Co / 16) * 4.0 * (double)a.ysTp * 16.0 >= 2147483648.0 || (double)(a.Ci / 16) * 4.0 * (double)a.xsTp * 16.0 >= 2147483648.0) return false;
-  const int mode = ys ? 0 : 1;
+  const int mode = (xs && ys) ? 2 : (ys ? 0 : 1);
   const int P = BN + (a.ktaps - 1) * a.dil;
   if (P > 384 || P > BN + 64) return false;
   const int Pm = (P + 7) & ~7;
@@ -607,7 +609,9 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   // (default 0: every eligible pair, also where a workgroup owns a single tile - the 256-channel stage, short clips: measured neutral there against the per-tile
   // kernel (C256 pairs 1018 -> 1008 us), one kernel for every ResBlock pair of the three wide stages)
   static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 0;
-  const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
+  // RVC_X3Q_SLOTPCT (experiment, round 5): the persistent grid takes only this share of the chip's workgroup slots, leaving CUs to the other lanes' narrow kernels
+  static const int slot_pct = getenv("RVC_X3Q_SLOTPCT") ? atoi(getenv("RVC_X3Q_SLOTPCT")) : 100;
+  const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu * (slot_pct > 0 && slot_pct < 100 ? slot_pct : 100) / 100;
   if (ntiles < min_rounds * slots || ntiles < 8) return false;
   // a multiple of 8 (a workgroup's later tiles stay on its XCD) unless every workgroup owns exactly one tile; decided before the dry-run answer and
   // before `a` is touched, so that "yes" in the dry run is "launched" in the real call

@@ -85,15 +85,30 @@ void conv_x3s_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 // UC = (chunk, tap) units per ring slot = per barrier.  With one unit per barrier a 64 x 64 tile issues 3 MFMAs per wave between two barriers:
 // measured (round 4, 768 -> 768 at T = 1599) a unit costs ~600 cycles for 96 cycles of MFMA issue - the wait, the barrier, the DMA issue and the
 // operand reads ARE the kernel.  Two units per barrier halve that fixed cost per product; the slot is two units wide, everything else is unchanged.
-template <int AM, int AN, int RS, int UC = 1>
-__global__ __launch_bounds__(256, (AM * AN >= 4 && RS != 3) ? 2 : 3) void conv_x3s_kernel(const GemmSArgs p) {
+//
+// DIRECT (round 5): the same tiles, accumulators, unit order and epilogue with NO LDS in the reduction at all.  The image formats are the MFMA operand
+// layout row by row - lane (li, lh) of a 32 x 32 x 16 block needs the 16 bytes [chunk][hi | lo][half lh][row li] - so a wave can load its operands
+// straight from L2 into the registers the MFMA reads: one buffer_load_dwordx4 per operand block (two contiguous 512-byte runs per instruction).
+// No DMA pieces (60 - 185 cycles of issue each: MI355X_MICROARCH.md, per-instruction constants), no barrier, no ring slot to publish: the four
+// waves of a workgroup are four independent streams, each RS units deep in registers (the compiler counts the plain loads itself).  What is
+// given up is the sharing of operand tiles between the waves of a workgroup (a 2 x 2 wave grid loads every byte twice from L2 / L1 instead of
+// once into LDS): at N = 1599 - 3198 columns the chip's L2 -> CU bandwidth (~64 B / clk / CU x 256) is abundant, the ring's latency chain is not.
+// workgroups per CU the register file admits: ring kernel as measured; register pipeline: accumulators + RS operand stages + ~28 others
+constexpr int x3s_wgs(int AM, int AN, int RS, bool DIRECT) {
+  if (!DIRECT) return (AM * AN >= 4 && RS != 3) ? 2 : 3;
+  const int regs = 16 * AM * AN + 8 * (AM + AN) * RS + 28;
+  return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+}
+template <int AM, int AN, int RS, int UC = 1, bool DIRECT = false>
+__global__ __launch_bounds__(256, x3s_wgs(AM, AN, RS, DIRECT)) void conv_x3s_kernel(const GemmSArgs p) {
   constexpr int WN = 2, NW = 4;
   constexpr int BM = 64 * AM, BN = 64 * AN;
   constexpr int NPA = BM / 16, NPB = BN / 16, NPW = (NPA + NPB) / NW;      // 1-KiB pieces of a unit: weights, input, per wave
   static_assert((NPA % NW) == 0 && (NPB % NW) == 0, "every wave's i-th piece is of one kind");
   constexpr int aslot = BM * 64, bslot = BN * 64, uslot = aslot + bslot;   // one unit: [hi | lo][half][rows][16 B]
   constexpr int slot = UC * uslot;                                        // one ring slot: UC units
-  static_assert(RS >= 3 && (RS - 2) * NPW * UC <= 63, "ring");
+  static_assert(DIRECT || (RS >= 3 && (RS - 2) * NPW * UC <= 63), "ring");
+  static_assert(!DIRECT || (UC == 1 && RS >= 2 && RS * 2 * (AM + AN) <= 60), "register pipeline: at most 60 loads in flight");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3s[];
 
   const int tid0 = threadIdx.x;
@@ -176,6 +191,90 @@ __global__ __launch_bounds__(256, (AM * AN >= 4 && RS != 3) ? 2 : 3) void conv_x
   int soff_a = (int)((unsigned)grp * p.wg_bytes) + u0 * wstep, soff_c = (grp * p.cig_chunks + u0 / KT) * cstep, soff_b = soff_c + (p.margin + tap_off(tap)) * 16;
   if (u0 >= p.seg2_u) { seg2 = true; soff_b = p.seg2_soff + (u0 - p.seg2_u) * cstep + p.margin * 16; }     // (a K slice that starts inside the second image)
   const int seg2_at = p.seg2_u - u0;                         // unit of this slice at which the second image starts
+  if constexpr (DIRECT) {
+    // ---- register pipeline: stage i of RS holds the operands of unit g RS + i; the loads of unit u + RS are issued right after unit u's MFMAs
+    // (same registers).  Units past the end read out of range (offset bit 31: the hardware range check returns zeros, no memory traffic) so that
+    // every group issues the same instructions; their MFMAs are skipped in the last group.
+    constexpr int D = RS;
+    int va[AM], vb[AN];
+#pragma unroll
+    for (int am = 0; am < AM; ++am) va[am] = (lh * p.CoPx + co0 + (wm * AM + am) * 32 + li) * 16;
+#pragma unroll
+    for (int an = 0; an < AN; ++an) vb[an] = (int)((lh * p.xsTp + n0 + (wn * AN + an) * 32 + li) * 16);
+    const int lo_a = p.CoPx * 32, lo_b = (int)(p.xsTp * 32);      // hi -> lo plane pair of the same unit
+    struct OpsD { u32x4 ah[AM], al[AM], bh[AN], bl[AN]; };
+    OpsD st[D];
+    int uw = 0;
+    // scalar offsets of the next unit.  k = 1 products without a second image (the transformer projections): two adds.  Otherwise the tap offset
+    // comes out of a per-lane copy of the table by v_readlane (a dynamically indexed kernel-argument load would put an s_load + lgkmcnt(0) in
+    // front of every unit), and tap wrap / second image are selects, not branches.
+    const bool simple = KT == 1 && seg2_at > U1;
+    const int toff_lane = arith ? 0 : p.toff[lane & 15];
+    auto pipeline = [&](auto simple_c) {
+    constexpr bool SIMPLE = decltype(simple_c)::value;
+    auto tap_off_v = [&](int t) { return arith ? t * p.tdil - p.tpad : __builtin_amdgcn_readlane(toff_lane, t); };
+    auto advance = [&]() {
+      ++uw;
+      soff_a += wstep;
+      if constexpr (SIMPLE) { soff_b += cstep; return; }
+      const bool in2 = uw > seg2_at, at2 = uw == seg2_at;
+      const bool wrap = tap + 1 == KT;
+      tap = (in2 || at2) ? tap : (wrap ? 0 : tap + 1);
+      soff_c += (!in2 && !at2 && wrap) ? cstep : 0;
+      const int b1 = soff_c + (p.margin + tap_off_v(tap)) * 16;
+      soff_b = at2 ? p.seg2_soff + p.margin * 16 : (in2 ? soff_b + cstep : b1);
+    };
+    auto load_unit = [&](OpsD& o, bool guard) {
+      const int poison = (guard && uw >= U1) ? (int)0x80000000u : 0;
+#pragma unroll
+      for (int am = 0; am < AM; ++am) {
+        o.ah[am] = __builtin_amdgcn_raw_buffer_load_b128(ars, va[am] | poison, soff_a, 0);
+        o.al[am] = __builtin_amdgcn_raw_buffer_load_b128(ars, va[am] | poison, soff_a + lo_a, 0);
+      }
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        o.bh[an] = __builtin_amdgcn_raw_buffer_load_b128(brs, vb[an] | poison, soff_b, 0);
+        o.bl[an] = __builtin_amdgcn_raw_buffer_load_b128(brs, vb[an] | poison, soff_b + lo_b, 0);
+      }
+      advance();
+    };
+    auto mfmas_d = [&](const OpsD& o) {                          // group order of the ring kernel: (hi_w lo_x), (lo_w hi_x), (hi_w hi_x)
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bl[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.al[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int an = 0; an < AN; ++an)
+          acc[am][an] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.ah[am]), __builtin_bit_cast(bf16x8, o.bh[an]), acc[am][an], 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) load_unit(st[i], true);
+    xs_last = XSTICK(); XSACC(1, xs_last - xs_begin);
+    const int G = (U1 + D - 1) / D;                              // groups of D units; the last one may be partial
+    int g = 0;
+    for (; g + 2 < G; ++g) {                                     // the next group is full: no guard in the steady state
+#pragma unroll
+      for (int i = 0; i < D; ++i) { mfmas_d(st[i]); load_unit(st[i], false); }
+    }
+    if (g + 1 < G) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) { mfmas_d(st[i]); load_unit(st[i], true); }
+      ++g;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (g * D + i < U1) mfmas_d(st[i]);
+    };
+    if (simple) pipeline(std::true_type{}); else pipeline(std::false_type{});
+  } else {
   int slw = 0, uw = 0;
   auto issue = [&]() {                                       // next UC units into slot slw; past the end the last unit is requested again
 #pragma unroll
@@ -271,9 +370,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 4 && RS != 3) ? 2 : 3) void conv_x
   int u = 0;
   for (; u + 1 < U; u += 2) { body(o0, o1); body(o1, o0); }
   if (u < U) body(o0, o1);
-  [[maybe_unused]] const long long xs_epi = XSTICK();
-  XSACC(2, xs_epi - xs_last);
+  XSACC(2, XSTICK() - xs_last);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the requests past the end: nothing may land in LDS after the workgroup has gone)
+  }
+  [[maybe_unused]] const long long xs_epi = XSTICK();
 
   // ---- K split: slabs in register order, write-through; the last slice to arrive sums them in slice order
   if (S > 1) {
@@ -535,8 +635,36 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
 }
+// register-direct variant: D units deep in registers, 1 KiB of LDS (the split-K ticket word)
+template <int AM, int AN, int D>
+static void launch_x3s_direct(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
+  hipLaunchKernelGGL((conv_x3s_kernel<AM, AN, D, 1, true>), dim3(blocks), dim3(256), 1024, s, a);
+}
+// 0: by shape (x3s_use_direct), 1: the LDS-ring kernel always, 2: the register-direct kernel always (rvc_debug_set_x3s_mode / RVC_X3S_MODE)
+static int g_x3s_mode = -1;
+void conv_x3s_set_mode(int m) { g_x3s_mode = m; }
+static int x3s_mode() {
+  if (g_x3s_mode < 0) g_x3s_mode = getenv("RVC_X3S_MODE") ? atoi(getenv("RVC_X3S_MODE")) : 0;
+  return g_x3s_mode;
+}
 
+// decided by x3s_plan for the launch that follows on this thread
+static thread_local bool t_plan_direct = false;
+static bool x3s_use_direct(const GemmSArgs& a, int AM, int AN, unsigned blocks) {
+  const int m = x3s_mode();
+  if (m == 1) return false;
+  if (m == 2) return true;
+  return t_plan_direct;
+}
 static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hipStream_t s) {
+  if (x3s_use_direct(a, AM, AN, blocks)) {
+    static const int d_env = getenv("RVC_X3S_D") ? atoi(getenv("RVC_X3S_D")) : 0;      // pipeline depth override (units in flight per wave)
+    if (AM == 2 && AN == 2) { if (d_env == 3) launch_x3s_direct<2, 2, 3>(a, blocks, s); else if (d_env == 5) launch_x3s_direct<2, 2, 5>(a, blocks, s); else launch_x3s_direct<2, 2, 4>(a, blocks, s); }
+    else if (AM == 2 && AN == 1) { if (d_env == 3) launch_x3s_direct<2, 1, 3>(a, blocks, s); else if (d_env == 8) launch_x3s_direct<2, 1, 8>(a, blocks, s); else launch_x3s_direct<2, 1, 4>(a, blocks, s); }
+    else if (AM == 1 && AN == 2) { if (d_env == 3) launch_x3s_direct<1, 2, 3>(a, blocks, s); else if (d_env == 8) launch_x3s_direct<1, 2, 8>(a, blocks, s); else launch_x3s_direct<1, 2, 4>(a, blocks, s); }
+    else { if (d_env == 4) launch_x3s_direct<1, 1, 4>(a, blocks, s); else if (d_env == 12) launch_x3s_direct<1, 1, 12>(a, blocks, s); else launch_x3s_direct<1, 1, 7>(a, blocks, s); }
+    return;
+  }
   // ring depth: RVC_X3S_RS = 3 / 4 / 6 for every launch; default 4, and 3 for the 128 x 128 tile on grids of three workgroups per CU and deep reductions - a ring of
   // three slots is 48 KiB and the kernel then fits 168 VGPRs, so THREE workgroups share a CU (MDX23C's 3x3 layers at 128 / 256 channels: 263 -> 235, 250 -> 217,
   // 526 -> 451 us in one call; smaller grids and the transformer projections lose 5 - 10 % with three slots and keep four)
@@ -563,7 +691,19 @@ static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hi
 // barriers and operand reads), tiles as large as that allows (L2 -> LDS bytes per MFMA fall with the tile), the deep reductions cut along K.
 static thread_local int t_force_s = 0, t_force_am = 0, t_force_an = 0;
 void conv_x3s_force(int ksplit, int am, int an) { t_force_s = ksplit; t_force_am = am; t_force_an = an; }
-static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int groups = 1) {
+static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int groups = 1, int ktaps = 1, bool swapped = false) {
+  // Which reduction loop (measured on MI355X, tools/bench_gemm.py, profiles/r5_bench_gemm_direct.txt; cold weights, both loops at their best tile / split):
+  //   3 x 3 over RMVPE's deep levels, 512 ch @ 606 positions: ring 27.4 us (split 6) vs direct 23.0 (split 3); 256 ch @ 2020: 21.7 (split 4) vs 18.9 (split 2)
+  //   k = 1, <= 768 rows: 768 -> 768 17.0 vs 16.5 (64 x 128), 512 -> 768 13.3 vs 12.6, 192 -> 576 @ 3198 9.2 vs 8.8, 192 -> 192 7.3 vs 6.6
+  //   k = 1, wide: 768 -> 3072 31.8 vs 38.3, 3072 -> 768 37.5 vs 40.4, 768 -> 2304 25.6 vs 24.3 (within the spread) -> ring
+  // i.e. the register pipeline wins where a launch is a few hundred small tiles of a short or tap-rich reduction (nothing to share through LDS that
+  // L2 does not deliver as fast, and no DMA / barrier chain per unit); the ring wins where operand sharing halves the L2 bytes of a wide product.
+  // MDX23C's large planes (N >= 64 K positions) keep the ring and its tuned tiles.
+  static const int d_auto = getenv("RVC_X3S_DIRECT_AUTO") ? atoi(getenv("RVC_X3S_DIRECT_AUTO")) : 0;      // (default OFF: in the pipeline the two loops measure the same - profiles/r5_exp_x3s_direct.txt)
+  const bool conv_small = ktaps >= 3 && ktaps <= 16 && groups == 1 && N <= 4096 && units >= 36;
+  const bool gemm_small = ktaps == 1 && groups == 1 && !swapped && M <= 768 && N <= 8192;
+  t_plan_direct = d_auto && x3s_mode() != 1 && (conv_small || gemm_small);
+  if (x3s_mode() == 2) t_plan_direct = true;
   static const int f_am = getenv("RVC_X3S_AM") ? atoi(getenv("RVC_X3S_AM")) : 0, f_an = getenv("RVC_X3S_AN") ? atoi(getenv("RVC_X3S_AN")) : 0;
   static const int f_s = getenv("RVC_X3S_SPLIT") ? atoi(getenv("RVC_X3S_SPLIT")) : 0;
   static const int target = getenv("RVC_X3S_BLK") ? atoi(getenv("RVC_X3S_BLK")) : 440;
@@ -571,6 +711,25 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int grou
   // measured on MI355X at N = 1599 (tools/bench_gemm.py, profiles/r3b_bench_gemm.txt): 768 -> 3072 128 x 64 35 us (64 x 128 the same, 128 x 128 38),
   // 768 -> 2304 128 x 64 28 us, 768 -> 768 64 x 64 16.3 us un-split (17.6 split in two), 3072 -> 768 64 x 64 split in two 37.8 us (128 x 64 in three 39.0)
   AM = 2; AN = 2;
+  if (t_plan_direct && x3s_mode() != 2) {
+    // register pipeline: 64 x 128 tiles for the k = 1 products while ~140 of them remain (the column operand is the one re-read per row tile), 64 x 64
+    // otherwise; K split to ~220 workgroups (half the ring's target: a wave streams deeper on its own)
+    auto tl = [&](int am, int an) { return (long long)((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
+    AM = 1; AN = (ktaps == 1 && tl(1, 2) >= 140) ? 2 : 1;
+    if (f_am && groups == 1) AM = f_am;
+    if (f_an) AN = f_an;
+    if ((t_force_am == 1 || t_force_am == 2)) AM = t_force_am;
+    if (t_force_an == 1 || t_force_an == 2) AN = t_force_an;
+    S = 1;
+    const long long nt = tl(AM, AN);
+    for (int c : {2, 3, 4, 6, 8}) {
+      if (nt * S >= 220) break;
+      if (units % c == 0 && units / c >= 32) S = c;
+    }
+    if (f_s) S = (units % f_s == 0) ? f_s : 1;
+    if (t_force_s > 0) S = (units % t_force_s == 0 && units / t_force_s >= 4) ? t_force_s : 1;
+    return;
+  }
   // (deep reductions - MDX23C's 3 x 3 layers at 384+ channels, 216+ units - keep the 128 x 128 tile from one tile per CU on: 384 -> 384 over 64 x 258 positions
   //  143 us on 387 tiles against 168 on 774 of 128 x 64; the transformer projections above have fewer tiles or shorter reductions and are not touched)
   const bool deep = units >= 128 && groups == 1 && tiles(2, 2) >= 256;
@@ -650,7 +809,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.bias = e.bias_override ? e.bias_override : L.bd_; a.R = e.R; a.ldR = e.ldR; a.Y = Y; a.ldY = ldY; a.Ys = e.ys_out; a.ysTp = e.ys_tp;
   a.act = e.act; a.act_slope = e.act_slope; a.act_before_res = e.act_before_res; a.out_scale = e.out_scale;
   int AM, AN, S;
-  x3s_plan(L.Co, T, a.nunits, AM, AN, S, G);
+  x3s_plan(L.Co, T, a.nunits, AM, AN, S, G, geom->ktaps);
   const int BM = 64 * AM, BN = 64 * AN;
   RVC_REQUIRE(L.CoPx % BM == 0, "weight image rows are padded to the tile");
   a.rows_pg = (L.Co + BM - 1) / BM;
@@ -708,7 +867,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   a.Y = Yrm; a.ldY = ldYrm;                                    // fp32 out[t][j], row-major (the GRU's input projection)
   a.R = Rrm; a.ldR = ldRrm;
   int AM, AN, S;
-  x3s_plan(T, rows, a.nunits, AM, AN, S, 1);
+  x3s_plan(T, rows, a.nunits, AM, AN, S, 1, 1, true);
   S = 1;                                                       // (48-unit reductions: never split)
   const int BM = 64 * AM, BN = 64 * AN;
   RVC_REQUIRE((long long)((T + BM - 1) / BM) * BM <= xsTp - kSplitMargin && (long long)row0 + (long long)((rows + BN - 1) / BN) * BN <= L.CoPx, "conv_x3s_run_swapped: a tile would read past an operand image");

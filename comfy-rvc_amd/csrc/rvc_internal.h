@@ -167,6 +167,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
                           const float* Rrm = nullptr, long long ldRrm = 0);  // Rrm: residual added to the product, laid out like Yrm (MDX23C's x + tdf(x))
 void split_image_from_tm(hipStream_t s, const float* x, int C, int T, int M, unsigned char* img, long long tp);      // x [C][T][M] -> image of the (C M) x T tensor
 void conv_x3s_force(int ksplit, int am, int an);
+void conv_x3s_set_mode(int mode);      // 0: by shape, 1: LDS-ring kernel, 2: register-direct kernel
 // one ConvBlockRes of 16 or 32 channels (3 x 3, 3 x 3, + x) in one launch (conv_cbr2.hip): x, out fp32 [C][H W], distinct
 bool cbr2_small_eligible(const ConvLayer& c1, const ConvLayer& c2);
 void cbr2_small_run(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* x, int H, int W, float* out);

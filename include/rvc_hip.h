@@ -373,6 +373,10 @@ int rvc_debug_conv_timing(uint64_t* out8, int reset);
 /* debug builds only (-DRVC_X3P_CHECK): number of waits of the pipelined bf16x3 kernel whose compile-time vmcnt exceeded the exact
  * run-time count since the last call (must be 0); -1 in ordinary builds */
 int rvc_debug_x3p_check(void);
+/* which reduction loop the split-resident GEMM / convolution (csrc/conv_x3s.hip) runs, process-wide: 0 = chosen by shape (default; RVC_X3S_MODE),
+ * 1 = operands through the LDS ring (LDS-DMA, one barrier per unit), 2 = operands loaded straight into the MFMA registers (no LDS, no barrier).
+ * Results are bit-identical between the two (same units, same MFMA order per accumulator); tools / tests A/B them in one process. */
+int rvc_debug_set_x3s_mode(int mode);
 /* kernel benchmark (tools/bench_gemm.py): `reps` back-to-back launches of the split-resident GEMM (csrc/conv_x3s.hip) for an [Co x Ci] layer
  * on T columns of device-resident random data (input image, fp32 output with a residual); ksplit / am / an as in rvc_op_gemm_split,
  * split_out != 0 writes the output as the split image (GELU epilogue) instead.  w2d > 0: a 3 x 3 convolution over a padded image of width w2d

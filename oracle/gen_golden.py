@@ -521,6 +521,44 @@ def gen_mdx23c_full():
     print("mdx23c_full_chunk", y.shape, "rms", float(np.sqrt((y ** 2).mean())), f"{time.time() - t0:.1f} s", {k: tuple(v.shape) for k, v in out.items()})
 
 
+def gen_mdx23c_demix_full():
+    """The reference's OWN demix_mdxv3 (lib/karafan/inference.py:32-74, imported through the shim with onnxruntime stubbed - the function never touches it)
+    around the reference's TFC_TDF_net at the SHIPPED recipe: a 2.96 s stereo clip at overlap 2 = THREE overlapping full-size chunks, zero padding,
+    NaN guard, overlap-add, division.  Stored: every 16th sample of both stems, a dense window across a chunk boundary, per-(stem, channel) norms.
+    ~10 minutes of CPU."""
+    import hashlib
+    import importlib
+    import time
+    ns = ref_shim.load_reference()
+    sys.modules.setdefault("onnxruntime", types.ModuleType("onnxruntime"))
+    with ref_shim.chdir_ws():
+        inf = importlib.import_module(f"{ref_shim.PKG}.lib.karafan.inference")
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+
+    def nsd(d):
+        return NS({k: nsd(v) if isinstance(v, dict) else v for k, v in d.items()})
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as cfg
+    net = inf.tfc_tdf.TFC_TDF_net(nsd(cfg)).eval()
+    net.load_state_dict(to_torch_sd(S.mdx23c_state_dict(cfg, 0)), strict=True)
+    C = cfg["audio"]["hop_length"] * (cfg["inference"]["dim_t"] - 1)
+    overlap = 2
+    L = C // overlap
+    mix = np.stack([S.synth_audio(L / 44100.0, seed=71, sr=44100)[:L], S.synth_audio(L / 44100.0, seed=72, sr=44100)[:L]]).astype(np.float32)
+    assert mix.shape == (2, L)
+    t0 = time.time()
+    est = inf.demix_mdxv3(mix, net, "cpu", nsd(cfg), overlap)
+    y = np.stack([est["Vocals"], est["Instrumental"]])
+    assert y.shape == (2, 2, L)
+    w0 = L // 2 - 2048
+    np.savez_compressed(os.path.join(OUT, "mdx23c_demix_full.npz"), seeds=np.array([71, 72]), n=np.int64(L), overlap=np.int64(overlap),
+                        audio_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(mix).tobytes()).digest(), dtype=np.uint8),
+                        out_sub=y[..., ::16].copy(), out_win=y[..., w0:w0 + 4096].copy(), win0=np.int64(w0),
+                        out_norm=np.sqrt((y.astype(np.float64) ** 2).sum(-1)), out_absmax=np.abs(y).max(-1))
+    print("mdx23c_demix_full", y.shape, "rms", float(np.sqrt((y ** 2).mean())), f"{time.time() - t0:.1f} s")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load_reference()
@@ -551,6 +589,8 @@ def main():
         gen_mdx23c()
     if "mdx23c_full" in which:       # one chunk at the shipped recipe (minutes of CPU)
         gen_mdx23c_full()
+    if "mdx23c_demix_full" in which: # three full-size chunks through the reference's own demix_mdxv3 (~10 minutes of CPU)
+        gen_mdx23c_demix_full()
     if {"full40", "full45", "full48", "rmvpe60"} & set(which):   # BASELINE.json's full-size configurations (minutes of CPU time)
         gen_fullsize(ns, which)
 

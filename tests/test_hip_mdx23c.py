@@ -131,6 +131,105 @@ def test_full_mdx23c_recipe_matches_reference_golden():
     assert rel_err(np.abs(y).max(-1), g["out_absmax"]) < 1e-3
 
 
+@pytest.fixture(scope="module")
+def full_net():
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG
+    from comfy_rvc_amd.lib.karafan.tfc_tdf import TFC_TDF_net
+    net = TFC_TDF_net(MDX23C_CONFIG)
+    net.load_state_dict(S.mdx23c_state_dict(MDX23C_CONFIG, 0))
+    return MDX23C_CONFIG, net
+
+
+def test_full_recipe_demix_matches_the_references_own_demix(full_net):
+    """VALUES of the whole demix_mdxv3 at the shipped recipe: three overlapping full-size chunks (2.96 s stereo clip, overlap 2) against what the
+    REFERENCE's own demix_mdxv3 + TFC_TDF_net produced in the build container (tests/golden/mdx23c_demix_full.npz, oracle/gen_golden.py
+    mdx23c_demix_full; reference lib/karafan/inference.py:32-74): padding, chunk order, overlap-add across the seams, the division."""
+    import hashlib
+    from comfy_rvc_amd.lib.karafan.inference import demix_mdxv3
+    cfg, net = full_net
+    g = golden("mdx23c_demix_full.npz")
+    L = int(g["n"])
+    mix = np.stack([S.synth_audio(L / 44100.0, seed=int(sd), sr=44100)[:L] for sd in g["seeds"]]).astype(np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(mix).tobytes()).digest(), dtype=np.uint8), g["audio_sha256"])
+    w0 = int(g["win0"])
+    outs = []
+    for k in (1, 3):
+        net.set_streams(k)
+        try:
+            est = demix_mdxv3(mix, net, net.device, cfg, int(g["overlap"]))
+        finally:
+            net.set_streams(1)
+        y = np.stack([est["Vocals"], est["Instrumental"]])
+        assert y.shape == (2, 2, L)
+        assert rel_err(y[..., ::16], g["out_sub"]) < 1e-3 and rel_err(y[..., w0:w0 + 4096], g["out_win"]) < 1e-3
+        assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), g["out_norm"]) < 1e-3 and rel_err(np.abs(y).max(-1), g["out_absmax"]) < 1e-3
+        outs.append(y)
+    assert rel_err(outs[1], outs[0]) < 1e-5                      # chunks over three streams: the same sums re-associated
+
+
+def test_c5_full_size_uvr_then_vc_chain(full_net, tmp_path, monkeypatch):
+    """BASELINE.json configs[4] at FULL size through the node surface: a 30 s stereo 44.1 kHz clip -> UVR5Node.split (MDX23C at the shipped recipe,
+    overlap 8: 48 chunks of 5.9 s) -> vocal stem thunk -> RVCNode.convert with the 48k_v2 synthesizer.  Values of the network and of demix_mdxv3 are
+    pinned by the golden tests above; here the size-independent properties at the real size: shapes, finiteness, bit-identical repeats, chunk
+    streams 1 vs 3 within re-association, output length and normalisation of the conversion."""
+    import comfy_rvc_amd.lib as lib
+    import comfy_rvc_amd.pitch_extraction as pe
+    from comfy_rvc_amd.custom_nodes import rvc_nodes as N, uvr as U
+    from comfy_rvc_amd.lib.audio import bytes_to_audio
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.vc_infer_pipeline import get_vc
+    cfg, net = full_net
+    models = tmp_path / "models"
+    (models / "karafan").mkdir(parents=True)
+    (models / "karafan" / "MDX23C-8KFFT-InstVoc_HQ.ckpt").write_bytes(b"")      # (the 450 MB checkpoint file itself is exercised at the reduced recipe)
+    as_t = lambda sd: {k: torch.as_tensor(np.ascontiguousarray(v)).clone() for k, v in sd.items()}   # noqa: E731
+    torch.save(as_t(S.rmvpe_state_dict(0)), str(models / "rmvpe.pt"))
+    for mod in (lib, pe, N, U):
+        monkeypatch.setattr(mod, "BASE_MODELS_DIR", str(models), raising=False)
+
+    def loader(path, config=None):
+        net.set_streams(3)                                       # what load_mdx23c sets for the node (one clip at a time)
+        return net, cfg
+    monkeypatch.setattr(U, "load_mdx23c", loader)
+    secs = 30.0
+    stereo = np.stack([S.synth_audio(secs, seed=100, sr=44100), S.synth_audio(secs, seed=300, sr=44100)]).astype(np.float32)
+    n = stereo.shape[1]
+    audio = N.to_audio_dict(stereo, 44100)
+    try:
+        stems = []
+        for _ in range(2):
+            vocals, music = U.UVR5Node().split(audio, "karafan/MDX23C-8KFFT-InstVoc_HQ.ckpt", format="wav")
+            v, sr = bytes_to_audio(vocals())
+            m, _ = bytes_to_audio(music())
+            assert sr == 44100 and v.shape == m.shape == stereo.shape and np.isfinite(v).all() and np.isfinite(m).all()
+            stems.append((v, m))
+        assert np.array_equal(stems[0][0], stems[1][0]) and np.array_equal(stems[0][1], stems[1][1])      # three chunk streams: bit-identical repeats
+        assert np.abs(stems[0][0]).max() > 1e-4 and not np.array_equal(stems[0][0], stems[0][1])
+        net.set_streams(1)
+        monkeypatch.setattr(U, "load_mdx23c", lambda path, config=None: (net, cfg))
+        N._MEMO.clear() if hasattr(N, "_MEMO") else None
+        v1, _ = bytes_to_audio(U.UVR5Node().split(audio, "karafan/MDX23C-8KFFT-InstVoc_HQ.ckpt", format="wav")[0]())
+        assert rel_err(v1, stems[0][0]) < 1e-4                 # (wav bytes: int16-quantised stems of the two summation orders)
+    finally:
+        net.set_streams(1)
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    vcd = get_vc(S.synth_checkpoint(S.CONFIG_48K_V2, "v2", 0))
+    (params,) = N.LoadPitchExtractionParams().load_params(f0_method="rmvpe", f0_autotune=False, index_rate=0.0, resample_sr=0, rms_mix_rate=0.25,
+                                                          protect=0.25, crepe_hop_length=160)
+    wavs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        out = N.RVCNode().convert(vocals, lambda: vcd, lambda: hub, params, f0_up_key=0, format="wav", use_cache=False)
+        wav, sr2 = bytes_to_audio(out["result"][0]())
+        wavs.append(wav)
+        assert sr2 == 48000 and wav.ndim == 1 and np.isfinite(wav).all()
+    n16 = int(round(n * 16000 / 44100))
+    expect = 2 * ((n16 + 32000 - 400) // 320 + 1) * 480 - 2 * 48000              # 2 T_h upp - 2 t_pad_tgt (SURVEY 9) of the 16 kHz vocal stem
+    assert abs(wavs[0].shape[0] - expect) <= 960, (wavs[0].shape, expect)            # (the resampler may round the 16 kHz length by a sample or two)
+    assert np.array_equal(wavs[0], wavs[1])                                        # same seed, same audio: bit-identical conversion
+    assert abs(np.abs(wavs[0]).max() - 0.99) < 2e-3                                # pipeline normalises the peak to 0.99 (reference vc_infer_pipeline.py:188-189)
+
+
 def test_uvr_then_vc_chain(small, tmp_path, monkeypatch):
     """BASELINE config C5 in miniature: UVR5Node (karafan MDX23C, reduced recipe with a yaml next to the checkpoint) splits a stereo
     44.1 kHz clip, the vocal stem thunk goes into RVCNode (48k_v2 synthesizer) and comes out as WAV bytes at 48 kHz."""

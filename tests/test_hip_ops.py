@@ -888,6 +888,65 @@ def test_gemm_split_resident_under_load(L):
         assert torch.equal(outs[i], outs[i % 2])
 
 
+def _x3s_modes(L, fn):
+    """fn() under the LDS-ring reduction loop (mode 1) and the register-direct one (mode 2) of csrc/conv_x3s.hip; the process-wide default is restored."""
+    outs = []
+    try:
+        for mode in (1, 2):
+            L.check(L.lib.rvc_debug_set_x3s_mode(mode))
+            outs.append(fn())
+    finally:
+        L.check(L.lib.rvc_debug_set_x3s_mode(0))
+    return outs
+
+
+@pytest.mark.parametrize("case", GEMM_SPLIT, ids=[f"g{i}" for i in range(len(GEMM_SPLIT))])
+def test_gemm_split_register_direct_equals_lds_ring(L, case):
+    """The register-direct reduction loop (operands loaded straight into the MFMA registers: no LDS, no barrier) against the LDS-ring loop on every
+    GEMM case above: same units, same MFMA order per accumulator, same K-split reduction => BIT-identical fp32 rows and split images; and against
+    float64 directly."""
+    Ci, Co, T, act, res, abr, scale, ks, am, an = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 10000)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci)
+    b = torch.randn(Co, generator=g) * 0.1
+    r = torch.randn(Co, T, generator=g) if res else None
+    v = w.double() @ x.double() + b.double()[:, None]
+    if res and not abr:
+        v = v + r.double()
+    v = _act(v, act, 0.1)
+    if res and abr:
+        v = v + r.double()
+    ref = (v * scale).numpy()
+    xd, rd = dev(x), (dev(r) if res else None)
+    wn, bn = w.contiguous().numpy(), b.contiguous().numpy()
+
+    def run():
+        y = torch.full((Co, T), float("nan"), device="cuda")
+        ys = torch.full((Co, T), float("nan"), device="cuda") if Co % 16 == 0 else None
+        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), L.ptr(rd) if res else None, L.ptr(y), L.ptr(ys) if ys is not None else None,
+                                        Ci, Co, T, ACT[act], 0.1, abr, scale, ks, am, an, 1, 1))
+        torch.cuda.synchronize()
+        return y, ys
+    (y1, ys1), (y2, ys2) = _x3s_modes(L, run)
+    assert rel_err(y2.cpu().numpy(), ref) < 2e-5
+    assert torch.equal(y1, y2) and (ys1 is None or torch.equal(ys1, ys2))
+    for dm, dn in ((1, 1), (2, 1), (1, 2), (2, 2)):           # every register tile of the direct kernel, un-split and split
+        for dks in (1, 2):
+            if (Ci // 16) % dks:
+                continue
+
+            def run_t():
+                y = torch.full((Co, T), float("nan"), device="cuda")
+                L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(wn), L.ptr(bn), L.ptr(rd) if res else None, L.ptr(y), None,
+                                                Ci, Co, T, ACT[act], 0.1, abr, scale, dks, dm, dn, 1, 1))
+                torch.cuda.synchronize()
+                return y
+            a, bb = _x3s_modes(L, run_t)
+            assert torch.equal(a, bb), (dm, dn, dks)
+            assert rel_err(bb.cpu().numpy(), ref) < 2e-5
+
+
 CONV_SPLIT_TAPS = [
     # Ci, Co, T, k, dil, act, res, ksplit, am, an
     (192, 768, 3198, 3, 1, "relu", False, 0, 0, 0),        # text-encoder FFN1 (attentions.py:383-395: k = 3 "same")
@@ -919,6 +978,15 @@ def test_conv1d_taps_on_split_resident_gemm(L, case):
                                     Ci, Co, T, ACT[act], 0.1, 0, 1.0, ks, am, an, k, dil))
     assert rel_err(y.cpu().numpy(), ref) < 2e-5 and rel_err(ys.cpu().numpy(), ref) < 2e-5
     assert rel_err(y.cpu().numpy()[:, :16], ref[:, :16]) < 2e-5 and rel_err(y.cpu().numpy()[:, -16:], ref[:, -16:]) < 2e-5
+
+    def run_mode():          # both reduction loops of the kernel: bit-identical (taps are row offsets in either)
+        yy, yys = torch.full((Co, T), float("nan"), device="cuda"), torch.full((Co, T), float("nan"), device="cuda")
+        L.check(L.lib.rvc_op_gemm_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(yy), L.ptr(yys),
+                                        Ci, Co, T, ACT[act], 0.1, 0, 1.0, ks, am, an, k, dil))
+        torch.cuda.synchronize()
+        return yy, yys
+    (a1, b1), (a2, b2) = _x3s_modes(L, run_mode)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and rel_err(a2.cpu().numpy(), ref) < 2e-5
 
 
 CONV2D_SPLIT = [
@@ -960,6 +1028,15 @@ def test_conv2d_3x3_on_padded_split_images(L, case):
     for sl in (np.s_[:, 0, :], np.s_[:, -1, :], np.s_[:, :, 0], np.s_[:, :, -1]):
         assert rel_err(y.cpu().numpy()[sl], ref[sl]) < 3e-5
 
+    def run_mode():
+        yy = torch.full((Co, H, W), float("nan"), device="cuda")
+        L.check(L.lib.rvc_op_conv2d_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(yy),
+                                          None, Ci, Co, H, W, ACT[act], abr, ks, am, an))
+        torch.cuda.synchronize()
+        return yy
+    a1, a2 = _x3s_modes(L, run_mode)
+    assert torch.equal(a1, a2) and rel_err(a2.cpu().numpy(), ref) < 2e-5
+
 
 @pytest.mark.parametrize("case", [(768, 768, 1599, 128, 64, 1, 16, "gelu", True, 1), (768, 768, 77, 128, 64, 1, 16, "gelu", True, 1),
                                   (192, 96, 333, 9, 4, 1, 2, "none", False, 0), (256, 256, 500, 4, 2, 1, 4, "relu", True, 0)],
@@ -985,3 +1062,12 @@ def test_grouped_long_kernel_conv1d_on_split_resident_gemm(L, case):
     L.check(L.lib.rvc_op_conv1d_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(y),
                                       Ci, Co, T, k, pad, dil, groups, ACT[act], abr))
     assert rel_err(y.cpu().numpy(), ref) < 2e-5
+
+    def run_mode():
+        yy = torch.full((Co, T), float("nan"), device="cuda")
+        L.check(L.lib.rvc_op_conv1d_split(None, L.ptr(xd), L.ptr(w.contiguous().numpy()), L.ptr(b.contiguous().numpy()), L.ptr(rd) if res else None, L.ptr(yy),
+                                          Ci, Co, T, k, pad, dil, groups, ACT[act], abr))
+        torch.cuda.synchronize()
+        return yy
+    a1, a2 = _x3s_modes(L, run_mode)
+    assert torch.equal(a1, a2) and rel_err(a2.cpu().numpy(), ref) < 2e-5

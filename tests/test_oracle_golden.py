@@ -260,3 +260,22 @@ def test_mdx23c_oracle_matches_reference_module_at_the_shipped_recipe():
     assert y.shape == (2, 2, cfg["audio"]["chunk_size"])
     assert rel_err(y[..., ::64], g["out_sub"]) < 2e-5 and rel_err(y[..., 100000:104096], g["out_win"]) < 2e-5
     assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), g["out_norm"]) < 1e-5
+
+
+def test_mdx23c_demix_oracle_matches_the_references_own_demix_at_the_shipped_recipe():
+    """demix_mdxv3 of the REFERENCE (lib/karafan/inference.py:32-74, imported in the build container) over the reference's TFC_TDF_net at the
+    shipped recipe, three overlapping full-size chunks (2.96 s stereo clip, overlap 2): the oracle's chunk loop, zero padding, overlap-add and
+    division against every 16th sample of both stems, a dense window across a chunk seam and the per-(stem, channel) norms."""
+    import hashlib
+    from comfy_rvc_amd.custom_nodes.uvr import MDX23C_CONFIG as cfg
+    from oracle import mdx23c as om
+    g = golden("mdx23c_demix_full.npz")
+    L = int(g["n"])
+    mix = np.stack([S.synth_audio(L / 44100.0, seed=int(sd), sr=44100)[:L] for sd in g["seeds"]]).astype(np.float32)
+    assert np.array_equal(np.frombuffer(hashlib.sha256(np.ascontiguousarray(mix).tobytes()).digest(), dtype=np.uint8), g["audio_sha256"])
+    est = om.demix_mdxv3(S.mdx23c_state_dict(cfg, 0), cfg, mix, int(g["overlap"]))
+    y = np.stack([est["Vocals"], est["Instrumental"]]) if isinstance(est, dict) else np.asarray(est)
+    w0 = int(g["win0"])
+    assert y.shape == (2, 2, L)
+    assert rel_err(y[..., ::16], g["out_sub"]) < 1e-5 and rel_err(y[..., w0:w0 + 4096], g["out_win"]) < 1e-5
+    assert rel_err(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), g["out_norm"]) < 1e-5

@@ -17,6 +17,7 @@ import os
 sel = sys.argv[1:]
 TMUL = int(os.environ.get("BENCH_TMUL", "1"))          # columns x TMUL: the asymptotic rate of a tile without the small-grid effects
 QUICK = os.environ.get("BENCH_QUICK") == "1"
+MODES = [int(m) for m in os.environ.get("BENCH_MODES", "1,2").split(",")]      # 1 = LDS ring, 2 = register-direct reduction loop
 for name, Ci, Co, T, w2d in SHAPES:
     if sel and not any(x in name for x in sel):
         continue
@@ -24,15 +25,17 @@ for name, Ci, Co, T, w2d in SHAPES:
     fl = 2.0 * Ci * Co * T * (9 if w2d else 1)
     for split_out in ((0,) if QUICK else (0, 1)):
         best = None
-        for am, an in ((0, 0), (2, 2), (2, 1), (1, 2), (1, 1)):
-            for ks in ((0,) if QUICK else (0, 1, 2, 3, 4, 6, 8, 12)):
-                if ks > 1 and (Ci // 16 * (9 if w2d else 1)) % ks:
-                    continue
-                us = C.c_float()
-                L.check(L.lib.rvc_debug_gemm_split_bench(None, Ci, Co, T, ks, am, an, split_out, 40, C.byref(us), w2d, NLAYERS))
-                tag = f"tile {'auto' if am == 0 else f'{64 * am}x{64 * an}'} split {'auto' if ks == 0 else ks}"
-                print(f"{name:24s} {'split-out+gelu' if split_out else 'fp32-out+res  '} {tag:28s} {us.value:8.1f} us {fl / us.value / 1e6:7.1f} TFLOP/s")
-                if am and ks and (best is None or us.value < best[0]):
-                    best = (us.value, tag)
+        for mode in MODES:
+            L.check(L.lib.rvc_debug_set_x3s_mode(mode))
+            for am, an in ((0, 0), (2, 2), (2, 1), (1, 2), (1, 1)):
+                for ks in ((0,) if QUICK else (0, 1, 2, 3, 4, 6, 8, 12)):
+                    if ks > 1 and (Ci // 16 * (9 if w2d else 1)) % ks:
+                        continue
+                    us = C.c_float()
+                    L.check(L.lib.rvc_debug_gemm_split_bench(None, Ci, Co, T, ks, am, an, split_out, 40, C.byref(us), w2d, NLAYERS))
+                    tag = f"{'ring  ' if mode == 1 else 'direct'} tile {'auto' if am == 0 else f'{64 * am}x{64 * an}'} split {'auto' if ks == 0 else ks}"
+                    print(f"{name:24s} {'split-out+gelu' if split_out else 'fp32-out+res  '} {tag:36s} {us.value:8.1f} us {fl / us.value / 1e6:7.1f} TFLOP/s")
+                    if am and ks and (best is None or us.value < best[0]):
+                        best = (us.value, tag)
         if best:
             print(f"{name:24s} best: {best[1]}  {best[0]:.1f} us  {fl / best[0] / 1e6:.1f} TFLOP/s\n")

@@ -23,7 +23,11 @@ for k, d in ((3, 1), (3, 5), (7, 3), (11, 5)):
         L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(y), 1.0, 0))
     variants = [("unfused", unfused), ("fused", fused)] + ([("split", split)] if Cc >= 64 else [])
     for name, fn in variants:
-        fn(); torch.cuda.synchronize()
+        try:
+            fn(); torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001 - a variant that does not exist for this shape (the fused pair at C = 128, ...)
+            print(f"C{Cc} k{k} d{d} {name:8s} n/a ({str(e)[-60:]})")
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5): fn()
