@@ -211,6 +211,8 @@ def main():
                          "rmvpe_60s = configs[1]: lib/rmvpe.RMVPE pitch extraction alone on 60 s clips (host audio in -> float64 f0 out)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc child passes (roofline.traffic then comes from the committed file)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the child of a --pmc pass: convert the clips, print nothing else
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the process group and run every step's gather (exercises RCCL on a 1-GPU box)")
     ap.add_argument("--ragged", action="store_true", help="--dry-run only: stub outputs of clip- and rank-dependent lengths (the gather's padded path)")
@@ -385,7 +387,7 @@ def main():
     # informational: one clip alone on the GPU (what a single ComfyUI graph execution sees), lane 0, a few untimed-for-the-headline passes
     sync()
     alone = []
-    for _ in range(9):
+    for _ in range(1 if args.pmc_child else 9):
         t1 = time.perf_counter()
         step()
         if use_gpu:
@@ -404,12 +406,15 @@ def main():
     sync()
 
     roofline, detail = None, None
-    if rank == 0 and use_gpu and not args.no_roofline:
-        roofline, detail = roofline_pass(_lib, vc, step, torch)
+    if rank == 0 and use_gpu and not args.no_roofline and not args.pmc_child:
+        live = None
+        if world == 1 and not args.no_traffic and os.environ.get("RVC_BENCH_TRAFFIC", "1") != "0":
+            live = pmc_traffic_live(args.variant, args.seconds)
+        roofline, detail = roofline_pass(_lib, vc, step, torch, live)
         if roofline is not None and pitch_only:
             roofline["note"] = "conv kernels only; rvc::gru_scan_kernel (serial, latency-bound) is the largest single kernel of this variant"
     cpu = None
-    if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and use_gpu and not args.no_cpu_baseline and not args.pmc_child:
         # the CPU baseline is "the reference's path on this box's host cores" (BASELINE.md section 4), not on the one NUMA node the rank was pinned
         # to for the GPU run: every thread of the process (torch's intra-op pool included) gets the original mask back for this leg
         if bound is not None and orig_affinity is not None:
@@ -467,7 +472,59 @@ KERNEL_DESC = {
 }
 
 
-def roofline_pass(_lib, vc, step, torch):
+def pmc_traffic_live(variant, seconds, timeout_s=170):
+    """HBM bytes per launch of every kernel, measured NOW: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters
+    only - no trace domains - as /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) around `python3 bench.py --pmc-child` (one lane, one clip
+    at a time), summarised like tools/pmc_traffic.py: KiB -> bytes, FETCH_SIZE x 2 on gfx950 (128-byte requests tallied at 64), WRITE_SIZE as reported.
+    The children are ordinary subprocesses started after this process's own measurement is over (nothing is exec'ed; the GPU is otherwise idle).  Returns
+    ({kernel family: {hbm_bytes_per_launch, launches}}, note) or None when rocprofv3 is missing, times out or writes nothing (the committed file is used then)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None
+    t0 = time.perf_counter()
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rvc_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--lanes", "1",
+                   "--steps", "1", "--warmup", "0", "--clips", "1", "--variant", variant, "--seconds", str(seconds), "--no-cpu-baseline", "--no-roofline", "--no-traffic", "--no-bind"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RVC_PROF_CSV"):
+                env.pop(k, None)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    m = re.match(r"(rvc::\w+)", re.sub(r"^void ", "", row["Kernel_Name"]))
+                    if not m:
+                        continue
+                    e = per.setdefault(m.group(1), {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+                    e[counter][0] += 1
+                    e[counter][1] += float(row["Counter_Value"])
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k, e in per.items():
+        n = max(e["FETCH_SIZE"][0], e["WRITE_SIZE"][0])
+        if n:
+            out[k] = {"launches": n, "hbm_bytes_per_launch": (e["FETCH_SIZE"][1] * 1024.0 * 2.0 + e["WRITE_SIZE"][1] * 1024.0) / n}
+    if not out:
+        return None
+    return out, f"measured in this run: rocprofv3 --pmc FETCH_SIZE(x2) + WRITE_SIZE, 2 child passes, {time.perf_counter() - t0:.0f} s"
+
+
+def roofline_pass(_lib, vc, step, torch, live=None):
     """One extra, untimed-for-the-headline clip with every conv-kernel launch bracketed by HIP events on the stream it is launched on
     (front-ends serialised for that pass) and tagged with its algorithmic FLOPs / HBM bytes.  The per-launch table is grouped by KERNEL.
     Returns (roofline, detail): `roofline` is the COMPACT object of the kernel with the most time per clip (the same kernel tops
@@ -496,12 +553,15 @@ def roofline_pass(_lib, vc, step, torch):
     if tmp is not None:
         os.unlink(tmp.name)
     traffic, traffic_src = {}, None
-    try:
-        with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
-            doc = json.load(f)
-        traffic, traffic_src = doc["kernels"], f"{PMC_TRAFFIC_FILE} (tree {str(doc.get('commit', '?')).split(' ')[0]})"
-    except (OSError, ValueError, KeyError):
-        pass
+    if live is not None:
+        traffic, traffic_src = live
+    else:
+        try:
+            with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
+                doc = json.load(f)
+            traffic, traffic_src = doc["kernels"], f"file {PMC_TRAFFIC_FILE} (tree {str(doc.get('commit', '?')).split(' ')[0]}), not measured in this run"
+        except (OSError, ValueError, KeyError):
+            pass
     return roofline_from_rows(rows, traffic, traffic_src)
 
 
