@@ -871,6 +871,29 @@ __global__ __launch_bounds__(768) void gru_scan_kernel_v1(const float* __restric
 // (96 weights per thread, 256 threads = one wave per SIMD: the same 384 FMA issue cycles per SIMD as twelve waves of 32), the DPP tree leaves
 // the three sums in the unit's lane 0, which computes the gates at once - no second barrier, no LDS round trip.  Segments, FMA chains and the
 // reduction tree are those of gru_scan_kernel_v1: identical numerics.  (RVC_GRU_V=1 selects the old kernel.)
+// NP polls in flight per thread (round 5).  With one, a granule that lands just after a poll was issued is seen a whole L2 round trip + back-off
+// later, and a step waits for the LATEST of seven peers: close to a full poll period on top of the hand-off.  With NP staggered loads outstanding
+// (each re-issued the moment it returns un-tagged) the detection delay falls to a period / NP; the loads retire in order, so checking the oldest
+// needs vmcnt(NP - 1) only - the compiler's own count.
+template <int NP>
+__device__ __forceinline__ unsigned long long gru_poll(const unsigned long long* gp, unsigned step, unsigned spin_limit, bool& failed, int* err) {
+  unsigned long long q[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    q[i] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i + 1 < NP) __builtin_amdgcn_s_sleep(1);
+  }
+  unsigned spins = 0;
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if ((unsigned)(q[i] >> 32) == step) return q[i];
+      if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; return q[i]; }
+      q[i] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+template <int NP>
 __global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                        const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                        float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
@@ -909,12 +932,16 @@ __global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__
       // gather h_{step-1}: one granule per thread
       const unsigned long long* gp = xb + ((step - 1) & 1) * H + tid;
       unsigned long long v;
-      unsigned spins = 0;
-      for (;;) {
-        v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(v >> 32) == (unsigned)step) break;
-        if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
-        __builtin_amdgcn_s_sleep(RVC_GRU_SLEEP);
+      if constexpr (NP > 1) {
+        v = gru_poll<NP>(gp, (unsigned)step, spin_limit, failed, err);
+      } else {
+        unsigned spins = 0;
+        for (;;) {
+          v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(v >> 32) == (unsigned)step) break;
+          if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
+          __builtin_amdgcn_s_sleep(RVC_GRU_SLEEP);
+        }
       }
       hsb[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
       __syncthreads();
@@ -1028,11 +1055,15 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
   if (coop) {
     void* args[] = {(void*)&gi, (void*)&b_ih, (void*)&w_hh, (void*)&b_hh, (void*)&out, (void*)&xbuf, (void*)&err, (void*)&T, (void*)&sl, (void*)&fault};
     if (ver == 1) RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel_v1), dim3(64), dim3(768), args, 0, s));
-    else RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel), dim3(64), dim3(256), args, 0, s));
+    else RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel<1>), dim3(64), dim3(256), args, 0, s));
   } else if (ver == 1) {
     hipLaunchKernelGGL(gru_scan_kernel_v1, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
   } else {
-    hipLaunchKernelGGL(gru_scan_kernel, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    static const int np = getenv("RVC_GRU_POLL") ? atoi(getenv("RVC_GRU_POLL")) : 1;      // polls in flight per thread (gru_poll)
+    if (np == 2) hipLaunchKernelGGL(gru_scan_kernel<2>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    else if (np == 3) hipLaunchKernelGGL(gru_scan_kernel<3>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    else if (np >= 4) hipLaunchKernelGGL(gru_scan_kernel<4>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    else hipLaunchKernelGGL(gru_scan_kernel<1>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
   }
   static const bool repair = !(getenv("RVC_GRU_REPAIR") && atoi(getenv("RVC_GRU_REPAIR")) == 0);
   if (repair && w_hh_t) hipLaunchKernelGGL(gru_serial_kernel, dim3(2), dim3(768), 0, s, gi, b_ih, w_hh_t, b_hh, out, err, T);
