@@ -1,6 +1,6 @@
 #!/bin/bash
 # full round evidence on one box: GPU test suite, tools/profile_round.sh TAG, the RMVPE-only variant's bench line + kernel stats
-tag=${1:-r3}
+tag=${1:-r5}
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.txt 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.txt
@@ -21,3 +21,4 @@ rm -rf gpurun_out/prof_uvr
 [ -x tools/micro/mfmabench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfmabench tools/micro/mfmabench.hip > /dev/null 2>&1
 timeout 300 tools/micro/mfmabench > gpurun_out/${tag}_mfmabench.txt 2>&1
 for v in 48k_v2 uvr_48k_v2; do timeout 600 python3 bench.py --variant $v --no-cpu-baseline > gpurun_out/${tag}_bench_$v.json 2>/dev/null; cut -c1-200 gpurun_out/${tag}_bench_$v.json; done
+timeout 600 python3 tools/mdx_memory.py > gpurun_out/${tag}_mdx_memory.txt 2>&1; tail -1 gpurun_out/${tag}_mdx_memory.txt
