@@ -36,7 +36,7 @@ CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r4zz_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r5y_pmc_traffic.json")      # (fallback only: --no-traffic, N > 1 or no rocprofv3)
 MAX_LINE_BYTES = 6144              # the driver parses ONE JSON line from stdout; round 4's 17.9 KB line was not parsed
 
 
@@ -356,6 +356,9 @@ def main():
             if len(batch) == n_clips:
                 if collective:   # every rank already holds ITS clips on the host (vc_single delivered them); rank 0 keeps the gathered copy in HBM
                     if isinstance(batch[0], Delivered):
+                        cur = torch.cuda.current_stream()
+                        for b in batch:      # produced (and completed) on the lanes' streams, consumed on this one: keep the caching allocator from re-using them early
+                            b.dev.record_stream(cur)
                         step_wav = torch.cat([b.dev for b in batch])                 # device-resident int16, concatenated on the device
                     else:
                         step_wav = np.concatenate(batch).view(np.int16)            # gloo / dry run / f0 vectors (which travel as their bytes)
