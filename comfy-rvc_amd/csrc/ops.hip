@@ -893,7 +893,7 @@ __device__ __forceinline__ unsigned long long gru_poll(const unsigned long long*
     }
   }
 }
-template <int NP>
+template <int NP, int SL = RVC_GRU_SLEEP>
 __global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                        const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                        float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void gru_scan_kernel(const float* __restrict__
           v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == (unsigned)step) break;
           if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; break; }
-          __builtin_amdgcn_s_sleep(RVC_GRU_SLEEP);
+          __builtin_amdgcn_s_sleep(SL);
         }
       }
       hsb[(tid >> 5) * HP + (tid & 31)] = __uint_as_float((unsigned)v);
@@ -1063,7 +1063,14 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
     if (np == 2) hipLaunchKernelGGL(gru_scan_kernel<2>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
     else if (np == 3) hipLaunchKernelGGL(gru_scan_kernel<3>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
     else if (np >= 4) hipLaunchKernelGGL(gru_scan_kernel<4>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-    else hipLaunchKernelGGL(gru_scan_kernel<1>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    else {
+      // back-off of the polling loop in units of 64 cycles (RVC_GRU_SLEEPN; experiment of round 5: does a politer spin leave power to the other lanes?)
+      static const int slp = getenv("RVC_GRU_SLEEPN") ? atoi(getenv("RVC_GRU_SLEEPN")) : RVC_GRU_SLEEP;
+      if (slp >= 16) hipLaunchKernelGGL((gru_scan_kernel<1, 16>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+      else if (slp >= 8) hipLaunchKernelGGL((gru_scan_kernel<1, 8>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+      else if (slp >= 4) hipLaunchKernelGGL((gru_scan_kernel<1, 4>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+      else hipLaunchKernelGGL((gru_scan_kernel<1>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+    }
   }
   static const bool repair = !(getenv("RVC_GRU_REPAIR") && atoi(getenv("RVC_GRU_REPAIR")) == 0);
   if (repair && w_hh_t) hipLaunchKernelGGL(gru_serial_kernel, dim3(2), dim3(768), 0, s, gi, b_ih, w_hh_t, b_hh, out, err, T);
