@@ -419,11 +419,15 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- group 3: lo_w * hi_x
+        // (-DRVC_X3Q_TWO_MFMA, variant builds only: the group is left out - two MFMAs per product, the weights effectively rounded to bf16 - to MEASURE what the
+        //  review's optional 2-MFMA mode would cost in accuracy and buy in time; profiles/r5_two_mfma.txt.  Never in the product build.)
+#ifndef RVC_X3Q_TWO_MFMA
 #pragma unroll
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
             acc[am][an] = q_mfma<false>(al[am], bh[an], acc[am][an]);
+#endif
       };
       q_for<0, KT>(unit);
       xb ^= 1;
