@@ -203,8 +203,9 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=0.0, help="clip length (default 30 s; 60 s for --variant rmvpe_60s)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "3")), help="clips in flight per GPU")
-    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default 12; 8 for --variant 48k_v2 as BASELINE.json configs[3] states)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("RVC_BENCH_LANES", "0")),
+                    help="clips in flight per GPU (default 3; 8 for --variant rmvpe_60s, whose GRU scan holds 16 CUs for 60 %% of a clip: profiles/r5_rmvpe_lanes.txt)")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step (default 12; 8 for --variant 48k_v2 as BASELINE.json configs[3] states; 24 for rmvpe_60s; 3 for uvr_48k_v2)")
     ap.add_argument("--variant", choices=["40k_v2", "48k_v2", "uvr_48k_v2", "rmvpe_60s"], default="40k_v2",
                     help="40k_v2 = the configuration the metric is quoted on (BASELINE.json configs[2]); 48k_v2 = configs[3]'s model; uvr_48k_v2 = "
                          "configs[4]'s chain: MDX23C vocal split of a stereo 44.1 kHz clip (overlap 8) -> VC of the vocal stem with the 48k_v2 model; "
@@ -220,6 +221,8 @@ def main():
     args = ap.parse_args()
     if args.seconds <= 0:
         args.seconds = 60.0 if args.variant == "rmvpe_60s" else CLIP_SECONDS
+    if args.lanes <= 0:
+        args.lanes = 8 if args.variant == "rmvpe_60s" else 3
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # nothing in this process has initialised HIP
@@ -267,7 +270,7 @@ def main():
     n_lanes = max(1, args.lanes)
     chain = args.variant == "uvr_48k_v2"
     pitch_only = args.variant == "rmvpe_60s"
-    n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else (3 if chain else 12))
+    n_clips = args.clips if args.clips > 0 else (8 if args.variant == "48k_v2" else (3 if chain else (24 if pitch_only else 12)))
     SYN_CFG = S.CONFIG_40K_V2 if args.variant == "40k_v2" else S.CONFIG_48K_V2
     if chain:      # stereo 44.1 kHz "song": the voice-like synthetic signal on both channels plus different noise beds
         audio = np.stack([S.synth_audio(args.seconds, seed=100 + rank, sr=44100), S.synth_audio(args.seconds, seed=300 + rank, sr=44100)])

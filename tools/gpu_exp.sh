@@ -1,13 +1,14 @@
 #!/bin/bash
 # scratch driver for one-off GPU experiments (edited per experiment; not part of the evidence):  gpurun --timeout 900 -- 'bash tools/gpu_exp.sh > gpurun_out/expN.txt 2>&1'
-# (this version, round 5: XCD tile order of the split-resident kernel on the UVR chain - RVC_X3S_ROWFAST: 0 column tiles fastest, 1 by operand size, 2 row tiles fastest;
-#  PMC traffic of MDX23C's products is 1.9x algorithmic with the default; profiles/r5_mdx_rowfast.txt)
+# (this version, round 5: clips in flight for the RMVPE-alone variant - its GRU scan holds 16 CUs for 60 % of a clip's time, so more lanes than three should pay; profiles/r5_rmvpe_lanes.txt)
 cd "$GRAFT_REPO_ROOT" || exit 1
-run() { env $@ timeout 400 python bench.py --variant uvr_48k_v2 --no-cpu-baseline --no-traffic --steps 6 --warmup 1 2>/dev/null | tail -1 | python -c "
+for l in 3 6 8 12 16; do
+  timeout 300 python bench.py --variant rmvpe_60s --lanes $l --clips 24 --steps 8 --warmup 1 --no-cpu-baseline --no-roofline --no-traffic 2>/dev/null | tail -1 | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); r=d['roofline']; print('$*', d['value'], d['config']['one_clip_alone_ms'], r['kernel'], r['kernel_ms_per_clip'], r['frac'])"; }
-run RVC_X3S_ROWFAST=0
-run RVC_X3S_ROWFAST=1
-run RVC_X3S_ROWFAST=2
-run RVC_X3S_ROWFAST=0
-run RVC_X3S_ROWFAST=1
+d=json.loads(sys.stdin.read()); print('lanes $l', d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"
+done
+for l in 3 4 5; do
+  timeout 300 python bench.py --lanes $l --no-cpu-baseline --no-roofline --no-traffic 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('40k_v2 lanes $l', d['value'], d['ms_per_step'], d['config']['one_clip_alone_ms'])"
+done
