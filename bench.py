@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the child of a --pmc pass: convert the clips, print nothing else
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: stub conversion; checks launcher / process group / gather / timing")
     ap.add_argument("--force-collective", action="store_true", help="N = 1: still create the process group and run every step's gather (exercises RCCL on a 1-GPU box)")
-    ap.add_argument("--ragged", action="store_true", help="--dry-run only: stub outputs of clip- and rank-dependent lengths (the gather's padded path)")
+    ap.add_argument("--ragged", action="store_true", help="ranks deliver different lengths (the gather's padded path): with --dry-run stub outputs of clip- and rank-dependent lengths, on the GPU rank r converts clips 0.25 r s longer (tests only: value is computed from rank 0's clip)")
     ap.add_argument("--no-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node")
     args = ap.parse_args()
     if args.seconds <= 0:
@@ -275,7 +275,7 @@ def main():
     if chain:      # stereo 44.1 kHz "song": the voice-like synthetic signal on both channels plus different noise beds
         audio = np.stack([S.synth_audio(args.seconds, seed=100 + rank, sr=44100), S.synth_audio(args.seconds, seed=300 + rank, sr=44100)])
     else:
-        audio = S.synth_audio(args.seconds, seed=100 + rank)
+        audio = S.synth_audio(args.seconds + (0.25 * rank if (args.ragged and not args.dry_run) else 0.0), seed=100 + rank)
     params = dict(sid=0, f0_up_key=0, f0_method="rmvpe", index_rate=0.0, rms_mix_rate=0.25, protect=0.33, resample_sr=0)
     vc = None
 
@@ -435,7 +435,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if use_gpu else "dry-run (stub conversion, NO GPU work: launcher / collective check only)",
-            "dtype_note": "fp32 tensors; convolutions as a 3-term bf16 hi/lo split on the MFMA units with fp32 accumulation (fp32-equivalent), rest fp32 MFMA",
+            "dtype_note": ("fp32 tensors, fp32 accumulation everywhere; matrix products as a 3-term bf16 hi/lo split (fp32-equivalent), the generator's ResBlock pairs as "
+                           "fp16x2 (weight = one fp16 term, activation fp16 hi+lo; full-size goldens <= 33 LSB) unless RVC_H2=0; rest fp32 MFMA") if _pair_arith(use_gpu) else
+                          "fp32 tensors; convolutions as a 3-term bf16 hi/lo split on the MFMA units with fp32 accumulation (fp32-equivalent), rest fp32 MFMA",
             "ranks": world, "backend": (backend if collective else None), "nccl_ranks": (world if (collective and backend == "nccl") else None),
             "cpu_affinity": (f"{len(bound)} CPUs of the GPU's NUMA node" if bound else "unbound (topology unknown or --no-bind)"),
             "self_launched": bool(os.environ.get("RVC_BENCH_SELF_LAUNCHED")), "timed_region_s": round(dt, 3),
@@ -454,7 +456,17 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         text = json.dumps(line, separators=(",", ":"))
-        assert len(text) < MAX_LINE_BYTES, f"bench line grew to {len(text)} bytes: the driver parses one short JSON line; move detail to write_detail()"
+        if len(text) >= MAX_LINE_BYTES:          # degrade instead of losing the whole result: drop the optional parts, largest first (the detail file keeps them)
+            for drop in (("roofline", "others"), ("cpu_baseline", "sample"), ("config", "parallelism"), ("dtype_note",), ("cpu_affinity",)):
+                obj = line
+                for k in drop[:-1]:
+                    obj = obj.get(k) if isinstance(obj, dict) else None
+                if isinstance(obj, dict) and drop[-1] in obj:
+                    obj.pop(drop[-1]); line["truncated"] = True
+                text = json.dumps(line, separators=(",", ":"))
+                if len(text) < MAX_LINE_BYTES:
+                    break
+            print(f"bench line exceeded {MAX_LINE_BYTES} bytes: optional fields dropped (see gpurun_out/bench_detail.json)", file=sys.stderr)
         if detail is not None:
             detail["line"] = line
             write_detail(detail)
@@ -465,9 +477,10 @@ def main():
 
 
 KERNEL_DESC = {
-    "conv_x3q_kernel": "rvc::conv_x3q_kernel<AM,AN,KT,R,XSPLIT,YSPLIT,RADD> - PERSISTENT software-pipelined bf16x3 implicit-GEMM Conv1d (the split-resident ResBlock pairs of "
-                       "the 128- / 64-channel generator stages): resident workgroups walk over their tiles in one stream of (tile, chunk, tap) units, residual added block "
-                       "by block inside the tile; 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
+    "conv_x3q_kernel": "rvc::conv_x3q_kernel<AM,AN,KT,R,XSPLIT,YSPLIT,RADD,H2> - PERSISTENT software-pipelined split-MFMA implicit-GEMM Conv1d (the split-resident ResBlock pairs of "
+                       "the three wide generator stages): resident workgroups walk over their tiles in one stream of (tile, chunk, tap) units, residual added block "
+                       "by block inside the tile; H2 (default): 2 v_mfma_f32_32x32x16_f16 per product block (weight one fp16 term, activation fp16 hi + lo), else 3 "
+                       "v_mfma_f32_32x32x16_bf16; fp32 accumulate",
     "conv_x3p_kernel": "rvc::conv_x3p_kernel<AM,AN,KT,XSPLIT,YSPLIT,S2> - software-pipelined bf16x3 implicit-GEMM Conv1d (generator ResBlocks / up-samplers, "
                        "HuBERT stride-2 layers): 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
     "conv_x3pf_kernel": "rvc::conv_x3pf_kernel<KT,WM> - fused ResBlock pair (32- / 64-channel generator stages), bf16x3",
@@ -478,7 +491,15 @@ KERNEL_DESC = {
 }
 
 
-def pmc_traffic_live(variant, seconds, timeout_s=170):
+def _pair_arith(use_gpu):
+    try:
+        from comfy_rvc_amd import _lib
+        return bool(use_gpu) and _lib.lib.rvc_get_pair_arithmetic() == 1
+    except Exception:   # noqa: BLE001 - dry runs without the library
+        return False
+
+
+def pmc_traffic_live(variant, seconds, timeout_s=75):
     """HBM bytes per launch of every kernel, measured NOW: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters
     only - no trace domains - as /opt/skills/guides/MI355X_MICROARCH.md's HBM section prescribes) around `python3 bench.py --pmc-child` (one lane, one clip
     at a time), summarised like tools/pmc_traffic.py: KiB -> bytes, FETCH_SIZE x 2 on gfx950 (128-byte requests tallied at 64), WRITE_SIZE as reported.
@@ -498,7 +519,7 @@ def pmc_traffic_live(variant, seconds, timeout_s=170):
         d = tempfile.mkdtemp(prefix="rvc_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--lanes", "1",
-                   "--steps", "1", "--warmup", "0", "--clips", "1", "--variant", variant, "--seconds", str(seconds), "--no-cpu-baseline", "--no-roofline", "--no-traffic", "--no-bind"]
+                   "--steps", "2", "--warmup", "1", "--clips", "1", "--variant", variant, "--seconds", str(seconds), "--no-cpu-baseline", "--no-roofline", "--no-traffic", "--no-bind"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RVC_PROF_CSV"):
                 env.pop(k, None)
@@ -527,7 +548,8 @@ def pmc_traffic_live(variant, seconds, timeout_s=170):
             out[k] = {"launches": n, "hbm_bytes_per_launch": (e["FETCH_SIZE"][1] * 1024.0 * 2.0 + e["WRITE_SIZE"][1] * 1024.0) / n}
     if not out:
         return None
-    return out, f"measured in this run: rocprofv3 --pmc FETCH_SIZE(x2) + WRITE_SIZE, 2 child passes, {time.perf_counter() - t0:.0f} s"
+    return out, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE(x2) + WRITE_SIZE, 2 child passes of 4 clips each (the first cold), "
+                 f"{time.perf_counter() - t0:.0f} s")
 
 
 def roofline_pass(_lib, vc, step, torch, live=None):
@@ -585,7 +607,10 @@ def roofline_from_rows(rows, traffic, traffic_src):
         mb = sum(float(r["alg_mbytes"]) for r in rs)
         n = len(rs)
         x3 = name != "conv_mfma_kernel"
-        peak_tf = x3_peak if x3 else FP32_MFMA_PEAK_TFLOPS
+        # matrix instructions per algorithmic product of THIS kernel's launches, FLOP-weighted: 3 (bf16x3), 2 (fp16x2: the ResBlock pairs on conv_x3q_kernel
+        # since round 6) - the peak a launch is priced against is the dense 16-bit MFMA peak divided by that
+        terms = (sum(float(r.get("mfma_per_product", 3) or 3) * float(r["alg_gflop"]) for r in rs) / gf) if (x3 and gf > 0) else 3.0
+        peak_tf = round(BF16_MFMA_PEAK_TFLOPS / terms, 1) if x3 else FP32_MFMA_PEAK_TFLOPS
         ridge = peak_tf * 1e12 / HBM_PEAK_BPS
         mfma = mb <= 0 or (gf * 1e9) / (mb * 1e6) >= ridge
         tf = gf / us * 1e3 if us > 0 else 0.0                    # 1 GFLOP / us = 1e15 FLOP/s = 1000 TFLOP/s
@@ -596,6 +621,8 @@ def roofline_from_rows(rows, traffic, traffic_src):
         else:
             e.update({"achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)})
         tr = traffic.get("rvc::" + name)
+        if x3 and abs(terms - 3.0) > 1e-6:
+            e.update({"mfma_per_product": round(terms, 3), "frac_if_priced_as_bf16x3": round(tf / x3_peak, 4) if mfma else None})
         e.update({"traffic": None if tr is None else round(tr["hbm_bytes_per_launch"]),
                   "traffic_src": None if tr is None else traffic_src,
                   "kernel": "rvc::" + name,
@@ -613,9 +640,9 @@ def roofline_from_rows(rows, traffic, traffic_src):
         top = sorted(cls.items(), key=lambda kv: -kv[1][1])[:8]
         d = dict(e)
         d.update({"description": KERNEL_DESC.get(name, "rvc::" + name),
-                  "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product" if x3 else "fp32 MFMA peak") + " at the nominal 2.4 GHz clock",
+                  "peak_note": (f"dense 16-bit MFMA peak 2500 TFLOP/s / {terms:.3g} MFMAs per algorithmic product (3 = bf16x3, 2 = fp16x2)" if x3 else "fp32 MFMA peak") + " at the nominal 2.4 GHz clock",
                   "traffic_note": "HBM bytes per launch of THIS kernel (mean over its launches): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes "
-                                  "(tools/pmc_traffic.py); read from the committed file named in traffic_src, not measured in this run",
+                                  "(tools/pmc_traffic.py); " + ("no figure" if tr is None else str(traffic_src)),
                   "frac_of_peaks": {"fp32_mfma_157.3": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "bf16x3_833.3": round(tf / x3_peak, 4),
                                     "bf16_dense_2500": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "hbm_8TBps": round(gbs / (HBM_PEAK_BPS / 1e9), 4)},
                   "top_classes": [{"tile": k[0], "Ci": int(k[1]), "Co": int(k[2]), "k": int(k[3]), "dil": int(k[4]), "stride": int(k[5]), "Tout": int(k[6]), "Wd": int(k[7]),

@@ -145,22 +145,36 @@ SIGNATURES = {
     "rvc_op_layernorm_c": (c_int, [c_void_p] * 6 + [c_int, c_int]),
     "rvc_resample": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_int64]),
     "rvc_set_conv_precision": (c_int, [c_int]),
+    "rvc_set_pair_arithmetic": (c_int, [c_int]),
+    "rvc_get_pair_arithmetic": (c_int, []),
+    "rvc_conv1d_plan_pair_arithmetic": (c_int, [c_void_p, c_void_p, c_int]),
     "rvc_prof_dump_csv": (c_int, [c_char_p]),
     "rvc_prof_enable": (c_int, [c_int]),
     "rvc_prof_collect": (c_int, [P(C.c_double), P(C.c_double), P(c_int64)]),
     "rvc_prof_collect_ex": (c_int, [P(C.c_double), C.c_double, C.c_double]),
     "rvc_prof_cfg_name": (c_char_p, [c_int]),
+    "rvc_op_sine_source": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 3),
+}
+
+# instrumentation hooks of -DRVC_EXPERIMENTS builds (include/rvc_hip.h, last section): bound when the loaded library has them (RVC_HIP_LIB=<variant build>),
+# absent from the product library - callers test `_lib.has_experiments`
+EXPERIMENT_SIGNATURES = {
     "rvc_debug_conv_timing": (c_int, [P(C.c_uint64), c_int]),
     "rvc_debug_x3p_check": (c_int, []),
     "rvc_debug_set_x3s_mode": (c_int, [c_int]),
     "rvc_debug_gemm_split_bench": (c_int, [c_void_p] + [c_int] * 8 + [P(c_float), c_int, c_int]),
-    "rvc_op_sine_source": (c_int, [c_void_p] * 5 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 3),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == the library does not export a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
+has_experiments = all(hasattr(lib, _n) for _n in EXPERIMENT_SIGNATURES)
+if has_experiments:
+    for _name, (_res, _args) in EXPERIMENT_SIGNATURES.items():
+        _fn = getattr(lib, _name)
+        _fn.restype = _res
+        _fn.argtypes = _args
 
 
 def check(status):

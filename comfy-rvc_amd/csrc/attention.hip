@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
 void attention_fused(hipStream_t s, const float* Q, const float* K, long long ldqk, const float* V, long long ldv, const float* bv,
                      float* out, long long ldo, int heads, int dhead, int T, unsigned char* out_img, long long img_tp) {
   RVC_REQUIRE(dhead == kAD, "fused attention is built for head dimension 64");
-  static const bool x3 = !(getenv("RVC_ATT_X3") && atoi(getenv("RVC_ATT_X3")) == 0);
+  static const bool x3 = (exp_int("RVC_ATT_X3", 1) != 0);
   RVC_REQUIRE(out != nullptr || out_img != nullptr, "fused attention: no output");
   RVC_REQUIRE(out_img == nullptr || x3, "the split-image output needs the bf16x3 attention kernel");
   if (x3) { hipLaunchKernelGGL(attention_x3_kernel, dim3((T + 63) / 64, heads), dim3(256), 0, s, Q, K, ldqk, V, ldv, bv, out, ldo, T, out_img, img_tp, (int)kSplitMargin); return; }

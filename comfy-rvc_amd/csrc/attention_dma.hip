@@ -77,9 +77,9 @@ void attention_split(hipStream_t s, const unsigned char* qk_img, long long qk_tp
   a.qk_bytes = (unsigned)qb; a.vt_bytes = (unsigned)vb;
   a.margin = kSplitMargin; a.T = T; a.scale = scale; a.bv = bv; a.out = out; a.ldo = ldo; a.img = out_img; a.img_tp = img_tp;
   a.win = win; a.ek_img = ek_img; a.evt_img = evt_img;
-  static const int nwq = getenv("RVC_ATT_NWQ") ? atoi(getenv("RVC_ATT_NWQ")) : 4;
-  static const int ks = getenv("RVC_ATT_KS") ? atoi(getenv("RVC_ATT_KS")) : 2;
-  static const int kz_env = getenv("RVC_ATT_KZ") ? atoi(getenv("RVC_ATT_KZ")) : 0;
+  static const int nwq = exp_int("RVC_ATT_NWQ", 4);
+  static const int ks = exp_int("RVC_ATT_KS", 2);
+  static const int kz_env = exp_int("RVC_ATT_KZ", 0);
   a.kz = 1;
   if (rel) {
     // two heads: the key tiles are also cut across workgroups until the grid covers the chip (each slice at least two tiles)

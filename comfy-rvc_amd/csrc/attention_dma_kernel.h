@@ -442,7 +442,7 @@ static void launch_att_dma(const AttnDmaArgs& a, int heads, hipStream_t s) {
   RVC_ALLOW_BIG_LDS(kern);
   AttnDmaArgs b = a;
   b.nqt = (a.T + 32 * NWQ - 1) / (32 * NWQ); b.heads = heads;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   b.xcd_remap = xcd_env;
   hipLaunchKernelGGL(kern, dim3((unsigned)(b.nqt * heads * a.kz)), dim3(64 * NWQ * KS), lds, s, b);
 }

@@ -24,6 +24,7 @@ struct ConvArgsX : ConvArgs {
   unsigned char* Ys; long long ysTp; float ys_slope;   // split-resident output image (replaces Y), activation slope applied before the split
   int wbufs;       // weight slabs in the LDS ring (2 .. 4)
   int xcd_remap;   // 1: tiles renumbered so that each XCD (L2) works on a contiguous run of them
+  int h2;          // conv_x3q_kernel only: fp16x2 arithmetic (Wx = the layer's one-plane fp16 image, activation images fp16 hi / lo)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -484,7 +484,7 @@ static void upload_layer(ConvLayer& L, const std::vector<float>& packed, const f
   L.bd_ = bias ? dev_upload(bias, nbias) : nullptr;
 }
 
-void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); dev_free(L.bd4_); L.Wd_ = L.bd_ = L.bd4_ = nullptr; L.Wx_ = nullptr; }
+void conv_layer_free(ConvLayer& L) { dev_free(L.Wd_); dev_free(L.bd_); dev_free(L.Wx_); dev_free(L.Wh_); dev_free(L.bd4_); L.Wd_ = L.bd_ = L.bd4_ = nullptr; L.Wx_ = L.Wh_ = nullptr; }
 
 // bf16x3 weight image (conv_x3.hip): every fp32 weight is split w = hi + lo (both bf16, round-to-nearest-even) and stored
 // [16-channel chunk][tap][hi|lo][8-channel half][CoPx rows][8 channels]: 16-B rows per half-plane, which is the layout the kernel
@@ -540,6 +540,38 @@ static void pack_x3(ConvLayer& L, const float* w, int Co, int Ci, int k) {
   RVC_HIP_CHECK(hipMemcpy(L.Wx_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 }
 
+// fp16x2 (H2) image of a ResBlock-pair layer (conv_x3q.hip): ONE fp16 term per weight, round-to-nearest-even, [chunk][tap][half][CoPx rows][8 ch].
+// fp16 keeps 11 significant bits down to 2^-14 and loses them gradually below (subnormals down to 2^-24): a layer whose weights are all tiny, or
+// that holds a weight beyond fp16's range, keeps the bf16x3 arithmetic (no image, conv1d_pair_h2_eligible says no).
+static uint16_t f16_rne(float f) {
+  const _Float16 h = (_Float16)f;                       // host conversion: round-to-nearest-even, subnormals kept
+  uint16_t u; memcpy(&u, &h, 2); return u;
+}
+static void pack_h2(ConvLayer& L, const float* w, int Co, int Ci, int k) {
+  float amax = 0.f;
+  for (size_t i = 0; i < (size_t)Co * Ci * k; ++i) amax = std::fmax(amax, std::fabs(w[i]));
+  if (!(amax < 60000.f) || amax < 0x1p-10f) return;
+  RVC_REQUIRE(L.CoPx == ((Co + 127) & ~127), "pack_h2 after pack_x3");
+  const int nch = Ci / 16;
+  std::vector<uint16_t> P((size_t)nch * k * 2 * L.CoPx * 8, 0);
+  for (int co = 0; co < Co; ++co)
+    for (int ci = 0; ci < Ci; ++ci)
+      for (int u = 0; u < k; ++u) {
+        const int chunk = ci >> 4, c16 = ci & 15;
+        const size_t base = (((size_t)chunk * k + u) * 2 + (size_t)(c16 >> 3)) * L.CoPx + co;   // (chunk, tap, half) plane, row co
+        P[base * 8 + (c16 & 7)] = f16_rne(w[((size_t)co * Ci + ci) * k + u]);
+      }
+  RVC_HIP_CHECK(hipMalloc(&L.Wh_, P.size() * sizeof(uint16_t)));
+  RVC_HIP_CHECK(hipMemcpy(L.Wh_, P.data(), P.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+}
+static std::atomic<int> g_pair_h2{-1};
+int conv_set_pair_arithmetic(int mode) {
+  int cur = g_pair_h2.load(std::memory_order_relaxed);
+  if (cur < 0) { cur = knob_int("RVC_H2", 1) ? 1 : 0; g_pair_h2.store(cur, std::memory_order_relaxed); }
+  if (mode >= 0) g_pair_h2.store(mode ? 1 : 0, std::memory_order_relaxed);
+  return cur;
+}
+
 void conv_layer_append_x3(ConvLayer& dst, const ConvLayer& extra) {
   RVC_REQUIRE(dst.Wx_ && extra.Wx_ && dst.CoPx == extra.CoPx && dst.Co == extra.Co && dst.groups == 1 && extra.groups == 1 && extra.mode == 1 && extra.k == 1 &&
               (extra.Ci & 15) == 0 && dst.seg2_chunks == 0 && !dst.bd_ == !extra.bd_, "conv_layer_append_x3: layers do not combine");
@@ -576,7 +608,11 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
               w[((size_t)(g * Cog + co) * Cig + ci) * k + tap];
         }
   upload_layer(L, P, bias, Co);
-  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) pack_x3(L, w, Co, Ci, k);
+  if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) {
+    pack_x3(L, w, Co, Ci, k);
+    // a candidate for the persistent ResBlock kernel: square, stride 1, 3 / 7 / 11 taps, "same" padding, whole 64-row tiles, an even number of chunks
+    if (stride == 1 && Ci == Co && (k == 3 || k == 7 || k == 11) && Co % 64 == 0 && Ci >= 64 && pad == dil * (k - 1) / 2) pack_h2(L, w, Co, Ci, k);
+  }
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups > 1 && stride == 1 && Cig % 16 == 0 && Cog % 16 == 0 && dil >= 1)
     pack_x3_grouped(L, w, groups, Cog, Cig, k);            // only conv_x3s_run reads it (the tiled bf16x3 kernels refuse groups > 1)
 }
@@ -731,7 +767,7 @@ TileCfg choose_tile(int M, long long N, int batch) {
     return TileCfg{1, 4, 1, 1};
   }
   auto blocks = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-  static const int fill = getenv("RVC_TILE_MINBLK") ? atoi(getenv("RVC_TILE_MINBLK")) : 384;    // workgroups a launch must have to take the larger tile
+  static const int fill = exp_int("RVC_TILE_MINBLK", 384);    // workgroups a launch must have to take the larger tile
   if (Mp >= 128 && blocks(128, 128) >= fill) return TileCfg{2, 2, 2, 2};
   if (Mp <= 64 && blocks(64, 256) >= fill) return TileCfg{2, 2, 1, 4};
   if (blocks(64, 128) >= fill) return TileCfg{2, 2, 1, 2};
@@ -739,7 +775,7 @@ TileCfg choose_tile(int M, long long N, int batch) {
 }
 
 // ---------------------------------------------------------------------------- optional per-launch profiling (HIP events)
-struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; int Ci, Co, k, dil, stride, Tout, Wd, ksplit, fused; long long blocks; };
+struct ProfRec { hipEvent_t a, b; double flops; int cfg; double bytes; int Ci, Co, k, dil, stride, Tout, Wd, ksplit, fused; long long blocks; int h2; };
 static std::atomic<bool> g_prof_on{false};
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
@@ -762,7 +798,7 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     ms[r.cfg] += t; flops[r.cfg] += r.flops; launches[r.cfg] += 1;
-    if (getenv("RVC_PROF_DUMP")) fprintf(stderr, "conv launch %-12s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", kCfgNames[r.cfg], t * 1e3, r.flops / 1e9, r.flops / t / 1e9);
+    if (exp_int("RVC_PROF_DUMP", 0)) fprintf(stderr, "conv launch %-12s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", kCfgNames[r.cfg], t * 1e3, r.flops / 1e9, r.flops / t / 1e9);
   }
   return (int)g_prof.size();
 }
@@ -775,8 +811,8 @@ ProfTicket conv_prof_begin(hipStream_t s) {
 void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes, const ConvArgsX* a, long long blocks, int fused) {
   if (!t.on) return;
   (void)hipEventRecord(t.b, s);
-  ProfRec r{t.a, t.b, flops, cfg, bytes, 0, 0, 0, 0, 0, 0, 0, 1, fused, blocks};
-  if (a) { r.Ci = a->Ci; r.Co = a->Co; r.k = a->kreal > 0 ? a->kreal : a->ktaps; r.dil = a->dil; r.stride = a->stride; r.Tout = a->Tout; r.Wd = a->Wd; r.ksplit = a->ksplit > 0 ? a->ksplit : 1; }
+  ProfRec r{t.a, t.b, flops, cfg, bytes, 0, 0, 0, 0, 0, 0, 0, 1, fused, blocks, 0};
+  if (a) { r.h2 = a->h2; r.Ci = a->Ci; r.Co = a->Co; r.k = a->kreal > 0 ? a->kreal : a->ktaps; r.dil = a->dil; r.stride = a->stride; r.Tout = a->Tout; r.Wd = a->Wd; r.ksplit = a->ksplit > 0 ? a->ksplit : 1; }
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(r);
 }
@@ -784,7 +820,7 @@ int conv_prof_dump_csv(const char* path) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   FILE* f = fopen(path, "w");
   if (!f) return -1;
-  fprintf(f, "launch,kernel,tile,Ci,Co,k,dil,stride,Tout,Wd,fused_pair,ksplit,workgroups,us,alg_gflop,alg_mbytes,tflops,alg_gbps\n");
+  fprintf(f, "launch,kernel,tile,Ci,Co,k,dil,stride,Tout,Wd,fused_pair,ksplit,workgroups,us,alg_gflop,alg_mbytes,tflops,alg_gbps,mfma_per_product\n");
   int i = 0;
   for (auto& r : g_prof) {
     (void)hipEventSynchronize(r.b);
@@ -792,9 +828,10 @@ int conv_prof_dump_csv(const char* path) {
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 6 persistent pipelined conv)
     static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_x3u_kernel", "conv_x3q_kernel", "conv_x3_kernel"};
-    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
+    // (last column: matrix instructions per algorithmic product - 3 bf16x3, 2 fp16x2 (conv_x3q_kernel, H2), 16 fp32 MFMA at the bf16 rate's scale: 1 fp32 MFMA)
+    fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f,%d\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
             r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,
-            t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0);
+            t > 0 ? r.flops / t / 1e9 : 0.0, t > 0 ? r.bytes / t / 1e6 : 0.0, r.cfg >= 14 ? (r.h2 ? 2 : 3) : 1);
   }
   fclose(f);
   return i;
@@ -870,7 +907,7 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   RVC_REQUIRE(a.act == ACT_NONE || a.act == ACT_LRELU || a.act == ACT_RELU, "in-kernel activations are identity / ReLU / leaky ReLU");
   RVC_REQUIRE(a.pre_act == ACT_NONE || a.pre_act == ACT_LRELU, "input activation must be identity or leaky ReLU");
   TileCfg t = choose_tile(a.Co, a.Tout, batch);
-  if (const char* f = getenv("RVC_FORCE_TILE")) {   // experiments: "WM,WN,AM,AN"
+  if (const char* f = RVC_EXP_STR("RVC_FORCE_TILE")) {   // experiments: "WM,WN,AM,AN"
     int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
   }
   size_t lds = 0;
@@ -889,8 +926,8 @@ static void run_conv(ConvArgsX a, int mode, int batch, hipStream_t s, double flo
   // slicing the reduction over S workgroups restores occupancy.  Partials are reduced in a fixed order (deterministic).
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM) * batch;
   int S = 1;
-  static const int max_split = getenv("RVC_SPLITK") ? atoi(getenv("RVC_SPLITK")) : 8;
-  static const int split_blk = getenv("RVC_SPLITK_BLK") ? atoi(getenv("RVC_SPLITK_BLK")) : 400;
+  static const int max_split = exp_int("RVC_SPLITK", 8);
+  static const int split_blk = exp_int("RVC_SPLITK_BLK", 400);
   if (a.ostride == 1 && !a.up2 && nblk < split_blk) {
     S = (int)((2 * split_blk + nblk - 1) / nblk);
     if (S > max_split) S = max_split;
@@ -980,6 +1017,10 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   const double flops = L.tconv_u > 0 ? 2.0 * Tin * L.Ci * L.co_real * L.k
                                      : 2.0 * L.groups * (double)L.Co * a.Tout * L.Ci * L.k;
   a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.wxBatch = L.wxBatch; a.kreal = L.tconv_u > 0 ? L.ktaps : L.k;
+  if (e.h2) {
+    RVC_REQUIRE(L.Wh_ && (e.xs_in || e.ys_out), "fp16x2 arithmetic is for the two halves of a split-resident ResBlock pair (conv1d_pair_h2_eligible)");
+    a.Wx = reinterpret_cast<const unsigned char*>(L.Wh_); a.h2 = 1;
+  }
   if (!(L.Wx_ && conv_x3_try(a, L.groups, s, flops))) {
     RVC_REQUIRE(!e.xs_in && !e.ys_out, "split-resident tensors need the bf16x3 kernel (check conv1d_split_eligible first)");
     run_conv(a, 1, L.groups, s, flops);
@@ -990,13 +1031,19 @@ void conv1d_run(const ConvLayer& L, hipStream_t s, const float* X, long long ldX
   }
 }
 
-bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role) {
-  if (L.mode != 1 || !L.Wx_ || L.tconv_u || L.stride != 1 || L.groups != 1 || (L.Co & 31) || (L.Ci & 15)) return false;
+bool conv1d_pair_h2_eligible(const ConvLayer& c1, const ConvLayer& c2, int Tin) {
+  if (!conv_set_pair_arithmetic(-1) || !c1.Wh_ || !c2.Wh_) return false;
+  return conv1d_split_eligible(c1, Tin, SPLIT_PRODUCER, 1) && conv1d_split_eligible(c2, Tin, SPLIT_CONSUMER, 1);
+}
+
+bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role, int h2) {
+  if (L.mode != 1 || !L.Wx_ || (h2 && !L.Wh_) || L.tconv_u || L.stride != 1 || L.groups != 1 || (L.Co & 31) || (L.Ci & 15)) return false;
   if (conv1d_out_len(L, Tin) != Tin || L.pad > kSplitMargin) return false;      // the image is addressed as a "same" convolution's: row = margin + t
   ConvArgsX a{};
   a.Ci = L.Ci; a.Co = L.Co; a.CoP = L.CoP; a.Tin = Tin; a.Wd = 0; a.ktaps = L.ktaps; a.dil = L.dil; a.stride = 1; a.pad = L.pad;
   a.Tout = conv1d_out_len(L, Tin); a.ostride = 1; a.orows = L.Co; a.ldX = Tin; a.ldY = a.Tout; a.ldR = a.Tout;
-  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.kreal = L.k;
+  a.Wx = reinterpret_cast<const unsigned char*>(L.Wx_); a.CoPx = L.CoPx; a.kreal = L.k; a.h2 = h2;
+  if (role == SPLIT_CONSUMER) a.R = reinterpret_cast<const float*>(L.Wx_);      // (c2 of a pair has a residual; the persistent kernel asks for it)
   // any non-null value asks for the role's geometry (dry run: never dereferenced)
   if (role == SPLIT_PRODUCER) { a.Ys = reinterpret_cast<unsigned char*>(L.Wx_); a.ysTp = split_image_tp(Tin); a.pre_act = ACT_LRELU; a.pre_slope = 0.1f; }
   else { a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_); a.xsTp = split_image_tp(Tin); }

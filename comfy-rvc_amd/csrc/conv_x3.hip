@@ -480,7 +480,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : ((WM == 2 && WN ==
 
 // ============================================================================ host side
 bool conv_x3_enabled() {
-  static const bool on = !(getenv("RVC_X3") && atoi(getenv("RVC_X3")) == 0);
+  static const bool on = (exp_int("RVC_X3", 1) != 0);
   return on;
 }
 
@@ -509,7 +509,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       (double)a0.Ci * (double)a0.ldX * 4.0 >= 2147483648.0) return false;
   ConvArgsX a = a0;
   if (a.Wd == 0) a.ktaps = a0.kreal;                      // true taps (the fp32 kernel folds the stride phases into virtual channels)
-  if (batch == 1 && a.up2 == 0) {
+  if (batch == 1 && a.up2 == 0 && !a.h2) {
     // k = 1, the 3 x 3 convolutions of small images and short 1-D sequences: the pipelined GEMM kernel (conv_x3p.hip)
     dim3 g; int S = 1;
     if (conv_x3g_try(a, s, g, S, true)) {
@@ -525,18 +525,18 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
     // wide tiles (8 accumulators per wave): every workgroup re-fetches the whole weight image from L2, so the L2 -> LDS stream
     // per output halves with twice the positions per workgroup; taken when the grid still fills the chip several times over
     // (measured: C128 k11 610 -> 470 us; deeper weight buffering instead of wider tiles was slower)
-    static const int wide_blk = getenv("RVC_X3_WIDE") ? atoi(getenv("RVC_X3_WIDE")) : 600;
+    static const int wide_blk = exp_int("RVC_X3_WIDE", 600);
     auto blocks = [&](int bm, int bn) { return (long long)((a.Co + bm - 1) / bm) * ((a.Tout + bn - 1) / bn); };
     if (wide_blk > 0 && a.stride == 1 && a.Wd == 0) {
       // (k <= 3 at 128+ channels is HBM-bound: three 128 x 128 workgroups per CU beat two wide ones, C128 k3 238 -> 219 us)
       // (round 2, after the staging / epilogue changes and with split-resident inputs: the 64 x 256 tile at three workgroups per CU now
       // beats 64 x 512 at two - C64 k7 205 -> 187 us - and a split-input consumer with k <= 7 prefers 128 x 128: 333 -> 317 us)
-      static const int wide64 = getenv("RVC_X3_WIDE64") ? atoi(getenv("RVC_X3_WIDE64")) : 0;
+      static const int wide64 = exp_int("RVC_X3_WIDE64", 0);
       // 8-wave workgroups (128 x 512 tile, one per CU): RVC_X3_W8 = minimum tap count that takes them (0 = never)
-      static const int w8_taps = getenv("RVC_X3_W8") ? atoi(getenv("RVC_X3_W8")) : 0;
-      static const int w8_blk = getenv("RVC_X3_W8_BLK") ? atoi(getenv("RVC_X3_W8_BLK")) : 400;
-      static const int wide_xs7 = getenv("RVC_X3_WIDE_XS7") ? atoi(getenv("RVC_X3_WIDE_XS7")) : 1;   // the wide tile also for a split-input consumer with k = 7 (persistent kernel: C128 k7 pair 399 -> 377 us; the per-tile kernel preferred 128 x 128 there)
-      static const int wide_k3 = getenv("RVC_X3_WIDE_K3") ? atoi(getenv("RVC_X3_WIDE_K3")) : 2;      // the wide tile also for k = 3 (1: fp32 inputs, 2: split inputs too): on the pipelined kernel C128 k3 135 -> 129 us; not for the up-samplers (240 -> 250)
+      static const int w8_taps = exp_int("RVC_X3_W8", 0);
+      static const int w8_blk = exp_int("RVC_X3_W8_BLK", 400);
+      static const int wide_xs7 = exp_int("RVC_X3_WIDE_XS7", 1);   // the wide tile also for a split-input consumer with k = 7 (persistent kernel: C128 k7 pair 399 -> 377 us; the per-tile kernel preferred 128 x 128 there)
+      static const int wide_k3 = exp_int("RVC_X3_WIDE_K3", 2);      // the wide tile also for k = 3 (1: fp32 inputs, 2: split inputs too): on the pipelined kernel C128 k3 135 -> 129 us; not for the up-samplers (240 -> 250)
       if (w8_taps > 0 && a.Co > 64 && a.ktaps >= w8_taps && blocks(128, 512) >= w8_blk) t = TileCfg{2, 4, 2, 4};
       else
       if (a.Co > 64 && blocks(128, 256) >= wide_blk && (a.ktaps > 3 || (wide_k3 >= 1 && a.ostride == 1)) &&
@@ -544,7 +544,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       else if (wide64 && a.Co > 32 && a.Co <= 64 && blocks(64, 512) >= wide_blk) t = TileCfg{1, 4, 2, 4};
     }
   }
-  if (const char* f = getenv("RVC_FORCE_TILE")) {
+  if (const char* f = RVC_EXP_STR("RVC_FORCE_TILE")) {
     int w[4]; if (sscanf(f, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4 && (a.Co > 32 || w[0] == 1)) t = TileCfg{w[0], w[1], w[2], w[3]};
   }
   int id = tile_cfg_id(t);
@@ -554,12 +554,11 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   const int NW = t.WM * t.WN;
   if (id < 0) return false;
   if ((xs || a0.Ys) && !(id == 3 || id == 4 || id == 7 || id == 8 || id == 9)) return false;   // tiles instantiated with the split-resident paths
-  static const int both_ok = getenv("RVC_X3Q_BOTH") ? atoi(getenv("RVC_X3Q_BOTH")) : 0;
-  if (xs && a0.Ys && !both_ok) return false;                                        // (one side at a time; both: the persistent kernel's experiment mode only)
+  if (xs && a0.Ys) return false;                                                    // (one side at a time)
   const int BM = t.WM * t.AM * 32, BN = t.WN * t.AN * 32;
   const long long nblk = (long long)((a.Tout + BN - 1) / BN) * ((a.Co + BM - 1) / BM);
-  static const int min_blk = getenv("RVC_X3_MINBLK") ? atoi(getenv("RVC_X3_MINBLK")) : 250;
-  static const int min_blk2d = getenv("RVC_X3_MINBLK2D") ? atoi(getenv("RVC_X3_MINBLK2D")) : 20;   // deep U-Net levels: bf16x3 + split-K beats fp32 + split-K
+  static const int min_blk = exp_int("RVC_X3_MINBLK", 250);
+  static const int min_blk2d = exp_int("RVC_X3_MINBLK2D", 20);   // deep U-Net levels: bf16x3 + split-K beats fp32 + split-K
   if (nblk < (a.Wd > 0 ? min_blk2d : min_blk)) return false;   // under-filled grids go to the fp32 kernel's split-K path
   if (t.WM == 2 && t.WN == 2 && batch == 1) {
     // the generator's stride-1 convolutions: software-pipelined kernel (conv_x3p.hip)
@@ -576,6 +575,7 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       conv_prof_end(tk, s, flops, 14 + id, conv_alg_bytes(a, batch), &a, (long long)g.x * g.y, 6 << 4);
       return true;
     }
+    if (a.h2) return false;                                  // fp16x2 images are the persistent kernel's alone
     if (conv_x3p_try(a, pam, pan, s, g, true)) {
       if (dry) return true;
       ProfTicket tk = conv_prof_begin(s);
@@ -584,7 +584,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
       return true;
     }
   }
-  static const int x3_split_blk = getenv("RVC_X3_SPLITK_BLK") ? atoi(getenv("RVC_X3_SPLITK_BLK")) : 600;
+  if (a.h2) return false;
+  static const int x3_split_blk = exp_int("RVC_X3_SPLITK_BLK", 600);
   int P = (BN - 1) * a.stride + (a.ktaps - 1) * a.dil + 1;
   if (a.Wd > 0) {
     // tile = whole image rows or a power-of-two fraction of one row (Wd is a power of two)
@@ -602,13 +603,13 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   // LDS budget per workgroup: 53 KiB = three workgroups per CU for the tiles whose registers allow it (<= 170 VGPRs), two for the
   // 8-accumulator tiles.  Measured: occupancy matters more than stage length (one 156 KiB workgroup per CU with 3x longer stages:
   // +32 % time; three 128x128 workgroups instead of two: -12 %).  X double-buffered when that still leaves >= 2 taps per stage.
-  static const int budget_kb = getenv("RVC_X3_LDS_KB") ? atoi(getenv("RVC_X3_LDS_KB")) : 53;
-  static const int budget8_kb = getenv("RVC_X3_LDS8_KB") ? atoi(getenv("RVC_X3_LDS8_KB")) : 156;   // 8-wave workgroups own the CU's LDS
+  static const int budget_kb = exp_int("RVC_X3_LDS_KB", 53);
+  static const int budget8_kb = exp_int("RVC_X3_LDS8_KB", 156);   // 8-wave workgroups own the CU's LDS
   const int budget = (NW == 8 ? budget8_kb : budget_kb) * 1024;
   // weight slabs: a ring of NS: the DMA of a slab is issued NS - 1 stages before its MFMAs, waited for with a counted vmcnt and published
   // with a barrier that does not drain the queue.  Measured: NS = 3 / 4 lose to NS = 2 (C128 k11 490 vs 433 us): the LDS they take
   // halves the taps per stage, and the per-stage costs (DMA issue, barrier) outweigh the ~400 cycles of DMA wait they would hide.
-  static const int wbufs_env = getenv("RVC_X3_WBUFS") ? atoi(getenv("RVC_X3_WBUFS")) : 2;
+  static const int wbufs_env = exp_int("RVC_X3_WBUFS", 2);
   int NS = wbufs_env < 2 ? 2 : (wbufs_env > 4 ? 4 : wbufs_env);
   int xbufs = 2, xbytes = 0, ktmax = 0;
   for (;;) {
@@ -627,13 +628,13 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
   a.KT = (a.ktaps + ntb - 1) / ntb;                        // balanced tap blocks
   if (dry) return true;
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = xbufs; a.ksplit = 1; a.partial = nullptr;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.wbufs = NS; a.xcd_remap = xcd_env;
   // split-K (k = 1 GEMMs on small grids): every stage of such a workgroup is a dependent global -> LDS round trip, so slicing the
   // reduction over S workgroups shortens the chain and puts more of them on a CU; partials are reduced in a fixed order
   int S = 1;
   // (measured on the HuBERT projections: K = 3072 203 -> 120 us, K = 768 unchanged or worse: only deep reductions are split)
-  static const int split_blk2d = getenv("RVC_X3_SPLITK_BLK2D") ? atoi(getenv("RVC_X3_SPLITK_BLK2D")) : 400;
+  static const int split_blk2d = exp_int("RVC_X3_SPLITK_BLK2D", 400);
   const int split_blk = a.Wd > 0 ? split_blk2d : x3_split_blk;
   if (split_blk > 0 && a.ostride == 1 && ((a.Wd == 0 && a.ktaps == 1 && a.Ci >= 2048) || (a.Wd > 0 && a.Ci >= 64)) && nblk < split_blk) {
     const int ngroups = nchunk / NC;
@@ -687,8 +688,8 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
 // residual too: 5 tensor passes per pair); fused, a pair reads x (+ halo) twice (tile + residual, the second from L2) and writes y.
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
                       const ConvEpilogue& e2) {
-  static const bool on = !(getenv("RVC_PAIR") && atoi(getenv("RVC_PAIR")) == 0);
-  static const bool pair64 = getenv("RVC_PAIR64") && atoi(getenv("RVC_PAIR64")) != 0;      // experiment: 64-channel stage (2 WGs per CU)
+  static const bool on = (exp_int("RVC_PAIR", 1) != 0);
+  static const bool pair64 = (exp_int("RVC_PAIR64", 0) != 0);      // experiment: 64-channel stage (2 WGs per CU)
   if (!on || !conv_x3_enabled() || !c1.Wx_ || !c2.Wx_) return false;
   const int C = c1.Co, k = c1.k;
   if (c1.mode != 1 || c2.mode != 1 || c1.groups != 1 || c2.groups != 1 || c1.stride != 1 || c2.stride != 1 || c1.tconv_u || c2.tconv_u) return false;
@@ -696,7 +697,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   if (c1.pad != (k - 1) / 2 * c1.dil || c2.pad != (k - 1) / 2) return false;                      // "same" convolutions
   if (e2.pre_act != ACT_LRELU || e2.act != ACT_NONE || e2.bias_override || e2.tout_limit || e2.R != X) return false;
   if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
-  static const int bn_env = getenv("RVC_PAIR_BN") ? atoi(getenv("RVC_PAIR_BN")) : 256;
+  static const int bn_env = exp_int("RVC_PAIR_BN", 256);
   const int BM = C;
   const int BN = (C == 64 || bn_env == 128) ? 128 : 256;
   const int P2 = (k - 1) / 2, P1 = c1.pad;
@@ -714,7 +715,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   if (c1.CoPx != c2.CoPx) return false;
   {
     // the software-pipelined fused pair (conv_x3p.hip): 32 and 64 channels
-    static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+    static const int xcd_env = exp_int("RVC_X3_XCD", 1);
     a.xcd_remap = xcd_env;
     dim3 gpf;
     if (conv_x3pf_try(a, T, s, gpf, true)) {
@@ -733,7 +734,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int xbytes = (NC * 2 * P * 32 + 1023) & ~1023;
   // three workgroups per CU with single-tap stages beat two with 4-tap stages (k3 233 -> 196 us, k7 279 -> 233, k11 352 -> 308):
   // occupancy is what hides the per-stage latencies of this narrow tile
-  static const int budget_kb_env = getenv("RVC_PAIR_LDS_KB") ? atoi(getenv("RVC_PAIR_LDS_KB")) : 53;
+  static const int budget_kb_env = exp_int("RVC_PAIR_LDS_KB", 53);
   const int budget_kb = C == 64 ? 80 : budget_kb_env;
   const int per_tap = 2 * NC * 2 * BM * 32;
   int ktmax = (budget_kb * 1024 - xbytes) / per_tap;
@@ -742,7 +743,7 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   const int ntb = (k + ktmax - 1) / ktmax;
   a.KT = (k + ntb - 1) / ntb;
   a.CK = 16; a.nchunk = nchunk; a.NC = NC; a.WROW = P; a.xbufs = 1; a.ksplit = 1; a.partial = nullptr; a.ldP = 0;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.wbufs = 2; a.xcd_remap = xcd_env;
   const size_t lds = (size_t)xbytes + (size_t)2 * NC * a.KT * 2 * BM * 32;
   dim3 grid((unsigned)((T + NO - 1) / NO), 1, 1);

@@ -21,6 +21,24 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
+// fp16x2 arithmetic of the ResBlock pairs (conv_x3q.hip, H2): x = hi + lo with hi = fp16(x) rounded toward zero (never past the largest finite
+// value: no infinities from finite inputs below 2 x 65504) and lo = fp16(x - hi), round-to-nearest - 22 bits of x; the weight is ONE fp16 term.
+// fp32(hi) is NOT obtained by converting hi back: rounding toward zero to fp16 keeps the top 10 mantissa bits, so fp32(hi) = x & 0xffffe000 over fp16's
+// normal range (below 2^-14 the mask keeps bits fp16 cannot hold: an error under 2^-24 absolute, the resolution of fp16 subnormals anyway).
+// Besides being one VALU cheaper per element, this avoids a sequence that CORRUPTS DATA on gfx950 / ROCm 7.2 (round 6, profiles/r6_sdwa_pk_hazard.txt): the
+// back-conversion compiles to v_cvt_f32_f16_e32 vN + v_cvt_f32_f16_sdwa vN+1 (src0_sel:WORD_1) feeding v_pk_add_f32 ..., v[N:N+1] neg_lo neg_hi, and beside
+// in-flight MFMAs under memory load that pair read stale registers in lanes 12-15 / 28-31 of the lower half-wave (first failing tile ~32 of 1250, different
+// positions every run).  Keeping the two subtractions scalar (no v_pk_add_f32) or removing the SDWA conversion each makes it disappear.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+  const f32x2_t r = {a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u)};
+  // round-to-nearest-even (v_cvt_pk_f16_f32): below |x| = 0.125 lo is an fp16 subnormal and a truncation there would be a bias that does not average out
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n: waits until at most n of this wave's VMEM operations (LDS-DMA pieces and register
 // loads alike, retired in issue order) are outstanding.  A smaller count than necessary only waits longer, so n is clamped to the table.
 __device__ __forceinline__ void wait_vmcnt_le(int n) {

@@ -944,7 +944,7 @@ static void launch_x3p_k(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t 
 // a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the geometry is not the
 // pipelined kernel's (the staged kernel takes it): kernel sizes 3 / 7 / 11 (the generator's), at least three 16-channel chunks.
 bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry) {
-  static const int on = getenv("RVC_X3P") ? atoi(getenv("RVC_X3P")) : 1;
+  static const int on = exp_int("RVC_X3P", 1);
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
   if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || (xs && ys)) return false;
@@ -966,7 +966,7 @@ bool conv_x3p_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   if (lds > (size_t)(AM * AN >= 8 || s2 ? 80 : 53) * 1024) return false;   // two / three workgroups per CU
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.xcd_remap = xcd_env;
   dim3 grid((unsigned)((a.Tout + BN - 1) / BN), (unsigned)((a.Co + BM - 1) / BM), 1);
   grid_out = grid;
@@ -987,32 +987,32 @@ static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s)
 // k = 1 convolutions (GEMMs) on the pipelined kernel: fp32 [K][N] input, K a multiple of 64 and >= 128.  Small grids are split over K
 // (deterministic second pass: splitk_reduce_launch).  Returns false when the geometry is not this kernel's.
 bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, bool dry) {
-  static const int on = getenv("RVC_X3G") ? atoi(getenv("RVC_X3G")) : 1;
+  static const int on = exp_int("RVC_X3G", 1);
   if (!on) return false;
   // 2-D: 3 x 3, pad 1, plain (no 2 x 2 up-sampling interleave), on images small enough that the nine shifted reads come from L2
-  static const int on2d = getenv("RVC_X3G_2D") ? atoi(getenv("RVC_X3G_2D")) : 1;
-  static const int max2d = getenv("RVC_X3G_2D_MAXPOS") ? atoi(getenv("RVC_X3G_2D_MAXPOS")) : 30000;
+  static const int on2d = exp_int("RVC_X3G_2D", 1);
+  static const int max2d = exp_int("RVC_X3G_2D_MAXPOS", 30000);
   const bool two_d = a.Wd > 0;
   if (two_d && !(on2d && a.ktaps == 9 && a.KW == 0 && !a.up2 && (a.Wd & (a.Wd - 1)) == 0 && a.Tout <= max2d)) return false;
   // (measured against the staged kernel + split-K, launch incl. the reduction: 128 / 256 channels 36 -> 31 us, the level changes 50 -> 38;
   // 512 x 512 on 404 positions 34.5 -> 37: that one stays)
   if (two_d && a.Ci >= 512 && a.Co <= 512 && a.Tout < 1000 && on2d < 2) return false;
   // 1-D with taps: only where the tiled kernels would not run (grids below their minimum: the 100-frames-per-second layers)
-  static const int on1d = getenv("RVC_X3G_TAPS") ? atoi(getenv("RVC_X3G_TAPS")) : 1;
+  static const int on1d = exp_int("RVC_X3G_TAPS", 1);
   const bool taps1d = !two_d && a.ktaps > 1;
   if (taps1d && !(on1d && a.ktaps <= 16 && (long long)((a.Co + 127) / 128) * ((a.Tout + 127) / 128) < 250)) return false;
   if (a.stride != 1 || a.ostride != 1 || a.Xs || a.Ys || (a.Ci & 15)) return false;
   if (!two_d && !taps1d && a.Tin != a.Tout) return false;
-  static const int am_env = getenv("RVC_X3G_AM") ? atoi(getenv("RVC_X3G_AM")) : 0;
+  static const int am_env = exp_int("RVC_X3G_AM", 0);
   // 64-row tiles for short reductions (K <= 1024: q/k/v 49 -> 40 us, flow 192 -> 192 16 -> 11), 128-row tiles for long ones (FFN2, K = 3072: 61 vs 75 us)
   const int AM = am_env ? am_env : ((a.Co > 64 && a.Ci * a.ktaps > 1024) ? 2 : 1), BM = 64 * AM, BN = 128;
   const int U = a.Ci / 16 * a.ktaps;
   if ((U & 3) || U < 8) return false;                              // unit loop unrolled by four
   const long long nblk = (long long)((a.Co + BM - 1) / BM) * ((a.Tout + BN - 1) / BN);
-  static const int min_blk = getenv("RVC_X3G_MINBLK") ? atoi(getenv("RVC_X3G_MINBLK")) : 24;
+  static const int min_blk = exp_int("RVC_X3G_MINBLK", 24);
   if (nblk < (two_d ? 8 : min_blk)) return false;
   // K split: enough workgroups for the chip (a 128 x 128 tile of a K = 768 GEMM is 9 us of MFMAs), at least 8 units per split, groups of 4
-  static const int target = getenv("RVC_X3G_BLK") ? atoi(getenv("RVC_X3G_BLK")) : 256;
+  static const int target = exp_int("RVC_X3G_BLK", 256);
   int S = 1;
   for (int c : {2, 3, 4, 6, 8}) {
     if (nblk * S >= target) break;
@@ -1041,8 +1041,8 @@ static void launch_x3pf(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s
 // a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32: 256 intermediate columns per tile; C = 64: 128).  false: not
 // this kernel's geometry.
 bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry) {
-  static const int on = getenv("RVC_X3PF") ? atoi(getenv("RVC_X3PF")) : 1;
-  static const int on64 = getenv("RVC_X3PF64") ? atoi(getenv("RVC_X3PF64")) : 1;
+  static const int on = exp_int("RVC_X3PF", 1);
+  static const int on64 = exp_int("RVC_X3PF64", 1);
   if (!on || !(a.Ci == 32 || (a.Ci == 64 && on64)) || a.Co != a.Ci || !(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   const int C = a.Ci, BN = C == 32 ? 256 : 128;
   // 64 channels: the narrow wave tile (32 rows: one operand read per MFMA) only wins where the pair is HBM-bound - k = 3: 220 -> 151 us;

@@ -1,4 +1,6 @@
-// Persistent bf16x3 split-MFMA Conv1d for the generator's stride-1 ResBlock convolutions (gfx950 only).
+// Persistent split-MFMA Conv1d for the generator's stride-1 ResBlock convolutions (gfx950 only), in two arithmetics: bf16x3 (three bf16 MFMAs
+// per product: hi_w lo_x + hi_w hi_x + lo_w hi_x) and fp16x2 (H2: two fp16 MFMAs, w lo_x + w hi_x with the weight as ONE fp16 term and the
+// activation as fp16 hi + lo - see the note above conv_x3q_try for what that costs in accuracy and why it is only offered to ResBlock pairs).
 //
 // conv_x3p_kernel (conv_x3p.hip) made the WAVE a pipeline; its tiles still were separate workgroups.  Per-phase cycle counters of that kernel
 // (profiles/r4a_x3p_phase_cycles.txt: C128 k11, 128 x 256 tiles) show what that costs: of 227 k cycles per tile 33 k are the prologue (all 512
@@ -67,25 +69,29 @@ struct QTile { int co0, n0, bx; bool edge, valid; };
 // channel and 4 x 4 consecutive positions, so residual loads and fp32 stores become 16-byte accesses without any transposition.  Measured
 // (round 4, profiles/r4b_x3q_steps.txt) and NOT used: a store instruction then writes 32 bytes per channel row instead of whole 128-byte lines,
 // the epilogue of a C128 k11 tile went from 10.4 k to 15.5 k cycles and every class got slower; the residual variant stages through LDS instead.
-template <bool SWAP>
+template <bool SWAP, bool H2 = false>
 __device__ __forceinline__ f32x16 q_mfma(const u32x4& w, const u32x4& x, const f32x16& c) {
-  if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
+  if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+  else if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, w), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
 // AM x AN accumulators per wave (2 x 2 waves), KT taps.  XSPLIT: split-resident input image (DMA) instead of fp32 rows (registers, converted);
 // YSPLIT: split-resident output image; RADD: residual (+ bias) added block by block during the tile (fp32 output, no activation after the sum).
-template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD>
+// H2: fp16x2 arithmetic - the weight image holds ONE fp16 plane per unit ([chunk][tap][half][CoPx rows][8 ch]: half the L2 -> LDS stream, one DMA
+// instruction per unit and wave), the activation image (staged from fp32 or split-resident) fp16 hi / lo planes, two MFMA groups per unit.
+template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD, bool H2>
 __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(const ConvArgsX p) {
   static_assert(!(YSPLIT && RADD), "an image output has no residual");
+  static_assert(XSPLIT != YSPLIT, "c1 of a pair (fp32 in, image out) or c2 (image in, fp32 out)");
   constexpr int WM = 2, WN = 2, NW = 4;
   constexpr int BM = WM * AM * 32, BN = WN * AN * 32, RB = BM / 32;
   // R = weight slots in the ring (a unit is requested R - 2 units before the barrier that publishes it; as many as the LDS budget admits)
   constexpr int XS = 3;                                     // fp32 staging slots per wave (8 channels x 64 positions each): P <= 384
-  constexpr int NPW = 2 * RB / NW;                          // weight pieces per unit and wave
+  constexpr int NPW = H2 ? 1 : 2 * RB / NW;                 // weight DMA instructions per unit and wave (H2, 64-row tiles: half-wave pieces)
   constexpr int NPX = (BN + 64) / 64;                       // split-resident input: pieces per chunk and wave
-  constexpr int wslot = 2 * BM * 32;
+  constexpr int wslot = (H2 ? 1 : 2) * BM * 32;
   constexpr int NBLK = AM * AN;                             // accumulator blocks = residual batches of 16 loads
   constexpr int TR = KT / 2;                                // tap at which the residual step runs
   static_assert(KT >= XS && (RB == 2 || RB == 4), "geometry");
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
   const long long t_begin = XQTICK();
   [[maybe_unused]] long long t_last = t_begin;
 #ifdef RVC_X3P_CHECK
-  int issued = 0, mk_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mk_x[XS] = {0, 0, 0}, mk_r = 0, uwc = 0;
+  int issued = 0, mk_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mk_x[XS] = {0, 0, 0}, mk_r = 0, uwc = 0, mk_xs[2] = {0, 0};
 #endif
 
   // ---- bias table (LDS): row m of the layer
@@ -154,18 +160,28 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
   // ---- weights: unit (chunk, tap) of a tile with rows co0 is 2 * RB pieces of 1 KiB; consecutive units are consecutive planes of the image.
   // Buffer DMA: one constant per-lane offset, the unit / row-tile position is a scalar offset (no 64-bit vector address arithmetic)
   const int NU = nck * KT;
-  const unsigned wstep = (unsigned)p.CoPx * 64u;
+  const unsigned wstep = (unsigned)p.CoPx * (H2 ? 32u : 64u);
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.Wx, (unsigned)NU * wstep);
-  const int wvoff = ((wave / RB) * p.CoPx * 32) + (((((wave % RB) * 64 + lane) / BM) * p.CoPx + (((wave % RB) * 64 + lane) % BM)) * 16);
+  // H2: a unit is [half][BM rows] of 16 B = RB pieces of 1 KiB: one per wave at BM = 128, half a piece (lanes 0 - 31: 32 rows) per wave at BM = 64
+  const int wrow_h2 = RB == 4 ? wave * 64 + lane : wave * 32 + (lane & 31);
+  const int wvoff = H2 ? ((wrow_h2 / BM) * p.CoPx + (wrow_h2 % BM)) * 16
+                       : ((wave / RB) * p.CoPx * 32) + (((((wave % RB) * 64 + lane) / BM) * p.CoPx + (((wave % RB) * 64 + lane) % BM)) * 16);
   QTile cur = geom(0), nxt = geom(1);
   unsigned wsoff = (unsigned)cur.co0 * 16u;                    // scalar offset of the next request
   int slw = 0, uw = 0;                                       // ring slot / unit-in-tile of the next request
   int wtile_co0_next = nxt.valid ? nxt.co0 : cur.co0;        // rows of the tile the request stream enters at its next wrap
   auto issue_w = [&]() {
-    unsigned char* dst = Ws + slw * wslot + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, wvoff, (int)wsoff, 0, 0);
-    if constexpr (RB == 4)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + NW * 1024), 16, wvoff, (int)(wsoff + (unsigned)p.CoPx * 32u), 0, 0);
+    if constexpr (H2) {
+      // (64-row tiles: the upper half-wave is switched off - the instruction still issues, so the counts below hold)
+      unsigned char* dst = Ws + slw * wslot + wave * (RB == 4 ? 1024 : 512);
+      if (RB == 4 || lane < 32)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, wvoff, (int)wsoff, 0, 0);
+    } else {
+      unsigned char* dst = Ws + slw * wslot + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, wvoff, (int)wsoff, 0, 0);
+      if constexpr (RB == 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + NW * 1024), 16, wvoff, (int)(wsoff + (unsigned)p.CoPx * 32u), 0, 0);
+    }
     ++uw;
     if (uw == NU) { uw = 0; wsoff = (unsigned)wtile_co0_next * 16u; } else wsoff += wstep;
     slw = slw + 1 == R ? 0 : slw + 1;
@@ -204,7 +220,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
       for (int j = 0; j < 4; ++j) {
         const float a = xr[s][2 * j], b = xr[s][2 * j + 1];
         unsigned h_, l_;
-        split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);
+        if constexpr (H2) split2h(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);
+        else split2(fmaxf(a, a * pre_slope), fmaxf(b, b * pre_slope), h_, l_);
         hi[j] = h_; lo[j] = l_;
       }
       unsigned char* d = Xs + xb * xbuf + hb * xhalf + q * 16;
@@ -227,6 +244,9 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (__attribute__((address_space(3))) void*)dst, 16, lane * 16, (int)(row * 16u), 0, 0);
     }
     X3Q_ISSUED(NPX);
+#ifdef RVC_X3P_CHECK
+    mk_xs[xb] = issued;
+#endif
   };
   auto zero_edges = [&](const QTile& tl, int xb) {
     for (int q = tid0; q < P; q += NW * 64) {
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         constexpr bool last_tap = T + 1 == KT;
         // registers hold hi_w (ah) and lo_x (bl) of this unit.  Groups: hi_w lo_x | hi_w hi_x | lo_w hi_x; the operand a group needs next is
         // requested before the group in front of it is issued, and nothing is copied: hi_w / lo_x of the NEXT unit land in ah / bl while the
-        // third group (which reads neither) runs.
+        // third group (which reads neither) runs.  H2: w lo_x | w hi_x, no third group.
         {
           const unsigned char* xa = Xs + xb * xbuf + T * dil16 + boff;
 #pragma unroll
@@ -334,8 +354,8 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
-            acc[am][an] = q_mfma<false>(ah[am], bl[an], acc[am][an]);
-        {
+            acc[am][an] = q_mfma<false, H2>(ah[am], bl[an], acc[am][an]);
+        if constexpr (!H2) {
           const unsigned char* wa = Ws + sl * wslot + BM * 32 + aoff;
 #pragma unroll
           for (int am = 0; am < AM; ++am) al[am] = *reinterpret_cast<const u32x4*>(wa + am * 512);
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
         for (int am = 0; am < AM; ++am)
 #pragma unroll
           for (int an = 0; an < AN; ++an)
-            acc[am][an] = q_mfma<false>(ah[am], bh[an], acc[am][an]);
+            acc[am][an] = q_mfma<false, H2>(ah[am], bh[an], acc[am][an]);
         __builtin_amdgcn_sched_barrier(0);
         // ---- next unit: its weight slot (and, at a chunk boundary, its input buffer) published; the slot of unit u - 1 refilled
         {
@@ -372,6 +392,10 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
           [[maybe_unused]] const long long ta = XQTICK();
           if (c0 && T < R - 2) { if (it > 0) X3Q_CHECK(NWT + EP, exact); q_wait<NWT + EP>(); }
           else { X3Q_CHECK(NWT, exact); q_wait<NWT>(); }
+          // the split-resident chunk this unit's tail starts to read (requested one chunk ago, right behind that unit's weight request) is covered by the
+          // same wait as long as the weight request waited for is not older than it: R - 2 <= KT - 1 (conv_x3q_try clamps the ring for 3-tap layers)
+          static_assert(!XSPLIT || R - 2 <= KT - 1, "weight ring deeper than a chunk: the input chunk's DMA would not be covered by the weight wait");
+          if constexpr (XSPLIT && last_tap) { if (it > 0 || c > 0) X3Q_CHECK(NWT, issued - mk_xs[xb ^ 1]); }
           [[maybe_unused]] const long long tb = XQTICK();
           lds_barrier();
           [[maybe_unused]] const long long tcc = XQTICK();
@@ -418,16 +442,15 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
           load_res(t1, in1 ? c + 1 : 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- group 3: lo_w * hi_x
-        // (-DRVC_X3Q_TWO_MFMA, variant builds only: the group is left out - two MFMAs per product, the weights effectively rounded to bf16 - to MEASURE what the
-        //  review's optional 2-MFMA mode would cost in accuracy and buy in time; profiles/r5_two_mfma.txt.  Never in the product build.)
-#ifndef RVC_X3Q_TWO_MFMA
+        // ---- group 3: lo_w * hi_x (bf16x3 only.  Leaving it out with bf16 operands - the weights rounded to bf16 - was measured in round 5:
+        // 130 LSB on the full-size goldens, profiles/r5_two_mfma.txt; the fp16 weight term of H2 is eight times finer.)
+        if constexpr (!H2) {
 #pragma unroll
-        for (int am = 0; am < AM; ++am)
+          for (int am = 0; am < AM; ++am)
 #pragma unroll
-          for (int an = 0; an < AN; ++an)
-            acc[am][an] = q_mfma<false>(al[am], bh[an], acc[am][an]);
-#endif
+            for (int an = 0; an < AN; ++an)
+              acc[am][an] = q_mfma<false>(al[am], bh[an], acc[am][an]);
+        }
       };
       q_for<0, KT>(unit);
       xb ^= 1;
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
     [[maybe_unused]] const long long t_epi = XQTICK();
     XQACC(2, t_epi - t_last);
     if constexpr (YSPLIT) {
-      // v = lrelu(acc + bias) as the bf16 hi / lo image the next layer stages by DMA (conv_x3_dev.h::ysplit_epilogue with the bias from LDS)
+      // v = lrelu(acc + bias) as the bf16 (H2: fp16) hi / lo image the next layer stages by DMA (conv_x3_dev.h::ysplit_epilogue with the bias from LDS)
       const float sl2 = p.ys_slope;
       const __amdgpu_buffer_rsrc_t ysr = make_rsrc(p.Ys, (unsigned)((long long)(p.Co / 16) * 4 * p.ysTp * 16));
 #pragma unroll
@@ -456,8 +479,13 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
             for (int e2 = 0; e2 < 2; ++e2) {
               float a0 = acc[am][an][8 * g2 + 2 * e2] + ba[2 * e2], a1 = acc[am][an][8 * g2 + 2 * e2 + 1] + ba[2 * e2 + 1];
               float b0 = acc[am][an][8 * g2 + 4 + 2 * e2] + bb[2 * e2], b1 = acc[am][an][8 * g2 + 5 + 2 * e2] + bb[2 * e2 + 1];
-              split2(fmaxf(a0, a0 * sl2), fmaxf(a1, a1 * sl2), hA[e2], lA[e2]);
-              split2(fmaxf(b0, b0 * sl2), fmaxf(b1, b1 * sl2), hB[e2], lB[e2]);
+              if constexpr (H2) {
+                split2h(fmaxf(a0, a0 * sl2), fmaxf(a1, a1 * sl2), hA[e2], lA[e2]);
+                split2h(fmaxf(b0, b0 * sl2), fmaxf(b1, b1 * sl2), hB[e2], lB[e2]);
+              } else {
+                split2(fmaxf(a0, a0 * sl2), fmaxf(a1, a1 * sl2), hA[e2], lA[e2]);
+                split2(fmaxf(b0, b0 * sl2), fmaxf(b1, b1 * sl2), hB[e2], lB[e2]);
+              }
             }
             u32x4 hi, lo;
 #pragma unroll
@@ -539,17 +567,23 @@ __global__ __launch_bounds__(256, (AM * AN >= 8) ? 2 : 3) void conv_x3q_kernel(c
 
 
 // ============================================================================ host side
-template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD>
+template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD, bool H2>
 static void launch_x3q(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_x3q_kernel<AM, AN, KT, R, XSPLIT, YSPLIT, RADD>;
+  auto kern = conv_x3q_kernel<AM, AN, KT, R, XSPLIT, YSPLIT, RADD, H2>;
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 template <int AM, int AN, int KT, int R>
 static void launch_x3q_io(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
-  if (mode == 0) launch_x3q<AM, AN, KT, R, false, true, false>(a, grid, lds, s);        // fp32 in, image out (c1 of a split pair)
-  else if (mode == 2) launch_x3q<AM, AN, KT, R, true, true, false>(a, grid, lds, s);   // image in, image out (round-5 experiment: c1 fed by a producer's image)
-  else launch_x3q<AM, AN, KT, R, true, false, true>(a, grid, lds, s);                  // image in, fp32 out + residual (c2 of a split pair)
+  constexpr bool c2_ok = R - 2 <= KT - 1;      // image in: the ring may not be deeper than a chunk (see the static_assert in the kernel; conv_x3q_try clamps R)
+  if (a.h2) {
+    if (mode == 0) launch_x3q<AM, AN, KT, R, false, true, false, true>(a, grid, lds, s);
+    else if constexpr (c2_ok) launch_x3q<AM, AN, KT, R, true, false, true, true>(a, grid, lds, s);
+  } else {
+    if (mode == 0) launch_x3q<AM, AN, KT, R, false, true, false, false>(a, grid, lds, s);      // fp32 in, image out (c1 of a split pair)
+    else if constexpr (c2_ok) launch_x3q<AM, AN, KT, R, true, false, true, false>(a, grid, lds, s);   // image in, fp32 out + residual (c2 of a split pair)
+  }
+  if (mode != 0 && !c2_ok) throw Error("conv_x3q: weight ring deeper than a chunk on an image-in launch");
 }
 template <int AM, int AN, int R>
 static void launch_x3q_k(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {
@@ -569,53 +603,60 @@ static void launch_x3q_r(const ConvArgsX& a, int R, int mode, dim3 grid, size_t 
 // a: arguments as conv_x3_try prepared them (true taps, tile chosen: WM = WN = 2).  Returns false when the layer is not this kernel's (the
 // per-tile pipelined kernel of conv_x3p.hip takes it): the two halves of a split-resident ResBlock pair - stride-1 Conv1d with 3 / 7 / 11 taps,
 // whole row tiles, at least three 16-channel chunks, at least 8 tiles.
+//
+// a.h2 (fp16x2): a.Wx is the layer's ONE-plane fp16 image (ConvLayer::Wh_) and the pair's intermediate image is fp16 hi / lo.  Accuracy: the
+// activation keeps 22 bits (bf16x3: 24 with the 2^-18 lo lo term dropped), the weight 11 instead of 16 - every product carries a relative weight
+// rounding of <= 2^-12.  Measured on the CPU oracle with the ResBlock weights of the three wide stages rounded to fp16 and everything else exact
+// (tools/exp/fp16_weight_rounding.py): max 16 LSB / mean 2.2 on the 30 s golden (gate 33; bf16 weights: 142 / 16.9, which is what round 5
+// measured on the GPU for the bf16 2-term variant).  Only the pair convolutions of a residual branch are offered this arithmetic: their errors
+// enter the stage tensor additively beside the exact skip path.  fp16 range: hi saturates at 65504 (round toward zero), |x| < 131008 stays finite.
 bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, bool dry) {
-  static const int on = getenv("RVC_X3Q") ? atoi(getenv("RVC_X3Q")) : 1;
+  static const int on = exp_int("RVC_X3Q", 1);
   if (!on) return false;
   const bool xs = a.Xs != nullptr, ys = a.Ys != nullptr;
-  static const int both_ok = getenv("RVC_X3Q_BOTH") ? atoi(getenv("RVC_X3Q_BOTH")) : 0;      // image in AND image out (experiment, profiles/r5_x3q_image_in.txt)
-  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || (xs == ys && !(xs && ys && both_ok)) || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
+  if (a.Wd > 0 || (a.Ci & 15) || a.Ci < 48 || xs == ys || a.stride != 1 || a.ostride != 1 || a.orows != a.Co) return false;
   if (!(a.ktaps == 3 || a.ktaps == 7 || a.ktaps == 11)) return false;
   if (!((AM == 2 && AN == 4) || (AM == 1 && AN == 4) || (AM == 2 && AN == 2))) return false;
   const int BM = 64 * AM, BN = 64 * AN;
   if (a.Co % BM || a.Co > 1024) return false;
-  if (xs && !ys && !(a.R != nullptr && a.act == ACT_NONE)) return false;     // image in: c2 of a pair (residual, nothing after the sum)
+  if (xs && !(a.R != nullptr && a.act == ACT_NONE)) return false;            // image in: c2 of a pair (residual, nothing after the sum)
   if (ys && (a.R || a.accumulate)) return false;
   if ((double)(a.Co / 16) * 4.0 * (double)a.ysTp * 16.0 >= 2147483648.0 || (double)(a.Ci / 16) * 4.0 * (double)a.xsTp * 16.0 >= 2147483648.0) return false;
-  const int mode = (xs && ys) ? 2 : (ys ? 0 : 1);
+  const int mode = ys ? 0 : 1;
   const int P = BN + (a.ktaps - 1) * a.dil;
   if (P > 384 || P > BN + 64) return false;
   const int Pm = (P + 7) & ~7;
   const int xbytes = (2 * 2 * Pm * 32 + 1023) & ~1023;
-  const int wslot = 2 * BM * 32;
+  const int wslot = (a.h2 ? 1 : 2) * BM * 32;
   const int per_cu = AM * AN >= 8 ? 2 : 3;
   // (LDS is allocated in granules: a footprint a few hundred bytes under a third of 160 KiB still admits only two workgroups per CU - measured,
   // C64 k7: ring of 4 at 54 528 B 279 us, ring of 3 251 us - so the budget is cut to whole 2-KiB granules)
   const size_t budget = (size_t)(160 * 1024 / per_cu) & ~(size_t)2047;
   const size_t fixed = (size_t)xbytes + (size_t)((a.Co * 4 + 255) & ~255) + (mode == 1 ? 4096 : 0);   // (mode 1: the epilogue's staging area)
-  static const int r_env = getenv("RVC_X3Q_R") ? atoi(getenv("RVC_X3Q_R")) : 0;
+  static const int r_env = exp_int("RVC_X3Q_R", 0);
   const int rmin = (AM == 2 && AN == 4) ? 4 : 3;
-  int R = 5;
+  // image in, three taps: at most four slots - the input chunk's DMA (requested KT units before its first read) is covered by the wait for the
+  // weight unit requested R - 2 units before, which must not be the older of the two (latent in rounds 4 - 5 with R = 5: the window was a whole chunk
+  // of MFMAs wide and never observed; the shorter fp16x2 units of round 6 made the full-size repeat test differ)
+  int R = (mode == 1 && a.ktaps == 3) ? 4 : 5;
   while (R > rmin && fixed + (size_t)R * wslot > budget) --R;
   if (r_env >= rmin && r_env < R) R = r_env;
   const size_t lds = fixed + (size_t)R * wslot;
   if (lds > budget) return false;
   const long long ntiles = (long long)((a.Tout + BN - 1) / BN) * (a.Co / BM);
-  // (RVC_X3Q_MINROUNDS: grids of fewer rounds of resident workgroups stay on the per-tile kernel)
   // (per device: one process may drive several GPUs, and the persistent grid is sized by the CURRENT device's CU count)
-  static int ncu_of[64] = {0};
+  static std::atomic<int> ncu_of[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
-  if (ncu_of[dev] == 0) { int n = 256; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); ncu_of[dev] = n > 0 ? n : 256; }
-  const int ncu = ncu_of[dev];
-  static const int wg_env = getenv("RVC_X3Q_WGS") ? atoi(getenv("RVC_X3Q_WGS")) : 0;     // workgroups per CU (0: what the tile's LDS / registers admit)
-  // (default 0: every eligible pair, also where a workgroup owns a single tile - the 256-channel stage, short clips: measured neutral there against the per-tile
-  // kernel (C256 pairs 1018 -> 1008 us), one kernel for every ResBlock pair of the three wide stages)
-  static const int min_rounds = getenv("RVC_X3Q_MINROUNDS") ? atoi(getenv("RVC_X3Q_MINROUNDS")) : 0;
-  // RVC_X3Q_SLOTPCT (experiment, round 5): the persistent grid takes only this share of the chip's workgroup slots, leaving CUs to the other lanes' narrow kernels
-  static const int slot_pct = getenv("RVC_X3Q_SLOTPCT") ? atoi(getenv("RVC_X3Q_SLOTPCT")) : 100;
-  const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu * (slot_pct > 0 && slot_pct < 100 ? slot_pct : 100) / 100;
+  int ncu = ncu_of[dev].load(std::memory_order_relaxed);
+  if (ncu == 0) { int n = 256; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); ncu = n > 0 ? n : 256; ncu_of[dev].store(ncu, std::memory_order_relaxed); }
+  static const int wg_env = exp_int("RVC_X3Q_WGS", 0);     // workgroups per CU (0: what the tile's LDS / registers admit)
+  // (RVC_X3Q_MINROUNDS: grids of fewer rounds of resident workgroups stay on the per-tile kernel.  Default 0: every eligible pair, also where a
+  // workgroup owns a single tile - the 256-channel stage, short clips: measured neutral there against the per-tile kernel (C256 pairs 1018 -> 1008 us),
+  // one kernel for every ResBlock pair of the three wide stages)
+  static const int min_rounds = exp_int("RVC_X3Q_MINROUNDS", 0);
+  const long long slots = (long long)(wg_env > 0 ? wg_env : per_cu) * ncu;
   if (ntiles < min_rounds * slots || ntiles < 8) return false;
   // a multiple of 8 (a workgroup's later tiles stay on its XCD) unless every workgroup owns exactly one tile; decided before the dry-run answer and
   // before `a` is touched, so that "yes" in the dry run is "launched" in the real call
@@ -623,7 +664,7 @@ bool conv_x3q_try(ConvArgsX& a, int AM, int AN, hipStream_t s, dim3& grid_out, b
   if (G < 8) return false;
   if (dry) return true;
   a.WROW = P; a.ni = (P + 63) / 64; a.nchunk = a.Ci / 16; a.NC = 1; a.KT = 1; a.xbufs = 2; a.ksplit = 1; a.partial = nullptr; a.wbufs = R;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.xcd_remap = xcd_env;
   dim3 grid((unsigned)G, 1, 1);
   grid_out = grid;

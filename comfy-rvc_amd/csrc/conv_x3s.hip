@@ -635,45 +635,49 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
 }
+// The register-direct reduction loop (round 5: bit-identical to the ring, neutral in the pipeline, profiles/r5_exp_x3s_direct.txt) exists in
+// -DRVC_EXPERIMENTS builds only: the product library neither instantiates nor reaches it.
+// decided by x3s_plan for the launch that follows on this thread - ONE launch is planned and dispatched under one mode
+static thread_local bool t_plan_direct = false;
+#ifdef RVC_EXPERIMENTS
 // register-direct variant: D units deep in registers, 1 KiB of LDS (the split-K ticket word)
 template <int AM, int AN, int D>
 static void launch_x3s_direct(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   hipLaunchKernelGGL((conv_x3s_kernel<AM, AN, D, 1, true>), dim3(blocks), dim3(256), 1024, s, a);
 }
-// 0: by shape (x3s_use_direct), 1: the LDS-ring kernel always, 2: the register-direct kernel always (rvc_debug_set_x3s_mode / RVC_X3S_MODE)
-static int g_x3s_mode = -1;
-void conv_x3s_set_mode(int m) { g_x3s_mode = m; }
+// 0: by shape (x3s_plan), 1: the LDS-ring kernel always, 2: the register-direct kernel always (rvc_debug_set_x3s_mode / RVC_X3S_MODE)
+static std::atomic<int> g_x3s_mode{-1};
+void conv_x3s_set_mode(int m) { g_x3s_mode.store(m, std::memory_order_relaxed); }
 static int x3s_mode() {
-  if (g_x3s_mode < 0) g_x3s_mode = getenv("RVC_X3S_MODE") ? atoi(getenv("RVC_X3S_MODE")) : 0;
-  return g_x3s_mode;
+  int m = g_x3s_mode.load(std::memory_order_relaxed);
+  if (m < 0) { m = exp_int("RVC_X3S_MODE", 0); g_x3s_mode.store(m, std::memory_order_relaxed); }
+  return m;
 }
-
-// decided by x3s_plan for the launch that follows on this thread
-static thread_local bool t_plan_direct = false;
-static bool x3s_use_direct(const GemmSArgs& a, int AM, int AN, unsigned blocks) {
-  const int m = x3s_mode();
-  if (m == 1) return false;
-  if (m == 2) return true;
-  return t_plan_direct;
-}
+#else
+void conv_x3s_set_mode(int) {}
+static int x3s_mode() { return 1; }
+#endif
 static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hipStream_t s) {
-  if (x3s_use_direct(a, AM, AN, blocks)) {
-    static const int d_env = getenv("RVC_X3S_D") ? atoi(getenv("RVC_X3S_D")) : 0;      // pipeline depth override (units in flight per wave)
+#ifdef RVC_EXPERIMENTS
+  if (t_plan_direct) {
+    static const int d_env = exp_int("RVC_X3S_D", 0);      // pipeline depth override (units in flight per wave)
     if (AM == 2 && AN == 2) { if (d_env == 3) launch_x3s_direct<2, 2, 3>(a, blocks, s); else if (d_env == 5) launch_x3s_direct<2, 2, 5>(a, blocks, s); else launch_x3s_direct<2, 2, 4>(a, blocks, s); }
     else if (AM == 2 && AN == 1) { if (d_env == 3) launch_x3s_direct<2, 1, 3>(a, blocks, s); else if (d_env == 8) launch_x3s_direct<2, 1, 8>(a, blocks, s); else launch_x3s_direct<2, 1, 4>(a, blocks, s); }
     else if (AM == 1 && AN == 2) { if (d_env == 3) launch_x3s_direct<1, 2, 3>(a, blocks, s); else if (d_env == 8) launch_x3s_direct<1, 2, 8>(a, blocks, s); else launch_x3s_direct<1, 2, 4>(a, blocks, s); }
     else { if (d_env == 4) launch_x3s_direct<1, 1, 4>(a, blocks, s); else if (d_env == 12) launch_x3s_direct<1, 1, 12>(a, blocks, s); else launch_x3s_direct<1, 1, 7>(a, blocks, s); }
     return;
   }
+#endif
   // ring depth: RVC_X3S_RS = 3 / 4 / 6 for every launch; default 4, and 3 for the 128 x 128 tile on grids of three workgroups per CU and deep reductions - a ring of
   // three slots is 48 KiB and the kernel then fits 168 VGPRs, so THREE workgroups share a CU (MDX23C's 3x3 layers at 128 / 256 channels: 263 -> 235, 250 -> 217,
   // 526 -> 451 us in one call; smaller grids and the transformer projections lose 5 - 10 % with three slots and keep four)
-  static const int rs_force = getenv("RVC_X3S_RS") ? atoi(getenv("RVC_X3S_RS")) : 0;
+  static const int rs_force = exp_int("RVC_X3S_RS", 0);
   const int rs_env = rs_force ? rs_force : ((AM == 2 && AN == 2 && blocks >= 768u && a.nunits / a.ksplit >= 64) ? 3 : 4);
   // units per barrier (RVC_X3S_UC=2: two, where the slice's unit count is even and the tile is small).  Measured in round 4 and NOT the default: the
   // average launch stays at 20.0 us (20.3 with one unit per barrier) - the K loop of these 300 - 600-workgroup grids is bound by the L2 -> LDS
   // latency per ring step, not by the barrier - and the doubled LDS footprint costs the three-lane bench 2.5 % (2095 -> 2040 xRT, same box).
-  static const int uc_env = getenv("RVC_X3S_UC") ? atoi(getenv("RVC_X3S_UC")) : 1;
+#ifdef RVC_EXPERIMENTS
+  static const int uc_env = exp_int("RVC_X3S_UC", 1);
   const bool two = uc_env >= 2 && rs_env != 3 && rs_env < 6 && ((a.nunits / a.ksplit) & 1) == 0 && (a.nunits / a.ksplit) >= 8 && AM * AN <= 2;
   if (two) {
     if (AM == 2 && AN == 1) launch_x3s<2, 1, 4, 2>(a, blocks, s);
@@ -681,10 +685,16 @@ static void x3s_dispatch(const GemmSArgs& a, int AM, int AN, unsigned blocks, hi
     else launch_x3s<1, 1, 4, 2>(a, blocks, s);
     return;
   }
-  if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 2, 6>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
-  else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<2, 1, 6>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
-  else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }
-  else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else if (rs_env >= 6) launch_x3s<1, 1, 6>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
+  if (rs_env >= 6) {
+    if (AM == 2 && AN == 2) launch_x3s<2, 2, 6>(a, blocks, s); else if (AM == 2 && AN == 1) launch_x3s<2, 1, 6>(a, blocks, s);
+    else if (AM == 1 && AN == 2) launch_x3s<1, 2, 6>(a, blocks, s); else launch_x3s<1, 1, 6>(a, blocks, s);
+    return;
+  }
+#endif
+  if (AM == 2 && AN == 2) { if (rs_env == 3) launch_x3s<2, 2, 3>(a, blocks, s); else launch_x3s<2, 2, 4>(a, blocks, s); }
+  else if (AM == 2 && AN == 1) { if (rs_env == 3) launch_x3s<2, 1, 3>(a, blocks, s); else launch_x3s<2, 1, 4>(a, blocks, s); }
+  else if (AM == 1 && AN == 2) { if (rs_env == 3) launch_x3s<1, 2, 3>(a, blocks, s); else launch_x3s<1, 2, 4>(a, blocks, s); }
+  else { if (rs_env == 3) launch_x3s<1, 1, 3>(a, blocks, s); else launch_x3s<1, 1, 4>(a, blocks, s); }
 }
 
 // Tile and K split for an M x N x K problem: enough workgroups for two per CU (two waves per SIMD from different tiles cover each other's
@@ -699,19 +709,20 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int grou
   // i.e. the register pipeline wins where a launch is a few hundred small tiles of a short or tap-rich reduction (nothing to share through LDS that
   // L2 does not deliver as fast, and no DMA / barrier chain per unit); the ring wins where operand sharing halves the L2 bytes of a wide product.
   // MDX23C's large planes (N >= 64 K positions) keep the ring and its tuned tiles.
-  static const int d_auto = getenv("RVC_X3S_DIRECT_AUTO") ? atoi(getenv("RVC_X3S_DIRECT_AUTO")) : 0;      // (default OFF: in the pipeline the two loops measure the same - profiles/r5_exp_x3s_direct.txt)
+  static const int d_auto = exp_int("RVC_X3S_DIRECT_AUTO", 0);      // (default OFF: in the pipeline the two loops measure the same - profiles/r5_exp_x3s_direct.txt)
   const bool conv_small = ktaps >= 3 && ktaps <= 16 && groups == 1 && N <= 4096 && units >= 36;
   const bool gemm_small = ktaps == 1 && groups == 1 && !swapped && M <= 768 && N <= 8192;
-  t_plan_direct = d_auto && x3s_mode() != 1 && (conv_small || gemm_small);
-  if (x3s_mode() == 2) t_plan_direct = true;
-  static const int f_am = getenv("RVC_X3S_AM") ? atoi(getenv("RVC_X3S_AM")) : 0, f_an = getenv("RVC_X3S_AN") ? atoi(getenv("RVC_X3S_AN")) : 0;
-  static const int f_s = getenv("RVC_X3S_SPLIT") ? atoi(getenv("RVC_X3S_SPLIT")) : 0;
-  static const int target = getenv("RVC_X3S_BLK") ? atoi(getenv("RVC_X3S_BLK")) : 440;
+  const int mode_now = x3s_mode();                     // latched: the launch is planned and dispatched under this one value
+  t_plan_direct = d_auto && mode_now != 1 && (conv_small || gemm_small);
+  if (mode_now == 2) t_plan_direct = true;
+  static const int f_am = exp_int("RVC_X3S_AM", 0), f_an = exp_int("RVC_X3S_AN", 0);
+  static const int f_s = exp_int("RVC_X3S_SPLIT", 0);
+  static const int target = exp_int("RVC_X3S_BLK", 440);
   auto tiles = [&](int am, int an) { return (long long)groups * ((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
   // measured on MI355X at N = 1599 (tools/bench_gemm.py, profiles/r3b_bench_gemm.txt): 768 -> 3072 128 x 64 35 us (64 x 128 the same, 128 x 128 38),
   // 768 -> 2304 128 x 64 28 us, 768 -> 768 64 x 64 16.3 us un-split (17.6 split in two), 3072 -> 768 64 x 64 split in two 37.8 us (128 x 64 in three 39.0)
   AM = 2; AN = 2;
-  if (t_plan_direct && x3s_mode() != 2) {
+  if (t_plan_direct && mode_now != 2) {
     // register pipeline: 64 x 128 tiles for the k = 1 products while ~140 of them remain (the column operand is the one re-read per row tile), 64 x 64
     // otherwise; K split to ~220 workgroups (half the ring's target: a wave streams deeper on its own)
     auto tl = [&](int am, int an) { return (long long)((M + 64 * am - 1) / (64 * am)) * ((N + 64 * an - 1) / (64 * an)); };
@@ -742,7 +753,7 @@ static void x3s_plan(int M, int N, int units, int& AM, int& AN, int& S, int grou
   if (t_force_an == 1 || t_force_an == 2) AN = t_force_an;
   S = 1;
   const long long nt = tiles(AM, AN);
-  static const int min_units = getenv("RVC_X3S_MINUNITS") ? atoi(getenv("RVC_X3S_MINUNITS")) : 32;
+  static const int min_units = exp_int("RVC_X3S_MINUNITS", 32);
   for (int c : {2, 3, 4, 6, 8, 12, 16}) {
     if (nt * S >= target) break;
     if (units % c == 0 && units / c >= min_units) S = c;      // (a slice shorter than K = 512 does not pay for its slab round trip)
@@ -814,9 +825,9 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   RVC_REQUIRE(L.CoPx % BM == 0, "weight image rows are padded to the tile");
   a.rows_pg = (L.Co + BM - 1) / BM;
   a.gx = (T + BN - 1) / BN; a.gy = a.rows_pg * G; a.ksplit = S;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.xcd_remap = xcd_env;
-  static const int rf_env = getenv("RVC_X3S_ROWFAST") ? atoi(getenv("RVC_X3S_ROWFAST")) : 0;      // 0: column tiles fastest always, 1: by operand size, 2: row tiles fastest always
+  static const int rf_env = exp_int("RVC_X3S_ROWFAST", 0);      // 0: column tiles fastest always, 1: by operand size, 2: row tiles fastest always
   a.row_fast = (G == 1 && xcd_env && (rf_env == 2 || (rf_env == 1 && (long long)L.Co < (long long)T))) ? 1 : 0;
   const unsigned blocks = (unsigned)((long long)a.gx * a.gy * S);
   if (S > 1) {
@@ -872,7 +883,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   const int BM = 64 * AM, BN = 64 * AN;
   RVC_REQUIRE((long long)((T + BM - 1) / BM) * BM <= xsTp - kSplitMargin && (long long)row0 + (long long)((rows + BN - 1) / BN) * BN <= L.CoPx, "conv_x3s_run_swapped: a tile would read past an operand image");
   a.rows_pg = (T + BM - 1) / BM; a.gx = (rows + BN - 1) / BN; a.gy = a.rows_pg; a.ksplit = 1;
-  static const int xcd_env = getenv("RVC_X3_XCD") ? atoi(getenv("RVC_X3_XCD")) : 1;
+  static const int xcd_env = exp_int("RVC_X3_XCD", 1);
   a.xcd_remap = xcd_env;
   const unsigned blocks = (unsigned)((long long)a.gx * a.gy);
   ProfTicket tk = conv_prof_begin(s);

@@ -136,7 +136,7 @@ FeatIndex* index_create(Ctx* ctx, const float* big_npy, long long N, int D) {
     RVC_HIP_CHECK(hipMemcpy(I->rows, big_npy, (size_t)N * D * sizeof(float), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(index_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, I->rows, I->cols, I->nhalf, N, D);
     RVC_HIP_CHECK(hipDeviceSynchronize());
-    static const bool as_conv = !(getenv("RVC_INDEX_X3") && atoi(getenv("RVC_INDEX_X3")) == 0);
+    static const bool as_conv = (exp_int("RVC_INDEX_X3", 1) != 0);
     if (as_conv && D % 16 == 0 && N >= 4096) {
       std::vector<float> nh((size_t)N);
       RVC_HIP_CHECK(hipMemcpy(nh.data(), I->nhalf, (size_t)N * sizeof(float), hipMemcpyDeviceToHost));   // the same bias values as the fp32 path

@@ -127,8 +127,8 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   const int T = Tc[7];
   // the positional convolution (k = 128, 16 groups) reads its input as a split-resident image through row offsets -64 .. +63: the margins
   // of that image are its zero padding, so it lives in a block of its own (first allocation, never aliased) that is zeroed per (layout, T)
-  static const bool x3s_on0 = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
-  static const bool pos_on = !(getenv("RVC_X3S_POS") && atoi(getenv("RVC_X3S_POS")) == 0);
+  static const bool x3s_on0 = (exp_int("RVC_X3S", 1) != 0);
+  static const bool pos_on = (exp_int("RVC_X3S_POS", 1) != 0);
   const bool pos_s = x3s_on0 && pos_on && conv_x3_enabled() && conv_x3s_eligible(H->pos) && conv_x3s_eligible(H->proj);
   unsigned char* hpos_s = nullptr;
   if (pos_s) {
@@ -141,7 +141,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
     }
   }
   // ---- feature encoder
-  static const bool fuse0 = !(getenv("RVC_HUBERT_FUSE0") && atoi(getenv("RVC_HUBERT_FUSE0")) == 0);
+  static const bool fuse0 = (exp_int("RVC_HUBERT_FUSE0", 1) != 0);
   float* fr = fuse0 ? nullptr : A.alloc<float>((size_t)10 * Tc[1]);
   float* c0 = A.alloc<float>((size_t)512 * Tc[1]);
   float* c1 = A.alloc<float>((size_t)512 * Tc[2]);
@@ -166,7 +166,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   // Split-resident GEMM path (conv_x3s.hip): the activations that feed a k = 1 projection live as the bf16 hi / lo image the kernel stages,
   // written by their producers (LayerNorm, the attention's epilogue, FFN1's GELU epilogue); the fp32 copy is kept only where a residual or
   // the attention reads it.  Needs the bf16x3 weight images (context precision 1 / 2); RVC_X3S=0 selects the fp32-input kernels.
-  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  static const bool x3s_on = (exp_int("RVC_X3S", 1) != 0);
   int need = version == 1 ? 8 : 11;
   if (n_layers > 0) need = n_layers;
   RVC_REQUIRE(need <= (int)H->layers.size(), "not enough encoder layers loaded");
@@ -200,7 +200,7 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   {
     const size_t mark = A.off;
     // attention on split-resident operands (attention_dma.hip): q / k as one image, V^T by the swapped product; RVC_ATT_DMA=0: fp32 q / k / v
-    static const bool att_dma = !(getenv("RVC_ATT_DMA") && atoi(getenv("RVC_ATT_DMA")) == 0);
+    static const bool att_dma = (exp_int("RVC_ATT_DMA", 1) != 0);
     const bool ad = gs && att_dma;
     float* qk = ad ? nullptr : A.alloc<float>((size_t)2304 * T);
     float* vr = ad ? nullptr : A.alloc<float>((size_t)T * 768);

@@ -143,14 +143,14 @@ void mdx23_finalize(Mdx23* M) {
   conv1d_layer_init(M->fin0, ts.get("final_conv.0.weight", {ch, ch + dim_c, 1, 1}).data.data(), nullptr, ch, ch + dim_c, 1, 1, 0, 1, 1);
   conv1d_layer_init(M->fin2, ts.get("final_conv.2.weight", {c.num_targets * dim_c, ch, 1, 1}).data.data(), nullptr, c.num_targets * dim_c, ch, 1, 1, 0, 1, 1);
   {
-    static const bool off = getenv("RVC_MDX_X3S") && atoi(getenv("RVC_MDX_X3S")) == 0;
+    static const bool off = (knob_int("RVC_MDX_X3S", 1) == 0);
     bool ok = !off && conv_x3_enabled();
     auto blocks_ok = [&](const std::vector<TfcBlock>& bs) { for (const TfcBlock& B : bs) ok = ok && conv_x3s_eligible(B.tfc1) && conv_x3s_eligible(B.tfc2); };
     for (auto& S : M->enc) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
     for (auto& S : M->dec) { blocks_ok(S.blocks); ok = ok && conv_x3s_eligible(S.rs); }
     blocks_ok(M->bott.blocks);
     M->pad_ok = ok; for (auto& Ln : M->lane) Ln.img_base = nullptr;
-    static const bool fuse = !(getenv("RVC_MDX_FUSE_SC") && atoi(getenv("RVC_MDX_FUSE_SC")) == 0);
+    static const bool fuse = (knob_int("RVC_MDX_FUSE_SC", 1) != 0);
     auto fuse_blocks = [&](std::vector<TfcBlock>& bs) {
       for (TfcBlock& B : bs)
         if (conv_x3s_eligible(B.shortcut) && B.shortcut.CoPx == B.tfc2.CoPx) { conv_layer_append_x3(B.tfc2, B.shortcut); B.fused_sc = true; }
@@ -874,7 +874,7 @@ void mdx23_demix(Mdx23* M, hipStream_t s, const float* mix, long long Lp, long l
   RVC_REQUIRE(M->ready, "mdx23_finalize has not been called");
   const long long C = (long long)M->cfg.hop * (M->cfg.dim_t - 1);
   RVC_REQUIRE(step > 0 && n_chunks > 0 && (n_chunks - 1) * step + C <= Lp && overlap > 0.f, "demix: the last chunk must end inside the padded mix");
-  static const int k_env = getenv("RVC_MDX_STREAMS") ? atoi(getenv("RVC_MDX_STREAMS")) : 0;
+  static const int k_env = knob_int("RVC_MDX_STREAMS", 0);
   const int k_want = k_env > 0 ? k_env : (M->streams > 0 ? M->streams : 1);
   const int K = (int)std::min<long long>(std::max(1, std::min(k_want, (int)Mdx23::kMaxLanes)), n_chunks);
   const size_t n = (size_t)M->cfg.num_targets * 2 * (size_t)Lp;

@@ -182,7 +182,7 @@ void rmvpe_finalize(Rmvpe* R) {
 static void run_cbr(const CBR& B, hipStream_t s, Arena& A, const float* x, int H, int W, float* out) {
   const long long plane = (long long)H * W;
   // the 16- and 32-channel blocks without a shortcut: both convolutions and the residual in one launch, the intermediate in LDS (conv_cbr2.hip)
-  static const bool fuse_small = !(getenv("RVC_RMVPE_CBR2") && atoi(getenv("RVC_RMVPE_CBR2")) == 0);
+  static const bool fuse_small = (exp_int("RVC_RMVPE_CBR2", 1) != 0);
   if (fuse_small && !B.has_sc && x != out && cbr2_small_eligible(B.c1, B.c2)) {
     if (!A.dry) cbr2_small_run(B.c1, B.c2, s, x, H, W, out);
     return;
@@ -239,7 +239,7 @@ static void rmvpe_pad_plan(Rmvpe* R, hipStream_t s, Arena& A, int H1, PadPlan& P
     P.icat[l] = l <= 4 ? A.alloc<unsigned char>(pad_img_bytes(2 * P.lv[l].C, P.lv[l])) : nullptr;              // [deconv out | encoder skip]
   }
   const size_t img_bytes = A.off - img0;
-  static const bool rezero = getenv("RVC_RMVPE_REZERO") && atoi(getenv("RVC_RMVPE_REZERO")) != 0;      // debugging: zero the image block on every forward
+  static const bool rezero = (exp_int("RVC_RMVPE_REZERO", 0) != 0);      // debugging: zero the image block on every forward
   // (a shorter clip in the same allocation leaves the longer one's rows behind its end: the length is part of the layout)
   if (!A.dry && (rezero || R->img_base != A.base + img0 || R->img_gen != A.gen || R->img_bytes != img_bytes || R->img_H1 != H1)) {
     RVC_HIP_CHECK(hipMemsetAsync(A.base + img0, 0, img_bytes, s));
@@ -334,7 +334,7 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
   ConvEpilogue E0;
   const int n = (int)(L / 160) + 1;
   const int Tr = 32 * ((n - 1) / 32 + 1);
-  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  static const bool x3s_on = (exp_int("RVC_X3S", 1) != 0);
   const bool padded = x3s_on && R->pad_ok && conv_x3_enabled();       // levels >= 2 on padded split-resident images (rmvpe_unet_padded)
   PadPlan pplan;
   if (padded) rmvpe_pad_plan(R, s, A, Tr >> 1, pplan);                // first allocation of the graph: the image block is never aliased
@@ -394,14 +394,14 @@ static void rmvpe_graph(Rmvpe* R, hipStream_t s, Arena& A, const float* audio, l
   // ---- cnn -> BiGRU -> Linear -> sigmoid
   float* c3 = A.alloc<float>((size_t)3 * Tr * 128);
   float* feat = A.alloc<float>((size_t)384 * Tr);
-  static const bool gi_env = !(getenv("RVC_RMVPE_GI_X3S") && atoi(getenv("RVC_RMVPE_GI_X3S")) == 0);
+  static const bool gi_env = (exp_int("RVC_RMVPE_GI_X3S", 1) != 0);
   const bool gi_x3s = gi_env && x3s_on && conv_x3_enabled() && R->wih.Wx_ != nullptr;
   unsigned char* feat_s = gi_x3s ? A.alloc<unsigned char>(split_image_bytes(384, Tr)) : nullptr;
   float* gi = A.alloc<float>((size_t)Tr * 1536);
   float* hid = A.alloc<float>((size_t)512 * Tr);
   float* sal = A.alloc<float>((size_t)360 * Tr);
   if (!dry) {
-    static const bool cnn_small = !(getenv("RVC_RMVPE_CBR2") && atoi(getenv("RVC_RMVPE_CBR2")) == 0);
+    static const bool cnn_small = (exp_int("RVC_RMVPE_CBR2", 1) != 0);
     if (cnn_small && conv3_small_eligible(R->cnn)) conv3_small_run(R->cnn, s, cur, Tr, 128, c3, nullptr, 3, 0, nullptr);      // 16 -> 3, no activation
     else conv2d_run(R->cnn, s, cur, (long long)Tr * 128, Tr, 128, c3, (long long)Tr * 128, E0);
     if (gi_x3s) {

@@ -232,7 +232,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   // ---- split-resident front (conv_x3s.hip): the activations that feed enc_p's / the flow's / conv_pre's projections live as bf16 hi / lo
   // images written by their producers; k = 3 / 5 / 7 layers read them with taps as row offsets, so the images' margins (the zero padding)
   // must stay zero: the block is the graph's first allocation (nothing else ever occupies it) and is zeroed once per layout.
-  static const bool x3s_on = !(getenv("RVC_X3S") && atoi(getenv("RVC_X3S")) == 0);
+  static const bool x3s_on = (exp_int("RVC_X3S", 1) != 0);
   bool gs = x3s_on && conv_x3_enabled() && (C & 15) == 0 && (IC & 31) == 0 && conv_x3s_eligible(S->proj) && conv_x3s_eligible(S->conv_pre);
   for (int l = 0; l < S->n_layers && gs; ++l) {
     const EncLayer& e = S->enc[l];
@@ -278,14 +278,14 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
   {
     const size_t mark = A.off;
     // attention on split-resident operands (attention_dma_kernel.h): q / k as one image, V^T by the swapped product; RVC_ATT_DMA=0: fp32 q / k / v
-    static const bool att_dma = !(getenv("RVC_ATT_DMA") && atoi(getenv("RVC_ATT_DMA")) == 0);
-    static const bool rel_in = !(getenv("RVC_ENCP_REL_FUSED") && atoi(getenv("RVC_ENCP_REL_FUSED")) == 0);
-    const bool ad = gs && att_dma && rel_in && kc == 96 && !(getenv("RVC_ENCP_FUSED") && atoi(getenv("RVC_ENCP_FUSED")) == 0);
+    static const bool att_dma = (exp_int("RVC_ATT_DMA", 1) != 0);
+    static const bool rel_in = (exp_int("RVC_ENCP_REL_FUSED", 1) != 0);
+    const bool ad = gs && att_dma && rel_in && kc == 96 && (exp_int("RVC_ENCP_FUSED", 1) != 0);
     unsigned char* qk_s = ad ? A.alloc<unsigned char>(split_image_bytes(2 * C, T)) : nullptr;
     unsigned char* vt_s = ad ? A.alloc<unsigned char>(attention_vt_bytes(C, T)) : nullptr;
     float* qk = ad ? nullptr : A.alloc<float>((size_t)3 * C * T);
     float* vr = ad ? nullptr : A.alloc<float>((size_t)T * C);
-    static const bool fused_env = [] { const char* e = getenv("RVC_ENCP_FUSED"); return !e || atoi(e) != 0; }();
+    static const bool fused_env = (exp_int("RVC_ENCP_FUSED", 1) != 0);
     const bool fused_att = fused_env && kc == 96;
     float* Sc = fused_att ? nullptr : A.alloc<float>((size_t)H * T * T);
     float* relk = ad ? nullptr : A.alloc<float>((size_t)H * 21 * T);
@@ -447,12 +447,14 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     float* fr = (S->f0 && st.noise_k > 1) ? A.alloc<float>((size_t)st.noise_k * Tn) : nullptr;
     // split-resident intermediate of a ResBlock pair: c1's epilogue writes t = lrelu(c1(..) + b1) as the bf16 hi / lo image c2 stages in
     // LDS (DMA, no conversion, no staging registers; 4 b128 stores per accumulator instead of 16 dword stores on c1's side)
-    static const bool split_on = !(getenv("RVC_SPLIT") && atoi(getenv("RVC_SPLIT")) == 0);
-    bool split_pair[3][3];
+    static const bool split_on = (exp_int("RVC_SPLIT", 1) != 0);
+    // h2_pair: both halves on the persistent kernel in its fp16x2 arithmetic (two MFMAs per product; conv_x3q.hip) - the pair's image is then fp16 hi / lo
+    bool split_pair[3][3], h2_pair[3][3];
     bool any_split = false;
     for (int j = 0; j < 3; ++j)
       for (int m = 0; m < 3; ++m) {
         split_pair[j][m] = split_on && conv1d_split_eligible(st.rb[j].c1[m], Tn, SPLIT_PRODUCER) && conv1d_split_eligible(st.rb[j].c2[m], Tn, SPLIT_CONSUMER);
+        h2_pair[j][m] = split_pair[j][m] && conv1d_pair_h2_eligible(st.rb[j].c1[m], st.rb[j].c2[m], Tn);
         any_split = any_split || split_pair[j][m];
       }
     unsigned char* t1s = any_split ? A.alloc<unsigned char>(split_image_bytes(Cc, Tn)) : nullptr;
@@ -463,7 +465,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       ConvEpilogue Eu; Eu.pre_act = ACT_LRELU; Eu.pre_slope = 0.1f;
       conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
       ConvEpilogue En; En.accumulate = 1;
-      static const bool noise_stream = !(getenv("RVC_NOISE_STREAM") && atoi(getenv("RVC_NOISE_STREAM")) == 0);
+      static const bool noise_stream = (exp_int("RVC_NOISE_STREAM", 1) != 0);
       if (!S->f0) {
         // plain Generator: nothing is added to the up-sampled signal
       } else if (noise_stream && st.noise_w.p && noise_add(s, up, Tn, Cc, Tn, har, N, st.noise_k, st.noise_s, st.noise_k > 1 ? st.noise_s / 2 : 0, st.noise_w.p, st.noise_b.p)) {
@@ -486,8 +488,9 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
             ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f;
             if (split_pair[j][m]) {
               E1.ys_out = t1s; E1.ys_tp = split_image_tp(Tn); E1.ys_slope = E2.pre_slope;       // c2's input activation, applied once by the producer
+              E1.h2 = h2_pair[j][m] ? 1 : 0;
               conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, nullptr, Tn, E1);
-              ConvEpilogue E2s = E2; E2s.pre_act = ACT_NONE; E2s.xs_in = t1s; E2s.xs_tp = E1.ys_tp;
+              ConvEpilogue E2s = E2; E2s.pre_act = ACT_NONE; E2s.xs_in = t1s; E2s.xs_tp = E1.ys_tp; E2s.h2 = E1.h2;
               conv1d_run(st.rb[j].c2[m], s, nullptr, Tn, Tn, dst, Tn, E2s);
             } else {
               conv1d_run(st.rb[j].c1[m], s, in, Tn, Tn, t1, Tn, E1);
@@ -502,7 +505,7 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
     cur = xs; Tc = Tn;
   }
   if (!dry) {
-    static const bool stream_post = [] { const char* e = getenv("RVC_CONVPOST_STREAM"); return !e || atoi(e) != 0; }();
+    static const bool stream_post = (exp_int("RVC_CONVPOST_STREAM", 1) != 0);
     if (stream_post) {
       conv_to1(s, cur, Tc, S->conv_post_w.p, S->up_init >> nu, 7, 3, Tc, 0.01f, 1, out);
     } else {

@@ -766,6 +766,7 @@ void avgpool2(hipStream_t s, const float* x, float* y, int C, int H, int W, long
 #ifndef RVC_GRU_SLEEP
 #define RVC_GRU_SLEEP 1      // back-off of the polling loop, in units of 64 cycles (measured: see DESIGN.md)
 #endif
+#ifdef RVC_EXPERIMENTS      // the round-3 scan kernel (three barriers per step): kept for A/B in variant builds (RVC_GRU_V=1)
 __global__ __launch_bounds__(768) void gru_scan_kernel_v1(const float* __restrict__ gi, const float* __restrict__ b_ih,
                                                           const float* __restrict__ w_hh, const float* __restrict__ b_hh,
                                                           float* __restrict__ out, unsigned long long* xbuf, int* err, int T,
@@ -866,6 +867,7 @@ __global__ __launch_bounds__(768) void gru_scan_kernel_v1(const float* __restric
     }
   }
 }
+#endif
 // Round 4: the same scan with ONE barrier per step.  The three gate rows (r, z, n) of a hidden unit used to live in three different waves:
 // their dot products met in LDS (write, barrier, read) before 32 threads computed the gates.  Here a unit's eight lanes hold all three rows
 // (96 weights per thread, 256 threads = one wave per SIMD: the same 384 FMA issue cycles per SIMD as twelve waves of 32), the DPP tree leaves
@@ -888,7 +890,7 @@ __device__ __forceinline__ unsigned long long gru_poll(const unsigned long long*
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       if ((unsigned)(q[i] >> 32) == step) return q[i];
-      if (failed || ++spins > spin_limit) { if (!failed && err) atomicExch(err, 1); failed = true; return q[i]; }
+      if (failed || ++spins > spin_limit * (unsigned)NP) { if (!failed && err) atomicExch(err, 1); failed = true; return q[i]; }      // (spins counts per outstanding load: NP of them per poll period)
       q[i] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1044,35 +1046,32 @@ void gru_scan(hipStream_t s, const float* gi, const float* b_ih, const float* w_
               unsigned long long* xbuf, int* err, int T, unsigned spin_limit, int fault) {
   (void)hipMemsetAsync(xbuf, 0, sizeof(unsigned long long) * 2 * 2 * 256, s);
   (void)hipMemsetAsync(err, 0, 2 * sizeof(int), s);
-  // RVC_GRU_COOP=1: cooperative launch - the runtime checks that the whole grid (64 workgroups of 768 threads, 16 of which work) can be
-  // resident at once and dispatches it as one unit.  Measured with three clips in flight (round 3, one gpurun call): 1793 -> 1621 xRT - a
-  // cooperative dispatch waits until the grid is launchable as a whole, which idles the chip under the other lanes' kernels - so the plain
-  // launch stays the default: its 16 working slices become resident as soon as ANY 16 CUs have 12 free waves (every other kernel of the path
-  // terminates without waiting for anything); the bounded spin detects the case that they do not, and the serial kernel behind it repairs it.
-  static const bool coop = getenv("RVC_GRU_COOP") && atoi(getenv("RVC_GRU_COOP")) != 0;
   unsigned sl = spin_limit ? spin_limit : (1u << 24);
-  static const int ver = getenv("RVC_GRU_V") ? atoi(getenv("RVC_GRU_V")) : 2;
+#ifdef RVC_EXPERIMENTS
+  // variant builds only (tools/build_variant.sh): cooperative launch (RVC_GRU_COOP=1: 1793 -> 1621 xRT with three clips in flight, round 3 - a cooperative dispatch
+  // waits until the grid is launchable as a whole, which idles the chip under the other lanes' kernels), the round-3 scan kernel (RVC_GRU_V=1), several polls in
+  // flight per thread (RVC_GRU_POLL) and longer poll back-off (RVC_GRU_SLEEPN) - all measured neutral or worse (profiles/r5_gru_poll.txt, r5_exp_gru_sleep.txt)
+  static const bool coop = (exp_int("RVC_GRU_COOP", 0) != 0);
+  static const int ver = exp_int("RVC_GRU_V", 2);
+  static const int np = exp_int("RVC_GRU_POLL", 1);
+  static const int slp = exp_int("RVC_GRU_SLEEPN", RVC_GRU_SLEEP);
   if (coop) {
     void* args[] = {(void*)&gi, (void*)&b_ih, (void*)&w_hh, (void*)&b_hh, (void*)&out, (void*)&xbuf, (void*)&err, (void*)&T, (void*)&sl, (void*)&fault};
     if (ver == 1) RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel_v1), dim3(64), dim3(768), args, 0, s));
     else RVC_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(gru_scan_kernel<1>), dim3(64), dim3(256), args, 0, s));
-  } else if (ver == 1) {
-    hipLaunchKernelGGL(gru_scan_kernel_v1, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-  } else {
-    static const int np = getenv("RVC_GRU_POLL") ? atoi(getenv("RVC_GRU_POLL")) : 1;      // polls in flight per thread (gru_poll)
-    if (np == 2) hipLaunchKernelGGL(gru_scan_kernel<2>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-    else if (np == 3) hipLaunchKernelGGL(gru_scan_kernel<3>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-    else if (np >= 4) hipLaunchKernelGGL(gru_scan_kernel<4>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-    else {
-      // back-off of the polling loop in units of 64 cycles (RVC_GRU_SLEEPN; experiment of round 5: does a politer spin leave power to the other lanes?)
-      static const int slp = getenv("RVC_GRU_SLEEPN") ? atoi(getenv("RVC_GRU_SLEEPN")) : RVC_GRU_SLEEP;
-      if (slp >= 16) hipLaunchKernelGGL((gru_scan_kernel<1, 16>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-      else if (slp >= 8) hipLaunchKernelGGL((gru_scan_kernel<1, 8>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-      else if (slp >= 4) hipLaunchKernelGGL((gru_scan_kernel<1, 4>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-      else hipLaunchKernelGGL((gru_scan_kernel<1>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
-    }
-  }
-  static const bool repair = !(getenv("RVC_GRU_REPAIR") && atoi(getenv("RVC_GRU_REPAIR")) == 0);
+  } else if (ver == 1) hipLaunchKernelGGL(gru_scan_kernel_v1, dim3(64), dim3(768), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (np == 2) hipLaunchKernelGGL(gru_scan_kernel<2>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (np == 3) hipLaunchKernelGGL(gru_scan_kernel<3>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (np >= 4) hipLaunchKernelGGL(gru_scan_kernel<4>, dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (slp >= 16) hipLaunchKernelGGL((gru_scan_kernel<1, 16>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (slp >= 8) hipLaunchKernelGGL((gru_scan_kernel<1, 8>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else if (slp >= 4) hipLaunchKernelGGL((gru_scan_kernel<1, 4>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  else
+#endif
+  // plain launch: the 16 working slices become resident as soon as ANY 16 CUs have free waves (every other kernel of the path terminates without waiting for
+  // anything); the bounded spin detects the case that they do not, and the serial kernel behind it repairs it
+  hipLaunchKernelGGL((gru_scan_kernel<1>), dim3(64), dim3(256), 0, s, gi, b_ih, w_hh, b_hh, out, xbuf, err, T, sl, fault);
+  static const bool repair = (exp_int("RVC_GRU_REPAIR", 1) != 0);
   if (repair && w_hh_t) hipLaunchKernelGGL(gru_serial_kernel, dim3(2), dim3(768), 0, s, gi, b_ih, w_hh_t, b_hh, out, err, T);
 }
 
@@ -1585,7 +1584,7 @@ static void iir_geometry(long long n, bool blocked, int& L, long long& Np) {
   const long long N = n + 2 * 3 * (kIirOrder + 1);
   if (!blocked) { L = 512; Np = (N + 7) & ~7LL; return; }
   static const int blk_env = [] {
-    const int v = getenv("RVC_IIR_L") ? atoi(getenv("RVC_IIR_L")) : 256;      // block length of the propagated evaluation
+    const int v = exp_int("RVC_IIR_L", 256);      // block length of the propagated evaluation
     RVC_REQUIRE(v >= 32 && v <= (1 << 20) && (v & (v - 1)) == 0, "RVC_IIR_L must be a power of two >= 32");
     return v;
   }();
@@ -1595,7 +1594,7 @@ static void iir_geometry(long long n, bool blocked, int& L, long long& Np) {
   L = (int)l; Np = ((N + l - 1) / l) * l;                    // whole blocks (zero-filled behind N)
 }
 static bool iir_blocked(bool have_sos) {
-  static const bool blocked_env = !(getenv("RVC_IIR_BLOCKED") && atoi(getenv("RVC_IIR_BLOCKED")) == 0);
+  static const bool blocked_env = (exp_int("RVC_IIR_BLOCKED", 1) != 0);
   return blocked_env && have_sos;
 }
 size_t preprocess_scratch_doubles(long long n, bool have_sos) {

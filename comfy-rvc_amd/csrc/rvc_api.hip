@@ -714,21 +714,24 @@ int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, voi
   hipStream_t s = (hipStream_t)stream;
   unsigned char* img = (unsigned char*)stream_scratch(s, 5, split_image_bytes(c1->L.Co, T));
   ConvEpilogue E1; E1.pre_act = ACT_LRELU; E1.pre_slope = 0.1f; E1.ys_out = img; E1.ys_tp = split_image_tp(T); E1.ys_slope = 0.1f;
-  static const int both = getenv("RVC_X3Q_BOTH") ? atoi(getenv("RVC_X3Q_BOTH")) : 0;
-  if (both) {
-    // TIMING experiment (round 5): c1 reads an image as well - the image a producer WOULD have written (here: of x itself, without the leaky ReLU, so the
-    // values are not the pair's; tools/bench_pair.py only times this mode) - to bound what an "every ResBlock convolution image-in" design could gain
-    unsigned char* xin = (unsigned char*)stream_scratch(s, 13, split_image_bytes(c1->L.Ci, T));
-    static thread_local const float* made_for = nullptr;
-    if (made_for != x) { RVC_HIP_CHECK(hipMemsetAsync(xin, 0, split_image_bytes(c1->L.Ci, T), s)); split_image_from_f32(s, x, T, c1->L.Ci, T, xin, split_image_tp(T)); made_for = x; }
-    ConvEpilogue E1b = E1; E1b.pre_act = ACT_NONE; E1b.xs_in = xin; E1b.xs_tp = split_image_tp(T);
-    conv1d_run(c1->L, s, nullptr, T, T, nullptr, T, E1b);
-  } else
+  // the arithmetic the generator would use for this pair at this length: fp16x2 on the persistent kernel where eligible (rvc_set_pair_arithmetic), else bf16x3
+  E1.h2 = conv1d_pair_h2_eligible(c1->L, c2->L, T) ? 1 : 0;
+#ifdef RVC_EXPERIMENTS
+  if (exp_int("RVC_EXP_PAIR_ZERO", 0)) RVC_HIP_CHECK(hipMemsetAsync(img, 0, split_image_bytes(c1->L.Co, T), s));
+#endif
   conv1d_run(c1->L, s, x, T, T, nullptr, T, E1);
-  ConvEpilogue E2; E2.R = x; E2.ldR = T; E2.out_scale = out_scale; E2.accumulate = accumulate; E2.xs_in = img; E2.xs_tp = E1.ys_tp;
+#ifdef RVC_EXPERIMENTS
+  if (exp_int("RVC_EXP_PAIR_SYNC", 0)) RVC_HIP_CHECK(hipDeviceSynchronize());
+  if (exp_int("RVC_EXP_PAIR_C1ONLY", 0)) { check_launch(); return 0; }
+#endif
+  ConvEpilogue E2; E2.R = x; E2.ldR = T; E2.out_scale = out_scale; E2.accumulate = accumulate; E2.xs_in = img; E2.xs_tp = E1.ys_tp; E2.h2 = E1.h2;
   conv1d_run(c2->L, s, nullptr, T, T, y, T, E2);
   check_launch();
   RVC_CATCH
+}
+int rvc_conv1d_plan_pair_arithmetic(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, int T) {
+  if (!c1 || !c2) return -1;
+  try { return conv1d_pair_h2_eligible(c1->L, c2->L, T) ? 1 : 0; } catch (...) { return -1; }
 }
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
 int rvc_op_attention(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, float* out, int heads, int T) {
@@ -791,6 +794,13 @@ int rvc_set_conv_precision(int mode) {
   conv_set_precision(mode);
   RVC_CATCH
 }
+int rvc_set_pair_arithmetic(int mode) {
+  RVC_TRY
+  RVC_REQUIRE(mode == 0 || mode == 1, "pair arithmetic must be 0 (bf16x3) or 1 (fp16x2)");
+  conv_set_pair_arithmetic(mode);
+  RVC_CATCH
+}
+int rvc_get_pair_arithmetic(void) { return conv_set_pair_arithmetic(-1); }
 int rvc_prof_collect(double* ms, double* flops, int64_t* launches) {
   RVC_TRY
   static_assert(RVC_PROF_CFGS == kProfCfgs, "profiling table size");
@@ -802,6 +812,14 @@ int rvc_prof_collect(double* ms, double* flops, int64_t* launches) {
 int rvc_prof_collect_ex(double* out, double ridge_fp32, double ridge_x3) { RVC_TRY conv_prof_collect_ex(out, ridge_fp32, ridge_x3); RVC_CATCH }
 const char* rvc_prof_cfg_name(int i) { return conv_prof_cfg_name(i); }
 int rvc_prof_dump_csv(const char* path) { RVC_TRY RVC_REQUIRE(path && conv_prof_dump_csv(path) >= 0, "cannot write the launch table"); RVC_CATCH }
+#ifdef RVC_EXPERIMENTS
+int rvc_debug_read_scratch(void* stream, int slot, void* host_dst, size_t bytes) {
+  RVC_TRY
+  void* p = stream_scratch((hipStream_t)stream, slot, bytes);
+  RVC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  RVC_HIP_CHECK(hipMemcpy(host_dst, p, bytes, hipMemcpyDeviceToHost));
+  RVC_CATCH
+}
 int rvc_debug_conv_timing(uint64_t* out8, int reset) { RVC_TRY conv_timing_read((unsigned long long*)out8, reset != 0); RVC_CATCH }
 int rvc_debug_set_x3s_mode(int mode) { conv_x3s_set_mode(mode < 0 || mode > 2 ? 0 : mode); return 0; }
 int rvc_debug_x3p_check(void) { const int a = conv_x3p_check_read(), b = conv_x3q_check_read(); return a < 0 ? a : a + (b > 0 ? b : 0); }
@@ -852,5 +870,7 @@ int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, 
   cleanup();
   RVC_CATCH
 }
+
+#endif  // RVC_EXPERIMENTS
 
 }  // extern "C"

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -30,6 +32,19 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
   do {                                                                                            \
     if (!(cond)) throw rvc::Error(std::string("requirement failed: ") + #cond + " : " + (msg));   \
   } while (0)
+
+// ----------------------------------------------------------------------------- run-time knobs
+// knob_int: a DOCUMENTED tuning / diagnosis knob of the product library (INTEGRATION.md lists every one with its test).
+// exp_int: an experiment knob (tile choices, kernel selection, thresholds that a measurement once swept): compiled to its default in the product
+// build - the name does not even reach the binary - and read from the environment only in -DRVC_EXPERIMENTS builds (tools/build_variant.sh).
+inline int knob_int(const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; }
+#ifdef RVC_EXPERIMENTS
+inline int exp_int(const char* name, int def) { return knob_int(name, def); }
+#define RVC_EXP_STR(name) getenv(name)
+#else
+#define exp_int(name, def) (def)
+#define RVC_EXP_STR(name) ((const char*)nullptr)
+#endif
 
 // ----------------------------------------------------------------------------- activations
 enum Act : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4, ACT_SIGMOID = 5, ACT_LOGCLAMP = 6 };
@@ -80,6 +95,7 @@ struct ConvLayer {
   int kh = 3, kw = 3, ph = 1, pwl = 1;   // 2-D window (conv2d_kx_layer_init; the 3 x 3 layers keep the defaults)
   uint16_t* Wx_ = nullptr; // bf16x3 split image (conv_x3.hip), null when the layer only runs on the fp32 kernel
   int CoPx = 0; long long wxBatch = 0;
+  uint16_t* Wh_ = nullptr; // fp16x2 (H2) image of a ResBlock-pair layer: ONE fp16 plane per (chunk, tap) unit, [chunk][tap][half][CoPx rows][8 ch] (conv_x3q.hip)
   int seg2_chunks = 0;     // conv_x3s only: 16-channel chunks of a SECOND input image appended to the reduction with tap offset 0 (conv_layer_append_x3:
                            // MDX23C's tfc2(x2) + shortcut(x) as one product); the caller names that image in SplitGeom::seg2_off
 };
@@ -97,6 +113,9 @@ struct ConvEpilogue {
   // and copied straight into LDS by the consumer (no conversion, no registers).  xs_in replaces X, ys_out replaces Y.
   const unsigned char* xs_in = nullptr; long long xs_tp = 0;
   unsigned char* ys_out = nullptr; long long ys_tp = 0; float ys_slope = 1.f;
+  // fp16x2 arithmetic (conv_x3q.hip, H2) for BOTH halves of a ResBlock pair: the intermediate image is fp16 hi / lo and each layer multiplies with its
+  // one-plane fp16 weight image; only valid when conv1d_pair_h2_eligible(c1, c2, T) said so (no other kernel reads that image format)
+  int h2 = 0;
 };
 constexpr int kSplitMargin = 64;                                                   // positions in front of t = 0 (covers every left halo)
 inline long long split_image_tp(long long T) { return (T + kSplitMargin + 704 + 63) & ~63LL; }   // rows per plane: margin + T + the last tile's overhang
@@ -105,7 +124,11 @@ inline size_t split_image_bytes(int C, long long T) { return (size_t)(C / 16) * 
 // (writes the image: ConvEpilogue::ys_out) and a consumer (stages it: xs_in) take different branches of the tile choice, so each role
 // is dry-run with its own geometry.  pre_lrelu: the producer's input activation (part of the real launch's arguments).
 enum SplitRole : int { SPLIT_CONSUMER = 0, SPLIT_PRODUCER = 1 };
-bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role = SPLIT_CONSUMER);
+bool conv1d_split_eligible(const ConvLayer& L, int Tin, SplitRole role = SPLIT_CONSUMER, int h2 = 0);
+// both layers of a ResBlock pair carry an fp16 image and both launches land on the persistent kernel at this length; false when the pair arithmetic is
+// switched to bf16x3 (rvc_set_pair_arithmetic(0) / RVC_H2=0)
+bool conv1d_pair_h2_eligible(const ConvLayer& c1, const ConvLayer& c2, int Tin);
+int conv_set_pair_arithmetic(int mode);   // process-wide: 1 = fp16x2 on eligible ResBlock pairs (default), 0 = bf16x3 everywhere; < 0 queries; returns the previous mode
 
 // host-side packing + upload (weights in PyTorch layouts)
 void conv1d_layer_init(ConvLayer& L, const float* w /*[Co][Ci/groups][k]*/, const float* bias, int Co, int Ci, int k,

@@ -120,6 +120,37 @@ class LoadRVCModelNode:
         return (lambda: _memoised("rvc", path, lambda: get_vc(path, file_index), extra=file_index), os.path.basename(model).split(".")[0])
 
 
+class _ByteLRU:
+    """Result cache of RVCNode bounded by BYTES (upstream caches on disk by file name, reference rvc_nodes.py:176-183; a long-lived ComfyUI server would
+    otherwise keep 2.4 MB per distinct 30 s conversion forever): least recently used entries go first, one entry larger than the bound is not kept."""
+
+    def __init__(self, max_bytes):
+        from collections import OrderedDict
+        self.max_bytes, self.bytes, self._d = int(max_bytes), 0, OrderedDict()
+
+    def __contains__(self, key):
+        return key in self._d
+
+    def __len__(self):
+        return len(self._d)
+
+    def get(self, key):
+        self._d.move_to_end(key)
+        return self._d[key]
+
+    def put(self, key, value):
+        n = int(np.asarray(value[0]).nbytes)
+        if key in self._d:
+            self.bytes -= int(np.asarray(self._d.pop(key)[0]).nbytes)
+        if n > self.max_bytes:
+            return
+        self._d[key] = value
+        self.bytes += n
+        while self.bytes > self.max_bytes:
+            _, old = self._d.popitem(last=False)
+            self.bytes -= int(np.asarray(old[0]).nbytes)
+
+
 class RVCNode:
     @classmethod
     def INPUT_TYPES(cls):
@@ -135,7 +166,8 @@ class RVCNode:
     RETURN_TYPES = ("VHS_AUDIO", "AUDIO")
     FUNCTION = "convert"
     CATEGORY = CATEGORY
-    _cache = {}
+    CACHE_BYTES = 256 << 20                        # ~ 100 conversions of 30 s at 40 kHz int16
+    _cache = _ByteLRU(CACHE_BYTES)
 
     def convert(self, audio, model, hubert_model, pitch_extraction_params, f0_up_key, format="flac", use_cache=True):
         input_audio = get_audio(audio)
@@ -148,14 +180,14 @@ class RVCNode:
         h.update(np.ascontiguousarray(input_audio[0]).tobytes())
         widget_id = h.hexdigest()
         if use_cache and widget_id in self._cache:
-            output_audio = self._cache[widget_id]
+            output_audio = self._cache.get(widget_id)
         else:
             output_audio = vc_single(hubert_model=feature_model, input_audio=input_audio, f0_up_key=f0_up_key, **voice_model,
                                      **pitch_extraction_params)
             if output_audio is None:
                 raise RuntimeError("voice conversion failed (vc_single returned None; see the message printed above)")
             if use_cache:
-                self._cache[widget_id] = output_audio
+                self._cache.put(widget_id, output_audio)
         wav, sr = output_audio
         audio_name = f"{widget_id}.{format}"
         ui = {"preview": [{"filename": audio_name, "type": "temp", "subfolder": "preview", "widgetId": widget_id}]}

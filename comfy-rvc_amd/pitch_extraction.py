@@ -90,11 +90,10 @@ class FeatureExtractor:
                             # is searched exactly instead of being dropped - the exact answer is what faiss converges to as nprobe grows
                             print(f"{file_index}: nprobe {nprobe} of {nlist} cells exceeds the device probe (16): using the exact search")
                         else:
+                            # (a frame whose probed cells are all empty gets faiss's label -1 and, through the reference's 1 / score^2 weights, a NaN feature
+                            # frame - reference behaviour, kept and documented in INTEGRATION.md; every index train_index writes has nprobe 1, so a message
+                            # here would greet every normal user with something they cannot act on)
                             ivf = (info["centroids"], info["list_of"], nprobe)
-                            if nprobe < nlist and not getattr(FeatureExtractor, "_warned_empty_cells", False):
-                                FeatureExtractor._warned_empty_cells = True
-                                print("IVF index: a frame whose probed cells are all empty gets faiss's label -1 and, through the reference's "
-                                      "1 / score^2 weights, a NaN feature frame (reference behaviour, kept)")
                 except ValueError:
                     import faiss   # noqa: PLC0415 - other index types (PQ ...): only faiss can decode them
                     fidx = faiss.read_index(file_index)

@@ -5,8 +5,10 @@ For every sliced 16 kHz training clip it writes the HuBERT features (`3_feature7
 `3_feature256`, [T_h, 256] for v1), the coarse pitch (`2a_f0/<name>.npy`, int16 [n]) and the NSF pitch (`2b-f0nsf/<name>.npy`,
 float64 [n]) - same arrays, dtypes and skip-if-present rule as the reference.  Differences: the networks are this build's HIP
 graphs; `go` can shard the file list over the ranks of an initialised process group (files are independent: clip i -> rank
-i mod N, no collective); audio files are read with scipy (PCM / float WAV at the working rate) because soundfile / librosa /
-ffmpeg are not available offline - other containers or rates raise, exactly like `lib.audio.load_input_audio` here.
+i mod N, no collective); audio files are read with scipy (PCM / float WAV) because soundfile / librosa / ffmpeg are not available
+offline - other containers raise.  A WAV at another rate is resampled to 16 kHz on load like the reference does (preprocessing_utils.py:171 ->
+load_input_audio(path, 16000) -> librosa.resample), here with the device polyphase kernel of lib/audio.py::resample_audio - PARITY-UNPINNED like the
+two other resampling branches (librosa / soxr absent: the kernel is pinned to its own float64 definition, tests/test_hip_ops.py).
 Note the reference's quirk that training prep quantises the pitch with f0_max = 1100 Hz (get_f0's default) while inference uses
 1600 Hz (vc_infer_pipeline.py:118).
 """
@@ -21,12 +23,10 @@ from .lib.audio import hz_to_mel
 from .pitch_extraction import FeatureExtractor
 
 
-def load_wav(path, sr):
-    """float32 mono/stereo samples in [-1, 1) of a WAV file that already has the working rate."""
+def load_wav(path, sr, device="cuda:0"):
+    """float32 mono / stereo samples in [-1, 1) of a WAV file at the working rate `sr` (resampled on the device when the file has another rate)."""
     from scipy.io import wavfile   # noqa: PLC0415
     rate, data = wavfile.read(path)
-    if rate != sr:
-        raise NotImplementedError(f"{path}: {rate} Hz; resampling needs librosa/soxr (absent here) - slice the dataset at {sr} Hz")
     if data.dtype == np.int16:
         x = data.astype(np.float32) / 32768.0
     elif data.dtype == np.int32:
@@ -35,7 +35,11 @@ def load_wav(path, sr):
         x = (data.astype(np.float32) - 128.0) / 128.0
     else:
         x = data.astype(np.float32)
-    return x, rate
+    if rate != sr:
+        from .lib.audio import resample_audio   # noqa: PLC0415
+        x = resample_audio(x.T if x.ndim > 1 else x, rate, sr, device=device)       # along the last axis, like librosa.resample
+        x = np.ascontiguousarray(x.T) if x.ndim > 1 else x
+    return x, sr
 
 
 class FeatureInput(FeatureExtractor):
@@ -92,7 +96,7 @@ class FeatureInput(FeatureExtractor):
             try:
                 if os.path.exists(opt_path1 + ".npy") and os.path.exists(opt_path2 + ".npy") and os.path.exists(opt_path3 + ".npy"):
                     continue
-                x, _ = load_wav(inp_path, self.sr)
+                x, _ = load_wav(inp_path, self.sr, self.device)
                 if self.model:
                     feats = self.compute_feats(x)
                     if feats is not None:

@@ -88,7 +88,51 @@ def hubert_spec(num_layers=12):
     return s
 
 
-def hubert_state_dict(seed=0):
+def _lognormal(seed, name, n, sigma):
+    """n gains exp(N(0, sigma)), rescaled to unit mean square (a layer's output power stays what the plain family gives it)."""
+    g = np.exp(_rng(seed, name).standard_normal(n) * sigma)
+    return (g / np.sqrt(np.mean(g * g))).astype(np.float32)
+
+
+def _outliers(seed, name, n, count, lo, hi):
+    """`count` channel indices of `n` and their gains in [lo, hi) - the few x10 - x30 channels trained checkpoints carry."""
+    rng = _rng(seed, name)
+    idx = rng.choice(n, size=count, replace=False)
+    return idx, rng.uniform(lo, hi, count).astype(np.float32)
+
+
+def _heavy_hubert(sd, seed):
+    """family="heavy": what a TRAINED ContentVec looks like to the kernels and the plain Gaussian family does not - per-channel gains spread log-normally
+    and a few outlier channels: six FFN hidden units per layer at x10 - x30 (their output_dense columns scaled back, so the residual stream keeps
+    its scale while the 3072-row intermediate carries the large values through GELU and the bf16 hi / lo split), and three residual-stream channels
+    per layer whose LayerNorm gain is x8 - x20 (the "massive activations" of transformer checkpoints; the next layer's projections read them through
+    columns scaled back).  Layer 10's output LayerNorm - the v2 feature the synthesizer and the index consume - keeps plain gains."""
+    for l in range(12):
+        p = f"encoder.layers.{l}."
+        g = _lognormal(seed, p + "ffn.gain", 3072, 0.4)
+        idx, big = _outliers(seed, p + "ffn.outliers", 3072, 6, 10.0, 30.0)
+        g[idx] *= big
+        sd[p + "feed_forward.intermediate_dense.weight"] = sd[p + "feed_forward.intermediate_dense.weight"] * g[:, None]
+        sd[p + "feed_forward.intermediate_dense.bias"] = sd[p + "feed_forward.intermediate_dense.bias"] * g
+        sd[p + "feed_forward.output_dense.weight"] = sd[p + "feed_forward.output_dense.weight"] / g[None, :]
+        if l in (10, 11):
+            continue
+        h = _lognormal(seed, p + "ln.gain", 768, 0.3)
+        idx, big = _outliers(seed, p + "ln.outliers", 768, 3, 8.0, 20.0)
+        h[idx] *= big
+        sd[p + "final_layer_norm.weight"] = sd[p + "final_layer_norm.weight"] * h
+        sd[p + "final_layer_norm.bias"] = sd[p + "final_layer_norm.bias"] * h
+        q = f"encoder.layers.{l + 1}."
+        for name in ("attention.q_proj", "attention.k_proj", "attention.v_proj", "feed_forward.intermediate_dense"):
+            sd[q + name + ".weight"] = sd[q + name + ".weight"] / h[None, :]
+    return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items())
+
+
+def hubert_state_dict(seed=0, family="plain"):
+    """family: "plain" (Gaussian, fan-in scaled) or "heavy" (_heavy_hubert: log-normal channel gains + outlier channels on top of the plain draw)."""
+    assert family in ("plain", "heavy")
+    if family == "heavy":
+        return _heavy_hubert(hubert_state_dict(seed), seed)
     sd = OrderedDict()
     for name, shape in hubert_spec().items():
         if name.endswith("layer_norm.weight"):
@@ -292,7 +336,43 @@ def synth_spec(config, version="v2"):
 F0_ONLY_KEYS = ("enc_p.emb_pitch.", "dec.m_source.", "dec.noise_convs.")   # absent from the *_nono (no-f0) synthesizers
 
 
-def synth_state_dict(config, version="v2", seed=0, fp16_round=True, f0=True):
+def _heavy_synth(sd, config, seed):
+    """family="heavy" for the synthesizer (before the fp16 rounding of the checkpoint): log-normal weight_g everywhere it exists (generator, flow), and in
+    every ResBlock pair three output channels of convs1 at x10 - x30 with the matching input columns of convs2's weight_v scaled back - the pair's
+    intermediate (the tensor the split-resident image carries) then holds a few channels an order of magnitude above the rest, as trained
+    vocoders do, while the stage tensor keeps its scale.  LayerNorm gains of the text encoder spread log-normally too."""
+    nk = len(config[10])
+    for name in list(sd.keys()):
+        if name.endswith("weight_g"):
+            sd[name] = sd[name] * _lognormal(seed, name + ".gain", sd[name].shape[0], 0.4).reshape(sd[name].shape)
+        elif name.endswith("gamma"):
+            sd[name] = sd[name] * _lognormal(seed, name + ".gain", sd[name].shape[0], 0.3)
+    for i in range(len(config[12])):
+        for j in range(nk):
+            for m in range(3):
+                p = f"dec.resblocks.{i * nk + j}."
+                ch = sd[p + f"convs1.{m}.weight_g"].shape[0]
+                idx, big = _outliers(seed, p + f"{m}.outliers", ch, 3, 10.0, 30.0)
+                g = sd[p + f"convs1.{m}.weight_g"].copy()
+                g[idx, 0, 0] *= big
+                sd[p + f"convs1.{m}.weight_g"] = g
+                b = sd[p + f"convs1.{m}.bias"].copy()
+                b[idx] *= big
+                sd[p + f"convs1.{m}.bias"] = b
+                v = sd[p + f"convs2.{m}.weight_v"].copy()
+                v[:, idx, :] /= big[None, :, None]
+                sd[p + f"convs2.{m}.weight_v"] = v
+    return sd
+
+
+def synth_state_dict(config, version="v2", seed=0, fp16_round=True, f0=True, family="plain"):
+    """family: "plain" or "heavy" (_heavy_synth)."""
+    assert family in ("plain", "heavy")
+    if family == "heavy":
+        sd = _heavy_synth(synth_state_dict(config, version, seed, fp16_round=False, f0=f0), config, seed)
+        if fp16_round:
+            sd = OrderedDict((k, v.astype(np.float16).astype(np.float32)) for k, v in sd.items())
+        return OrderedDict((k, np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items())
     spec = synth_spec(config, version)
     sd = OrderedDict()
     for name, shape in spec.items():
@@ -345,10 +425,10 @@ def synth_state_dict(config, version="v2", seed=0, fp16_round=True, f0=True):
     return sd
 
 
-def synth_checkpoint(config=None, version="v2", seed=0, f0=1):
+def synth_checkpoint(config=None, version="v2", seed=0, f0=1, family="plain"):
     """The `cpt` dict layout `get_vc` reads (reference vc_infer_pipeline.py:199-221), as numpy arrays."""
     config = list(CONFIG_40K_V2 if config is None else config)
-    return {"weight": synth_state_dict(config, version, seed, f0=bool(f0)), "config": config, "f0": int(f0), "version": version,
+    return {"weight": synth_state_dict(config, version, seed, f0=bool(f0), family=family), "config": config, "f0": int(f0), "version": version,
             "sr": {32000: "32k", 40000: "40k", 48000: "48k"}[config[-1]], "info": "synthetic"}
 
 

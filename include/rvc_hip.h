@@ -291,6 +291,9 @@ int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, voi
                                    float out_scale, int accumulate);
 int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x_dev, int T, float* y_dev, float out_scale,
                              int accumulate);
+/* The arithmetic rvc_conv1d_plan_pair_split_run (and the generator) uses for this pair at length T under the current rvc_set_pair_arithmetic mode:
+ * 1 fp16x2, 0 bf16x3 (mode 0, a layer without an fp16 image, or a length / shape the persistent kernel declines); -1 on a null argument. */
+int rvc_conv1d_plan_pair_arithmetic(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, int T);
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p);
 /* fused softmax(K^T Q) V + bias for head dimension 64: q_dev, k_dev channel-major [heads*64][T] (q pre-scaled), v_rm_dev row-major
  * [T][heads*64], bv_dev [heads*64] or NULL, out_dev channel-major [heads*64][T] */
@@ -352,6 +355,16 @@ int rvc_resample(void* stream, const float* x_dev, int64_t n_in, const double* t
  *      ~1e-5 relative error per layer); grouped / Ci % 16 != 0 / under-filled launches and free-standing ops / plans stay fp32
  *   2  bf16x3 for every eligible layer (stride 1, groups 1, Ci % 16 == 0), including rvc_op_conv1d / plans (parity tests) */
 int rvc_set_conv_precision(int mode);
+/* Arithmetic of the generator's ResBlock pairs (reference lib/infer_pack/modules.py:295-308: x + c2(lrelu(c1(lrelu(x))))) on the persistent kernel,
+ * PROCESS-WIDE, read at every launch (switching needs no reload: layers carry both weight images):
+ *   1  default: fp16x2 - the weight is ONE fp16 term (2^-12 relative rounding), the activation fp16 hi + lo (22 bits), two
+ *      v_mfma_f32_32x32x16_f16 per product, fp32 accumulation.  Full-size goldens stay within the 33-LSB (1e-3) gate; see DESIGN.md.
+ *      Activations beyond +-131008 would saturate (fp16 range): not reachable by a tanh-terminated vocoder, and a layer whose weights
+ *      exceed 60000 or are all below 2^-10 keeps mode 0 by itself.
+ *   0  bf16x3 as everywhere else (three MFMAs per product, ~1e-5 relative error per layer).
+ * Environment RVC_H2=0 sets the initial mode to 0.  rvc_get_pair_arithmetic returns the current mode. */
+int rvc_set_pair_arithmetic(int mode);
+int rvc_get_pair_arithmetic(void);
 
 /* ------------------------------------------------------------------ kernel profiling (bench.py roofline leg) */
 /* While enabled, every launch of the MFMA convolution kernels is bracketed by HIP events on its own stream and tagged with its
@@ -368,6 +381,11 @@ const char* rvc_prof_cfg_name(int i);
 /* writes one CSV row per launch recorded since rvc_prof_enable(1): kernel, tile, Ci, Co, k, dilation, stride, Tout, workgroups, us,
  * algorithmic GFLOP / MB, TFLOP/s, GB/s (profiles/ per-launch-class tables) */
 int rvc_prof_dump_csv(const char* path);
+/* ------------------------------------------------------------------ experiment / instrumentation hooks
+ * NOT part of the product ABI: librvc_hip.so exports them only when it is built with -DRVC_EXPERIMENTS (tools/build_variant.sh: variant builds for
+ * A/B timing, wait-count checks, per-phase cycle counters).  The product build also compiles every experiment knob (tile choices, kernel
+ * selection, thresholds) to its default; the run-time knobs it does read are listed in INTEGRATION.md. */
+#ifdef RVC_EXPERIMENTS
 /* debug builds only (-DRVC_CONV_TIMING): cycle sums {blocks, prologue, stage fill, prefetch issue, MFMA, epilogue, total, -}; zeros otherwise */
 int rvc_debug_conv_timing(uint64_t* out8, int reset);
 /* debug builds only (-DRVC_X3P_CHECK): number of waits of the pipelined bf16x3 kernel whose compile-time vmcnt exceeded the exact
@@ -384,6 +402,8 @@ int rvc_debug_set_x3s_mode(int mode);
  * *us_out = mean microseconds per launch (HIP events). */
 int rvc_debug_gemm_split_bench(void* stream, int Ci, int Co, int T, int ksplit, int am, int an, int split_out, int reps, float* us_out, int w2d,
                                int nlayers);
+
+#endif /* RVC_EXPERIMENTS */
 
 #ifdef __cplusplus
 }

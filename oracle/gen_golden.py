@@ -59,14 +59,14 @@ def np_(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
-def build_models(ns, config, version, seed=0):
+def build_models(ns, config, version, seed=0, family="plain", rmvpe_seed=None):
     from transformers import HubertConfig
     hub = ns.loaders.HubertModelWithFinalProj(HubertConfig())
-    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(seed)))
+    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(seed, family=family)))
     hub.eval()
     mdir = os.path.join(ns.ws, "models")
-    torch.save(to_torch_sd(S.rmvpe_state_dict(seed)), os.path.join(mdir, "rmvpe.pt"))
-    cpt = S.synth_checkpoint(config, version, seed)
+    torch.save(to_torch_sd(S.rmvpe_state_dict(seed if rmvpe_seed is None else rmvpe_seed)), os.path.join(mdir, "rmvpe.pt"))
+    cpt = S.synth_checkpoint(config, version, seed, family=family)
     cpt["weight"] = {k: v.half() for k, v in to_torch_sd(cpt["weight"]).items()}
     name = f"synth_{version}_{config[-1]}.pth"
     torch.save(cpt, os.path.join(mdir, name))
@@ -75,10 +75,10 @@ def build_models(ns, config, version, seed=0):
     return hub, vcd
 
 
-def gen_hubert(ns):
+def gen_hubert(ns, seed=0, family="plain", name="hubert_1s"):
     from transformers import HubertConfig
     hub = ns.loaders.HubertModelWithFinalProj(HubertConfig())
-    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(0)))
+    hub.load_state_dict(to_torch_sd(S.hubert_state_dict(seed, family=family)))
     hub.eval()
     audio = torch.from_numpy(S.synth_audio(1.0, seed=3)).view(1, -1)
     with torch.no_grad():
@@ -90,9 +90,9 @@ def gen_hubert(ns):
     v2 = hub.extract_features(audio, version="v2")
     v1 = hub.extract_features(audio, version="v1")
     assert len(hs) == 13 and torch.equal(v2, hs[11])
-    np.savez_compressed(os.path.join(OUT, "hubert_1s.npz"), audio=np_(audio), conv_stack=np_(conv), pos_conv=np_(pos),
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), audio=np_(audio), conv_stack=np_(conv), pos_conv=np_(pos),
                         hidden_0=np_(hs[0]), hidden_8=np_(hs[8]), out_v2=np_(v2), out_v1=np_(v1))
-    print("hubert_1s", v2.shape, v1.shape, float(v2.abs().mean()), float(v2.std()))
+    print(name, v2.shape, v1.shape, float(v2.abs().mean()), float(v2.std()), "max |hidden_8|", float(hs[8].abs().max()), "max |v2|", float(v2.abs().max()))
 
 
 def gen_rmvpe(ns):
@@ -138,11 +138,11 @@ def gen_synth_nono(ns, config, version, tag, T=12):
     print(f"synth_{tag}", o.shape, "wav rms", float(o.pow(2).mean().sqrt()), "max", float(o.abs().max()))
 
 
-def gen_synth(ns, config, version, tag, T=16, full_taps=False):
+def gen_synth(ns, config, version, tag, T=16, full_taps=False, seed=0, family="plain"):
     cls = ns.models.SynthesizerTrnMs768NSFsid if version == "v2" else ns.models.SynthesizerTrnMs256NSFsid
     net = cls(*config, is_half=False)
     del net.enc_q
-    sd = to_torch_sd(S.synth_state_dict(config, version, 0))
+    sd = to_torch_sd(S.synth_state_dict(config, version, seed, family=family))
     missing = net.load_state_dict(sd, strict=True)
     net.eval()
     rng = np.random.default_rng(21)
@@ -370,6 +370,38 @@ def _audio_digest(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8).copy()
 
 
+def gen_heavy(ns, which):
+    """Second weight family (synthetic.*_state_dict(seed=1, family="heavy"): log-normal channel gains + x10 - x30 outlier channels in HuBERT's FFN /
+    LayerNorm and the generator's ResBlock pairs) through the REAL reference: the guard for the reduced-precision matrix arithmetic (bf16x3 everywhere,
+    fp16x2 on the ResBlock pairs), which the plain Gaussian family exercises on one distribution only.  RMVPE keeps its seed-0 weights (its procedural
+    family is rescaled for a sensible voiced / unvoiced mix; the pitch path is pinned elsewhere).
+      heavy_hubert   hubert_1s_heavy           stage taps
+      heavy_synth    synth_40k_v2_heavy        stage taps, T = 16
+      heavy_2s       pipeline_2s_rmvpe_heavy   vc_single, 2 s
+      heavy_30s      pipeline_30s_40k_v2_heavy BASELINE configs[2] size"""
+    import time
+    if "heavy_hubert" in which:
+        gen_hubert(ns, seed=1, family="heavy", name="hubert_1s_heavy")
+    if "heavy_synth" in which:
+        gen_synth(ns, S.CONFIG_40K_V2, "v2", "40k_v2_heavy", T=16, full_taps=True, seed=1, family="heavy")
+    if "heavy_2s" in which or "heavy_30s" in which:
+        hub, vcd = build_models(ns, S.CONFIG_40K_V2, "v2", seed=1, family="heavy", rmvpe_seed=0)
+        if "heavy_2s" in which:
+            audio = S.synth_audio(2.0, seed=7)
+            i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=99)
+            np.savez_compressed(os.path.join(OUT, "pipeline_2s_rmvpe_heavy.npz"), audio=audio, out_i16=i16, sr=np.int64(sr),
+                                pitch=cap["pitch"], pitchf=cap["pitchf"], noise_seed=np.int64(99))
+            print("pipeline_2s_rmvpe_heavy", i16.shape, sr, shapes, "voiced", (cap["pitchf"] > 0).mean(), "rms", float(np.sqrt(np.mean(i16.astype(np.float64) ** 2))))
+        if "heavy_30s" in which:
+            audio = S.synth_audio(30.0, seed=100)
+            t0 = time.time()
+            i16, sr, cap, shapes = run_ref_pipeline(ns, hub, vcd, audio, seed=301)
+            np.savez_compressed(os.path.join(OUT, "pipeline_30s_40k_v2_heavy.npz"), audio_seconds=np.float64(30.0), audio_seed=np.int64(100), audio_sha256=_audio_digest(audio),
+                                out_i16=i16, sr=np.int64(sr), pitch=cap["pitch"].astype(np.int16), pitchf=cap["pitchf"], noise_seed=np.int64(301),
+                                n_segments=np.int64(len(shapes) // 2), seg_T=np.array([s[2] for s in shapes[0::2]], dtype=np.int64))
+            print("pipeline_30s_40k_v2_heavy", i16.shape, sr, "voiced", (cap["pitchf"] > 0).mean(), "rms", float(np.sqrt(np.mean(i16.astype(np.float64) ** 2))), f"{time.time() - t0:.1f} s")
+
+
 def gen_fullsize(ns, which):
     """BASELINE.json's full-size configurations through the REAL reference with the real segmentation constants (x_pad 1, x_query 6,
     x_center 38, x_max 41).  The input clips are regenerated from comfy-rvc_amd/synthetic.py::synth_audio on both sides (a SHA-256 of the
@@ -591,6 +623,8 @@ def main():
         gen_mdx23c_full()
     if "mdx23c_demix_full" in which: # three full-size chunks through the reference's own demix_mdxv3 (~10 minutes of CPU)
         gen_mdx23c_demix_full()
+    if {"heavy_hubert", "heavy_synth", "heavy_2s", "heavy_30s"} & set(which):   # round 6: the second weight family
+        gen_heavy(ns, which)
     if {"full40", "full45", "full48", "rmvpe60"} & set(which):   # BASELINE.json's full-size configurations (minutes of CPU time)
         gen_fullsize(ns, which)
 

@@ -25,10 +25,30 @@ def _x3p_wait_count_check():
         if not torch.cuda.is_available():
             return
         from comfy_rvc_amd import _lib
+        if not _lib.has_experiments:          # product library: no instrumentation hooks (include/rvc_hip.h, last section)
+            return
         bad = _lib.lib.rvc_debug_x3p_check()
     except Exception:
         return
     assert bad <= 0, f"{bad} waits of the pipelined kernels had a too large compile-time count"
+
+
+@pytest.fixture
+def pair_arith():
+    """Sets the ResBlock-pair arithmetic (rvc_set_pair_arithmetic: 0 bf16x3, 1 fp16x2) for one test and restores the previous mode afterwards."""
+    from comfy_rvc_amd import _lib
+    prev = _lib.lib.rvc_get_pair_arithmetic()
+
+    def set_mode(mode):
+        _lib.check(_lib.lib.rvc_set_pair_arithmetic(int(mode)))
+    yield set_mode
+    _lib.check(_lib.lib.rvc_set_pair_arithmetic(prev))
+
+
+def x3p_check_count(L):
+    """Waits of the pipelined / persistent kernels whose compile-time vmcnt exceeded the exact run-time count since the last call: a number on a
+    -DRVC_X3P_CHECK -DRVC_EXPERIMENTS build (RVC_HIP_LIB=.../variants/librvc_hip_x3pcheck.so), -1 on every other build."""
+    return L.lib.rvc_debug_x3p_check() if L.has_experiments else -1
 
 
 def golden(name):

@@ -55,6 +55,37 @@ def test_hubert_matches_reference_golden(hubert):
     assert torch.equal(vcm.t()[None], v2)
 
 
+def test_heavy_family_hubert_and_synth_match_reference_golden(pair_arith):
+    """The second weight family (outlier channels: conftest / oracle/gen_golden.py heavy_*) on the stage level: HuBERT's taps with 15 - 30 x channels in
+    the residual stream and the FFN intermediate through the bf16 hi / lo images, the synthesizer's taps and waveform with x10 - x30 channels in every
+    ResBlock pair's intermediate (T = 16: the per-tile kernels) - same 1e-3 as the plain family."""
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    g = golden("hubert_1s_heavy.npz")
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(1, family="heavy"), S.HUBERT_CONFIG)
+    audio = torch.from_numpy(g["audio"])
+    Th = hub.num_frames(audio.shape[1])
+    taps = {"conv_stack": torch.empty(512, Th, device="cuda"), "pos_conv": torch.empty(768, Th, device="cuda"),
+            "hidden_0": torch.empty(768, Th, device="cuda"), "hidden_8": torch.empty(768, Th, device="cuda")}
+    v2 = hub.extract_features(audio, version="v2", taps=taps)
+    for k in ("pos_conv", "hidden_0", "hidden_8"):
+        assert rel_err(taps[k].cpu().numpy().T[None], g[k]) < TOL, k
+    assert rel_err(v2.cpu(), g["out_v2"]) < TOL
+    assert rel_err(hub.extract_features(audio, version="v1").cpu(), g["out_v1"]) < TOL
+    g = golden("synth_40k_v2_heavy.npz")
+    from comfy_rvc_amd.lib.infer_pack import models as M
+    net = M.SynthesizerTrnMs768NSFsid(*S.CONFIG_40K_V2, is_half=False)
+    net.load_state_dict(S.synth_state_dict(S.CONFIG_40K_V2, "v2", 1, family="heavy"))
+    T = g["phone"].shape[1]
+    for arith in (1, 0):
+        pair_arith(arith)
+        taps = {k: None for k in ("enc_p_layer0", "m_p", "logs_p", "z_p", "z", "har_source", "sine_waves")}
+        o, mask, _ = net.infer(torch.from_numpy(g["phone"]), torch.LongTensor([T]), torch.from_numpy(g["pitch"]), torch.from_numpy(g["pitchf"]),
+                               torch.LongTensor([int(g["sid"])]), noise=(g["noise_z"], g["noise_src"]), taps=taps)
+        for k in ("m_p", "logs_p", "z_p", "z", "enc_p_layer0"):
+            assert rel_err(cm(taps[k]), g[k]) < TOL, k
+        assert rel_err(o.cpu(), g["wav"]) < TOL, arith
+
+
 def test_hubert_matches_oracle_other_length(hubert):
     from oracle import nets
     audio = S.synth_audio(2.37, seed=21)[None]

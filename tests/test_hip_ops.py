@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import rel_err, x3p_check_count
 
 pytestmark = pytest.mark.gpu
 
@@ -667,20 +667,25 @@ def test_resample_kernel_matches_polyphase_definition(L, orig, target, n):
 @pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(128, 11, 5, 70003, 1.0 / 3, True), (128, 7, 3, 66001, 1.0, False), (128, 3, 1, 80000, 1.0, False),
                                                   (64, 11, 1, 131000, 1.0, False), (64, 7, 5, 140001, 1.0 / 3, True), (64, 3, 3, 140000, 1.0, False),
                                                   (192, 7, 1, 60000, 1.0, False), (256, 11, 3, 32000, 1.0, True), (256, 3, 5, 30001, 1.0, False)])
-def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
-    """One ResBlock1 pair as the wide generator stages run it: conv1 writes its output as the bf16 hi / lo image (split-resident), conv2
-    stages that image by DMA - both on the persistent software-pipelined kernel (conv_x3q.hip; conv_x3p.hip with RVC_X3Q=0; channel counts from three chunks up, every kernel size
-    of the generator, sequence ends inside / at tile borders) - against fp64 torch."""
+@pytest.mark.parametrize("arith", [0, 1])
+def test_split_resident_resblock_pair(L, pair_arith, arith, Cc, k, d, T, scale, accum):
+    """One ResBlock1 pair as the wide generator stages run it: conv1 writes its output as the hi / lo image (split-resident), conv2
+    stages that image by DMA - both on the persistent software-pipelined kernel (conv_x3q.hip; conv_x3p.hip where the persistent kernel declines; channel counts from three
+    chunks up, every kernel size of the generator, sequence ends inside / at tile borders) - against fp64 torch, in both pair arithmetics (rvc_set_pair_arithmetic):
+    0 = bf16x3, 1 = fp16x2.  fp16x2 is held to the SAME 2e-5 against fp64 with the weights rounded to fp16 (that rounding is the mode's whole definition; the
+    activations keep 22 bits) and to 6e-4 against the exact weights (2^-12 per weight)."""
+    pair_arith(arith)
     g = torch.Generator().manual_seed(2000 + 37 * k + d + Cc)
     x = torch.randn(Cc, T, generator=g)
     w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
     w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
     xd = x.double()
-    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
-    ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
     y0 = torch.randn(Cc, T, generator=g)
-    if accum:
-        ref = ref + y0
+
+    def pair_ref(wa, wb):
+        h = F.conv1d(F.leaky_relu(xd, 0.1)[None], wa.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+        r = (F.conv1d(F.leaky_relu(h, 0.1), wb.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+        return r + y0 if accum else r
     y, xg = dev(y0), dev(x)
     L.check(L.lib.rvc_set_conv_precision(2))
     plans = []
@@ -691,6 +696,10 @@ def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
             plans.append(pl)
     finally:
         L.check(L.lib.rvc_set_conv_precision(1))
+    # what the library will do for this pair at this length (192 channels: no 128-row tiling -> the per-tile kernel, which only knows bf16x3)
+    h2 = L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == 1
+    assert h2 == (arith == 1 and Cc != 192), (arith, Cc, h2)
+    ref = pair_ref(w1.half().float(), w2.half().float()) if h2 else pair_ref(w1, w2)
     try:
         L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
     except L.RvcHipError as e:
@@ -702,20 +711,102 @@ def test_split_resident_resblock_pair(L, Cc, k, d, T, scale, accum):
     assert rel_err(y.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
     for c0 in (0, 126, 254, T // 2, T - 40):                      # sequence ends and tile seams carry the same error as the interior
         assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
-    bad = L.lib.rvc_debug_x3p_check()                             # (a -DRVC_X3P_CHECK build counts waits whose compile-time vmcnt was too large)
+    if h2:
+        assert rel_err(y.cpu().double(), pair_ref(w1, w2)) < 6e-4
+    bad = x3p_check_count(L)                             # (a -DRVC_X3P_CHECK build counts waits whose compile-time vmcnt was too large)
     assert bad <= 0, f"{bad} waits of the pipelined kernel with a too large compile-time count"
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
+@pytest.mark.parametrize("Cc,k,d,T", [(128, 7, 1, 319800), (128, 3, 5, 319800), (128, 11, 3, 319800), (64, 7, 5, 639600), (64, 11, 1, 639600), (256, 7, 3, 31980)])
+def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, T):
+    """The window checks of test_persistent_resblock_pair cannot see a fault that strikes a few tiles out of a thousand, differently in every run - which is
+    what round 6's first fp16x2 build did at the generator's REAL stage lengths only (profiles/r6_sdwa_pk_hazard.txt: a packed fp32 add fed by an SDWA
+    conversion read stale registers beside in-flight MFMAs under memory load; a latent wait-count race of the 3-tap image-in launches sat next to it).
+    Here every element of three fp16x2 runs is compared: with each other (bit-identical) and with the bf16x3 result of the same pair computed on the device
+    (no NaN, 6e-4: the weight rounding), at the three wide stages' true lengths."""
+    g = torch.Generator().manual_seed(9000 + Cc + 13 * k + d)
+    x = torch.randn(Cc, T, generator=g)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
+    xg = dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    outs = {}
+    for arith, reps in ((0, 1), (1, 3)):
+        pair_arith(arith)
+        assert L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == arith
+        outs[arith] = []
+        for _ in range(reps):
+            y = torch.full((Cc, T), float("nan"), device="cuda")
+            L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), 1.0, 0))
+            torch.cuda.synchronize()
+            outs[arith].append(y)
+    ref = outs[0][0]
+    assert bool(torch.isfinite(ref).all())
+    for y in outs[1]:
+        assert bool(torch.isfinite(y).all())
+        assert torch.equal(y, outs[1][0])
+    assert float((outs[1][0] - ref).abs().max() / ref.abs().max()) < 6e-4
+    assert x3p_check_count(L) <= 0
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
+@pytest.mark.parametrize("xscale,tol", [(0.03, 2e-5), (1e-3, 1.5e-4), (3e-5, 3e-3), (300.0, 2e-5)])
+def test_fp16x2_pair_keeps_its_accuracy_at_small_and_large_activations(L, pair_arith, xscale, tol):
+    """fp16x2's activation split x = hi + lo leaves lo below fp16's normal range (6.1e-5) for every |x| < 0.125: the mode relies on the matrix cores
+    taking fp16 SUBNORMAL operands at full value (they do on gfx950; a flush would cost 2^-11 of every such activation, 5e-4 here).  What remains is fp16's
+    absolute floor of 2^-24 = 6e-8 per element: invisible at activations of 0.03 and above (2e-5 against fp64 with the fp16-rounded weights, like bf16x3),
+    5e-5 at a tensor scale of 1e-3 (the leaky ReLU's negative side is then 1e-4: hi itself is subnormal for a third of it), 1.4e-3 at 3e-5 - measured on
+    MI355X; a generator stage carries 0.01 - 10.  Activations of a few hundred (the top of what a vocoder stage carries) keep the 2e-5."""
+    pair_arith(1)
+    Cc, k, d, T = 128, 7, 3, 70001
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(Cc, T, generator=g) * xscale
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1 * xscale
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1 * xscale
+    xd = x.double()
+    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.half().double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+    ref = F.conv1d(F.leaky_relu(h, 0.1), w2.half().double(), b2.double(), padding=(k - 1) // 2)[0] + xd
+    branch = ref - xd                                             # the pair's own contribution (the skip path is exact)
+    y, xg = torch.empty(Cc, T, device="cuda"), dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == 1
+    L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), 1.0, 0))
+    torch.cuda.synchronize()
+    err = float(((y.cpu().double() - xd) - branch).abs().max() / branch.abs().max())
+    assert err < tol, err
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
 @pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(128, 11, 5, 274489, 1.0 / 3, True), (128, 7, 3, 270001, 1.0, False), (128, 3, 1, 262144 + 256 * 3 + 5, 1.0, True),
                                                   (64, 11, 1, 400003, 1.0, False), (64, 7, 5, 393216 + 77, 1.0 / 3, True)])
-def test_persistent_resblock_pair(L, tmp_path, Cc, k, d, T, scale, accum):
+@pytest.mark.parametrize("arith", [0, 1])
+def test_persistent_resblock_pair(L, pair_arith, arith, tmp_path, Cc, k, d, T, scale, accum):
     """The split-resident ResBlock pair at lengths where the PERSISTENT kernel takes it (conv_x3q.hip: at least two rounds of resident
     workgroups - the sizes of the generator's 128- / 64-channel stages): every workgroup walks over several tiles in one stream of units, the
     residual joins the sum block by block, stores go through the LDS staging area.  The launch profile must name conv_x3q_kernel for both
     halves; values are checked against fp64 torch on windows at both ends of the sequence, at tile seams and in the middle (the whole tensor in
-    fp64 on the CPU would take minutes), the -DRVC_X3P_CHECK build's wait bookkeeping must stay clean."""
+    fp64 on the CPU would take minutes), the -DRVC_X3P_CHECK build's wait bookkeeping must stay clean.  Both pair arithmetics (see test_split_resident_resblock_pair)."""
+    pair_arith(arith)
     g = torch.Generator().manual_seed(4000 + 37 * k + d + Cc)
     x = torch.randn(Cc, T, generator=g)
     w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
@@ -741,6 +832,7 @@ def test_persistent_resblock_pair(L, tmp_path, Cc, k, d, T, scale, accum):
         L.check(L.lib.rvc_prof_enable(0))
     kernels = [ln.split(",")[1] for ln in open(csv_path).read().strip().split("\n")[1:]]
     assert kernels == ["conv_x3q_kernel", "conv_x3q_kernel"], kernels
+    assert L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == arith
     yc = y.cpu().double()
     halo = (k - 1) // 2 * (d + 1) + 8
     BN = 256
@@ -751,9 +843,10 @@ def test_persistent_resblock_pair(L, tmp_path, Cc, k, d, T, scale, accum):
     for lo, hi in wins:
         a0, a1 = max(lo - halo, 0), min(hi + halo, T)
         xd = x[:, a0:a1].double()
-        h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+        wa, wb = (w1.half().float(), w2.half().float()) if arith == 1 else (w1, w2)
+        h = F.conv1d(F.leaky_relu(xd, 0.1)[None], wa.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
         # (positions outside the sequence are the second convolution's zero padding; inside the window's margin they are simply not compared)
-        ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+        ref = (F.conv1d(F.leaky_relu(h, 0.1), wb.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
         o = lo - a0
         # trim the part of the window whose halo was cut by the slice (not by the true sequence ends)
         tl = 0 if a0 == 0 else halo
@@ -765,7 +858,7 @@ def test_persistent_resblock_pair(L, tmp_path, Cc, k, d, T, scale, accum):
         err = float((got - ref).abs().max() / ref.abs().max())
         worst = max(worst, err)
         assert err < 2e-5, (lo, hi, err)
-    bad = L.lib.rvc_debug_x3p_check()
+    bad = x3p_check_count(L)
     assert bad <= 0, f"{bad} waits of the persistent kernel with a too large compile-time count"
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
@@ -890,6 +983,8 @@ def test_gemm_split_resident_under_load(L):
 
 def _x3s_modes(L, fn):
     """fn() under the LDS-ring reduction loop (mode 1) and the register-direct one (mode 2) of csrc/conv_x3s.hip; the process-wide default is restored."""
+    if not L.has_experiments:
+        pytest.skip("the register-direct loop exists in -DRVC_EXPERIMENTS builds only (RVC_HIP_LIB=<variant>); the product library runs the LDS ring")
     outs = []
     try:
         for mode in (1, 2):

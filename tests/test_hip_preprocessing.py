@@ -80,8 +80,44 @@ def test_feature_input_dump_matches_reference_golden(tmp_path):
             assert np.abs(feat - rf).max() <= 1e-3 * np.abs(rf).max()
             assert np.array_equal(nsf > 0, rn > 0) and np.allclose(nsf, rn, rtol=1e-3, atol=1e-3)
             dc = np.abs(coarse.astype(int) - rc.astype(int))
-            record_parity(f"feature_dump_golden_{version}_{i}", {"frames": int(rc.shape[0]), "coarse_equal": float((dc == 0).mean()), "coarse_max_diff": int(dc.max())})
-            assert dc.max() <= 1 and (dc == 0).mean() > 0.99
+            # equal on every frame, or an EXPLAINED tie: the reference's own mel value sits closer to a rounding boundary (x.5) than a 1e-3 relative change
+            # of its f0 can move it - no percentile (measured on MI355X: 0 differing frames of 804)
+            from comfy_rvc_amd.lib.audio import hz_to_mel
+            scale = 254.0 / (hz_to_mel(1100.0) - hz_to_mel(50.0))
+            mel_ref = (hz_to_mel(rn) - hz_to_mel(50.0)) * scale + 1
+            reach = 1e-3 * (2595.0 / np.log(10.0)) * (rn / (700.0 + rn)) * scale                # |d mel| for |d f0| / f0 = 1e-3
+            near_boundary = np.abs(np.abs(mel_ref - np.floor(mel_ref)) - 0.5) <= reach
+            unexplained = int(((dc != 0) & ~((dc == 1) & near_boundary)).sum())
+            record_parity(f"feature_dump_golden_{version}_{i}", {"frames": int(rc.shape[0]), "coarse_differing": int((dc != 0).sum()), "unexplained": unexplained})
+            assert unexplained == 0, (version, i, int((dc != 0).sum()), int(dc.max()))
         log = open(str(d / "extract_f0_feature.log")).read().split("\n")
         ref_log = bytes(g[f"{version}_log"]).decode().split("\n")
         assert log[:2] == ref_log[:2] == ["todo-f0-2", "todo-f0-2"]
+
+
+def test_feature_input_resamples_other_rates_on_load(tmp_path):
+    """A training clip stored at 40 kHz / 48 kHz is resampled to 16 kHz on load, as the reference's load_input_audio(path, 16000) does (reference
+    preprocessing_utils.py:171, lib/audio.py:149-150) - with the device polyphase kernel (parity-unpinned: librosa / soxr absent).  The dump of a
+    band-limited clip written at 48 kHz equals the dump of the same clip written at 16 kHz up to the resampler's 2e-5 pass-band error."""
+    from scipy.io import wavfile
+    from comfy_rvc_amd.lib.infer_pack.loaders import HubertModelWithFinalProj
+    from comfy_rvc_amd.lib.rmvpe import RMVPE
+    from comfy_rvc_amd.preprocessing_utils import FeatureInput, load_wav
+    hub = HubertModelWithFinalProj(S.hubert_state_dict(0), S.HUBERT_CONFIG)
+    fi = FeatureInput(hub, "rmvpe", str(tmp_path), version="v2", if_f0=True)
+    fi.model_rmvpe = RMVPE(S.rmvpe_state_dict(0))
+    secs = 2.0
+    t16, t48 = np.arange(int(16000 * secs)) / 16000.0, np.arange(int(48000 * secs)) / 48000.0
+    sig = lambda t: (0.3 * np.sin(2 * np.pi * 220.0 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.1 * np.sin(2 * np.pi * 1800.0 * t)).astype(np.float32)
+    wavfile.write(str(tmp_path / "a16.wav"), 16000, sig(t16))
+    wavfile.write(str(tmp_path / "a48.wav"), 48000, np.stack([sig(t48), sig(t48)], axis=1))        # stereo at 48 kHz
+    x48, sr = load_wav(str(tmp_path / "a48.wav"), 16000)
+    assert sr == 16000 and x48.shape == (t16.shape[0], 2)
+    mid = slice(2000, -2000)
+    assert np.abs(x48[mid, 0] - sig(t16)[mid]).max() < 1e-4
+    paths = [(str(tmp_path / f"{n}.wav"), str(tmp_path / f"c_{n}"), str(tmp_path / f"n_{n}"), str(tmp_path / f"f_{n}")) for n in ("a16", "a48")]
+    assert fi.go(paths) == 2
+    f16, f48 = np.load(paths[0][3] + ".npy"), np.load(paths[1][3] + ".npy")
+    assert f16.shape == f48.shape and np.abs(f16[5:-5] - f48[5:-5]).max() <= 2e-3 * np.abs(f16).max()
+    n16, n48 = np.load(paths[0][2] + ".npy"), np.load(paths[1][2] + ".npy")
+    assert n16.shape == n48.shape and np.mean(np.isclose(n16[10:-10], n48[10:-10], rtol=2e-3, atol=1e-3)) > 0.98

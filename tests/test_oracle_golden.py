@@ -181,14 +181,14 @@ def test_synth_nono_oracle_matches_reference():
 
 
 # ------------------------------------------------------------------ BASELINE.json's full-size configurations (oracle/gen_golden.py full40 full48 full45 rmvpe60)
-def _fullsize_oracle(gname, cfg):
+def _fullsize_oracle(gname, cfg, seed=0, family="plain"):
     from conftest import check_clip_digest, golden_clip, parity_stats
     g = golden(gname)
     audio = golden_clip(g)
     check_clip_digest(audio, g)
     gen = torch.Generator().manual_seed(int(g["noise_seed"]))
     taps = {}
-    out = opl.pipeline(S.hubert_state_dict(0), S.rmvpe_state_dict(0), S.synth_state_dict(cfg, "v2", 0), cfg, "v2", audio,
+    out = opl.pipeline(S.hubert_state_dict(seed, family=family), S.rmvpe_state_dict(0), S.synth_state_dict(cfg, "v2", seed, family=family), cfg, "v2", audio,
                        noise_fn=lambda shp: torch.randn(tuple(shp), generator=gen))
     assert out.shape == g["out_i16"].shape and out.dtype == np.int16
     st = parity_stats(out, g["out_i16"], 33)
@@ -200,6 +200,37 @@ def test_pipeline_30s_40k_v2_oracle_matches_reference():
     """BASELINE.json configs[2] (C3) at full size: every int16 sample within 33 LSB of the reference's own output."""
     g = _fullsize_oracle("pipeline_30s_40k_v2.npz", S.CONFIG_40K_V2)
     assert int(g["n_segments"]) == 1
+
+
+# ------------------------------------------------------------------ second weight family (oracle/gen_golden.py heavy_*): log-normal channel gains + x10 - x30 outlier channels
+def test_heavy_family_hubert_and_synth_oracle_match_reference():
+    """synthetic.*_state_dict(seed=1, family="heavy") through the real reference: HuBERT taps (FFN hidden units and residual-stream channels an order of
+    magnitude above the rest) and the synthesizer's taps / waveform (ResBlock intermediates with x10 - x30 channels)."""
+    g = golden("hubert_1s_heavy.npz")
+    sd = S.hubert_state_dict(1, family="heavy")
+    taps = {}
+    v2 = nets.hubert_extract_features(sd, g["audio"], "v2", taps)
+    v1 = nets.hubert_extract_features(sd, g["audio"], "v1")
+    for k in ("pos_conv", "hidden_0", "hidden_8"):
+        assert rel_err(taps[k], g[k]) < 1e-5, k
+    assert rel_err(v2, g["out_v2"]) < 1e-5 and rel_err(v1, g["out_v1"]) < 1e-5
+    assert float(np.abs(g["hidden_8"]).max()) > 15.0                  # the family does what it says: massive channels in the residual stream
+    g = golden("synth_40k_v2_heavy.npz")
+    taps = {}
+    wav = nets.synth_infer(S.synth_state_dict(S.CONFIG_40K_V2, "v2", 1, family="heavy"), S.CONFIG_40K_V2, g["phone"], g["pitch"], g["pitchf"], int(g["sid"]),
+                           g["noise_z"], g["noise_src"], taps)
+    for k in ("m_p", "logs_p", "z_p", "z", "har_source", "enc_p_layer0"):
+        assert rel_err(taps[k], g[k]) < 2e-5, k
+    assert rel_err(wav, g["wav"]) < 1e-4
+    assert float(np.abs(g["wav"]).max()) < 0.9                        # not a saturated tanh (which would hide errors)
+
+
+def test_heavy_family_pipeline_oracle_matches_reference(noise_tape):
+    g = golden("pipeline_2s_rmvpe_heavy.npz")
+    out = opl.pipeline(S.hubert_state_dict(1, family="heavy"), S.rmvpe_state_dict(0), S.synth_state_dict(S.CONFIG_40K_V2, "v2", 1, family="heavy"),
+                       S.CONFIG_40K_V2, "v2", g["audio"], noise_fn=noise_tape(g["noise_seed"]))
+    assert out.shape == g["out_i16"].shape and np.max(np.abs(out.astype(np.int32) - g["out_i16"].astype(np.int32))) <= 33
+    _fullsize_oracle("pipeline_30s_40k_v2_heavy.npz", S.CONFIG_40K_V2, seed=1, family="heavy")
 
 
 def test_pipeline_45s_cut_search_oracle_matches_reference():
