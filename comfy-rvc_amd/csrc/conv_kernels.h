@@ -154,8 +154,10 @@ int conv_x3q_check_read();
 bool conv_x3g_try(ConvArgsX& a, hipStream_t s, dim3& grid_out, int& ksplit_out, bool dry);
 // fused ResBlock pair of the 32-channel stage on the pipelined kernel (conv_x3p.hip)
 bool conv_x3pf_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry);
+// the same pair in the fp16x2 arithmetic with both weight sets resident in LDS, persistent workgroups (conv_rbh.hip); Wx / Wx2 = the one-plane fp16 images
+bool conv_rbh_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry);
 // y = (x + c2(lrelu(c1(lrelu(x))))) * scale [+ y] for a ResBlock1 pair of narrow layers in ONE launch; false when not eligible
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
-                      const ConvEpilogue& e2);
+                      const ConvEpilogue& e2, bool dry_only = false);
 
 }  // namespace rvc

@@ -376,6 +376,7 @@ void conv_x3_timing_read(unsigned long long* out8, bool reset);
 void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
 void conv_x3q_timing_read(unsigned long long* out8, bool reset);
+void conv_rbh_timing_read(unsigned long long* out8, bool reset);
 void conv_x3s_timing_read(unsigned long long* out8, bool reset);
 void cbr2_timing_read(unsigned long long* out8, bool reset);
 void attention_dma_timing_read(unsigned long long* out8, bool reset);
@@ -394,6 +395,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   conv_x3p_timing_read(x3, reset);      // (pipelined kernel: [0] tiles, [1] prologue, [2] compute, [3] weight wait, [4] barrier, [5] epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3q_timing_read(x3, reset);      // (persistent kernel: the same slots; [1] once per workgroup, [6] per workgroup)
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  conv_rbh_timing_read(x3, reset);      // (persistent fused pair, LDS-resident weights: [0] tiles, [1] stage, [2] conv1, [3] h + requests, [4] conv2, [5] epilogue, [6] total per workgroup)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3s_timing_read(x3, reset);      // (split-resident GEMM: [0] workgroups, [1] prologue, [2] reads + MFMA issue, [3] DMA wait, [4] barrier, [5] split-K + epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
@@ -611,7 +614,8 @@ void conv1d_layer_init(ConvLayer& L, const float* w, const float* bias, int Co, 
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups == 1 && Ci % 16 == 0 && Co >= 32) {
     pack_x3(L, w, Co, Ci, k);
     // a candidate for the persistent ResBlock kernel: square, stride 1, 3 / 7 / 11 taps, "same" padding, whole 64-row tiles, an even number of chunks
-    if (stride == 1 && Ci == Co && (k == 3 || k == 7 || k == 11) && Co % 64 == 0 && Ci >= 64 && pad == dil * (k - 1) / 2) pack_h2(L, w, Co, Ci, k);
+    // ... or the 32-channel stage's fused pair with LDS-resident weights (conv_rbh.hip)
+    if (stride == 1 && Ci == Co && (k == 3 || k == 7 || k == 11) && ((Co % 64 == 0 && Ci >= 64) || Co == 32) && pad == dil * (k - 1) / 2) pack_h2(L, w, Co, Ci, k);
   }
   if ((g_precision == 2 || (g_precision == 1 && g_x3_default)) && groups > 1 && stride == 1 && Cig % 16 == 0 && Cog % 16 == 0 && dil >= 1)
     pack_x3_grouped(L, w, groups, Cog, Cig, k);            // only conv_x3s_run reads it (the tiled bf16x3 kernels refuse groups > 1)
@@ -826,8 +830,8 @@ int conv_prof_dump_csv(const char* path) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    // (fused >> 4 names the kernel of the bf16x3 family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 6 persistent pipelined conv)
-    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_x3u_kernel", "conv_x3q_kernel", "conv_x3_kernel"};
+    // (fused >> 4 names the kernel of the split-MFMA family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 5 persistent fused pair with LDS-resident fp16 weights, 6 persistent pipelined conv)
+    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_rbh_kernel", "conv_x3q_kernel", "conv_x3_kernel"};
     // (last column: matrix instructions per algorithmic product - 3 bf16x3, 2 fp16x2 (conv_x3q_kernel, H2), 16 fp32 MFMA at the bf16 rate's scale: 1 fp32 MFMA)
     fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f,%d\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
             r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,

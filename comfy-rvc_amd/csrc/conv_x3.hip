@@ -686,8 +686,9 @@ bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry
 // ---------------------------------------------------------------------------- fused ResBlock pair (narrow generator stages)
 // The C = 32 stage of the generator is HBM-bound on the unfused kernels (each conv reads + writes [C][T] and the second one reads the
 // residual too: 5 tensor passes per pair); fused, a pair reads x (+ halo) twice (tile + residual, the second from L2) and writes y.
+// dry_only: answers whether the pair would run in the fp16x2 arithmetic on the LDS-resident-weights kernel (nothing is launched)
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
-                      const ConvEpilogue& e2) {
+                      const ConvEpilogue& e2, bool dry_only) {
   static const bool on = (exp_int("RVC_PAIR", 1) != 0);
   static const bool pair64 = (exp_int("RVC_PAIR64", 0) != 0);      // experiment: 64-channel stage (2 WGs per CU)
   if (!on || !conv_x3_enabled() || !c1.Wx_ || !c2.Wx_) return false;
@@ -713,6 +714,21 @@ bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, c
   a.Wx = reinterpret_cast<const unsigned char*>(c1.Wx_); a.Wx2 = reinterpret_cast<const unsigned char*>(c2.Wx_); a.CoPx = c1.CoPx;
   a.fuse_p2 = P2;
   if (c1.CoPx != c2.CoPx) return false;
+  if (C == 32 && c1.Wh_ && c2.Wh_ && conv_set_pair_arithmetic(-1)) {
+    // fp16x2 pair arithmetic: persistent workgroups with both weight sets resident in LDS (conv_rbh.hip)
+    ConvArgsX h = a;
+    h.Wx = reinterpret_cast<const unsigned char*>(c1.Wh_); h.Wx2 = reinterpret_cast<const unsigned char*>(c2.Wh_); h.h2 = 1;
+    dim3 gh;
+    if (conv_rbh_try(h, T, s, gh, true)) {
+      if (dry_only) return true;
+      ProfTicket tk = conv_prof_begin(s);
+      RVC_REQUIRE(conv_rbh_try(h, T, s, gh, false), "conv_rbh_try accepted the pair in its dry run and declined the launch");
+      const double bytes = 4.0 * ((double)C * T * (2.0 + (e2.accumulate ? 1.0 : 0.0)) + 2.0 * C * C * k);
+      conv_prof_end(tk, s, 2.0 * 2.0 * (double)C * C * k * T, 14 + 1, bytes, &h, (long long)gh.x, 1 | (5 << 4));
+      return true;
+    }
+  }
+  if (dry_only) return false;
   {
     // the software-pipelined fused pair (conv_x3p.hip): 32 and 64 channels
     static const int xcd_env = exp_int("RVC_X3_XCD", 1);

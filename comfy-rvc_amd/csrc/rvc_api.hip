@@ -731,7 +731,11 @@ int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, voi
 }
 int rvc_conv1d_plan_pair_arithmetic(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, int T) {
   if (!c1 || !c2) return -1;
-  try { return conv1d_pair_h2_eligible(c1->L, c2->L, T) ? 1 : 0; } catch (...) { return -1; }
+  try {
+    if (conv1d_pair_h2_eligible(c1->L, c2->L, T)) return 1;
+    ConvEpilogue e; e.pre_act = ACT_LRELU; e.pre_slope = 0.1f; const float* dummy = reinterpret_cast<const float*>(c1->L.Wd_); e.R = dummy; e.ldR = T;
+    return conv_x3_pair_try(c1->L, c2->L, nullptr, dummy, T, T, nullptr, T, e, true) ? 1 : 0;      // (the fused pair of the 32-channel stage: dry run)
+  } catch (...) { return -1; }
 }
 int rvc_conv1d_plan_destroy(rvc_conv1d_plan* p) { if (p) { conv_layer_free(p->L); delete p; } return 0; }
 int rvc_op_attention(void* stream, const float* q, const float* k, const float* v_rm, const float* bv, float* out, int heads, int T) {

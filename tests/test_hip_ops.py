@@ -867,21 +867,29 @@ def test_persistent_resblock_pair(L, pair_arith, arith, tmp_path, Cc, k, d, T, s
 @pytest.mark.parametrize("Cc,k,d,T,scale,accum", [(32, 11, 5, 140003, 1.0 / 3, True), (32, 7, 3, 131072, 1.0, False), (32, 3, 1, 200001, 1.0, False),
                                                   (32, 3, 5, 136100, 1.0 / 3, True), (32, 11, 1, 150000, 1.0, False),
                                                   (32, 11, 5, 140004, 1.0 / 3, True), (32, 11, 3, 131076, 1.0, False), (32, 7, 5, 128000, 1.0 / 3, True), (32, 7, 1, 130052, 1.0, False), (32, 3, 3, 160000, 1.0, False),
-                                                  (64, 3, 5, 70001, 1.0 / 3, True), (64, 3, 3, 66000, 1.0, False), (64, 3, 1, 80003, 1.0, False)])   # (64 channels: k = 3 only by default)
-def test_fused_resblock_pair(L, Cc, k, d, T, scale, accum):
-    """One ResBlock1 pair of the generator's 32-channel stage in a single launch (conv_x3_kernel FUSE: the intermediate stays in LDS,
-    zero outside the sequence like the second conv's padding) against fp64 torch: y = (x + c2(lrelu(c1_d(lrelu(x))))) * s [+ y].
-    32 channels: 256-column tiles; 64 channels: 128-column tiles (conv_x3pf_kernel); lengths with and without a multiple of 4."""
+                                                  (64, 3, 5, 70001, 1.0 / 3, True), (64, 3, 3, 66000, 1.0, False), (64, 3, 1, 80003, 1.0, False),   # (64 channels: k = 3 only by default)
+                                                  # lengths of two and more rounds of 512-column tiles: the persistent fp16x2 kernel with LDS-resident weights (conv_rbh.hip) in arithmetic 1
+                                                  (32, 11, 5, 600003, 1.0 / 3, True), (32, 11, 1, 530001, 1.0, False), (32, 7, 3, 777777, 1.0, False), (32, 7, 5, 262200, 1.0 / 3, True),
+                                                  (32, 3, 1, 700000, 1.0, False), (32, 3, 5, 513 * 510 + 7, 1.0 / 3, True)])
+@pytest.mark.parametrize("arith", [0, 1])
+def test_fused_resblock_pair(L, pair_arith, arith, tmp_path, Cc, k, d, T, scale, accum):
+    """One ResBlock1 pair of the generator's narrow stages in a single launch, the intermediate in LDS (zero outside the sequence like the second conv's
+    padding), against fp64 torch: y = (x + c2(lrelu(c1_d(lrelu(x))))) * s [+ y].  bf16x3: conv_x3pf_kernel (32 channels: 256-column tiles; 64 channels:
+    128-column tiles).  fp16x2 (arithmetic 1) at 32 channels and two or more rounds of tiles: conv_rbh_kernel - persistent workgroups, both weight sets
+    resident in LDS, 512-column tiles - held to 2e-5 against fp64 with the fp16-rounded weights and 6e-4 against the exact ones; shorter sequences and 64
+    channels keep conv_x3pf_kernel in either arithmetic.  Lengths with and without a multiple of 4."""
+    pair_arith(arith)
     g = torch.Generator().manual_seed(1000 + 37 * k + d)
     x = torch.randn(Cc, T, generator=g)
     w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b1 = torch.randn(Cc, generator=g) * 0.1
     w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.randn(Cc, generator=g) * 0.1
     xd = x.double()
-    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
-    ref = (F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
     y0 = torch.randn(Cc, T, generator=g)
-    if accum:
-        ref = ref + y0
+
+    def pair_ref(wa, wb):
+        h = F.conv1d(F.leaky_relu(xd, 0.1)[None], wa.double(), b1.double(), padding=(k - 1) // 2 * d, dilation=d)
+        r = (F.conv1d(F.leaky_relu(h, 0.1), wb.double(), b2.double(), padding=(k - 1) // 2)[0] + xd) * scale
+        return r + y0 if accum else r
     y, xg = dev(y0), dev(x)
     L.check(L.lib.rvc_set_conv_precision(2))
     plans = []
@@ -892,15 +900,33 @@ def test_fused_resblock_pair(L, Cc, k, d, T, scale, accum):
             plans.append(pl)
     finally:
         L.check(L.lib.rvc_set_conv_precision(1))
-    L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
-    torch.cuda.synchronize()
+    h2 = L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == 1
+    assert h2 == (arith == 1 and Cc == 32 and T >= 2 * 256 * (512 - (k - 1))), (arith, Cc, T, h2)       # (256 CUs: two rounds of tiles)
+    ref = pair_ref(w1.half().float(), w2.half().float()) if h2 else pair_ref(w1, w2)
+    csv_path = str(tmp_path / "launches.csv")
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), scale, int(accum)))
+        torch.cuda.synchronize()
+        L.check(L.lib.rvc_prof_dump_csv(csv_path.encode()))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+    kernels = [ln.split(",")[1] for ln in open(csv_path).read().strip().split("\n")[1:]]
+    assert kernels == (["conv_rbh_kernel"] if h2 else ["conv_x3pf_kernel"]), kernels
     err = (y.cpu().double() - ref).abs()
     assert rel_err(y.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
-    # sequence ends and tile seams (tiles of 256 - (k - 1) columns) carry the same error as the interior
-    NO = (256 if Cc == 32 else 128) - (k - 1)
+    # sequence ends and tile seams (tiles of 256 / 512 - (k - 1) columns) carry the same error as the interior
+    NO = (512 if h2 else (256 if Cc == 32 else 128)) - (k - 1)
     TN = 256 - 4 * ((k - 1 + 3) // 4)
-    for c0 in (0, NO - 2, 7 * NO - 3, TN - 20, 9 * TN - 20, T - 40):
-        assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    for c0 in (0, NO - 2, 7 * NO - 3, 257 * NO - 20, TN - 20, 9 * TN - 20, T - 40):
+        if 0 <= c0 < T - 40 or c0 == T - 40:
+            assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    if h2:
+        assert rel_err(y.cpu().double(), pair_ref(w1, w2)) < 6e-4
+        y2 = dev(y0)                                              # a second run is bit-identical (fixed summation order, no races between the phases)
+        L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y2), scale, int(accum)))
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y)
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
 

@@ -1,0 +1,26 @@
+"""Per-phase cycle counters of conv_rbh_kernel (32-channel fused pair, fp16x2, LDS-resident weights); needs a -DRVC_CONV_TIMING -DRVC_EXPERIMENTS build."""
+import sys, ctypes as C, os
+sys.path.insert(0, '.')
+import numpy as np, torch
+from comfy_rvc_amd import _lib as L
+L.get_ctx(0)
+L.check(L.lib.rvc_set_conv_precision(2)); L.check(L.lib.rvc_set_pair_arithmetic(1))
+Cc, T = 32, 1279200
+for k, d in ((3, 1), (7, 3), (11, 5)):
+    plans = []
+    for dd in (d, 1):
+        w = (np.random.randn(Cc, Cc, k) / np.sqrt(Cc * k)).astype(np.float32); b = np.zeros(Cc, np.float32)
+        pl = C.c_void_p(); L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w), L.ptr(b), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl))); plans.append(pl)
+    x = torch.randn(Cc, T, device="cuda"); y = torch.empty_like(x)
+    fn = lambda: L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(y), 1.0, 0))
+    fn(); torch.cuda.synchronize()
+    tm = (C.c_uint64 * 8)(); L.lib.rvc_debug_conv_timing(tm, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 5 * 1e3
+    L.lib.rvc_debug_conv_timing(tm, 1)
+    nt = max(tm[0], 1)
+    print(f"C32 k{k} d{d}: pair {us:7.1f} us | per tile cycles (wave 0): stage {tm[1]/nt:6.0f} conv1 {tm[2]/nt:6.0f} h+req {tm[3]/nt:6.0f} conv2 {tm[4]/nt:6.0f} epilogue {tm[5]/nt:6.0f} | total per workgroup {tm[6]/(5*256):8.0f} tiles/launch {nt/5:.0f}", flush=True)
+    for pl in plans: L.lib.rvc_conv1d_plan_destroy(pl)
