@@ -13,6 +13,13 @@
 //     accumulators; the next tile's input rows and, when accumulating (ACC), the previous output are requested into registers before the second
 //     convolution and consumed after it: HBM latency sits behind 88 (KT = 11) MFMAs per wave;
 //   * per (chunk, tap): one weight operand read serves 2 column blocks x 2 terms; activations as fp16 hi / lo rows (split2h), two MFMAs per product.
+// Where its time goes (per-phase cycle counters, -DRVC_CONV_TIMING, profiles/r6c_rbh_phase_cycles.txt): the two convolutions take 3.6 k cycles each of a
+// 24 k-cycle tile at 11 taps; staging, the intermediate and the epilogue stretch as the convolutions get shorter - a CU moves ~100 KB per 250 outputs
+// (input tile with halo, the residual again, the output) at 8 - 9.4 B / cycle, the vector-memory path's limit: a 3-tap pair takes ~100 us whichever kernel
+// runs it.  Three restructurings were built and measured in round 6 and NOT kept (same file's history, same evidence file): 16-byte global accesses with
+// a per-wave LDS transposition (26 instead of 104 VMEM instructions per wave and tile: slower, 1269 us for the nine pairs against 1089); two halves of four
+// waves one phase apart, so that a matrix phase always runs beside a memory phase (1117 - 1143 us); the residual recovered from the staged fp16 tile instead
+// of read again (1083 us).  What would move it is fewer bytes per output: a whole ResBlock (three pairs) per launch.
 // LDS: 2 KT x 2 KiB weights + 256 B biases + 2 chunks x (hi | lo) x 2 halves x P rows x 16 B, P = 512 + (KT - 1) dil <= 562: 118 KiB at KT = 11.
 // Numerics: the formula, the fp16 weight rounding and the hi / lo split are those of the persistent pair kernel's H2 mode; fp32 accumulation, bias and
 // residual in fp32.  The bf16x3 arithmetic (rvc_set_pair_arithmetic(0), or a layer without an fp16 image) keeps conv_x3pf_kernel.
