@@ -286,3 +286,21 @@ def test_oracle_ivf_probe_semantics():
     cen2 = np.concatenate([cen, np.full((1, 24), 40.0, np.float32)])
     s, i = index_search_ivf(np.full((2, 24), 40.0, np.float32), big, cen2, lo, 1)
     assert list(i[:, 0]) == [-1, -1] and np.all(s == np.finfo(np.float32).max)
+
+
+def test_rvc_node_result_cache_is_bounded_by_bytes():
+    """RVCNode caches conversions by content hash (upstream caches preview files by name, reference custom_nodes/rvc_nodes.py:176-183); here the cache is an LRU
+    bounded by BYTES, so a long-lived ComfyUI server cannot grow by 2.4 MB per distinct 30 s conversion for ever."""
+    from comfy_rvc_amd.custom_nodes.rvc_nodes import RVCNode, _ByteLRU
+    c = _ByteLRU(10_000)
+    wav = lambda n: (np.zeros(n, dtype=np.int16), 40000)
+    c.put("a", wav(2000)); c.put("b", wav(2000))                      # 4000 B each
+    assert "a" in c and "b" in c and c.bytes == 8000
+    c.get("a")                                                         # "a" is now the most recently used
+    c.put("c", wav(2000))                                              # 12000 B > bound: the least recently used ("b") goes
+    assert "a" in c and "c" in c and "b" not in c and c.bytes == 8000 and len(c) == 2
+    c.put("a", wav(1000))                                              # replacing an entry accounts for its old size
+    assert c.bytes == 6000
+    c.put("huge", wav(6000))                                           # one entry larger than the bound is not kept, nothing else is evicted for it
+    assert "huge" not in c and c.bytes == 6000
+    assert isinstance(RVCNode._cache, _ByteLRU) and RVCNode._cache.max_bytes == RVCNode.CACHE_BYTES >= 64 << 20
