@@ -177,6 +177,13 @@ if has_experiments:
         _fn.argtypes = _args
 
 
+def require_experiments():
+    """Tools that read the instrumentation hooks call this first: they need a -DRVC_EXPERIMENTS build (tools/build_variant.sh NAME ..., RVC_HIP_LIB=<path>)."""
+    if not has_experiments:
+        raise RuntimeError(f"{LIB_PATH} is the product library: the rvc_debug_* hooks exist in -DRVC_EXPERIMENTS builds only - "
+                           "bash tools/build_variant.sh exp && RVC_HIP_LIB=comfy-rvc_amd/csrc/variants/librvc_hip_exp.so python <tool>")
+
+
 def check(status):
     if status != 0:
         raise RvcHipError(lib.rvc_last_error().decode("utf-8", "replace"))

@@ -761,6 +761,38 @@ def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, 
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
+@pytest.mark.parametrize("wscale", [1e-5, 1e5])
+def test_fp16x2_is_not_offered_to_layers_outside_fp16s_range(L, pair_arith, wscale):
+    """A layer whose weights are all below 2^-10 (fp16 would keep only a few bits of them) or reach beyond 60000 (fp16 overflows at 65504) gets no fp16 image:
+    the pair keeps bf16x3 whatever rvc_set_pair_arithmetic says, and its accuracy."""
+    pair_arith(1)
+    Cc, k, d, T = 128, 7, 1, 70001
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(Cc, T, generator=g) * (1.0 if wscale < 1 else 1e-5)
+    w1 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k) * wscale; b1 = torch.zeros(Cc)
+    w2 = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b2 = torch.zeros(Cc)
+    xd = x.double()
+    h = F.conv1d(F.leaky_relu(xd, 0.1)[None], w1.double(), None, padding=(k - 1) // 2 * d, dilation=d)
+    branch = F.conv1d(F.leaky_relu(h, 0.1), w2.double(), None, padding=(k - 1) // 2)[0]
+    y, xg = torch.empty(Cc, T, device="cuda"), dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for w, b, dd in ((w1, b1, d), (w2, b2, 1)):
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    assert L.lib.rvc_conv1d_plan_pair_arithmetic(plans[0], plans[1], T) == 0
+    L.check(L.lib.rvc_conv1d_plan_pair_split_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(y), 1.0, 0))
+    torch.cuda.synchronize()
+    err = float(((y.cpu().double() - xd) - branch).abs().max() / branch.abs().max())
+    assert err < 2e-5, err
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
 @pytest.mark.parametrize("xscale,tol", [(0.03, 2e-5), (1e-3, 1.5e-4), (3e-5, 3e-3), (300.0, 2e-5)])
 def test_fp16x2_pair_keeps_its_accuracy_at_small_and_large_activations(L, pair_arith, xscale, tol):
     """fp16x2's activation split x = hi + lo leaves lo below fp16's normal range (6.1e-5) for every |x| < 0.125: the mode relies on the matrix cores

@@ -3,6 +3,7 @@ import sys
 sys.path.insert(0, '.')
 import torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 for heads, T in ((12, 1599), (12, 3199)):
     q = torch.randn(heads * 64, T, device="cuda") * 0.3; k = torch.randn(heads * 64, T, device="cuda"); v = torch.randn(T, heads * 64, device="cuda")

@@ -3,6 +3,7 @@ import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 import os
 T = int(os.environ.get('BENCH_T', 3198))

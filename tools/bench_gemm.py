@@ -5,6 +5,7 @@ import ctypes as C
 import sys
 sys.path.insert(0, '.')
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 # name, Ci, Co, T, w2d (> 0: 3 x 3 over a padded image of that width, T = H (w2d + 2))
 SHAPES = [("hubert ffn1 768->3072", 768, 3072, 1599, 0), ("hubert ffn2 3072->768", 3072, 768, 1599, 0), ("hubert qkv 768->2304", 768, 2304, 1599, 0),

@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 L.check(L.lib.rvc_set_conv_precision(2))
 sel = sys.argv[1:] or ["x3s", "staged", "lin"]

@@ -4,6 +4,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 heads, T, D = 2, 3198, 96
 g = torch.Generator().manual_seed(1)

@@ -5,6 +5,7 @@ import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 for Cc, H, W in ((16, 3232, 128), (32, 1616, 64)):
     g = torch.Generator().manual_seed(1)

@@ -3,6 +3,7 @@ import sys, ctypes as C, os
 sys.path.insert(0, '.')
 import numpy as np, torch
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 L.check(L.lib.rvc_set_conv_precision(2)); L.check(L.lib.rvc_set_pair_arithmetic(1))
 Cc, T = 32, 1279200

@@ -5,6 +5,7 @@ import os
 import sys
 sys.path.insert(0, '.')
 from comfy_rvc_amd import _lib as L
+L.require_experiments()      # (reads rvc_debug_* hooks: variant builds only)
 L.get_ctx(0)
 SHAPES = [("hubert ffn1 768->3072", 768, 3072, 1599, 0), ("hubert ffn2 3072->768", 3072, 768, 1599, 0), ("hubert qkv 768->2304", 768, 2304, 1599, 0),
           ("hubert out 768->768", 768, 768, 1599, 0), ("flow 192->192", 192, 192, 3198, 0),
