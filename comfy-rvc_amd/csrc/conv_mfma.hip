@@ -377,6 +377,7 @@ void attention_timing_read(unsigned long long* out8, bool reset);
 void conv_x3p_timing_read(unsigned long long* out8, bool reset);
 void conv_x3q_timing_read(unsigned long long* out8, bool reset);
 void conv_rbh_timing_read(unsigned long long* out8, bool reset);
+void conv_rb3_timing_read(unsigned long long* out8, bool reset);
 void conv_x3s_timing_read(unsigned long long* out8, bool reset);
 void cbr2_timing_read(unsigned long long* out8, bool reset);
 void attention_dma_timing_read(unsigned long long* out8, bool reset);
@@ -397,6 +398,8 @@ void conv_timing_read(unsigned long long* out8, bool reset) {
   conv_x3q_timing_read(x3, reset);      // (persistent kernel: the same slots; [1] once per workgroup, [6] per workgroup)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_rbh_timing_read(x3, reset);      // (persistent fused pair, LDS-resident weights: [0] tiles, [1] stage, [2] conv1, [3] h + requests, [4] conv2, [5] epilogue, [6] total per workgroup)
+  for (int i = 0; i < 8; ++i) out8[i] += x3[i];
+  conv_rb3_timing_read(x3, reset);      // (whole ResBlock per launch: [0] tiles, [1] x image + requests, [2] first convolutions, [3] images, [4] second convolutions, [5] epilogue, [6] total per workgroup, [7] barrier waits)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
   conv_x3s_timing_read(x3, reset);      // (split-resident GEMM: [0] workgroups, [1] prologue, [2] reads + MFMA issue, [3] DMA wait, [4] barrier, [5] split-K + epilogue, [6] total)
   for (int i = 0; i < 8; ++i) out8[i] += x3[i];
@@ -830,8 +833,8 @@ int conv_prof_dump_csv(const char* path) {
     (void)hipEventSynchronize(r.b);
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    // (fused >> 4 names the kernel of the split-MFMA family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 5 persistent fused pair with LDS-resident fp16 weights, 6 persistent pipelined conv)
-    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_rbh_kernel", "conv_x3q_kernel", "conv_x3_kernel"};
+    // (fused >> 4 names the kernel of the split-MFMA family: 0 staged, 1 pipelined conv, 2 pipelined GEMM, 3 pipelined fused pair, 4 split-resident GEMM, 5 persistent fused pair with LDS-resident fp16 weights, 6 persistent pipelined conv, 7 whole ResBlock (three pairs) per launch)
+    static const char* kX3Fam[8] = {"conv_x3_kernel", "conv_x3p_kernel", "conv_x3g_kernel", "conv_x3pf_kernel", "conv_x3s_kernel", "conv_rbh_kernel", "conv_x3q_kernel", "conv_rb3_kernel"};
     // (last column: matrix instructions per algorithmic product - 3 bf16x3, 2 fp16x2 (conv_x3q_kernel, H2), 16 fp32 MFMA at the bf16 rate's scale: 1 fp32 MFMA)
     fprintf(f, "%d,%s,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%.2f,%.4f,%.3f,%.2f,%.1f,%d\n", i++, r.cfg >= 14 ? kX3Fam[(r.fused >> 4) & 7] : "conv_mfma_kernel", kCfgNames[r.cfg],
             r.Ci, r.Co, r.k, r.dil, r.stride, r.Tout, r.Wd, r.fused & 15, r.ksplit, r.blocks, t * 1e3, r.flops / 1e9, r.bytes / 1e6,

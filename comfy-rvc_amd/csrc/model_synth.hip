@@ -479,6 +479,12 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       if (taps && i == 0) tap(taps->gen_ups0, up, (size_t)Cc * Tn);
       for (int j = 0; j < 3; ++j) {
         const float* in = up;
+        {
+          // 32-channel stage in the fp16x2 arithmetic: the whole ResBlock (three pairs) in one launch, x read once, the sum written once (conv_rb3.hip)
+          const ConvLayer* r1[3] = {&st.rb[j].c1[0], &st.rb[j].c1[1], &st.rb[j].c1[2]};
+          const ConvLayer* r2[3] = {&st.rb[j].c2[0], &st.rb[j].c2[1], &st.rb[j].c2[2]};
+          if (conv_rb3_try(r1, r2, s, up, Tn, Tn, xs, Tn, 0.1f, 1.f / 3.f, j > 0)) continue;
+        }
         for (int m = 0; m < 3; ++m) {
           ConvEpilogue E2; E2.pre_act = ACT_LRELU; E2.pre_slope = 0.1f; E2.R = in; E2.ldR = Tn;
           float* dst = (m == 0) ? ya : (m == 1 ? yb : xs);

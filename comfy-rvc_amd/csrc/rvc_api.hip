@@ -706,6 +706,19 @@ int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* str
   check_launch();
   RVC_CATCH
 }
+int rvc_conv1d_plan_resblock_run(rvc_conv1d_plan* const* plans6, void* stream, const float* x, int T, float* y, float out_scale, int accumulate,
+                                 int* ran_out) {
+  RVC_TRY
+  RVC_REQUIRE(plans6 && x && y && ran_out, "null argument");
+  const ConvLayer* c1[3]; const ConvLayer* c2[3];
+  for (int i = 0; i < 3; ++i) {
+    RVC_REQUIRE(plans6[2 * i] && plans6[2 * i + 1], "null plan");
+    c1[i] = &plans6[2 * i]->L; c2[i] = &plans6[2 * i + 1]->L;
+  }
+  *ran_out = conv_rb3_try(c1, c2, (hipStream_t)stream, x, T, T, y, T, 0.1f, out_scale, accumulate) ? 1 : 0;
+  check_launch();
+  RVC_CATCH
+}
 int rvc_conv1d_plan_pair_split_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* stream, const float* x, int T, float* y, float out_scale,
                                    int accumulate) {
   RVC_TRY

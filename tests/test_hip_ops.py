@@ -761,6 +761,99 @@ def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, 
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
+@pytest.mark.parametrize("k,T,scale,accum", [(3, 260003, 1.0 / 3, True), (3, 2 * 256 * 488, 1.0, False), (7, 300001, 1.0 / 3, True), (7, 230000, 1.0 / 3, False),
+                                             (11, 262144, 1.0 / 3, True), (11, 2 * 256 * 392 + 1, 1.0, False), (11, 1279200, 1.0 / 3, True)])
+def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, k, T, scale, accum):
+    """A whole ResBlock1 of the 32-channel stage (dilations 1, 3, 5; reference lib/infer_pack/modules.py:295-308) in ONE launch of conv_rb3_kernel: bit-identical
+    to the chain of three fused-pair launches (conv_rbh_kernel) it replaces - same unit order, same accumulator initial values - on every element, at lengths
+    with ragged last tiles, and within 2e-5 of fp64 torch on the fp16-rounded weights.  The stage's real length (1 279 200) is one of the cases."""
+    pair_arith(1)
+    Cc, dils = 32, (1, 3, 5)
+    g = torch.Generator().manual_seed(4000 + k)
+    x = torch.randn(Cc, T, generator=g)
+    ws, bs = [], []
+    for i in range(6):
+        ws.append(torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k)); bs.append(torch.randn(Cc, generator=g) * 0.1)
+    y0 = torch.randn(Cc, T, generator=g)
+    xg = dev(x)
+    L.check(L.lib.rvc_set_conv_precision(2))
+    plans = []
+    try:
+        for i in range(6):
+            dd = dils[i // 2] if i % 2 == 0 else 1
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(ws[i].contiguous().numpy()), L.ptr(bs[i].numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    # the chain of pairs, the way the generator ran it before: x -> a -> b -> y (the last pair scales and accumulates)
+    ya, yb, yc = torch.empty_like(xg), torch.empty_like(xg), dev(y0)
+    L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(xg), T, L.ptr(ya), 1.0, 0))
+    L.check(L.lib.rvc_conv1d_plan_pair_run(plans[2], plans[3], None, L.ptr(ya), T, L.ptr(yb), 1.0, 0))
+    L.check(L.lib.rvc_conv1d_plan_pair_run(plans[4], plans[5], None, L.ptr(yb), T, L.ptr(yc), scale, int(accum)))
+    yf = dev(y0)
+    arr = (C.c_void_p * 6)(*[pl.value for pl in plans])
+    ran = C.c_int(-1)
+    csv_path = str(tmp_path / "launches.csv")
+    try:
+        L.check(L.lib.rvc_prof_enable(1))
+        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf), scale, int(accum), C.byref(ran)))
+        torch.cuda.synchronize()
+        L.check(L.lib.rvc_prof_dump_csv(csv_path.encode()))
+    finally:
+        L.check(L.lib.rvc_prof_enable(0))
+    assert ran.value == 1
+    kernels = [ln.split(",")[1] for ln in open(csv_path).read().strip().split("\n")[1:]]
+    assert kernels == ["conv_rb3_kernel"], kernels
+    assert torch.equal(yf, yc), (int((yf != yc).sum()), float((yf - yc).abs().max()))
+    # a second run gives the same bits (the tile walk has no run-to-run freedom)
+    yf2 = dev(y0)
+    L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf2), scale, int(accum), C.byref(ran)))
+    torch.cuda.synchronize()
+    assert torch.equal(yf, yf2)
+    if T <= 400000:                                                                   # fp64 torch on the fp16-rounded weights (the arithmetic's definition)
+        h = x.double()
+        for i in range(3):
+            w1, w2 = ws[2 * i].half().double(), ws[2 * i + 1].half().double()
+            t = F.conv1d(F.leaky_relu(h, 0.1)[None], w1, bs[2 * i].double(), padding=(k - 1) // 2 * dils[i], dilation=dils[i])
+            h = h + F.conv1d(F.leaky_relu(t, 0.1), w2, bs[2 * i + 1].double(), padding=(k - 1) // 2)[0]
+        ref = h * scale + (y0.double() if accum else 0.0)
+        err = (yf.cpu().double() - ref).abs()
+        assert rel_err(yf.cpu().double(), ref) < 2e-5, (float(err.max()), int(err.argmax()) % T)
+        NO = 512 - 24 * ((k - 1) // 2)
+        for c0 in (0, NO - 20, 7 * NO - 20, 256 * NO - 20, T - 40):                     # sequence ends and tile seams carry the same error as the interior
+            assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
+def test_fused_resblock_declines_what_it_cannot_run(L, pair_arith):
+    """Short sequences (fewer than two rounds of tiles), the bf16x3 pair arithmetic and unequal kernel sizes are left to the pair kernels: ran = 0, y untouched."""
+    Cc, k, T = 32, 7, 50000
+    g = torch.Generator().manual_seed(9)
+    plans = []
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        for i in range(6):
+            dd = (1, 3, 5)[i // 2] if i % 2 == 0 else 1
+            w = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k)
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), None, Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    arr = (C.c_void_p * 6)(*[pl.value for pl in plans])
+    ran = C.c_int(-1)
+    for arith, TT in ((1, T), (0, 300000)):
+        pair_arith(arith)
+        x, y = dev(torch.randn(Cc, TT, generator=g)), torch.full((Cc, TT), 7.0).cuda()
+        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), TT, L.ptr(y), 1.0, 0, C.byref(ran)))
+        torch.cuda.synchronize()
+        assert ran.value == 0 and bool((y == 7.0).all())
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
 @pytest.mark.parametrize("case", ["tiny", "huge"])
 def test_fp16x2_is_not_offered_to_layers_outside_fp16s_range(L, pair_arith, case):
     """A layer whose weights are all below 2^-10 (fp16 would keep only a few bits of them) or reach beyond 60000 (fp16 overflows at 65504) gets no fp16 image:

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../comfy-rvc_amd/csrc"
 name=$1; shift
 mkdir -p variants/obj_$name
-for f in conv_mfma conv_x3 conv_x3p conv_x3q conv_rbh conv_x3s split2d conv_cbr2 attention attention_dma attention_dma_rel ops model_synth model_hubert model_rmvpe model_crepe model_mdx23 index rvc_api; do
+for f in conv_mfma conv_x3 conv_x3p conv_x3q conv_rbh conv_rb3 conv_x3s split2d conv_cbr2 attention attention_dma attention_dma_rel ops model_synth model_hubert model_rmvpe model_crepe model_mdx23 index rvc_api; do
   extra=""; [ $f = attention_dma ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -DRVC_EXPERIMENTS $extra "$@" -c $f.hip -o variants/obj_$name/$f.o &
 done
