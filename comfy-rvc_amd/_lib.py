@@ -130,7 +130,7 @@ SIGNATURES = {
     "rvc_conv1d_plan_create": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [P(c_void_p)]),
     "rvc_conv1d_plan_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_float]),
     "rvc_conv1d_plan_pair_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int]),
-    "rvc_conv1d_plan_resblock_run": (c_int, [P(c_void_p), c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, P(c_int)]),
+    "rvc_conv1d_plan_resblock_run": (c_int, [P(c_void_p), c_void_p, c_void_p, c_int, c_void_p, c_float, c_int, P(c_int), c_void_p, c_void_p, c_void_p]),
     "rvc_conv1d_plan_pair_split_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int]),
     "rvc_conv1d_plan_destroy": (c_int, [c_void_p]),
     "rvc_op_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),

@@ -159,7 +159,8 @@ bool conv_rbh_try(ConvArgsX& a, int T, hipStream_t s, dim3& grid_out, bool dry);
 // a whole ResBlock1 (three (dilated, plain) pairs) of the 32-channel stage in one launch, fp16x2 arithmetic, bit-identical to the chain of three conv_rbh
 // launches (conv_rb3.hip); y = x3 * out_scale [+ y]; false: not eligible (the caller runs the pairs one by one)
 bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
-                  float pre_slope, float out_scale, int accumulate, bool dry = false);
+                  float pre_slope, float out_scale, int accumulate, bool dry = false, const float* nsrc = nullptr, const float* nw = nullptr,
+                  const float* nb = nullptr);      // nsrc [T], nw [32], nb [32]: x[c][t] + fmaf(nw[c], nsrc[t], nb[c]) is what the ResBlock reads (the last stage's noise branch)
 // y = (x + c2(lrelu(c1(lrelu(x))))) * scale [+ y] for a ResBlock1 pair of narrow layers in ONE launch; false when not eligible
 bool conv_x3_pair_try(const ConvLayer& c1, const ConvLayer& c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
                       const ConvEpilogue& e2, bool dry_only = false);

@@ -466,7 +466,17 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       conv1d_run(st.up, s, cur, Tc, Tc, up, Tn, Eu);
       ConvEpilogue En; En.accumulate = 1;
       static const bool noise_stream = (exp_int("RVC_NOISE_STREAM", 1) != 0);
-      if (!S->f0) {
+      // last stage (one tap of the source per position) with all three ResBlocks on conv_rb3_kernel: the noise term is added where x is read
+      bool noise_in_rb3 = S->f0 && noise_stream && st.noise_k == 1 && st.noise_w.p != nullptr && N == (long long)Tn;
+      for (int j = 0; j < 3 && noise_in_rb3; ++j) {
+        const ConvLayer* r1[3] = {&st.rb[j].c1[0], &st.rb[j].c1[1], &st.rb[j].c1[2]};
+        const ConvLayer* r2[3] = {&st.rb[j].c2[0], &st.rb[j].c2[1], &st.rb[j].c2[2]};
+        noise_in_rb3 = conv_rb3_try(r1, r2, s, up, Tn, Tn, xs, Tn, 0.1f, 1.f / 3.f, j > 0, true);
+      }
+      if (taps && i == 0) noise_in_rb3 = false;                  // (the gen_ups0 tap wants the summed tensor)
+      if (noise_in_rb3) {
+        // nothing here
+      } else if (!S->f0) {
         // plain Generator: nothing is added to the up-sampled signal
       } else if (noise_stream && st.noise_w.p && noise_add(s, up, Tn, Cc, Tn, har, N, st.noise_k, st.noise_s, st.noise_k > 1 ? st.noise_s / 2 : 0, st.noise_w.p, st.noise_b.p)) {
         // narrow stages (k <= 8 taps of the one source channel): a streaming add instead of im2col + GEMM
@@ -483,7 +493,9 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
           // 32-channel stage in the fp16x2 arithmetic: the whole ResBlock (three pairs) in one launch, x read once, the sum written once (conv_rb3.hip)
           const ConvLayer* r1[3] = {&st.rb[j].c1[0], &st.rb[j].c1[1], &st.rb[j].c1[2]};
           const ConvLayer* r2[3] = {&st.rb[j].c2[0], &st.rb[j].c2[1], &st.rb[j].c2[2]};
-          if (conv_rb3_try(r1, r2, s, up, Tn, Tn, xs, Tn, 0.1f, 1.f / 3.f, j > 0)) continue;
+          if (conv_rb3_try(r1, r2, s, up, Tn, Tn, xs, Tn, 0.1f, 1.f / 3.f, j > 0, false, noise_in_rb3 ? har : nullptr, noise_in_rb3 ? st.noise_w.p : nullptr,
+                           noise_in_rb3 ? st.noise_b.p : nullptr)) continue;
+          RVC_REQUIRE(!noise_in_rb3, "conv_rb3_try accepted the ResBlock in its dry run and declined the launch");
         }
         for (int m = 0; m < 3; ++m) {
           ConvEpilogue E2; E2.pre_act = ACT_LRELU; E2.pre_slope = 0.1f; E2.R = in; E2.ldR = Tn;

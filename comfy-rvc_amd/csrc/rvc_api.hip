@@ -707,7 +707,7 @@ int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* str
   RVC_CATCH
 }
 int rvc_conv1d_plan_resblock_run(rvc_conv1d_plan* const* plans6, void* stream, const float* x, int T, float* y, float out_scale, int accumulate,
-                                 int* ran_out) {
+                                 int* ran_out, const float* noise_src, const float* noise_w, const float* noise_b) {
   RVC_TRY
   RVC_REQUIRE(plans6 && x && y && ran_out, "null argument");
   const ConvLayer* c1[3]; const ConvLayer* c2[3];
@@ -715,7 +715,7 @@ int rvc_conv1d_plan_resblock_run(rvc_conv1d_plan* const* plans6, void* stream, c
     RVC_REQUIRE(plans6[2 * i] && plans6[2 * i + 1], "null plan");
     c1[i] = &plans6[2 * i]->L; c2[i] = &plans6[2 * i + 1]->L;
   }
-  *ran_out = conv_rb3_try(c1, c2, (hipStream_t)stream, x, T, T, y, T, 0.1f, out_scale, accumulate) ? 1 : 0;
+  *ran_out = conv_rb3_try(c1, c2, (hipStream_t)stream, x, T, T, y, T, 0.1f, out_scale, accumulate, false, noise_src, noise_w, noise_b) ? 1 : 0;
   check_launch();
   RVC_CATCH
 }

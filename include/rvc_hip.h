@@ -295,9 +295,10 @@ int rvc_conv1d_plan_pair_run(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, void* str
  * generator's xs += resblock(x), x = xs / 3 of models.py:555-560 is out_scale / accumulate): plans = {c1_0, c2_0, c1_1, c2_1, c1_2, c2_2};
  * y = x3 * out_scale [+ y] with x_{i+1} = x_i + c2_i(lrelu(c1_i(lrelu(x_i)))); x_dev, y_dev [32][T].  fp16x2 pair arithmetic only; bit-identical to three
  * rvc_conv1d_plan_pair_run calls.  *ran_out = 1 when the fused kernel ran, 0 when the layers / length are not eligible (nothing is written then: the caller
- * runs the pairs one by one). */
+ * runs the pairs one by one).  noise_*_dev (all three or none): the last generator stage's noise branch (models.py GeneratorNSF.forward, x = ups(x) +
+ * noise_convs[-1](har), a Conv1d(1, 32, 1)) folded into the read of x: the ResBlock sees x[c][t] + fmaf(noise_w[c], noise_src[t], noise_b[c]). */
 int rvc_conv1d_plan_resblock_run(rvc_conv1d_plan* const* plans6, void* stream, const float* x_dev, int T, float* y_dev, float out_scale, int accumulate,
-                                 int* ran_out);
+                                 int* ran_out, const float* noise_src_dev, const float* noise_w_dev, const float* noise_b_dev);
 /* The arithmetic rvc_conv1d_plan_pair_split_run (and the generator) uses for this pair at length T under the current rvc_set_pair_arithmetic mode:
  * 1 fp16x2, 0 bf16x3 (mode 0, a layer without an fp16 image, or a length / shape the persistent kernel declines); -1 on a null argument. */
 int rvc_conv1d_plan_pair_arithmetic(rvc_conv1d_plan* c1, rvc_conv1d_plan* c2, int T);

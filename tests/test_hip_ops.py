@@ -761,8 +761,8 @@ def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, 
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
-@pytest.mark.parametrize("k,T,scale,accum", [(3, 260003, 1.0 / 3, True), (3, 2 * 256 * 488, 1.0, False), (7, 300001, 1.0 / 3, True), (7, 230000, 1.0 / 3, False),
-                                             (11, 262144, 1.0 / 3, True), (11, 2 * 256 * 392 + 1, 1.0, False), (11, 1279200, 1.0 / 3, True)])
+@pytest.mark.parametrize("k,T,scale,accum", [(3, 270003, 1.0 / 3, True), (3, 2 * 256 * 510, 1.0, False), (7, 300001, 1.0 / 3, True), (7, 2 * 256 * 506 + 2, 1.0 / 3, False),
+                                             (11, 262144, 1.0 / 3, True), (11, 2 * 256 * 502 + 1, 1.0, False), (11, 1279200, 1.0 / 3, True)])      # (from two rounds of the PAIR kernel's 512 - (k - 1)-column tiles on: below that the chain runs in bf16x3)
 def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, k, T, scale, accum):
     """A whole ResBlock1 of the 32-channel stage (dilations 1, 3, 5; reference lib/infer_pack/modules.py:295-308) in ONE launch of conv_rb3_kernel: bit-identical
     to the chain of three fused-pair launches (conv_rbh_kernel) it replaces - same unit order, same accumulator initial values - on every element, at lengths
@@ -797,7 +797,7 @@ def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, k, T, scale,
     csv_path = str(tmp_path / "launches.csv")
     try:
         L.check(L.lib.rvc_prof_enable(1))
-        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf), scale, int(accum), C.byref(ran)))
+        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf), scale, int(accum), C.byref(ran), None, None, None))
         torch.cuda.synchronize()
         L.check(L.lib.rvc_prof_dump_csv(csv_path.encode()))
     finally:
@@ -808,7 +808,7 @@ def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, k, T, scale,
     assert torch.equal(yf, yc), (int((yf != yc).sum()), float((yf - yc).abs().max()))
     # a second run gives the same bits (the tile walk has no run-to-run freedom)
     yf2 = dev(y0)
-    L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf2), scale, int(accum), C.byref(ran)))
+    L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(yf2), scale, int(accum), C.byref(ran), None, None, None))
     torch.cuda.synchronize()
     assert torch.equal(yf, yf2)
     if T <= 400000:                                                                   # fp64 torch on the fp16-rounded weights (the arithmetic's definition)
@@ -823,6 +823,43 @@ def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, k, T, scale,
         NO = 512 - 24 * ((k - 1) // 2)
         for c0 in (0, NO - 20, 7 * NO - 20, 256 * NO - 20, T - 40):                     # sequence ends and tile seams carry the same error as the interior
             assert float(err[:, c0:c0 + 40].max()) < 1e-4 * float(ref.abs().max())
+    for pl in plans:
+        L.lib.rvc_conv1d_plan_destroy(pl)
+
+
+def test_fused_resblock_folds_the_noise_branch(L, pair_arith):
+    """The last stage's noise branch (reference models.py GeneratorNSF.forward: x = ups(x) + noise_convs[-1](har), a Conv1d(1, 32, 1)) folded into the ResBlock's
+    read of x: the same result as the ResBlock of the summed tensor (the sum formed in fp64 and rounded once differs from the kernel's fmaf + add by an ulp of x
+    here and there: 1e-6 of the output's scale)."""
+    pair_arith(1)
+    Cc, k, T = 32, 7, 300007
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(Cc, T, generator=g); har = torch.randn(T, generator=g) * 0.3
+    nw = torch.randn(Cc, generator=g) * 0.5; nb = torch.randn(Cc, generator=g) * 0.1
+    plans = []
+    L.check(L.lib.rvc_set_conv_precision(2))
+    try:
+        for i in range(6):
+            dd = (1, 3, 5)[i // 2] if i % 2 == 0 else 1
+            w = torch.randn(Cc, Cc, k, generator=g) / np.sqrt(Cc * k); b = torch.randn(Cc, generator=g) * 0.1
+            pl = C.c_void_p()
+            L.check(L.lib.rvc_conv1d_plan_create(L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), Cc, Cc, k, 1, (k - 1) // 2 * dd, dd, 1, C.byref(pl)))
+            plans.append(pl)
+    finally:
+        L.check(L.lib.rvc_set_conv_precision(1))
+    arr = (C.c_void_p * 6)(*[pl.value for pl in plans])
+    ran = C.c_int(-1)
+    xs = dev((x.double() + nw.double()[:, None] * har.double()[None, :] + nb.double()[:, None]).float())
+    xg, hg, wg, bg = dev(x), dev(har), dev(nw), dev(nb)
+    y1, y2 = torch.zeros(Cc, T).cuda(), torch.zeros(Cc, T).cuda()
+    L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xs), T, L.ptr(y1), 1.0 / 3, 0, C.byref(ran), None, None, None))
+    assert ran.value == 1
+    L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(xg), T, L.ptr(y2), 1.0 / 3, 0, C.byref(ran), L.ptr(hg), L.ptr(wg), L.ptr(bg)))
+    torch.cuda.synchronize()
+    assert ran.value == 1
+    d = (y1 - y2).abs()
+    assert float(d.max()) < 2e-6 * float(y1.abs().max()), (float(d.max()), int(d.argmax()) % T)
+    assert float(d[:, :600].max()) < 2e-6 * float(y1.abs().max()) and float(d[:, -600:].max()) < 2e-6 * float(y1.abs().max())
     for pl in plans:
         L.lib.rvc_conv1d_plan_destroy(pl)
 
@@ -847,7 +884,7 @@ def test_fused_resblock_declines_what_it_cannot_run(L, pair_arith):
     for arith, TT in ((1, T), (0, 300000)):
         pair_arith(arith)
         x, y = dev(torch.randn(Cc, TT, generator=g)), torch.full((Cc, TT), 7.0).cuda()
-        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), TT, L.ptr(y), 1.0, 0, C.byref(ran)))
+        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), TT, L.ptr(y), 1.0, 0, C.byref(ran), None, None, None))
         torch.cuda.synchronize()
         assert ran.value == 0 and bool((y == 7.0).all())
     for pl in plans:

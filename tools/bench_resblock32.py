@@ -29,7 +29,7 @@ for j, k in enumerate((3, 7, 11)):
         L.check(L.lib.rvc_conv1d_plan_pair_run(plans[4], plans[5], None, L.ptr(yb), T, L.ptr(out), 1.0 / 3, acc))
 
     def fused(out):
-        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), T, L.ptr(out), 1.0 / 3, acc, C.byref(ran)))
+        L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), T, L.ptr(out), 1.0 / 3, acc, C.byref(ran), None, None, None))
 
     y.zero_(); y2.zero_()
     chain(y); fused(y2); torch.cuda.synchronize()

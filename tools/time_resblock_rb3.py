@@ -17,7 +17,7 @@ for k in (3, 7, 11):
     arr = (C.c_void_p * 6)(*[pl.value for pl in plans]); ran = C.c_int(-1)
     x = torch.randn(Cc, T, device="cuda"); y = torch.zeros_like(x)
     for acc in (0, 1):
-        fn = lambda: L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), T, L.ptr(y), 1.0 / 3, acc, C.byref(ran)))
+        fn = lambda: L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), T, L.ptr(y), 1.0 / 3, acc, C.byref(ran), None, None, None))
         fn(); torch.cuda.synchronize()
         tm = (C.c_uint64 * 8)(); L.lib.rvc_debug_conv_timing(tm, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
