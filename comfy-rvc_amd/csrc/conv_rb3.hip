@@ -60,20 +60,21 @@ void conv_rb3_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 #define R3ACC(i, v) do {} while (0)
 #endif
 
-template <int KT, bool ACC, bool RESIDENT>
+template <int CH, int KT, bool ACC, bool RESIDENT>
 __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
-  constexpr int C = 32, NCK = 2, NW = 8, AN = 2, P2 = (KT - 1) / 2;
+  // CH = 32: a wave owns 32 rows x 64 columns (one row block, two column blocks), the tile is 512 columns; CH = 64: 64 rows x 32 columns, 256 columns
+  constexpr int C = CH, NCK = C / 16, NW = 8, AM = C / 32, AN = 64 / C, TILE = NW * AN * 32, P2 = (KT - 1) / 2;
+  constexpr int DMAX = 5, M = P2 * DMAX, P = TILE + 2 * M;   // dilations 1, 3, 5 (the host declines anything else): every LDS offset is an immediate
   constexpr int NU = NCK * KT;                               // (chunk, tap) units of one convolution
-  constexpr int WB = NU * 2 * C * 16;                        // bytes of one convolution's weights: [unit][half][32 rows][16 B]
+  constexpr int WB = NU * 2 * C * 16;                        // bytes of one convolution's weights: [unit][half][C rows][16 B]
   constexpr int WROWS = NU * 2 * C;                          // 16-byte rows of one convolution's weights
   constexpr int NWB = RESIDENT ? 6 : 2;
   constexpr int WQ = (WROWS + NW * 64 - 1) / (NW * 64);      // rows per thread when a convolution's weights travel through registers
+  constexpr int xplane = P * 32, xhalf = P * 16, xbuf = 2 * xplane;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
-  const int P = p.P, M = p.M;
-  const int xplane = P * 32, xhalf = P * 16, xbuf = 2 * xplane;
   unsigned char* Ws = smem3;
-  float* Bs = reinterpret_cast<float*>(smem3 + NWB * WB);    // 6 x 32 biases
-  unsigned char* Xs = smem3 + NWB * WB + 1024;
+  float* Bs = reinterpret_cast<float*>(smem3 + NWB * WB);    // 6 x C biases [, noise weights | biases]
+  unsigned char* Xs = smem3 + NWB * WB + 2048;
 
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63;
@@ -85,17 +86,17 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   const __amdgpu_buffer_rsrc_t xrs = make_rsrc(p.X, (unsigned)C * (unsigned)p.ldX * 4u);
   const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)C * (unsigned)p.ldY * 4u);
 
-  // ---- weights: source row r of a convolution = (unit, half) r / 32, channel row r % 32
+  // ---- weights: source row r of a convolution = (unit, half) r / C, channel row r % C
   u32x4 wreg[WQ];
-  auto wload = [&](int c) {
+  auto wload = [&](int c) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.W[c], (unsigned)(NU * 2) * (unsigned)p.CoPx * 16u);
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
       const int r = tid0 + NW * 64 * q;
-      wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(r < WROWS ? (unsigned)((r >> 5) * p.CoPx + (r & 31)) * 16u : kOOB), 0, 0);
+      wreg[q] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(r < WROWS ? (unsigned)((r / C) * p.CoPx + (r % C)) * 16u : kOOB), 0, 0);
     }
   };
-  auto wstore = [&](unsigned char* dst) {
+  auto wstore = [&](unsigned char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
       const int r = tid0 + NW * 64 * q;
@@ -107,36 +108,38 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   } else {
     wload(0); wstore(Ws);
   }
-  if (tid0 < 6 * C) Bs[tid0] = p.B[tid0 >> 5] ? p.B[tid0 >> 5][tid0 & 31] : 0.f;
-  const bool noise = p.nsrc != nullptr;
+  if (tid0 < 6 * C) Bs[tid0] = p.B[tid0 / C] ? p.B[tid0 / C][tid0 % C] : 0.f;
+  const bool noise = C == 32 && p.nsrc != nullptr;
   if (noise && tid0 < 2 * C) Bs[6 * C + tid0] = tid0 < C ? p.nw[tid0] : p.nb[tid0 - C];      // noise weights | biases
-  // the margins (M rows in front of column 0 and behind column 511 of every half-plane) are read by the edge columns' taps and never written again
-  for (int r = tid0; r < 8 * 2 * M; r += NW * 64) {
+  // the margins (M rows in front of column 0 and behind the last column of every half-plane) are read by the edge columns' taps and never written again
+  for (int r = tid0; r < NCK * 4 * 2 * M; r += NW * 64) {
     const int pl = r / (2 * M), q = r - pl * 2 * M;           // half-plane (chunk, hi | lo, half), margin row
-    const int row = q < M ? q : 512 + q;
+    const int row = q < M ? q : TILE + q;
     *reinterpret_cast<u32x4*>(Xs + (pl >> 2) * xbuf + ((pl >> 1) & 1) * xplane + (pl & 1) * xhalf + row * 16) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  // ---- global <-> accumulator layout: register r of block j = channel (r & 3) + 8 (r >> 2) + 4 lh, tile column (2 wave + j) 32 + li.  The row part of an
-  // address that does not depend on the lane is the instruction's scalar offset: one VGPR per block instead of sixteen
-  auto tile_voff = [&](long long ld, int tile, int j, int c_lo, int c_hi) -> unsigned {
+  // ---- global <-> accumulator layout: register r of block (am, j) = channel 32 am + (r & 3) + 8 (r >> 2) + 4 lh, tile column (AN wave + j) 32 + li.  The row
+  // part of an address that does not depend on the lane is the instruction's scalar offset: one VGPR per column block instead of sixteen
+  auto tile_voff = [&](long long ld, int tile, int j, int c_lo, int c_hi) __attribute__((always_inline)) -> unsigned {
     const int c = (wave * AN + j) * 32 + li;
     const int n = tile * NO - HALO + c;
     const bool ok = tile < ntiles && c >= c_lo && c < c_hi && n >= 0 && n < T;
     return ok ? ((unsigned)(4 * lh) * (unsigned)ld + (unsigned)n) * 4u : kOOB;
   };
-  auto load_tile = [&](const __amdgpu_buffer_rsrc_t& rs, long long ld, int tile, f32x16 (&v)[AN], int c_lo, int c_hi) {
+  auto load_tile = [&](const __amdgpu_buffer_rsrc_t& rs, long long ld, int tile, f32x16 (&v)[AM][AN], int c_lo, int c_hi) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < AN; ++j) {
       const unsigned voff = tile_voff(ld, tile, j, c_lo, c_hi);
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        v[j][r] = buf_load(rs, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)ld * 4u);
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          v[am][j][r] = buf_load(rs, voff, (unsigned)(32 * am + (r & 3) + 8 * (r >> 2)) * (unsigned)ld * 4u);
     }
   };
-  // ---- accumulator layout -> fp16 hi / lo rows of this wave's 64 columns: v = lrelu(a + bias) inside the sequence, 0 outside (every convolution pads with zeros)
+  // ---- accumulator layout -> fp16 hi / lo rows of this wave's columns: v = lrelu(a + bias) inside the sequence, 0 outside (every convolution pads with zeros)
   // (EDGE = false: the whole tile lies inside the sequence - every tile but the first and the last one or two - and the selects are not compiled)
-  auto put_image_t = [&](auto edge_c, const f32x16 (&a)[AN], const float* bias, float slope, int n0) {
+  auto put_image_t = [&](auto edge_c, const f32x16 (&a)[AM][AN], const float* bias, float slope, int n0) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
     for (int j = 0; j < AN; ++j) {
@@ -144,14 +147,16 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       const int pos = n0 + c;
       const bool inside = !EDGE || (pos >= 0 && pos < T);
 #pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         f32x4q ba = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-        if (bias) { ba = *reinterpret_cast<const f32x4q*>(bias + 16 * g2 + 4 * lh); bb = *reinterpret_cast<const f32x4q*>(bias + 16 * g2 + 4 * lh + 8); }
+        if (bias) { ba = *reinterpret_cast<const f32x4q*>(bias + 32 * am + 16 * g2 + 4 * lh); bb = *reinterpret_cast<const f32x4q*>(bias + 32 * am + 16 * g2 + 4 * lh + 8); }
         unsigned hA[2], lA[2], hB[2], lB[2];
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {
-          float a0 = a[j][8 * g2 + 2 * e2] + ba[2 * e2], a1 = a[j][8 * g2 + 2 * e2 + 1] + ba[2 * e2 + 1];
-          float b0 = a[j][8 * g2 + 4 + 2 * e2] + bb[2 * e2], b1 = a[j][8 * g2 + 5 + 2 * e2] + bb[2 * e2 + 1];
+          float a0 = a[am][j][8 * g2 + 2 * e2] + ba[2 * e2], a1 = a[am][j][8 * g2 + 2 * e2 + 1] + ba[2 * e2 + 1];
+          float b0 = a[am][j][8 * g2 + 4 + 2 * e2] + bb[2 * e2], b1 = a[am][j][8 * g2 + 5 + 2 * e2] + bb[2 * e2 + 1];
           a0 = inside ? fmaxf(a0, a0 * slope) : 0.f; a1 = inside ? fmaxf(a1, a1 * slope) : 0.f;
           b0 = inside ? fmaxf(b0, b0 * slope) : 0.f; b1 = inside ? fmaxf(b1, b1 * slope) : 0.f;
           split2h(a0, a1, hA[e2], lA[e2]);
@@ -165,32 +170,35 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
           const u32x2_t sl = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
           hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl.x; lo[2 + e2] = sl.y;
         }
-        unsigned char* d = Xs + g2 * xbuf + lh * xhalf + (M + c) * 16;
+        unsigned char* d = Xs + (2 * am + g2) * xbuf + lh * xhalf + (M + c) * 16;
         *reinterpret_cast<u32x4*>(d) = hi;
         *reinterpret_cast<u32x4*>(d + xplane) = lo;
       }
     }
   };
-  auto put_image = [&](const f32x16 (&a)[AN], const float* bias, float slope, int n0) {
-    if (n0 >= 0 && n0 + 512 <= T) put_image_t(std::false_type{}, a, bias, slope, n0); else put_image_t(std::true_type{}, a, bias, slope, n0);
+  auto put_image = [&](const f32x16 (&a)[AM][AN], const float* bias, float slope, int n0) __attribute__((always_inline)) {
+    if (n0 >= 0 && n0 + TILE <= T) put_image_t(std::false_type{}, a, bias, slope, n0); else put_image_t(std::true_type{}, a, bias, slope, n0);
   };
 
-  // ---- one centred convolution over the wave's 64 columns: NU units, the operands of unit u + 1 requested before the MFMAs of unit u
+  // ---- one centred convolution over the wave's rows x columns: NU units, the operands of unit u + 1 requested before the MFMAs of unit u
   const int aoff = (lh * C + li) * 16;
   const int boff = lh * xhalf + (wave * AN * 32 + li) * 16;
   // ZERO: the accumulators start from zero - the first matrix instruction takes the constant as its addend, nothing is cleared beforehand
-  auto conv = [&](auto zero_c, f32x16 (&acc)[AN], const unsigned char* W, int dil) {
+  auto conv = [&](auto zero_c, auto dil_c, f32x16 (&acc)[AM][AN], const unsigned char* W) __attribute__((always_inline)) {
     constexpr bool ZERO = decltype(zero_c)::value;
-    const int d16 = dil * 16, base = (M - P2 * dil) * 16 + boff;
-    u32x4 a, bh[AN], bl[AN], an_, bhn[AN], bln[AN];
-    auto read_ops = [&](u32x4& a_, u32x4 (&b_h)[AN], u32x4 (&b_l)[AN], int u, int xoff) {
-      a_ = *reinterpret_cast<const u32x4*>(W + u * (2 * C * 16) + aoff);
+    constexpr int dil = decltype(dil_c)::value;
+    constexpr int d16 = dil * 16;
+    const int base = (M - P2 * dil) * 16 + boff;
+    u32x4 a[AM], bh[AN], bl[AN], an_[AM], bhn[AN], bln[AN];
+    auto read_ops = [&](u32x4 (&a_)[AM], u32x4 (&b_h)[AN], u32x4 (&b_l)[AN], int u, int xoff) __attribute__((always_inline)) {
+#pragma unroll
+      for (int am = 0; am < AM; ++am) a_[am] = *reinterpret_cast<const u32x4*>(W + u * (2 * C * 16) + am * 512 + aoff);
       const unsigned char* xa = Xs + xoff + base;
 #pragma unroll
       for (int j = 0; j < AN; ++j) { b_h[j] = *reinterpret_cast<const u32x4*>(xa + j * 512); b_l[j] = *reinterpret_cast<const u32x4*>(xa + xplane + j * 512); }
     };
     read_ops(a, bh, bl, 0, 0);
-    auto unit = [&](auto uc) {
+    auto unit = [&](auto uc) __attribute__((always_inline)) {
       constexpr int U = decltype(uc)::value;
       if constexpr (U + 1 < NU) {
         constexpr int Tn = (U + 1) % KT, Cn = (U + 1) / KT;
@@ -198,20 +206,25 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < AN; ++j) {
-        if constexpr (ZERO && U == 0) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bl[j]), z, 0, 0, 0);
-        } else {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bl[j]), acc[j], 0, 0, 0);
-        }
-      }
+      for (int am = 0; am < AM; ++am)
 #pragma unroll
-      for (int j = 0; j < AN; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bh[j]), acc[j], 0, 0, 0);
+        for (int j = 0; j < AN; ++j) {
+          if constexpr (ZERO && U == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[am][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[am]), __builtin_bit_cast(f16x8, bl[j]), z, 0, 0, 0);
+          } else {
+            acc[am][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[am]), __builtin_bit_cast(f16x8, bl[j]), acc[am][j], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int j = 0; j < AN; ++j)
+          acc[am][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[am]), __builtin_bit_cast(f16x8, bh[j]), acc[am][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (U + 1 < NU) {
-        a = an_;
+#pragma unroll
+        for (int am = 0; am < AM; ++am) a[am] = an_[am];
 #pragma unroll
         for (int j = 0; j < AN; ++j) { bh[j] = bhn[j]; bl[j] = bln[j]; }
       }
@@ -220,12 +233,12 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   };
   // convolution c of the tile (0 .. 5): resident weights are where they are; streamed ones alternate between the two buffers and the next
   // convolution's travel through registers under this one
-  auto run_conv = [&](auto zero_c, f32x16 (&acc)[AN], int c, int dil) {
+  auto run_conv = [&](auto zero_c, auto dil_c, f32x16 (&acc)[AM][AN], int c) __attribute__((always_inline)) {
     if constexpr (RESIDENT) {
-      conv(zero_c, acc, Ws + c * WB, dil);
+      conv(zero_c, dil_c, acc, Ws + c * WB);
     } else {
       wload(c == 5 ? 0 : c + 1);
-      conv(zero_c, acc, Ws + (c & 1) * WB, dil);
+      conv(zero_c, dil_c, acc, Ws + (c & 1) * WB);
       wstore(Ws + ((c + 1) & 1) * WB);                        // (last read by convolution c - 1: a barrier ago)
     }
   };
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
 #endif
   // xn: the next tile's x, in flight across the whole tile.  rs: the fp32 residual stream x_i - the second convolution of every pair accumulates INTO it
   // (x_{i+1} = x_i + b2 + c2(h): no copies).  ac: the first convolution's accumulators; dead once h is written, so the previous output (ACC) is loaded into them
-  f32x16 xn[AN], rs[AN], ac[AN];
+  f32x16 xn[AM][AN], rs[AM][AN], ac[AM][AN];
   float sn[AN];                                               // the noise source at this lane's columns of the next tile
   const __amdgpu_buffer_rsrc_t srs = make_rsrc(noise ? p.nsrc : p.X, noise ? (unsigned)T * 4u : 0u);
   auto load_src = [&](int tile) __attribute__((always_inline)) {
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       sn[j] = buf_load(srs, (noise && tile < ntiles && n >= 0 && n < T) ? (unsigned)n * 4u : kOOB);
     }
   };
-  load_tile(xrs, p.ldX, (int)blockIdx.x, xn, 0, 512);
+  load_tile(xrs, p.ldX, (int)blockIdx.x, xn, 0, TILE);
   load_src((int)blockIdx.x);
   __syncthreads();                                            // weights, biases and the zero margins are in LDS
   [[maybe_unused]] long long tq = R3TICK();
@@ -256,60 +269,69 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
     const int n0 = tile * NO - HALO;                          // position of tile column 0
     // ---- x (requested a tile ago) becomes the residual stream and, leaky-ReLU'd, the first image; the next tile's x is requested
 #pragma unroll
-    for (int j = 0; j < AN; ++j) rs[j] = xn[j];
-    if (noise) {
+    for (int am = 0; am < AM; ++am)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4q w4 = *reinterpret_cast<const f32x4q*>(Bs + 6 * C + 8 * g + 4 * lh), b4 = *reinterpret_cast<const f32x4q*>(Bs + 7 * C + 8 * g + 4 * lh);
+      for (int j = 0; j < AN; ++j) rs[am][j] = xn[am][j];
+    if constexpr (C == 32) {
+      if (noise) {
 #pragma unroll
-        for (int j = 0; j < AN; ++j)
+        for (int g = 0; g < 4; ++g) {
+          const f32x4q w4 = *reinterpret_cast<const f32x4q*>(Bs + 6 * C + 8 * g + 4 * lh), b4 = *reinterpret_cast<const f32x4q*>(Bs + 7 * C + 8 * g + 4 * lh);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rs[j][4 * g + e] += fmaf(w4[e], sn[j], b4[e]);
+          for (int j = 0; j < AN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rs[0][j][4 * g + e] += fmaf(w4[e], sn[j], b4[e]);
+        }
       }
     }
     put_image(rs, nullptr, pre_slope, n0);
-    load_tile(xrs, p.ldX, tile + (int)gridDim.x, xn, 0, 512);
+    load_tile(xrs, p.ldX, tile + (int)gridDim.x, xn, 0, TILE);
     load_src(tile + (int)gridDim.x);
     R3BARRIER();
     R3PHASE(1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      run_conv(std::true_type{}, ac, 2 * i, p.dil[i]);
+    auto pair = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      run_conv(std::true_type{}, std::integral_constant<int, 2 * i + 1>{}, ac, 2 * i);      // dilation 1, 3, 5
       R3PHASE(2);
       R3BARRIER();                                            // every wave is done with the pair's input image
       put_image(ac, Bs + (2 * i) * C, hs, n0);                 // h = lrelu(c1 + b1) over it
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4q b2 = *reinterpret_cast<const f32x4q*>(Bs + (2 * i + 1) * C + 8 * g + 4 * lh);
+      for (int am = 0; am < AM; ++am)
 #pragma unroll
-        for (int j = 0; j < AN; ++j)
+        for (int g = 0; g < 4; ++g) {
+          const f32x4q b2 = *reinterpret_cast<const f32x4q*>(Bs + (2 * i + 1) * C + 32 * am + 8 * g + 4 * lh);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rs[j][4 * g + e] += b2[e];
-      }
-      // the previous output, under the last convolution (at 7 and 11 taps there are no registers for it beside the convolution's operands: requested behind the convolution)
-      if constexpr (ACC && KT < 7) { if (i == 2) load_tile(yrs, p.ldY, tile, ac, HALO, HALO + NO); }
+          for (int j = 0; j < AN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rs[am][j][4 * g + e] += b2[e];
+        }
+      // the previous output, under the last convolution (at 7 and 11 taps and at 64 channels there are no registers for it beside the convolution's operands: requested behind it)
+      if constexpr (ACC && KT < 7 && C == 32 && i == 2) load_tile(yrs, p.ldY, tile, ac, HALO, HALO + NO);
       R3BARRIER();                                            // the intermediate is complete
       R3PHASE(3);
-      run_conv(std::false_type{}, rs, 2 * i + 1, 1);           // rs = x_{i+1}
-      if constexpr (ACC && KT >= 7) { if (i == 2) load_tile(yrs, p.ldY, tile, ac, HALO, HALO + NO); }
+      run_conv(std::false_type{}, std::integral_constant<int, 1>{}, rs, 2 * i + 1);          // rs = x_{i+1}
+      if constexpr (ACC && !(KT < 7 && C == 32) && i == 2) load_tile(yrs, p.ldY, tile, ac, HALO, HALO + NO);
       R3PHASE(4);
-      if (i < 2) {
+      if constexpr (i < 2) {
         R3BARRIER();                                          // every wave is done with the intermediate
         put_image(rs, nullptr, pre_slope, n0);
         R3BARRIER();
         R3PHASE(3);
       }
-    }
+    };
+    rb3_for<0, 3>(pair);
     // ---- epilogue: the inner NO columns
 #pragma unroll
     for (int j = 0; j < AN; ++j) {
       const unsigned voff = tile_voff(p.ldY, tile, j, HALO, HALO + NO);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = rs[j][r] * oscale;
-        if constexpr (ACC) v += ac[j][r];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)voff, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)p.ldY * 4u), 0);
-      }
+      for (int am = 0; am < AM; ++am)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = rs[am][j][r] * oscale;
+          if constexpr (ACC) v += ac[am][j][r];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (int)voff, (int)((unsigned)(32 * am + (r & 3) + 8 * (r >> 2)) * (unsigned)p.ldY * 4u), 0);
+        }
     }
     R3BARRIER();                                              // every wave is done with the last intermediate: the next tile's image may be written over it
     R3PHASE(5);
@@ -323,15 +345,15 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
 #endif
 }
 
-template <int KT, bool ACC, bool RESIDENT>
+template <int CH, int KT, bool ACC, bool RESIDENT>
 static void launch_rb3c(const Rb3Args& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_rb3_kernel<KT, ACC, RESIDENT>;
+  auto kern = conv_rb3_kernel<CH, KT, ACC, RESIDENT>;
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
 }
-template <int KT, bool RESIDENT>
+template <int CH, int KT, bool RESIDENT>
 static void launch_rb3(const Rb3Args& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
-  if (acc) launch_rb3c<KT, true, RESIDENT>(a, grid, lds, s); else launch_rb3c<KT, false, RESIDENT>(a, grid, lds, s);
+  if (acc) launch_rb3c<CH, KT, true, RESIDENT>(a, grid, lds, s); else launch_rb3c<CH, KT, false, RESIDENT>(a, grid, lds, s);
 }
 
 // c1[i] / c2[i]: the three (dilated, plain) pairs of one ResBlock1.  32 channels, equal odd kernel size 3 / 7 / 11, "same" padding, every layer with its
@@ -339,20 +361,22 @@ static void launch_rb3(const Rb3Args& a, bool acc, dim3 grid, size_t lds, hipStr
 bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStream_t s, const float* X, long long ldX, int T, float* Y, long long ldY,
                   float pre_slope, float out_scale, int accumulate, bool dry, const float* nsrc, const float* nw, const float* nb) {
   static const int on = exp_int("RVC_RB3", 1);
+  static const int on64 = exp_int("RVC_RB3_64", 1);             // the 64-channel stage's 3-tap ResBlock (otherwise three conv_x3pf_kernel launches in bf16x3)
   if (!on || !conv_x3_enabled() || !conv_set_pair_arithmetic(-1)) return false;
-  const int k = c1[0]->k;
-  if (!(k == 3 || k == 7 || k == 11)) return false;
-  int dmax = 1, dsum = 0;
+  const int k = c1[0]->k, C = c1[0]->Co;
+  if (!((C == 32 && (k == 3 || k == 7 || k == 11)) || (C == 64 && k == 3 && on64))) return false;
+  int dsum = 0;
   for (int i = 0; i < 3; ++i) {
     const ConvLayer& a = *c1[i]; const ConvLayer& b = *c2[i];
     if (!a.Wh_ || !b.Wh_ || a.mode != 1 || b.mode != 1 || a.groups != 1 || b.groups != 1 || a.stride != 1 || b.stride != 1 || a.tconv_u || b.tconv_u) return false;
-    if (a.Ci != 32 || a.Co != 32 || b.Ci != 32 || b.Co != 32 || a.k != k || b.k != k || b.dil != 1 || a.dil < 1) return false;
-    if (a.pad != (k - 1) / 2 * a.dil || b.pad != (k - 1) / 2 || a.CoPx != c1[0]->CoPx || b.CoPx != c1[0]->CoPx || a.CoPx < 32) return false;
-    dmax = std::max(dmax, a.dil); dsum += a.dil;
+    if (a.Ci != C || a.Co != C || b.Ci != C || b.Co != C || a.k != k || b.k != k || b.dil != 1 || a.dil != 2 * i + 1) return false;      // dilations 1, 3, 5: the kernel's LDS offsets are compiled for these
+    if (a.pad != (k - 1) / 2 * a.dil || b.pad != (k - 1) / 2 || a.CoPx != c1[0]->CoPx || b.CoPx != c1[0]->CoPx || a.CoPx < C) return false;
+    dsum += a.dil;
   }
-  const int P2 = (k - 1) / 2, M = P2 * dmax, P = 512 + 2 * M, halo = P2 * (dsum + 3), NO = 512 - 2 * halo;
-  if (P > 576 || NO < 256) return false;
-  if ((double)32 * (double)ldX * 4.0 >= 2147483648.0 || (double)32 * (double)ldY * 4.0 >= 2147483648.0) return false;
+  const int TILE = C == 32 ? 512 : 256;
+  const int P2 = (k - 1) / 2, M = P2 * 5, P = TILE + 2 * M, halo = P2 * (dsum + 3), NO = TILE - 2 * halo;
+  if ((double)C * (double)ldX * 4.0 >= 2147483648.0 || (double)C * (double)ldY * 4.0 >= 2147483648.0) return false;
+  if (nsrc && C != 32) return false;
   int dev = 0, ncu = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -371,22 +395,24 @@ bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStr
   a.pre_slope = pre_slope; a.mid_slope = pre_slope; a.out_scale = out_scale;
   RVC_REQUIRE((nsrc == nullptr) == (nw == nullptr) && (nsrc == nullptr) == (nb == nullptr), "conv_rb3_try: the noise branch is source, weights and biases together");
   a.nsrc = nsrc; a.nw = nw; a.nb = nb;
-  const size_t wb = (size_t)2 * k * 2 * 32 * 16;
-  const size_t tile_bytes = (size_t)P * 128;
-  const bool resident = 6 * wb + 1024 + tile_bytes <= 160 * 1024;
-  const size_t lds = (resident ? 6 : 2) * wb + 1024 + tile_bytes;
+  const size_t wb = (size_t)(C / 16) * k * 2 * C * 16;
+  const size_t tile_bytes = (size_t)P * (C / 16) * 64;
+  const bool resident = C == 32 && k <= 7;                      // six weight sets beside the image: 36 / 84 KiB fit, 132 KiB (11 taps) and 144 KiB (64 channels) do not
+  const size_t lds = (resident ? 6 : 2) * wb + 2048 + tile_bytes;
+  RVC_REQUIRE(lds <= 160 * 1024, "conv_rb3_try: LDS budget");
   dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
-  if (k == 3) { if (resident) launch_rb3<3, true>(a, accumulate != 0, grid, lds, s); else launch_rb3<3, false>(a, accumulate != 0, grid, lds, s); }
-  else if (k == 7) { if (resident) launch_rb3<7, true>(a, accumulate != 0, grid, lds, s); else launch_rb3<7, false>(a, accumulate != 0, grid, lds, s); }
-  else launch_rb3<11, false>(a, accumulate != 0, grid, lds, s);
+  if (C == 64) launch_rb3<64, 3, false>(a, accumulate != 0, grid, lds, s);
+  else if (k == 3) launch_rb3<32, 3, true>(a, accumulate != 0, grid, lds, s);
+  else if (k == 7) launch_rb3<32, 7, true>(a, accumulate != 0, grid, lds, s);
+  else launch_rb3<32, 11, false>(a, accumulate != 0, grid, lds, s);
   if (tk.on) {
     ConvArgsX pa{};
-    pa.Ci = 32; pa.Co = 32; pa.ktaps = k; pa.kreal = k; pa.dil = dmax; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.ksplit = 1; pa.h2 = 1;
+    pa.Ci = C; pa.Co = C; pa.ktaps = k; pa.kreal = k; pa.dil = 5; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.ksplit = 1; pa.h2 = 1;
     pa.R = X; pa.X = X; pa.accumulate = accumulate;
     // algorithmic traffic of the ResBlock: x read once, y written once (+ the previous y when accumulating), six weight sets
-    const double bytes = 4.0 * ((double)32 * T * (2.0 + (accumulate ? 1.0 : 0.0)) + 6.0 * 32 * 32 * k);
-    conv_prof_end(tk, s, 3.0 * 2.0 * 2.0 * 32.0 * 32.0 * k * (double)T, 14 + 1, bytes, &pa, (long long)grid.x, 3 | (7 << 4));
+    const double bytes = 4.0 * ((double)C * T * (2.0 + (accumulate ? 1.0 : 0.0)) + 6.0 * C * C * k);
+    conv_prof_end(tk, s, 3.0 * 2.0 * 2.0 * (double)C * C * k * (double)T, 14 + (C == 32 ? 1 : 5), bytes, &pa, (long long)grid.x, 3 | (7 << 4));
   }
   return true;
 }

@@ -1,6 +1,7 @@
 """The three ResBlocks of the generator's 32-channel stage (k = 3 / 7 / 11, dilations 1 / 3 / 5) at the stage's length, fp16x2 arithmetic:
 the chain of three fused-pair launches (conv_rbh_kernel) against one launch per ResBlock (conv_rb3_kernel); the third pair / the fused launch
-scales by 1/3 and the second and third ResBlock accumulate, as in the generator.  RB_T=<length> overrides the length."""
+scales by 1/3 and the second and third ResBlock accumulate, as in the generator.  RB_T=<length> overrides the length; RB_C=64: the 64-channel stage's
+3-tap ResBlock (its chain is three conv_x3pf_kernel launches in bf16x3: a different arithmetic, not bit-comparable)."""
 import sys, ctypes as C, os
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -8,12 +9,12 @@ from comfy_rvc_amd import _lib as L
 L.get_ctx(0)
 L.check(L.lib.rvc_set_conv_precision(2))
 L.check(L.lib.rvc_set_pair_arithmetic(1))
-Cc, T = 32, int(os.environ.get("RB_T", 1279200))
+Cc = int(os.environ.get("RB_C", 32)); T = int(os.environ.get("RB_T", 1279200 if Cc == 32 else 639600))
 REP = 10
 rng = np.random.default_rng(0)
 tot = [0.0, 0.0]
 x = torch.randn(Cc, T, device="cuda"); ya = torch.empty_like(x); yb = torch.empty_like(x); y = torch.zeros_like(x); y2 = torch.zeros_like(x)
-for j, k in enumerate((3, 7, 11)):
+for j, k in enumerate((3, 7, 11) if Cc == 32 else (3,)):
     plans = []
     for i in range(6):
         dd = (1, 3, 5)[i // 2] if i % 2 == 0 else 1
