@@ -484,6 +484,9 @@ KERNEL_DESC = {
     "conv_x3p_kernel": "rvc::conv_x3p_kernel<AM,AN,KT,XSPLIT,YSPLIT,S2> - software-pipelined bf16x3 implicit-GEMM Conv1d (generator ResBlocks / up-samplers, "
                        "HuBERT stride-2 layers): 3 v_mfma_f32_32x32x16_bf16 per fp32 product block, fp32 accumulate",
     "conv_x3pf_kernel": "rvc::conv_x3pf_kernel<KT,WM> - fused ResBlock pair (32- / 64-channel generator stages), bf16x3",
+    "conv_rbh_kernel": "rvc::conv_rbh_kernel<KT,ACC> - persistent fused ResBlock pair of the 32-channel stage, fp16x2, both weight sets resident in LDS (sequences too short for conv_rb3_kernel)",
+    "conv_rb3_kernel": "rvc::conv_rb3_kernel<CH,KT,ACC,RESIDENT> - a whole ResBlock1 (three pairs) of the 32-channel stage / the 64-channel stage's 3-tap ResBlock per launch, fp16x2: "
+                       "x read once, residual stream in registers, six convolutions over an LDS-resident fp16 hi / lo image",
     "conv_x3g_kernel": "rvc::conv_x3g_kernel - pipelined bf16x3 GEMM (k = 1 projections, taps / 3x3 modes on short sequences)",
     "conv_x3s_kernel": "rvc::conv_x3s_kernel - bf16x3 GEMM on split-resident operands (both tiles by LDS-DMA, in-kernel split-K)",
     "conv_x3_kernel": "rvc::conv_x3_kernel<WM,WN,AM,AN> - staged bf16x3 kernel (2-D 3x3, other strides)",

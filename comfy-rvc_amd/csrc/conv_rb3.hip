@@ -60,7 +60,7 @@ void conv_rb3_timing_read(unsigned long long* out8, bool) { for (int i = 0; i < 
 #define R3ACC(i, v) do {} while (0)
 #endif
 
-template <int CH, int KT, bool ACC, bool RESIDENT>
+template <int CH, int KT, bool ACC, int WM>
 __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   // CH = 32: a wave owns 32 rows x 64 columns (one row block, two column blocks), the tile is 512 columns; CH = 64: 64 rows x 32 columns, 256 columns
   constexpr int C = CH, NCK = C / 16, NW = 8, AM = C / 32, AN = 64 / C, TILE = NW * AN * 32, P2 = (KT - 1) / 2;
@@ -68,7 +68,11 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   constexpr int NU = NCK * KT;                               // (chunk, tap) units of one convolution
   constexpr int WB = NU * 2 * C * 16;                        // bytes of one convolution's weights: [unit][half][C rows][16 B]
   constexpr int WROWS = NU * 2 * C;                          // 16-byte rows of one convolution's weights
-  constexpr int NWB = RESIDENT ? 6 : 2;
+  // WM: where the six convolutions' weights live.  0: all resident in LDS.  1: two LDS buffers - the next convolution's rows travel through registers under the
+  // current convolution and are stored into the other buffer behind it.  2: ONE LDS buffer (64 channels x 7 taps: 56 KiB per convolution) - the rows
+  // travel the same way but are stored in the image interval that follows (after the barrier that retires the convolution, before the one that opens the next)
+  constexpr bool RESIDENT = WM == 0;
+  constexpr int NWB = WM == 0 ? 6 : (WM == 1 ? 2 : 1);
   constexpr int WQ = (WROWS + NW * 64 - 1) / (NW * 64);      // rows per thread when a convolution's weights travel through registers
   constexpr int xplane = P * 32, xhalf = P * 16, xbuf = 2 * xplane;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3[];
@@ -103,10 +107,12 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       if (r < WROWS) *reinterpret_cast<u32x4*>(dst + r * 16) = wreg[q];
     }
   };
-  if constexpr (RESIDENT) {
+  if constexpr (WM == 0) {
     for (int c = 0; c < 6; ++c) { wload(c); wstore(Ws + c * WB); }
-  } else {
+  } else if constexpr (WM == 1) {
     wload(0); wstore(Ws);
+  } else {
+    wload(0);                                                  // (stored at the top of the first tile)
   }
   if (tid0 < 6 * C) Bs[tid0] = p.B[tid0 / C] ? p.B[tid0 / C][tid0 % C] : 0.f;
   const bool noise = C == 32 && p.nsrc != nullptr;
@@ -234,12 +240,15 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   // convolution c of the tile (0 .. 5): resident weights are where they are; streamed ones alternate between the two buffers and the next
   // convolution's travel through registers under this one
   auto run_conv = [&](auto zero_c, auto dil_c, f32x16 (&acc)[AM][AN], int c) __attribute__((always_inline)) {
-    if constexpr (RESIDENT) {
+    if constexpr (WM == 0) {
       conv(zero_c, dil_c, acc, Ws + c * WB);
-    } else {
+    } else if constexpr (WM == 1) {
       wload(c == 5 ? 0 : c + 1);
       conv(zero_c, dil_c, acc, Ws + (c & 1) * WB);
       wstore(Ws + ((c + 1) & 1) * WB);                        // (last read by convolution c - 1: a barrier ago)
+    } else {
+      wload(c == 5 ? 0 : c + 1);                               // (stored by the image interval behind this convolution)
+      conv(zero_c, dil_c, acc, Ws);
     }
   };
 
@@ -284,6 +293,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
         }
       }
     }
+    if constexpr (WM == 2) wstore(Ws);                         // convolution 0's weights (the previous tile's last convolution was retired by its closing barrier)
     put_image(rs, nullptr, pre_slope, n0);
     load_tile(xrs, p.ldX, tile + (int)gridDim.x, xn, 0, TILE);
     load_src(tile + (int)gridDim.x);
@@ -294,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       run_conv(std::true_type{}, std::integral_constant<int, 2 * i + 1>{}, ac, 2 * i);      // dilation 1, 3, 5
       R3PHASE(2);
       R3BARRIER();                                            // every wave is done with the pair's input image
+      if constexpr (WM == 2) wstore(Ws);
       put_image(ac, Bs + (2 * i) * C, hs, n0);                 // h = lrelu(c1 + b1) over it
 #pragma unroll
       for (int am = 0; am < AM; ++am)
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
       R3PHASE(4);
       if constexpr (i < 2) {
         R3BARRIER();                                          // every wave is done with the intermediate
+        if constexpr (WM == 2) wstore(Ws);
         put_image(rs, nullptr, pre_slope, n0);
         R3BARRIER();
         R3PHASE(3);
@@ -345,15 +357,15 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
 #endif
 }
 
-template <int CH, int KT, bool ACC, bool RESIDENT>
+template <int CH, int KT, bool ACC, int WM>
 static void launch_rb3c(const Rb3Args& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv_rb3_kernel<CH, KT, ACC, RESIDENT>;
+  auto kern = conv_rb3_kernel<CH, KT, ACC, WM>;
   RVC_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
 }
-template <int CH, int KT, bool RESIDENT>
+template <int CH, int KT, int WM>
 static void launch_rb3(const Rb3Args& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {
-  if (acc) launch_rb3c<CH, KT, true, RESIDENT>(a, grid, lds, s); else launch_rb3c<CH, KT, false, RESIDENT>(a, grid, lds, s);
+  if (acc) launch_rb3c<CH, KT, true, WM>(a, grid, lds, s); else launch_rb3c<CH, KT, false, WM>(a, grid, lds, s);
 }
 
 // c1[i] / c2[i]: the three (dilated, plain) pairs of one ResBlock1.  32 channels, equal odd kernel size 3 / 7 / 11, "same" padding, every layer with its
@@ -364,7 +376,8 @@ bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStr
   static const int on64 = exp_int("RVC_RB3_64", 1);             // the 64-channel stage's 3-tap ResBlock (otherwise three conv_x3pf_kernel launches in bf16x3)
   if (!on || !conv_x3_enabled() || !conv_set_pair_arithmetic(-1)) return false;
   const int k = c1[0]->k, C = c1[0]->Co;
-  if (!((C == 32 && (k == 3 || k == 7 || k == 11)) || (C == 64 && k == 3 && on64))) return false;
+  static const int on64k7 = exp_int("RVC_RB3_64K7", 1);         // the 64-channel stage's 7-tap ResBlock (otherwise six conv_x3q_kernel launches with the intermediate images through HBM)
+  if (!((C == 32 && (k == 3 || k == 7 || k == 11)) || (C == 64 && k == 3 && on64) || (C == 64 && k == 7 && on64 && on64k7))) return false;
   int dsum = 0;
   for (int i = 0; i < 3; ++i) {
     const ConvLayer& a = *c1[i]; const ConvLayer& b = *c2[i];
@@ -397,15 +410,18 @@ bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStr
   a.nsrc = nsrc; a.nw = nw; a.nb = nb;
   const size_t wb = (size_t)(C / 16) * k * 2 * C * 16;
   const size_t tile_bytes = (size_t)P * (C / 16) * 64;
-  const bool resident = C == 32 && k <= 7;                      // six weight sets beside the image: 36 / 84 KiB fit, 132 KiB (11 taps) and 144 KiB (64 channels) do not
-  const size_t lds = (resident ? 6 : 2) * wb + 2048 + tile_bytes;
+  // six weight sets beside the image: 36 / 84 KiB fit (32 channels, 3 / 7 taps); two buffers at 11 taps (2 x 22 KiB) and at 64 channels x 3 taps (2 x 24 KiB); one at
+  // 64 channels x 7 taps (56 KiB beside the 82 KiB image)
+  const int wm = (C == 32 && k <= 7) ? 0 : ((C == 64 && k == 7) ? 2 : 1);
+  const size_t lds = (wm == 0 ? 6 : (wm == 1 ? 2 : 1)) * wb + 2048 + tile_bytes;
   RVC_REQUIRE(lds <= 160 * 1024, "conv_rb3_try: LDS budget");
   dim3 grid((unsigned)(ntiles < ncu ? ntiles : ncu), 1, 1);
   ProfTicket tk = conv_prof_begin(s);
-  if (C == 64) launch_rb3<64, 3, false>(a, accumulate != 0, grid, lds, s);
-  else if (k == 3) launch_rb3<32, 3, true>(a, accumulate != 0, grid, lds, s);
-  else if (k == 7) launch_rb3<32, 7, true>(a, accumulate != 0, grid, lds, s);
-  else launch_rb3<32, 11, false>(a, accumulate != 0, grid, lds, s);
+  if (C == 64 && k == 3) launch_rb3<64, 3, 1>(a, accumulate != 0, grid, lds, s);
+  else if (C == 64) launch_rb3<64, 7, 2>(a, accumulate != 0, grid, lds, s);
+  else if (k == 3) launch_rb3<32, 3, 0>(a, accumulate != 0, grid, lds, s);
+  else if (k == 7) launch_rb3<32, 7, 0>(a, accumulate != 0, grid, lds, s);
+  else launch_rb3<32, 11, 1>(a, accumulate != 0, grid, lds, s);
   if (tk.on) {
     ConvArgsX pa{};
     pa.Ci = C; pa.Co = C; pa.ktaps = k; pa.kreal = k; pa.dil = 5; pa.stride = 1; pa.Tin = T; pa.Tout = T; pa.ksplit = 1; pa.h2 = 1;

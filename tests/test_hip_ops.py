@@ -764,11 +764,12 @@ def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, 
 @pytest.mark.parametrize("Cc,k,T,scale,accum", [(32, 3, 270003, 1.0 / 3, True), (32, 3, 2 * 256 * 510, 1.0, False), (32, 7, 300001, 1.0 / 3, True), (32, 7, 2 * 256 * 506 + 2, 1.0 / 3, False),
                                                 (32, 11, 262144, 1.0 / 3, True), (32, 11, 2 * 256 * 502 + 1, 1.0, False), (32, 11, 1279200, 1.0 / 3, True),
                                                 # (32 channels: from two rounds of the PAIR kernel's 512 - (k - 1)-column tiles on - below that the chain runs in bf16x3)
-                                                (64, 3, 130001, 1.0 / 3, False), (64, 3, 2 * 256 * 232, 1.0, True), (64, 3, 639600, 1.0 / 3, True)])
+                                                (64, 3, 130001, 1.0 / 3, False), (64, 3, 2 * 256 * 232, 1.0, True), (64, 3, 639600, 1.0 / 3, True),
+                                                (64, 7, 100001, 1.0 / 3, True), (64, 7, 2 * 256 * 184, 1.0, False), (64, 7, 639600, 1.0 / 3, True)])
 def test_fused_resblock_matches_pair_chain(L, pair_arith, tmp_path, Cc, k, T, scale, accum):
     """A whole ResBlock1 of a narrow generator stage (dilations 1, 3, 5; reference lib/infer_pack/modules.py:295-308) in ONE launch of conv_rb3_kernel.
     32 channels (3 / 7 / 11 taps): bit-identical to the chain of three fused-pair launches (conv_rbh_kernel) it replaces - same unit order, same accumulator
-    initial values - on every element, at lengths with ragged last tiles.  64 channels (3 taps; the pairs would run on conv_x3pf_kernel in bf16x3): held to the
+    initial values - on every element, at lengths with ragged last tiles.  64 channels (3 taps: the pairs would run on conv_x3pf_kernel in bf16x3; 7 taps: on conv_x3q_kernel as two launches each): held to the
     arithmetic's definition.  Both: within 2e-5 of fp64 torch on the fp16-rounded weights, seams and ends included, repeatable to the bit.  The stages' real
     lengths (1 279 200 and 639 600) are among the cases."""
     pair_arith(1)

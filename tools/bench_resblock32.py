@@ -14,7 +14,7 @@ REP = 10
 rng = np.random.default_rng(0)
 tot = [0.0, 0.0]
 x = torch.randn(Cc, T, device="cuda"); ya = torch.empty_like(x); yb = torch.empty_like(x); y = torch.zeros_like(x); y2 = torch.zeros_like(x)
-for j, k in enumerate((3, 7, 11) if Cc == 32 else (3,)):
+for j, k in enumerate((3, 7, 11) if Cc == 32 else (3, 7)):
     plans = []
     for i in range(6):
         dd = (1, 3, 5)[i // 2] if i % 2 == 0 else 1
@@ -24,10 +24,12 @@ for j, k in enumerate((3, 7, 11) if Cc == 32 else (3,)):
     ran = C.c_int(-1)
     acc = int(j > 0)
 
+    pair_run = L.lib.rvc_conv1d_plan_pair_split_run if (Cc == 64 and k > 3) else L.lib.rvc_conv1d_plan_pair_run      # (64 channels x 7 taps: two launches per pair on conv_x3q_kernel, the intermediate image through HBM)
+
     def chain(out):
-        L.check(L.lib.rvc_conv1d_plan_pair_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(ya), 1.0, 0))
-        L.check(L.lib.rvc_conv1d_plan_pair_run(plans[2], plans[3], None, L.ptr(ya), T, L.ptr(yb), 1.0, 0))
-        L.check(L.lib.rvc_conv1d_plan_pair_run(plans[4], plans[5], None, L.ptr(yb), T, L.ptr(out), 1.0 / 3, acc))
+        L.check(pair_run(plans[0], plans[1], None, L.ptr(x), T, L.ptr(ya), 1.0, 0))
+        L.check(pair_run(plans[2], plans[3], None, L.ptr(ya), T, L.ptr(yb), 1.0, 0))
+        L.check(pair_run(plans[4], plans[5], None, L.ptr(yb), T, L.ptr(out), 1.0 / 3, acc))
 
     def fused(out):
         L.check(L.lib.rvc_conv1d_plan_resblock_run(arr, None, L.ptr(x), T, L.ptr(out), 1.0 / 3, acc, C.byref(ran), None, None, None))
