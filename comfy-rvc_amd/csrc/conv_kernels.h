@@ -2,6 +2,7 @@
 // conv_x3.hip: bf16x3 split MFMA).  Private to csrc/.
 #pragma once
 #include "rvc_internal.h"
+#include <hip/hip_ext.h>
 
 namespace rvc {
 
@@ -131,6 +132,18 @@ int tile_cfg_id(const TileCfg& t);            // 0..6, -1 if not an instantiated
 constexpr int kProfCfgs = 24;
 struct ProfTicket { hipEvent_t a = nullptr, b = nullptr; bool on = false; };
 ProfTicket conv_prof_begin(hipStream_t s);
+// While a profiling bracket is open on this thread, the FIRST kernel launched through conv_launch carries its own start / stop events (hipExtLaunchKernelGGL:
+// the dispatch packet's begin / end timestamps - what rocprofv3's kernel trace reports).  A bracket that held exactly one such launch is timed by them; a
+// bracket with several launches (split-K + reduction) or with launches that do not go through conv_launch keeps the event pair recorded around it, which
+// also counts the command processor's ~2.4 us between the markers and the dispatch.
+struct ProfKernelEvents { hipEvent_t ka = nullptr, kb = nullptr; bool armed = false; int launches = 0; };
+ProfKernelEvents& prof_kernel_events();
+template <class K, class A>
+inline void conv_launch(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& a) {
+  ProfKernelEvents& pe = prof_kernel_events();
+  if (pe.armed && pe.launches++ == 0) hipExtLaunchKernelGGL(kern, grid, block, lds, s, pe.ka, pe.kb, 0, a);
+  else hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+}
 void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes = 0.0, const ConvArgsX* shape = nullptr, long long blocks = 0,
                    int fused = 0);
 int conv_prof_dump_csv(const char* path);   // one row per recorded launch: shape, tile, grid, us, algorithmic FLOPs / bytes

@@ -366,6 +366,7 @@ void splitk_reduce_launch(const ConvArgsX& a, int S, int batch, hipStream_t s) {
   const long long total = (long long)batch * a.Co * a.Tout;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
   const float lslope = a.act == ACT_NONE ? 1.f : (a.act == ACT_RELU ? 0.f : a.act_slope);
+  { ProfKernelEvents& pe = prof_kernel_events(); if (pe.armed) ++pe.launches; }      // (a second launch of an open profiling bracket: the bracket is timed as a whole)
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, S, batch, a.Co, a.Tout, a.ldP, a.bias, a.bBatch, a.R, a.ldR,
                      a.rBatch, a.Y, a.ldY, a.yBatch, a.orows, lslope, a.act_before_res, a.out_scale, a.accumulate);
 }
@@ -761,7 +762,7 @@ template <int WM, int WN, int AM, int AN, int MODE>
 static void launch_cfg(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_mfma_kernel<WM, WN, AM, AN, MODE>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  conv_launch(kern, grid, dim3(256), lds, s, a);
 }
 
 TileCfg choose_tile(int M, long long N, int batch) {
@@ -810,14 +811,28 @@ int conv_prof_collect(double* ms, double* flops, long long* launches) {
   return (int)g_prof.size();
 }
 const char* conv_prof_cfg_name(int i) { return (i >= 0 && i < kProfCfgs) ? kCfgNames[i] : ""; }
+ProfKernelEvents& prof_kernel_events() { static thread_local ProfKernelEvents pe; return pe; }
 ProfTicket conv_prof_begin(hipStream_t s) {
   ProfTicket t; t.on = g_prof_on.load(std::memory_order_relaxed);
-  if (t.on) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); (void)hipEventRecord(t.a, s); }
+  if (t.on) {
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); (void)hipEventRecord(t.a, s);
+    ProfKernelEvents& pe = prof_kernel_events();
+    (void)hipEventCreate(&pe.ka); (void)hipEventCreate(&pe.kb); pe.armed = true; pe.launches = 0;
+  }
   return t;
 }
 void conv_prof_end(ProfTicket& t, hipStream_t s, double flops, int cfg, double bytes, const ConvArgsX* a, long long blocks, int fused) {
   if (!t.on) return;
   (void)hipEventRecord(t.b, s);
+  ProfKernelEvents& pe = prof_kernel_events();
+  pe.armed = false;
+  if (pe.launches == 1) {                                     // one kernel in the bracket: its own begin / end timestamps
+    (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    t.a = pe.ka; t.b = pe.kb;
+  } else {
+    (void)hipEventDestroy(pe.ka); (void)hipEventDestroy(pe.kb);
+  }
+  pe.ka = pe.kb = nullptr;
   ProfRec r{t.a, t.b, flops, cfg, bytes, 0, 0, 0, 0, 0, 0, 0, 1, fused, blocks, 0};
   if (a) { r.h2 = a->h2; r.Ci = a->Ci; r.Co = a->Co; r.k = a->kreal > 0 ? a->kreal : a->ktaps; r.dil = a->dil; r.stride = a->stride; r.Tout = a->Tout; r.Wd = a->Wd; r.ksplit = a->ksplit > 0 ? a->ksplit : 1; }
   std::lock_guard<std::mutex> lk(g_prof_mu);

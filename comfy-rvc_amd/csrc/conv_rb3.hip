@@ -361,7 +361,7 @@ template <int CH, int KT, bool ACC, int WM>
 static void launch_rb3c(const Rb3Args& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_rb3_kernel<CH, KT, ACC, WM>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+  conv_launch(kern, grid, dim3(512), lds, s, a);
 }
 template <int CH, int KT, int WM>
 static void launch_rb3(const Rb3Args& a, bool acc, dim3 grid, size_t lds, hipStream_t s) {

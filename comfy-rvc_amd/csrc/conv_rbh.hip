@@ -279,7 +279,7 @@ template <int KT, bool ACC>
 static void launch_rbh2(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_rbh_kernel<KT, ACC>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+  conv_launch(kern, grid, dim3(512), lds, s, a);
 }
 template <int KT>
 static void launch_rbh(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {

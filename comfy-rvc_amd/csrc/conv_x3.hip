@@ -488,7 +488,7 @@ template <int WM, int WN, int AM, int AN, bool FUSE = false, bool XSPLIT = false
 static void launch_x3(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3_kernel<WM, WN, AM, AN, FUSE, XSPLIT, YSPLIT>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
+  conv_launch(kern, grid, dim3(WM * WN * 64), lds, s, a);
 }
 
 bool conv_x3_try(ConvArgsX& a0, int batch, hipStream_t s, double flops, bool dry) {

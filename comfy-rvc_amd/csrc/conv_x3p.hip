@@ -926,7 +926,7 @@ template <int AM, int AN, int KT, bool XSPLIT, bool YSPLIT, bool S2 = false>
 static void launch_x3p(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3p_kernel<AM, AN, KT, XSPLIT, YSPLIT, S2>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  conv_launch(kern, grid, dim3(256), lds, s, a);
 }
 template <int AM, int AN, int KT>
 static void launch_x3p_io(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -981,7 +981,7 @@ template <int AM, int AN, int C2D = 0>
 static void launch_x3g(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3g_kernel<AM, AN, C2D>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  conv_launch(kern, grid, dim3(256), lds, s, a);
 }
 
 // k = 1 convolutions (GEMMs) on the pipelined kernel: fp32 [K][N] input, K a multiple of 64 and >= 128.  Small grids are split over K
@@ -1036,7 +1036,7 @@ template <int KT, int WM>
 static void launch_x3pf(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3pf_kernel<KT, WM>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  conv_launch(kern, grid, dim3(256), lds, s, a);
 }
 // a: the fused pair's arguments as conv_x3_pair_try prepared them (C = 32: 256 intermediate columns per tile; C = 64: 128).  false: not
 // this kernel's geometry.

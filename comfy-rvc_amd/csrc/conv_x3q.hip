@@ -571,7 +571,7 @@ template <int AM, int AN, int KT, int R, bool XSPLIT, bool YSPLIT, bool RADD, bo
 static void launch_x3q(const ConvArgsX& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_x3q_kernel<AM, AN, KT, R, XSPLIT, YSPLIT, RADD, H2>;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  conv_launch(kern, grid, dim3(256), lds, s, a);
 }
 template <int AM, int AN, int KT, int R>
 static void launch_x3q_io(const ConvArgsX& a, int mode, dim3 grid, size_t lds, hipStream_t s) {

@@ -633,7 +633,7 @@ static void launch_x3s(const GemmSArgs& a, unsigned blocks, hipStream_t s) {
   auto kern = conv_x3s_kernel<AM, AN, RS, UC>;
   constexpr size_t lds = (size_t)RS * UC * (64 * AM + 64 * AN) * 64;
   RVC_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+  conv_launch(kern, dim3(blocks), dim3(256), lds, s, a);
 }
 // The register-direct reduction loop (round 5: bit-identical to the ring, neutral in the pipeline, profiles/r5_exp_x3s_direct.txt) exists in
 // -DRVC_EXPERIMENTS builds only: the product library neither instantiates nor reaches it.
