@@ -36,7 +36,7 @@ CLIP_SECONDS = 30.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table, "Peak BF16/FP16 MFMA" dense
 HBM_PEAK_BPS = 8.0e12              # same guide, HBM3E 8 TB/s (6.3 TB/s achievable)
-PMC_TRAFFIC_FILE = os.path.join("profiles", "r6z_pmc_traffic.json")      # (fallback only: --no-traffic, N > 1 or no rocprofv3)
+PMC_TRAFFIC_FILE = os.path.join("profiles", "r6zz_pmc_traffic.json")      # (fallback only: --no-traffic, N > 1 or no rocprofv3)
 MAX_LINE_BYTES = 6144              # the driver parses ONE JSON line from stdout; round 4's 17.9 KB line was not parsed
 
 
