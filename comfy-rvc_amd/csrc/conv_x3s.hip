@@ -44,6 +44,7 @@ struct GemmSArgs {
   int ymargin;                              // output image: position n lives at row ymargin + n (= margin except for the swapped product)
   int zero_tail;                            // rows >= Co of the last stored 16-row chunk are written as zeros (swapped product: keys past the end)
   int row_fast;                             // tile numbering inside an XCD's run: 1 = row tiles fastest (the XCD owns a column range), 0 = column tiles fastest
+  int ydeint;                               // > 0: output image de-interleaved for a stride-2 consumer - position n at row ymargin + (n >> 1) + (n & 1) ydeint
   int seg2_u, seg2_soff;                    // units >= seg2_u read a SECOND image (same rows per plane, same margin) at byte offset seg2_soff of Xs, one tap of offset 0 per
                                             // chunk: two products over one accumulator; INT_MAX: none
 };
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256, x3s_wgs(AM, AN, RS, DIRECT)) void conv_x3s_ker
       for (int an = 0; an < AN; ++an) {
         const int n = n0 + (wn * AN + an) * 32 + li;
         const int mb = co0 + (wm * AM + am) * 32;
-        const long long pos = (long long)n + p.ymargin;
+        const long long pos = p.ydeint > 0 ? (long long)p.ymargin + (n >> 1) + (long long)(n & 1) * p.ydeint : (long long)n + p.ymargin;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
           unsigned hA[2], lA[2], hB[2], lB[2];
@@ -770,6 +771,17 @@ bool conv_x3s_eligible(const ConvLayer& L) {
   return L.k <= 16 && L.pad == (L.k - 1) / 2 * L.dil && (L.k & 1) == 1;        // 1-D "same" convolution, taps as row offsets of the image
 }
 
+SplitGeom split_geom_s2(int k, long long Tin) {
+  SplitGeom g; g.ktaps = k; g.s2_h = split_s2_h(Tin); g.margin = kSplitMargin; g.padw = 0;
+  RVC_REQUIRE(k >= 1 && k <= 16, "split_geom_s2: at most 16 taps");
+  for (int t = 0; t < k; ++t) g.toff[t] = (t & 1) * g.s2_h + (t >> 1);
+  return g;
+}
+bool conv_x3s_s2_eligible(const ConvLayer& L) {
+  return conv_x3_enabled() && L.Wx_ != nullptr && L.mode == 1 && L.stride == 2 && L.pad == 0 && L.dil == 1 && L.groups == 1 && L.tconv_u == 0 && L.up2 == 0 &&
+         (L.Ci & 15) == 0 && (L.Co & 15) == 0 && L.k >= 2 && L.k <= 16 && L.seg2_chunks == 0;
+}
+
 SplitGeom split_geom_2d(int Wd, int KH, int KW, int PH, int PWL) {
   SplitGeom g; g.padw = Wd + 2; g.ktaps = KH * KW;
   RVC_REQUIRE(g.ktaps <= 16 && PWL <= 1 && KW - 1 - PWL <= 1, "split_geom_2d: at most one pad column on each side");
@@ -783,7 +795,8 @@ SplitGeom split_geom_2d(int Wd, int KH, int KW, int PH, int PWL) {
 
 void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
                   const SplitGeom* geom) {
-  RVC_REQUIRE(conv_x3s_eligible(L), "conv_x3s_run: layer without a bf16x3 weight image or not a stride-1 'same' geometry");
+  const bool s2 = geom != nullptr && geom->s2_h > 0;
+  RVC_REQUIRE(s2 ? conv_x3s_s2_eligible(L) : conv_x3s_eligible(L), "conv_x3s_run: layer without a bf16x3 weight image or not a stride-1 'same' (stride-2 'valid' with a de-interleaved image) geometry");
   SplitGeom g1;
   if (!geom) {
     RVC_REQUIRE(L.mode == 1, "conv_x3s_run: a 2-D layer needs its padded-image geometry");
@@ -792,14 +805,20 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
     geom = &g1;
   }
   RVC_REQUIRE(geom->ktaps == L.ktaps || (L.mode == 1 && geom->ktaps == L.k), "conv_x3s_run: geometry and layer disagree about the taps");
+  if (s2) {
+    // (T = output positions; the taps reach rows margin .. margin + s2_h + T of a plane - all inside the producer's rows or the untouched gap between the planes, whose columns are not stored)
+    RVC_REQUIRE(Xs != nullptr && xsTp >= geom->margin + 2LL * geom->s2_h + 704 && (long long)T + 1 <= geom->s2_h, "conv_x3s_run: de-interleaved input image missing or too short");
+  } else {
   int maxoff = L.mode == 1 ? std::max(L.pad, (L.k - 1) * L.dil - L.pad) : 0;
   for (int t = 0; t < geom->ktaps && t < 16; ++t) maxoff = std::max(maxoff, std::abs(geom->toff[t]));
   RVC_REQUIRE(geom->margin >= maxoff && geom->margin >= kSplitMargin, "conv_x3s_run: image margin smaller than the largest tap offset");
   RVC_REQUIRE(Xs != nullptr && xsTp >= geom->margin + T + 704, "conv_x3s_run: split-resident input image missing or too short (margin + T + 704 rows per plane)");
+  }
   RVC_REQUIRE(Y != nullptr || e.ys_out != nullptr, "conv_x3s_run: no output");
   RVC_REQUIRE(e.pre_act == ACT_NONE && !e.accumulate && !e.tout_limit && !e.xs_in, "conv_x3s_run: unsupported epilogue option");
   RVC_REQUIRE(e.act == ACT_NONE || e.act == ACT_LRELU || e.act == ACT_RELU || e.act == ACT_GELU, "conv_x3s_run: activation must be identity / (leaky) ReLU / GELU");
-  RVC_REQUIRE(!e.ys_out || (e.ys_tp >= geom->margin + T + 704 && (L.Co & 15) == 0), "conv_x3s_run: split output image too short or Co not a multiple of 16");
+  RVC_REQUIRE(!e.ys_out || ((e.ys_deint_h > 0 ? (e.ys_tp >= geom->margin + 2LL * e.ys_deint_h + 704 && (T + 1) / 2 + 1 <= e.ys_deint_h) : e.ys_tp >= geom->margin + T + 704) && (L.Co & 15) == 0),
+              "conv_x3s_run: split output image too short or Co not a multiple of 16");
   RVC_REQUIRE((double)L.groups * L.Co * (double)(Y ? ldY : 1) * 4.0 < 2147483648.0 && (double)L.groups * L.Co * (double)e.ldR * 4.0 < 2147483648.0, "tensor extent exceeds 32-bit buffer addressing");
   const int G = L.mode == 1 ? L.groups : 1;
   RVC_REQUIRE(L.seg2_chunks == 0 || (G == 1 && geom->seg2_off > 0), "conv_x3s_run: a layer with an appended product needs its second image");
@@ -812,10 +831,11 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.wx_bytes = (unsigned)wx_bytes; a.xs_bytes = (unsigned)xs_bytes;
   a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps + L.seg2_chunks;
   a.seg2_u = L.seg2_chunks ? L.Ci / 16 * geom->ktaps : 0x7fffffff; a.seg2_soff = (int)geom->seg2_off;
-  a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw;
+  a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw; a.ydeint = e.ys_out ? e.ys_deint_h : 0;
   a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
   for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
   a.tdil = L.mode == 1 ? L.dil : 1; a.tpad = L.mode == 1 ? L.pad : 0;
+  if (s2) { a.tdil = 1; a.tpad = 0; }
   a.groups = G; a.co_g = L.Co; a.cig_chunks = L.Ci / 16; a.wg_bytes = (unsigned)((double)(L.Ci / 16) * geom->ktaps * 4.0 * (double)L.CoPx * 16.0);
   a.bias = e.bias_override ? e.bias_override : L.bd_; a.R = e.R; a.ldR = e.ldR; a.Y = Y; a.ldY = ldY; a.Ys = e.ys_out; a.ysTp = e.ys_tp;
   a.act = e.act; a.act_slope = e.act_slope; a.act_before_res = e.act_before_res; a.out_scale = e.out_scale;
@@ -844,7 +864,7 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   x3s_dispatch(a, AM, AN, blocks, s);
   if (tk.on) {
     ConvArgsX pa{};
-    pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = geom->ktaps; pa.kreal = geom->ktaps; pa.dil = L.mode == 1 ? L.dil : 1; pa.stride = 1; pa.Tin = T; pa.Tout = T;
+    pa.Ci = L.Ci; pa.Co = L.Co; pa.ktaps = geom->ktaps; pa.kreal = geom->ktaps; pa.dil = L.mode == 1 ? L.dil : 1; pa.stride = s2 ? 2 : 1; pa.Tin = T; pa.Tout = T;
     pa.Wd = geom->padw > 0 ? geom->padw - 2 : 0; pa.ksplit = S;
     pa.R = e.R; pa.X = nullptr;
     // algorithmic bytes: the input image (4 B per element, like fp32), the outputs that are written, the residual, the weights

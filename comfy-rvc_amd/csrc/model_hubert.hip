@@ -142,6 +142,31 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
   }
   // ---- feature encoder
   static const bool fuse0 = (exp_int("RVC_HUBERT_FUSE0", 1) != 0);
+  // Layers 1 .. 6 (k = 3 / 2, stride 2, no padding) on the split-resident GEMM: every layer's output is written by its producer's epilogue as the bf16 hi / lo
+  // image of the next one, DE-INTERLEAVED (even | odd positions), so that a stride-2 tap is a row offset and no layer converts its input per tile; the exact-erf
+  // GELU sits in the epilogue (the pipelined kernel ran it as a second pass over the tensor).  RVC_HUBERT_S2=0: the fp32 path on conv_x3p_kernel / conv_x3_kernel.
+  static const bool s2_on = (exp_int("RVC_HUBERT_S2", 1) != 0);
+  bool s2 = s2_on && fuse0 && conv_x3_enabled();
+  for (int i = 1; i < 7 && s2; ++i) s2 = conv_x3s_s2_eligible(H->conv[i]) && Tc[i + 1] >= 1;
+  float* feat = nullptr;
+  if (s2) {
+    unsigned char* imgA = A.alloc<unsigned char>(split_s2_bytes(512, Tc[1]));
+    unsigned char* imgB = A.alloc<unsigned char>(split_s2_bytes(512, Tc[2]));
+    double* c0part = A.alloc<double>(hubert_conv0_scratch_doubles(512, Tc[1]));
+    float* c0stat = A.alloc<float>(1024);
+    feat = A.alloc<float>((size_t)512 * Tc[7]);
+    if (!dry) {
+      hubert_conv0_gn_gelu_img(s, audio, L, H->w0.p, H->gn_g.p, H->gn_b.p, 512, Tc[1], 1e-5f, imgA, split_s2_tp(Tc[1]), kSplitMargin, split_s2_h(Tc[1]), c0part, c0stat);
+      unsigned char* in_s = imgA; unsigned char* out_s = imgB;
+      for (int i = 1; i < 7; ++i) {
+        const SplitGeom g = split_geom_s2(kKern[i], Tc[i]);
+        ConvEpilogue Eg; Eg.act = ACT_GELU;
+        if (i < 6) { Eg.ys_out = out_s; Eg.ys_tp = split_s2_tp(Tc[i + 1]); Eg.ys_deint_h = split_s2_h(Tc[i + 1]); }
+        conv_x3s_run(H->conv[i], s, in_s, split_s2_tp(Tc[i]), Tc[i + 1], i < 6 ? nullptr : feat, Tc[i + 1], Eg, &g);
+        std::swap(in_s, out_s);      // ping-pong inside the two largest images (each layer's output is half its input)
+      }
+    }
+  } else {
   float* fr = fuse0 ? nullptr : A.alloc<float>((size_t)10 * Tc[1]);
   float* c0 = A.alloc<float>((size_t)512 * Tc[1]);
   float* c1 = A.alloc<float>((size_t)512 * Tc[2]);
@@ -161,7 +186,9 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
     if (!dry) { ConvEpilogue Eg; Eg.act = ACT_GELU; conv1d_run(H->conv[i], s, in, Tc[i], Tc[i], outb, Tc[i + 1], Eg); }
     std::swap(in, outb);      // ping-pong inside the two largest buffers (each layer's output is smaller than its input)
   }
-  float* feat = in;           // [512][T]
+  feat = in;
+  }
+  // feat: [512][T]
   if (taps) tap(taps->conv_stack, feat, (size_t)512 * T);
   // Split-resident GEMM path (conv_x3s.hip): the activations that feed a k = 1 projection live as the bf16 hi / lo image the kernel stages,
   // written by their producers (LayerNorm, the attention's epilogue, FFN1's GELU epilogue); the fp32 copy is kept only where a residual or

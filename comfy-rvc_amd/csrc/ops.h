@@ -10,6 +10,9 @@ void wn_gate_split(hipStream_t s, const float* a, const float* g, unsigned char*
 // evaluated twice instead of being stored: ops.hip).  partial: hubert_conv0_scratch_doubles(C, T1) doubles, stat: 2 C floats.
 void hubert_conv0_gn_gelu(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
                           float* out, long long ld, double* partial, float* stat);
+// the same, the result written only as the DE-INTERLEAVED bf16 hi / lo image a stride-2 layer on the split-resident GEMM reads (split_geom_s2; H = split_s2_h(T1), tp = split_s2_tp(T1))
+void hubert_conv0_gn_gelu_img(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
+                              unsigned char* img, long long tp, int margin, int H, double* partial, float* stat);
 size_t hubert_conv0_scratch_doubles(int C, int T1);
 void layernorm_c_split(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, unsigned char* img, long long tp, int margin,
                        int C, int T, long long ld, float eps);

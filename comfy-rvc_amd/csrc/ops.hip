@@ -297,6 +297,71 @@ __global__ __launch_bounds__(256) void hubert_conv0_apply_kernel(const float* __
     }
   }
 }
+// The same apply pass writing the bf16 hi / lo image of the output, DE-INTERLEAVED for the stride-2 layer that reads it (rvc_internal.h split_geom_s2: position t at
+// row margin + (t >> 1) + (t & 1) H): a thread owns 4 positions and walks the channels eight at a time - one 16-byte row of the hi and of the lo plane per step.
+__global__ __launch_bounds__(256) void hubert_conv0_apply_img_kernel(const float* __restrict__ audio, long long L, const float* __restrict__ w, int C, int T1,
+                                                                     const float* __restrict__ stat, const float* __restrict__ beta, unsigned char* __restrict__ img,
+                                                                     long long tp, int margin, int H) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  __shared__ float xs[kC0T * kC0S + kC0K];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * kC0T, c0 = blockIdx.y * kC0C;
+  const long long a0 = (long long)t0 * kC0S;
+  for (int i = tid; i < kC0T * kC0S + kC0K; i += 256) xs[i] = (a0 + i < L) ? audio[a0 + i] : 0.f;
+  __syncthreads();
+  float x[4][kC0K];
+  bool ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tl = tid + 256 * j;
+    ok[j] = t0 + tl < T1;
+#pragma unroll
+    for (int k = 0; k < kC0K; ++k) x[j][k] = xs[tl * kC0S + k];
+  }
+  for (int cg = 0; cg < kC0C; cg += 8) {
+    const int cb = c0 + cg;                                   // eight channels = one half of a 16-channel chunk (C is a multiple of 16: host)
+    if (cb >= C) break;
+    float v[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cb + e;
+      const float* wc = w + (long long)c * kC0K;
+      const float mean = stat[2 * c], sc = stat[2 * c + 1], b = beta[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < kC0K; ++k) a = fmaf(wc[k], x[j][k], a);
+        v[j][e] = gelu_bf(fmaf(a - mean, sc, b));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!ok[j]) continue;
+      u32x4_t hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const __bf16 ah = (__bf16)v[j][2 * q], bh = (__bf16)v[j][2 * q + 1];
+        const __bf16 al = (__bf16)(v[j][2 * q] - (float)ah), bl = (__bf16)(v[j][2 * q + 1] - (float)bh);
+        hi[q] = (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+        lo[q] = (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+      }
+      const int t = t0 + tid + 256 * j;
+      const int chunk = cb >> 4, half = (cb >> 3) & 1;
+      unsigned char* row = img + (((long long)chunk * 4 + half) * tp + margin + (t >> 1) + (long long)(t & 1) * H) * 16;
+      *reinterpret_cast<u32x4_t*>(row) = hi;
+      *reinterpret_cast<u32x4_t*>(row + tp * 32) = lo;
+    }
+  }
+}
+void hubert_conv0_gn_gelu_img(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
+                              unsigned char* img, long long tp, int margin, int H, double* partial, float* stat) {
+  RVC_REQUIRE((C & 15) == 0 && (T1 + 1) / 2 + 1 <= H && tp >= margin + 2LL * H, "hubert_conv0_gn_gelu_img: image geometry");
+  const int stiles = (T1 + kC0ST - 1) / kC0ST, tiles = (T1 + kC0T - 1) / kC0T;
+  hipLaunchKernelGGL(hubert_conv0_stats_kernel, dim3((unsigned)stiles, (unsigned)((C + 255) / 256)), dim3(256), 0, s, audio, L, w, C, T1, partial);
+  hipLaunchKernelGGL(hubert_conv0_reduce_kernel, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, partial, stiles, C, T1, gamma, eps, stat);
+  hipLaunchKernelGGL(hubert_conv0_apply_img_kernel, dim3((unsigned)tiles, (unsigned)((C + kC0C - 1) / kC0C)), dim3(256), 0, s, audio, L, w, C, T1, stat, beta, img, tp, margin, H);
+}
 void hubert_conv0_gn_gelu(hipStream_t s, const float* audio, long long L, const float* w, const float* gamma, const float* beta, int C, int T1, float eps,
                           float* out, long long ld, double* partial, float* stat) {
   const int stiles = (T1 + kC0ST - 1) / kC0ST, tiles = (T1 + kC0T - 1) / kC0T;

@@ -113,6 +113,7 @@ struct ConvEpilogue {
   // and copied straight into LDS by the consumer (no conversion, no registers).  xs_in replaces X, ys_out replaces Y.
   const unsigned char* xs_in = nullptr; long long xs_tp = 0;
   unsigned char* ys_out = nullptr; long long ys_tp = 0; float ys_slope = 1.f;
+  int ys_deint_h = 0;                     // conv_x3s_run only: the output image is written de-interleaved for a stride-2 consumer (split_s2_h of the output length)
   // fp16x2 arithmetic (conv_x3q.hip, H2) for BOTH halves of a ResBlock pair: the intermediate image is fp16 hi / lo and each layer multiplies with its
   // one-plane fp16 weight image; only valid when conv1d_pair_h2_eligible(c1, c2, T) said so (no other kernel reads that image format)
   int h2 = 0;
@@ -177,10 +178,19 @@ bool conv_x3_enabled();                       // bf16x3 kernels not switched off
 // producers keep the margins zero).  2-D convolutions run over PADDED images: row pitch W + 2 with a zero column on either side, position
 // p = h (W + 2) + w + 1, T = H (W + 2); the kernel writes zeros into the pad columns of its outputs (SplitGeom from split_geom_2d).
 struct SplitGeom { int ktaps = 1; int toff[16] = {0}; int padw = 0; int margin = kSplitMargin;
-                   long long seg2_off = 0; };   // byte offset (from the first image, < 2 GiB, same rows per plane and margin) of the second image of a layer with seg2_chunks
+                   long long seg2_off = 0;      // byte offset (from the first image, < 2 GiB, same rows per plane and margin) of the second image of a layer with seg2_chunks
+                   int s2_h = 0; };             // > 0: stride-2 "valid" convolution over a DE-INTERLEAVED image (split_geom_s2): even positions at rows margin + p, odd ones at margin + s2_h + p   // byte offset (from the first image, < 2 GiB, same rows per plane and margin) of the second image of a layer with seg2_chunks
 // dst (a conv_x3s-eligible layer) += the k = 1 layer `extra` over a second input: the weight image of `extra` is appended as further units of dst's reduction
 void conv_layer_append_x3(ConvLayer& dst, const ConvLayer& extra);
 SplitGeom split_geom_2d(int Wd, int KH = 3, int KW = 3, int PH = 1, int PWL = 1);
+// Stride-2 convolutions without padding (HuBERT's feature encoder, modeling_hubert.py conv_layers 1 .. 6: k = 3 / 2) on the split-resident GEMM: the producer writes the
+// input image de-interleaved (ConvEpilogue::ys_deint_h / hubert_conv0_gn_gelu), so tap t of output p - input position 2 p + t - is row p + (t >> 1) of plane t & 1: a row
+// offset like every other tap.  H = rows between the two planes (split_s2_h(T_in)); the image has split_s2_tp(T_in) rows per plane.
+inline int split_s2_h(long long Tin) { return (int)(((Tin + 1) / 2 + 64 + 63) & ~63LL); }
+inline long long split_s2_tp(long long Tin) { return (kSplitMargin + 2LL * split_s2_h(Tin) + 704 + 63) & ~63LL; }
+inline size_t split_s2_bytes(int C, long long Tin) { return (size_t)(C / 16) * 2 * (size_t)split_s2_tp(Tin) * 32; }
+SplitGeom split_geom_s2(int k, long long Tin);
+bool conv_x3s_s2_eligible(const ConvLayer& L);
 bool conv_x3s_eligible(const ConvLayer& L);
 void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
                   const SplitGeom* geom = nullptr);
