@@ -624,6 +624,43 @@ void split_image_from_tm(hipStream_t s, const float* x, int C, int T, int M, uns
   RVC_REQUIRE((M & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "split_image_from_tm: rows of a multiple of 8 values, 16-byte aligned");
   hipLaunchKernelGGL(split_image_tm_kernel, dim3((T + 255) / 256, (C * M + 15) / 16 * 2), dim3(256), 0, s, x, C, T, M, img, tp);
 }
+// fp32 [C][T] <-> DE-INTERLEAVED image (split_geom_s2: position t at row margin + (t >> 1) + (t & 1) H): tests of the stride-2 path; in the models the producers' epilogues write it
+__global__ __launch_bounds__(256) void split_image_deint_kernel(const float* __restrict__ X, long long ldX, int C, int T, unsigned char* __restrict__ img, long long tp, int H) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int hp = blockIdx.y;
+  if (t >= T) return;
+  const float* x = X + (long long)(hp * 8) * ldX + t;
+  u32x4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = (hp * 8 + 2 * j) < C ? x[(long long)(2 * j) * ldX] : 0.f, b = (hp * 8 + 2 * j + 1) < C ? x[(long long)(2 * j + 1) * ldX] : 0.f;
+    unsigned h_, l_;
+    split2(a, b, h_, l_);
+    hi[j] = h_; lo[j] = l_;
+  }
+  unsigned char* row = img + (((long long)(hp >> 1) * 4 + (hp & 1)) * tp + kSplitMargin + (t >> 1) + (long long)(t & 1) * H) * 16;
+  *reinterpret_cast<u32x4*>(row) = hi;
+  *reinterpret_cast<u32x4*>(row + tp * 32) = lo;
+}
+__global__ __launch_bounds__(256) void unsplit_image_deint_kernel(const unsigned char* __restrict__ img, long long tp, int H, int C, int T, float* __restrict__ Y, long long ldY) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int hp = blockIdx.y;
+  if (t >= T) return;
+  const unsigned char* row = img + (((long long)(hp >> 1) * 4 + (hp & 1)) * tp + kSplitMargin + (t >> 1) + (long long)(t & 1) * H) * 16;
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(row), lo = *reinterpret_cast<const u32x4*>(row + tp * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = hp * 8 + 2 * j;
+    if (c < C) Y[(long long)c * ldY + t] = __uint_as_float(hi[j] << 16) + __uint_as_float(lo[j] << 16);
+    if (c + 1 < C) Y[(long long)(c + 1) * ldY + t] = __uint_as_float(hi[j] & 0xffff0000u) + __uint_as_float(lo[j] & 0xffff0000u);
+  }
+}
+void split_image_deint_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp, int H) {
+  hipLaunchKernelGGL(split_image_deint_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, X, ldX, C, T, img, tp, H);
+}
+void split_image_deint_to_f32(hipStream_t s, const unsigned char* img, long long tp, int H, int C, int T, float* Y, long long ldY) {
+  hipLaunchKernelGGL(unsplit_image_deint_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, img, tp, H, C, T, Y, ldY);
+}
 void split_image_to_f32(hipStream_t s, const unsigned char* img, long long tp, int C, int T, float* Y, long long ldY) {
   hipLaunchKernelGGL(unsplit_image_kernel, dim3((T + 255) / 256, (C + 15) / 16 * 2), dim3(256), 0, s, img, tp, C, T, Y, ldY);
 }

@@ -600,6 +600,34 @@ int rvc_op_conv1d_split(void* stream, const float* x, const float* w, const floa
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_conv1d_s2_split(void* stream, const float* x, const float* w, const float* bias, float* y, float* y_img_f32, int Ci, int Co, int T, int k, int act) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && y && Ci > 0 && Co > 0 && k >= 2 && T >= k, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, k, 2, 0, 1, 1); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr;
+  try {
+    RVC_REQUIRE(conv_x3s_s2_eligible(L), "layer not eligible for the stride-2 path of the split-resident kernel (Ci, Co multiples of 16)");
+    const int Tout = (T - k) / 2 + 1;
+    const SplitGeom g = split_geom_s2(k, T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_s2_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0xff, split_s2_bytes(Ci, T), s));      // (NaN patterns wherever the producer does not write: what a consumer reads there must not reach a stored column)
+    split_image_deint_from_f32(s, x, T, Ci, T, xs, split_s2_tp(T), g.s2_h);
+    ConvEpilogue e; e.act = act; e.act_slope = 0.1f;
+    if (y_img_f32) {
+      RVC_HIP_CHECK(hipMalloc(&ys, split_s2_bytes(Co, Tout)));
+      e.ys_out = ys; e.ys_tp = split_s2_tp(Tout); e.ys_deint_h = split_s2_h(Tout);
+    }
+    conv_x3s_run(L, s, xs, split_s2_tp(T), Tout, y, Tout, e, &g);
+    if (y_img_f32) split_image_deint_to_f32(s, ys, split_s2_tp(Tout), split_s2_h(Tout), Co, Tout, y_img_f32, Tout);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw; }
+  (void)hipFree(xs); if (ys) (void)hipFree(ys);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_conv2d_split(void* stream, const float* x, const float* w, const float* bias, const float* res, float* y, float* ysplit_f32, int Ci, int Co,
                         int H, int W, int act, int act_before_res, int ksplit, int am, int an) {
   RVC_TRY

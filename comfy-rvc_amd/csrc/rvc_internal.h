@@ -191,6 +191,8 @@ inline long long split_s2_tp(long long Tin) { return (kSplitMargin + 2LL * split
 inline size_t split_s2_bytes(int C, long long Tin) { return (size_t)(C / 16) * 2 * (size_t)split_s2_tp(Tin) * 32; }
 SplitGeom split_geom_s2(int k, long long Tin);
 bool conv_x3s_s2_eligible(const ConvLayer& L);
+void split_image_deint_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp, int H);      // (tests: in the models the producers' epilogues write the image)
+void split_image_deint_to_f32(hipStream_t s, const unsigned char* img, long long tp, int H, int C, int T, float* Y, long long ldY);
 bool conv_x3s_eligible(const ConvLayer& L);
 void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, long long xsTp, int T, float* Y, long long ldY, const ConvEpilogue& e,
                   const SplitGeom* geom = nullptr);

@@ -260,6 +260,12 @@ int rvc_op_gemm_split(void* stream, const float* x_dev, const float* w_host, con
  * (the first T positions), taps are row offsets tap * dil - pad into the zero-margined image. */
 int rvc_op_conv1d_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev, float* y_dev,
                         int Ci, int Co, int T, int k, int pad, int dil, int groups, int act, int act_before_res);
+/* Stride-2 Conv1d without padding on the split-resident kernel, the way HuBERT's feature-encoder layers 1 .. 6 run (transformers modeling_hubert.py HubertNoLayerNormConvLayer,
+ * k = 3 / 2, stride 2, through lib/infer_pack/loaders.py:55-61): the input is turned into the DE-INTERLEAVED bf16 hi / lo image (even | odd positions) a producer's epilogue
+ * would write, a tap is then a row offset; y_dev [Co][Tout] fp32, Tout = (T - k) / 2 + 1; y_img_f32_dev (or NULL): the same result read back from the de-interleaved OUTPUT
+ * image (what the next stride-2 layer stages).  Test / benchmark op. */
+int rvc_op_conv1d_s2_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_dev, float* y_img_f32_dev, int Ci, int Co, int T, int k,
+                           int act);
 /* Conv2d 3 x 3, pad 1 (reference lib/rmvpe.py:233-268 ConvBlockRes convolutions) on the same kernel over PADDED split-resident images (row pitch
  * W + 2, taps as row offsets): x_dev [Ci][H][W] plain fp32 is padded and split on the device, y = act(conv(x) + b) with the residual before
  * or after the activation, returned plain [Co][H][W]; ysplit_f32_dev as above (plain layout). */

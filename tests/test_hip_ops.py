@@ -761,6 +761,31 @@ def test_fp16x2_pair_whole_tensor_at_generator_lengths(L, pair_arith, Cc, k, d, 
         L.lib.rvc_conv1d_plan_destroy(pl)
 
 
+@pytest.mark.parametrize("Ci,Co,T,k,act", [(512, 512, 15999, 3, "gelu"), (512, 512, 16000, 3, "gelu"), (512, 512, 7999, 2, "gelu"), (512, 512, 8002, 2, "none"),
+                                           (64, 128, 1001, 3, "none"), (32, 48, 200, 3, "gelu"), (16, 32, 3, 3, "none"), (512, 512, 159999, 3, "gelu")])
+def test_conv1d_stride2_on_deinterleaved_image(L, Ci, Co, T, k, act):
+    """HuBERT's feature-encoder layers 1 .. 6 (Conv1d k = 3 / 2, stride 2, no padding, GELU; modeling_hubert.py conv_layers through lib/infer_pack/loaders.py:55-61) on the
+    split-resident GEMM: the input as a de-interleaved (even | odd positions) bf16 hi / lo image, a tap = a row offset, the exact-erf GELU in the epilogue; result as fp32
+    rows and as the de-interleaved image of the next layer - both against fp64 torch, odd and even lengths, the unwritten parts of the input image poisoned with NaN."""
+    g = torch.Generator().manual_seed(Ci + Co + T + k)
+    x = torch.randn(Ci, T, generator=g)
+    w = torch.randn(Co, Ci, k, generator=g) / np.sqrt(Ci * k); b = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv1d(x.double()[None], w.double(), b.double(), stride=2)[0]
+    if act == "gelu":
+        ref = F.gelu(ref)
+    Tout = ref.shape[1]
+    assert Tout == (T - k) // 2 + 1
+    xg = dev(x)
+    y, yi = torch.full((Co, Tout), float("nan")).cuda(), torch.full((Co, Tout), float("nan")).cuda()
+    L.check(L.lib.rvc_op_conv1d_s2_split(None, L.ptr(xg), L.ptr(w.contiguous().numpy()), L.ptr(b.numpy()), L.ptr(y), L.ptr(yi), Ci, Co, T, k, ACT[act]))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(yi).all())
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+    assert rel_err(yi.cpu().double(), ref) < 2e-5                  # (the image keeps hi + lo = 16 bits of mantissa: 4e-6 of each value)
+    err = (y.cpu().double() - ref).abs()
+    assert float(err[:, :8].max()) < 1e-4 * float(ref.abs().max()) and float(err[:, -8:].max()) < 1e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("Cc,k,T,scale,accum", [(32, 3, 270003, 1.0 / 3, True), (32, 3, 2 * 256 * 510, 1.0, False), (32, 7, 300001, 1.0 / 3, True), (32, 7, 2 * 256 * 506 + 2, 1.0 / 3, False),
                                                 (32, 11, 262144, 1.0 / 3, True), (32, 11, 2 * 256 * 502 + 1, 1.0, False), (32, 11, 1279200, 1.0 / 3, True),
                                                 # (32 channels: from two rounds of the PAIR kernel's 512 - (k - 1)-column tiles on - below that the chain runs in bf16x3)
