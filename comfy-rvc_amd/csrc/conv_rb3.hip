@@ -1,27 +1,36 @@
-// A whole ResBlock1 of the generator's 32-channel stage in ONE launch, fp16x2 arithmetic (gfx950 only).
+// A whole ResBlock1 of the generator's narrow stages in ONE launch, fp16x2 arithmetic (gfx950 only): all three ResBlocks (3 / 7 / 11 taps) of the 32-channel
+// stage, the 3- and 7-tap ResBlocks of the 64-channel stage.
 //
-//   x1 = x  + c2_0(lrelu(c1_0(lrelu(x )) + b))      (dilation d0)
-//   x2 = x1 + c2_1(lrelu(c1_1(lrelu(x1)) + b))      (dilation d1)
-//   x3 = x2 + c2_2(lrelu(c1_2(lrelu(x2)) + b))      (dilation d2)
+//   x1 = x  + c2_0(lrelu(c1_0(lrelu(x )) + b))      (dilation 1)
+//   x2 = x1 + c2_1(lrelu(c1_1(lrelu(x1)) + b))      (dilation 3)
+//   x3 = x2 + c2_2(lrelu(c1_2(lrelu(x2)) + b))      (dilation 5)
 //   y  = x3 * scale [+ y]                                          (reference lib/infer_pack/modules.py:295-308, models.py:555-560: xs += resblock(x); x = xs / 3)
 //
 // conv_rbh_kernel (conv_rbh.hip) runs ONE (c1, c2) pair per launch: every pair reads the 164 MB stage tensor twice (input tile + residual) and writes it
 // once, the third pair reads the running sum as well, and its two convolutions are 2 - 7 k cycles of a 17 - 24 k-cycle tile - the rest is the memory
 // path (profiles/r6c_rbh_phase_cycles.txt: "the next step is bytes, not scheduling").  Here the three pairs of a ResBlock stay in the workgroup:
-//   * a tile is 32 channels x 512 columns; wave w owns columns 64 w .. 64 w + 63 of EVERY convolution and of the fp32 residual stream, which never
-//     leaves its accumulator registers between pairs (x_i is the initial value of the next pair's second accumulator);
+//   * a tile is 32 channels x 512 columns (a wave owns 32 rows x 64 columns: one row block, two column blocks) or 64 channels x 256 columns (64 rows x 32
+//     columns: two row blocks, one column block); a wave owns its columns in EVERY convolution and in the fp32 residual stream, which never leaves its
+//     registers between pairs (the second convolution of a pair accumulates INTO x_i + b2: x_{i+1} with no copy);
 //   * convolutions are centred (column c reads c + (tap - P2) dil), so coordinates never shift and the residual needs no realignment; garbage creeps in
-//     from the tile edges by the halo of each convolution - HALO = P2 (d0 + d1 + d2 + 3) columns per side in total - and only the inner
-//     NO = 512 - 2 HALO columns are stored (488 / 440 / 392 at 3 / 7 / 11 taps): 5 - 31 % more matrix work for a third of the bytes;
+//     from the tile edges by the halo of each convolution - HALO = P2 (1 + 3 + 5 + 3) columns per side in total - and only the inner
+//     NO = tile - 2 HALO columns are stored (32 channels: 488 / 440 / 392 at 3 / 7 / 11 taps; 64 channels: 232 / 184 at 3 / 7): 5 - 39 % more matrix work for a
+//     third of the bytes (64 channels x 7 taps: a sixth - those pairs ran as two launches each with the intermediate image through HBM);
 //   * x is read ONCE, in the accumulator layout (it is the residual), and its leaky-ReLU'd fp16 hi / lo image is written to LDS from those registers -
 //     the pair kernel's second read of the tile is gone; the next tile's x is requested at the top of the tile and consumed a tile later, the previous
-//     output (ACC) under the last convolution: the barriers are LDS-only (lds_barrier), global requests stay in flight across the convolutions;
-//   * weights: one-plane fp16 images of the six layers, [unit][half][32 rows][16 B] = KT KiB per convolution x 2.  All six resident in LDS at 3 and 7
-//     taps (36 / 84 KiB); at 11 taps (132 KiB: does not fit beside the 72 KiB tile) the NEXT convolution's 22 KiB are fetched from L2 into registers
-//     under the current one and stored into the other of two LDS buffers before the barrier that precedes their use.
-// Numerics: operation for operation the chain of three conv_rbh_kernel launches (same unit order, lo term before hi term, fp32 accumulation, bias and
-// residual as the accumulator's initial value), so the result is BIT-IDENTICAL to it (tests/test_hip_ops.py::test_fused_resblock_matches_pair_chain).
-// LDS: weights + 1 KiB biases + 2 chunks x (hi | lo) x 2 halves x P rows x 16 B, P = 512 + 2 P2 dmax <= 562: 104 / 155 / 117 KiB.
+//     output (ACC) under or behind the last convolution: the barriers are LDS-only (lds_barrier), global requests stay in flight across the convolutions;
+//   * weights: one-plane fp16 images of the six layers, [unit][half][C rows][16 B].  WM = 0: all six resident in LDS (32 channels, 3 / 7 taps: 36 / 84 KiB).
+//     WM = 1: the NEXT convolution's rows are fetched from L2 into registers under the current one and stored into the other of two LDS buffers before the
+//     barrier that precedes their use (32 channels x 11 taps: 2 x 22 KiB; 64 x 3: 2 x 24 KiB).  WM = 2: ONE buffer (64 channels x 7 taps: 56 KiB beside the 82 KiB
+//     image) - the rows travel the same way and are stored in the image interval behind the convolution, between the barrier that retires it and the one that
+//     opens the next;
+//   * the last stage's noise branch (Conv1d(1, 32, 1) of the harmonic source) can be added where x is read (Rb3Args::nsrc): noise_add_kernel's pass disappears.
+// Numerics: at 32 channels operation for operation the chain of three conv_rbh_kernel launches (same unit order, lo term before hi term, fp32 accumulation, bias and
+// residual as the accumulator's initial value), so the result is BIT-IDENTICAL to it (tests/test_hip_ops.py::test_fused_resblock_matches_pair_chain); at 64 channels
+// the same arithmetic against fp64 (the pairs it replaces ran in bf16x3 / as split pairs).
+// Where the time goes (profiles/r6f_rb3_resblock.txt): the fp16 hi / lo conversion of every image (6.5 VALU instructions per element) costs as much issue time as
+// the MFMAs at 3 taps, and the two waves of a SIMD run their phases one after the other - a variant with two phase-shifted groups of waves did not overlap them.
+// LDS: weights + 2 KiB biases / noise + (C / 16) chunks x (hi | lo) x 2 halves x P rows x 16 B, P = tile + 2 x 5 P2: 105 / 157 / 118 KiB (32 ch), 117 / 142 KiB (64 ch).
 #include "conv_x3_dev.h"
 
 namespace rvc {
