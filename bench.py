@@ -659,6 +659,18 @@ def roofline_from_rows(rows, traffic, traffic_src):
     roofline = ents[0][0]
     # a one-line table of the rest (name, ms per clip, fraction of its own bound) so that the line still shows where the other time goes
     roofline["others"] = [[e["kernel"].replace("rvc::", "").replace("_kernel", ""), e["kernel_ms_per_clip"], e["bound"], e["frac"]] for e, _ in ents[1:8]]
+    # the generator's Conv1d kernels taken together (BASELINE.json's "fraction of the conv1d roofline"): their algorithmic FLOPs over their summed launch time, priced against
+    # the dense 16-bit MFMA peak divided by the FLOP-weighted matrix instructions per product of their launches (2 fp16x2, 3 bf16x3)
+    fam = [(n, rs) for n, rs in kernels.items() if n in ("conv_x3q_kernel", "conv_rb3_kernel", "conv_rbh_kernel", "conv_x3pf_kernel", "conv_x3p_kernel")]
+    if fam:
+        f_us = sum(float(r["us"]) for _, rs in fam for r in rs)
+        f_gf = sum(float(r["alg_gflop"]) for _, rs in fam for r in rs)
+        f_terms = sum(float(r.get("mfma_per_product", 3) or 3) * float(r["alg_gflop"]) for _, rs in fam for r in rs) / max(f_gf, 1e-9)
+        f_peak = BF16_MFMA_PEAK_TFLOPS / f_terms
+        roofline["conv1d_family"] = {"kernels": sorted(n.replace("_kernel", "") for n, _ in fam), "launches_per_clip": sum(len(rs) for _, rs in fam), "ms_per_clip": round(f_us / 1e3, 3),
+                                     "algorithmic_tflop_per_clip": round(f_gf / 1e3, 3), "tflops": round(f_gf / f_us * 1e3, 1) if f_us > 0 else 0.0,
+                                     "mfma_per_product": round(f_terms, 3), "peak": round(f_peak, 1), "frac": round(f_gf / f_us * 1e3 / f_peak, 4) if f_us > 0 else 0.0,
+                                     "frac_if_priced_as_bf16x3": round(f_gf / f_us * 1e3 / x3_peak, 4) if f_us > 0 else 0.0}
     roofline["all_conv_kernels_ms_per_clip"] = round(sum(e["kernel_ms_per_clip"] for e, _ in ents), 3)
     roofline["all_conv_kernels_tflops"] = round(sum(e["algorithmic_tflop_per_clip"] for e, _ in ents) / max(roofline["all_conv_kernels_ms_per_clip"], 1e-9) * 1e3, 1)
     return roofline, {"kernels": [d for _, d in ents]}
