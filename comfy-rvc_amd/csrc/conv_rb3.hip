@@ -40,8 +40,7 @@ struct Rb3Args {
   const unsigned char* W[6];      // c1_0, c2_0, c1_1, c2_1, c1_2, c2_2: one-plane fp16 images [chunk][tap][half][CoPx rows][8 ch]
   const float* B[6];              // their biases (or null)
   int CoPx;
-  int dil[3];
-  int T, P, M, halo, NO;          // sequence length; staged rows incl. the two margins of M rows; columns lost per side; columns stored per tile
+  int T, halo, NO;                // sequence length; columns lost per side of a tile; columns stored per tile (dilations 1 / 3 / 5, the margins and the rows of the image are compiled in)
   float pre_slope, mid_slope, out_scale;
   // NSF noise branch of the last generator stage folded into the read of x (reference models.py GeneratorNSF.forward: x = ups(x) + noise_convs[i](har), the
   // last stage's Conv1d(1, C, 1)): x[c][t] + fmaf(nw[c], nsrc[t], nb[c]) - the same operations as noise_add_kernel<1> (ops.hip), whose pass over the
@@ -80,7 +79,6 @@ __global__ __launch_bounds__(512, 2) void conv_rb3_kernel(const Rb3Args p) {
   // WM: where the six convolutions' weights live.  0: all resident in LDS.  1: two LDS buffers - the next convolution's rows travel through registers under the
   // current convolution and are stored into the other buffer behind it.  2: ONE LDS buffer (64 channels x 7 taps: 56 KiB per convolution) - the rows
   // travel the same way but are stored in the image interval that follows (after the barrier that retires the convolution, before the one that opens the next)
-  constexpr bool RESIDENT = WM == 0;
   constexpr int NWB = WM == 0 ? 6 : (WM == 1 ? 2 : 1);
   constexpr int WQ = (WROWS + NW * 64 - 1) / (NW * 64);      // rows per thread when a convolution's weights travel through registers
   constexpr int xplane = P * 32, xhalf = P * 16, xbuf = 2 * xplane;
@@ -411,9 +409,8 @@ bool conv_rb3_try(const ConvLayer* const* c1, const ConvLayer* const* c2, hipStr
   for (int i = 0; i < 3; ++i) {
     a.W[2 * i] = reinterpret_cast<const unsigned char*>(c1[i]->Wh_); a.W[2 * i + 1] = reinterpret_cast<const unsigned char*>(c2[i]->Wh_);
     a.B[2 * i] = c1[i]->bd_; a.B[2 * i + 1] = c2[i]->bd_;
-    a.dil[i] = c1[i]->dil;
   }
-  a.T = T; a.P = P; a.M = M; a.halo = halo; a.NO = NO;
+  a.T = T; a.halo = halo; a.NO = NO;
   a.pre_slope = pre_slope; a.mid_slope = pre_slope; a.out_scale = out_scale;
   RVC_REQUIRE((nsrc == nullptr) == (nw == nullptr) && (nsrc == nullptr) == (nb == nullptr), "conv_rb3_try: the noise branch is source, weights and biases together");
   a.nsrc = nsrc; a.nw = nw; a.nb = nb;
