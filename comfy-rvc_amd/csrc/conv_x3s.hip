@@ -44,6 +44,8 @@ struct GemmSArgs {
   int ymargin;                              // output image: position n lives at row ymargin + n (= margin except for the swapped product)
   int zero_tail;                            // rows >= Co of the last stored 16-row chunk are written as zeros (swapped product: keys past the end)
   int row_fast;                             // tile numbering inside an XCD's run: 1 = row tiles fastest (the XCD owns a column range), 0 = column tiles fastest
+  unsigned char* Vt; long long vtTp;        // row tiles from vt_row0 on (the v rows of a fused q | k | v projection) are written TRANSPOSED, as the V^T image of the attention
+  int vt_row0, vt_rows;                     // ([16-position chunk][hi | lo][8-position half][kSplitMargin + row - vt_row0][8 positions], like conv_x3s_run_swapped); INT_MAX: none
   int ydeint;                               // > 0: output image de-interleaved for a stride-2 consumer - position n at row ymargin + (n >> 1) + (n & 1) ydeint
   int seg2_u, seg2_soff;                    // units >= seg2_u read a SECOND image (same rows per plane, same margin) at byte offset seg2_soff of Xs, one tap of offset 0 per
                                             // chunk: two products over one accumulator; INT_MAX: none
@@ -491,7 +493,48 @@ __global__ __launch_bounds__(256, x3s_wgs(AM, AN, RS, DIRECT)) void conv_x3s_ker
       }
     }
   }
-  if (p.Y) {
+  const bool vt_tile = co0 >= p.vt_row0;                       // (tile-uniform: vt_row0 is a multiple of the tile height)
+  if constexpr (!DIRECT) {
+  if (vt_tile) {
+    // The v rows of a fused q | k | v projection: the attention's P V product reduces over keys, so it wants V with 8 consecutive POSITIONS per 16-byte row.  A lane
+    // holds one position (column) of 16 channels; the 32 x 32 block goes through a wave-private 4 KiB of the (now dead) ring as fp32 [channel][position] and comes
+    // back as (channel, 8 positions) items, two per lane.  Positions past T are written as zeros (keys past the end), like conv_x3s_run_swapped's zero_tail.
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    unsigned char* tl = smem3s + 1024 + wave * 4096;
+    const int Tc16 = (p.T + 15) & ~15;
+#pragma unroll
+    for (int am = 0; am < AM; ++am)
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int nb = n0 + (wn * AN + an) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jj = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          *reinterpret_cast<float*>(tl + (jj * 32 + li) * 4) = (nb + li < p.T) ? acc[am][an][r] : 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int item = lane + 64 * it, jj = item >> 2, tg = item & 3;
+          const f32x4v va = *reinterpret_cast<const f32x4v*>(tl + (jj * 32 + tg * 8) * 4), vb = *reinterpret_cast<const f32x4v*>(tl + (jj * 32 + tg * 8 + 4) * 4);
+          u32x4 hi, lo;
+          unsigned h_, l_;
+          split2(va[0], va[1], h_, l_); hi[0] = h_; lo[0] = l_;
+          split2(va[2], va[3], h_, l_); hi[1] = h_; lo[1] = l_;
+          split2(vb[0], vb[1], h_, l_); hi[2] = h_; lo[2] = l_;
+          split2(vb[2], vb[3], h_, l_); hi[3] = h_; lo[3] = l_;
+          const int t0 = nb + tg * 8, j = co0 + (wm * AM + am) * 32 + jj - p.vt_row0;
+          if (t0 < Tc16 && j < p.vt_rows) {
+            unsigned char* row = p.Vt + ((((long long)(t0 >> 4)) * 4 + ((t0 >> 3) & 1)) * p.vtTp + kSplitMargin + j) * 16;
+            *reinterpret_cast<u32x4*>(row) = hi;
+            *reinterpret_cast<u32x4*>(row + p.vtTp * 32) = lo;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+  }
+  }
+  if (p.Y && !vt_tile) {
     const __amdgpu_buffer_rsrc_t yrs = make_rsrc(p.Y, (unsigned)(p.groups * p.co_g) * (unsigned)p.ldY * 4u);
 #pragma unroll
     for (int am = 0; am < AM; ++am)
@@ -505,7 +548,7 @@ __global__ __launch_bounds__(256, x3s_wgs(AM, AN, RS, DIRECT)) void conv_x3s_ker
         }
       }
   }
-  if (p.Ys) {
+  if (p.Ys && !vt_tile) {
     if (p.zero_tail) {
 #pragma unroll
       for (int am = 0; am < AM; ++am)
@@ -869,6 +912,12 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps + L.seg2_chunks;
   a.seg2_u = L.seg2_chunks ? L.Ci / 16 * geom->ktaps : 0x7fffffff; a.seg2_soff = (int)geom->seg2_off;
   a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw; a.ydeint = e.ys_out ? e.ys_deint_h : 0;
+  a.vt_row0 = 0x7fffffff;
+  if (e.vt_out) {
+    RVC_REQUIRE(G == 1 && L.mode == 1 && e.vt_row0 > 0 && (e.vt_row0 & 127) == 0 && e.vt_row0 < L.Co && e.vt_tp >= kSplitMargin + (L.Co - e.vt_row0) && Y == nullptr && !e.R && !s2,
+                "conv_x3s_run: the transposed rows are the tail of an image-only k = 1 projection, from a multiple of 128 rows on");
+    a.Vt = e.vt_out; a.vtTp = e.vt_tp; a.vt_row0 = e.vt_row0; a.vt_rows = L.Co - e.vt_row0;
+  }
   a.padmagic = geom->padw > 0 ? (unsigned)((0x100000000ULL + (unsigned)geom->padw - 1) / (unsigned)geom->padw) : 0u;
   for (int t = 0; t < 16; ++t) a.toff[t] = t < geom->ktaps ? geom->toff[t] : 0;
   a.tdil = L.mode == 1 ? L.dil : 1; a.tpad = L.mode == 1 ? L.pad : 0;
@@ -929,7 +978,7 @@ void conv_x3s_run_swapped(const ConvLayer& L, int row0, int rows, hipStream_t s,
   GemmSArgs a{};
   a.Wx = Xs + (size_t)kSplitMargin * 16; a.CoPx = (int)xsTp; a.wx_bytes = (unsigned)xs_bytes - (unsigned)kSplitMargin * 16u;
   a.Xs = reinterpret_cast<const unsigned char*>(L.Wx_) + (size_t)row0 * 16; a.xsTp = L.CoPx; a.xs_bytes = (unsigned)wx_bytes - (unsigned)row0 * 16u;
-  a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1; a.seg2_u = 0x7fffffff;
+  a.Co = T; a.T = rows; a.nunits = L.Ci / 16; a.ktaps = 1; a.margin = 0; a.ymargin = kSplitMargin; a.zero_tail = 1; a.seg2_u = 0x7fffffff; a.vt_row0 = 0x7fffffff;
   a.groups = 1; a.co_g = T; a.cig_chunks = L.Ci / 16; a.tdil = 1;
   a.Ys = Ys; a.ysTp = ysTp; a.act = ACT_NONE; a.out_scale = 1.f;
   a.Y = Yrm; a.ldY = ldYrm;                                    // fp32 out[t][j], row-major (the GRU's input projection)

@@ -246,10 +246,17 @@ static void hubert_graph(Hubert* H, hipStream_t s, Arena& A, const float* audio,
         ConvEpilogue Er; Er.R = h; Er.ldR = T;
         if (gs) {
           if (ad) {
-            ConvLayer qkL = Y.qk; qkL.Co = 1536;                                 // the q and k rows of the 2304-row projection -> image only
-            ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
-            conv_x3s_run(qkL, s, hs, tp, T, nullptr, T, Eqk);
-            conv_x3s_run_swapped(Y.qk, 1536, 768, s, hs, tp, T, vt_s, attention_vt_tp(768));      // V^T image (v's bias after the attention)
+            static const bool qkv1 = (exp_int("RVC_QKV_FUSED", 1) != 0);
+            if (qkv1) {
+              // q | k | v in ONE launch: the q and k rows go to their image, the v rows through the transposing epilogue into the V^T image (v's bias after the attention)
+              ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp; Eqk.vt_out = vt_s; Eqk.vt_tp = attention_vt_tp(768); Eqk.vt_row0 = 1536;
+              conv_x3s_run(Y.qk, s, hs, tp, T, nullptr, T, Eqk);
+            } else {
+              ConvLayer qkL = Y.qk; qkL.Co = 1536;                               // the q and k rows of the 2304-row projection -> image only
+              ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
+              conv_x3s_run(qkL, s, hs, tp, T, nullptr, T, Eqk);
+              conv_x3s_run_swapped(Y.qk, 1536, 768, s, hs, tp, T, vt_s, attention_vt_tp(768));      // V^T image by the swapped product
+            }
             attention_split(s, qk_s, tp, 1536, 0, 48, vt_s, 12, 64, T, 1.f, Y.bv.p, nullptr, T, attn_s, tp);
           } else {
             conv_x3s_run(Y.qk, s, hs, tp, T, qk, T, E0);

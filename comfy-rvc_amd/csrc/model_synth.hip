@@ -297,10 +297,17 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
       for (int l = 0; l < S->n_layers; ++l) {
         EncLayer& e = S->enc[l];
         if (ad) {
-          ConvLayer qkL = e.qk; qkL.Co = 2 * C;                                   // the q and k rows of the 3 C-row projection -> image only
-          ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
-          conv_x3s_run(qkL, s, x_s, tp, T, nullptr, T, Eqk);
-          conv_x3s_run_swapped(e.qk, 2 * C, C, s, x_s, tp, T, vt_s, attention_vt_tp(C));
+          static const bool qkv1 = (exp_int("RVC_QKV_FUSED", 1) != 0);
+          if (qkv1 && ((2 * C) & 127) == 0) {
+            // q | k | v in ONE launch: q and k rows to their image, the v rows through the transposing epilogue into the V^T image
+            ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp; Eqk.vt_out = vt_s; Eqk.vt_tp = attention_vt_tp(C); Eqk.vt_row0 = 2 * C;
+            conv_x3s_run(e.qk, s, x_s, tp, T, nullptr, T, Eqk);
+          } else {
+            ConvLayer qkL = e.qk; qkL.Co = 2 * C;                                 // the q and k rows of the 3 C-row projection -> image only
+            ConvEpilogue Eqk; Eqk.ys_out = qk_s; Eqk.ys_tp = tp;
+            conv_x3s_run(qkL, s, x_s, tp, T, nullptr, T, Eqk);
+            conv_x3s_run_swapped(e.qk, 2 * C, C, s, x_s, tp, T, vt_s, attention_vt_tp(C));
+          }
           const unsigned char* ri = reinterpret_cast<const unsigned char*>(e.rel_img.p);
           // softmax(K^T Q + banded rel-k bias) V + bv + banded P . E_v, written as the image the out-projection stages
           attention_split(s, qk_s, tp, 2 * C, 0, C / 16, vt_s, H, kc, T, 1.f, e.bv.p, nullptr, T, attn_s, tp, 10, ri, ri + e.evt_off);

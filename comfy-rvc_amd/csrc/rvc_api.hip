@@ -429,6 +429,36 @@ int rvc_op_gemm_split_swapped(void* stream, const float* x, const float* w, floa
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_gemm_split_qkv(void* stream, const float* x, const float* w, const float* bias, float* y_img_f32, float* yt, int Ci, int Co, int T, int vt_row0) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && y_img_f32 && yt && Ci > 0 && Co > 0 && T > 0 && vt_row0 > 0 && vt_row0 < Co, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, w, bias, Co, Ci, 1, 1, 0, 1, 1); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr; unsigned char* vt = nullptr;
+  const int rows = Co - vt_row0;
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident kernel");
+    const long long tp = split_image_tp(T), vtp = attention_vt_tp(rows);
+    const size_t vbytes = attention_vt_bytes(rows, T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0xff, split_image_bytes(Ci, T), s));       // NaN patterns past T: the transposed rows past T must come out as zeros regardless
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes(vt_row0, T)));
+    RVC_HIP_CHECK(hipMalloc(&vt, vbytes));
+    RVC_HIP_CHECK(hipMemsetAsync(vt, 0xff, vbytes, s));
+    ConvEpilogue e; e.ys_out = ys; e.ys_tp = tp; e.vt_out = vt; e.vt_tp = vtp; e.vt_row0 = vt_row0;
+    conv_x3s_run(L, s, xs, tp, T, nullptr, T, e);
+    attention_vt_clear_tail(s, vt, rows, T);
+    split_image_to_f32(s, ys, tp, vt_row0, T, y_img_f32, T);                      // y_img_f32 [vt_row0][T]: the rows below vt_row0, from their image
+    split_image_to_f32(s, vt, vtp, (T + 63) / 64 * 64, rows, yt, rows);            // yt [ceil64(T)][rows]: the rows from vt_row0 on, transposed
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); if (vt) (void)hipFree(vt); conv_layer_free(L); throw; }
+  (void)hipFree(xs); (void)hipFree(ys); (void)hipFree(vt);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_conv2d3x3_plus_1x1(void* stream, const float* x1, const float* w1, const float* x2, const float* w2, float* y, float* y_img_f32, int Ci1, int Ci2, int Co, int H, int W,
                               int ksplit) {
   RVC_TRY

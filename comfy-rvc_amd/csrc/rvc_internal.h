@@ -113,6 +113,9 @@ struct ConvEpilogue {
   // and copied straight into LDS by the consumer (no conversion, no registers).  xs_in replaces X, ys_out replaces Y.
   const unsigned char* xs_in = nullptr; long long xs_tp = 0;
   unsigned char* ys_out = nullptr; long long ys_tp = 0; float ys_slope = 1.f;
+  // conv_x3s_run only: rows [vt_row0, Co) of an image-only k = 1 projection are written TRANSPOSED as the V^T image of the attention (attention_vt_tp rows per plane) instead of
+  // into ys_out - q | k | v in ONE launch (the rows below vt_row0 go to ys_out as usual); vt_row0 a multiple of 128
+  unsigned char* vt_out = nullptr; long long vt_tp = 0; int vt_row0 = 0;
   int ys_deint_h = 0;                     // conv_x3s_run only: the output image is written de-interleaved for a stride-2 consumer (split_s2_h of the output length)
   // fp16x2 arithmetic (conv_x3q.hip, H2) for BOTH halves of a ResBlock pair: the intermediate image is fp16 hi / lo and each layer multiplies with its
   // one-plane fp16 weight image; only valid when conv1d_pair_h2_eligible(c1, c2, T) said so (no other kernel reads that image format)

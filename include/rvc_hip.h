@@ -337,6 +337,12 @@ int rvc_op_layernorm_c_split(void* stream, const float* x_dev, const float* gamm
  * the ReLU; rows < split_row go to y (+ res when given), the others to y2 (row - split_row): first convolution + 1 x 1 shortcut of a block in one launch. */
 int rvc_op_conv3_small(void* stream, const float* x_dev, const float* w_host, const float* b_host, const float* res_dev, float* y_dev, float* y2_dev, int Ci, int Co,
                        int H, int W, int split_row, int relu_rows);
+/* A fused q | k | v projection on the split-resident GEMM (the attentions of HuBERT and of the synthesizer's text encoder: transformers modeling_hubert.py HubertAttention,
+ * lib/infer_pack/attentions.py:57-69): y = W x + b in ONE launch, rows [0, vt_row0) written as their bf16 hi / lo image (read back into y_img_f32_dev [vt_row0][T]), rows
+ * [vt_row0, Co) written TRANSPOSED as the attention's V^T image (read back into yt_dev [ceil64(T)][Co - vt_row0]; rows T .. ceil64(T) exact zeros).  vt_row0 a multiple of
+ * 128.  Test / benchmark op. */
+int rvc_op_gemm_split_qkv(void* stream, const float* x_dev, const float* w_host, const float* bias_host, float* y_img_f32_dev, float* yt_dev, int Ci, int Co, int T,
+                          int vt_row0);
 /* the swapped product of the split-resident GEMM: yt[t][j] = sum_c x[c][t] w[row0 + j][c], j < rows (the V^T image of the attention, read back as
  * fp32 [ceil64(T)][rows]; rows t >= T are zeros).  w host [Co][Ci]. */
 int rvc_op_gemm_split_swapped(void* stream, const float* x_dev, const float* w_host, float* yt_dev, int Ci, int Co, int T, int row0, int rows);

@@ -434,6 +434,27 @@ def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
     assert torch.equal(y[T:], torch.zeros(T64 - T, rows, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("Ci,Co,T,vt_row0", [(768, 2304, 1599, 1536), (192, 576, 3198, 384), (768, 2304, 100, 1536), (192, 576, 61, 384), (64, 256, 333, 128), (256, 384, 1000, 256)])
+def test_gemm_split_fused_qkv_with_transposed_v(L, Ci, Co, T, vt_row0):
+    """q | k | v as ONE launch of the split-resident GEMM (HuBERT: 768 -> 2304, text encoder: 192 -> 576): rows below vt_row0 as their image, the rows from vt_row0 on
+    through the transposing epilogue into the attention's V^T image - both against float64; the transposed rows T .. ceil64(T) exact zeros although the input image holds
+    NaN patterns past T."""
+    g = torch.Generator().manual_seed(11 + T + Co)
+    x = torch.randn(Ci, T, generator=g); w = torch.randn(Co, Ci, generator=g) / np.sqrt(Ci); b = torch.randn(Co, generator=g) * 0.1
+    b[vt_row0:] = 0.0                                                      # (v's bias is added behind the attention)
+    ref = w.double() @ x.double() + b.double()[:, None]
+    rows = Co - vt_row0
+    T64 = (T + 63) // 64 * 64
+    yq = torch.full((vt_row0, T), 3.0, device="cuda"); yt = torch.full((T64, rows), 3.0, device="cuda")
+    xd = dev(x)
+    L.check(L.lib.rvc_op_gemm_split_qkv(None, L.ptr(xd), w.contiguous().data_ptr(), b.contiguous().data_ptr(), L.ptr(yq), L.ptr(yt), Ci, Co, T, vt_row0))
+    torch.cuda.synchronize()
+    assert rel_err(yq.cpu().double(), ref[:vt_row0]) < 2e-5
+    y = yt.cpu().double()
+    assert rel_err(y[:T], ref[vt_row0:].t()) < 2e-5
+    assert torch.equal(y[T:], torch.zeros(T64 - T, rows, dtype=torch.float64))
+
+
 @pytest.mark.parametrize("Ci,Co,T,ld,off", [(256, 1024, 700, 1026, 1), (32, 128, 333, 130, 1), (64, 192, 129, 192, 0)])
 def test_gemm_split_swapped_product_with_residual(L, Ci, Co, T, ld, off):
     """y[t][off + j] = sum_c x[c][t] w[j][c] + res[t][off + j], rows of pitch ld (MDX23C's second TDF linear lands in the padded plane layout with
