@@ -120,6 +120,7 @@ SIGNATURES = {
     "rvc_postprocess": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p]),
     "rvc_op_gemm_split": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_float] + [c_int] * 5),
     "rvc_op_conv2d_split": (c_int, [c_void_p] * 7 + [c_int] * 9),
+    "rvc_op_wn_in_gate_split": (c_int, [c_void_p] * 6 + [c_int] * 4),
     "rvc_op_gemm_split_qkv": (c_int, [c_void_p] * 6 + [c_int] * 4),
     "rvc_op_conv1d_s2_split": (c_int, [c_void_p] * 6 + [c_int] * 5),
     "rvc_op_conv1d_split": (c_int, [c_void_p] * 6 + [c_int] * 9),

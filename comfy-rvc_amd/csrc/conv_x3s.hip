@@ -46,6 +46,8 @@ struct GemmSArgs {
   int row_fast;                             // tile numbering inside an XCD's run: 1 = row tiles fastest (the XCD owns a column range), 0 = column tiles fastest
   unsigned char* Vt; long long vtTp;        // row tiles from vt_row0 on (the v rows of a fused q | k | v projection) are written TRANSPOSED, as the V^T image of the attention
   int vt_row0, vt_rows;                     // ([16-position chunk][hi | lo][8-position half][kSplitMargin + row - vt_row0][8 positions], like conv_x3s_run_swapped); INT_MAX: none
+  const float* gate_g; int gate_h;          // WaveNet gate in the epilogue (gate_h = H > 0): the 2 H rows are packed so that every 32-row block holds 16 tanh rows and the 16 sigmoid rows of the
+                                            // same channels; the image gets tanh(a + g[c]) sigmoid(a' + g[H + c]) of H channels; gate_g: the conditioning vector [2 H] (or null)
   int ydeint;                               // > 0: output image de-interleaved for a stride-2 consumer - position n at row ymargin + (n >> 1) + (n & 1) ydeint
   int seg2_u, seg2_soff;                    // units >= seg2_u read a SECOND image (same rows per plane, same margin) at byte offset seg2_soff of Xs, one tap of offset 0 per
                                             // chunk: two products over one accumulator; INT_MAX: none
@@ -548,7 +550,54 @@ __global__ __launch_bounds__(256, x3s_wgs(AM, AN, RS, DIRECT)) void conv_x3s_ker
         }
       }
   }
-  if (p.Ys && !vt_tile) {
+  if (p.Ys && p.gate_h > 0) {
+    // in_layer -> fused_add_tanh_sigmoid_multiply (reference lib/infer_pack/modules.py WN.forward, commons.py) without the 2 H-row tensor ever reaching memory: registers
+    // r and r + 8 of a lane are the tanh and the sigmoid row of one channel (the host packed the rows that way); the product leaves as ONE 16-channel chunk of the image per
+    // 32-row block.
+    const int H = p.gate_h;
+#pragma unroll
+    for (int am = 0; am < AM; ++am) {
+      const int blk = (co0 + (wm * AM + am) * 32) >> 5;          // 16-channel chunk of the gate's output
+      float gt[8], gsg[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int c = 16 * blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        gt[r] = (p.gate_g && c < H) ? p.gate_g[c] : 0.f; gsg[r] = (p.gate_g && c < H) ? p.gate_g[H + c] : 0.f;
+      }
+#pragma unroll
+      for (int an = 0; an < AN; ++an) {
+        const int n = n0 + (wn * AN + an) * 32 + li;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          // hardware exp2 / reciprocal (1 ulp each), as the GRU scan's gates: tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1), sigmoid(x) = 1 / (1 + 2^(-x log2 e))
+          constexpr float kL2E = 1.44269504088896340736f;
+          const float ta = acc[am][an][r] + gt[r], sa = acc[am][an][r + 8] + gsg[r];
+          const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.f * kL2E * ta) + 1.f);
+          v[r] = th * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * sa));
+        }
+        unsigned hA[2], lA[2], hB[2], lB[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          split2(v[2 * e2], v[2 * e2 + 1], hA[e2], lA[e2]);
+          split2(v[4 + 2 * e2], v[5 + 2 * e2], hB[e2], lB[e2]);
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t sh = __builtin_amdgcn_permlane32_swap(hA[e2], hB[e2], false, false);
+          const u32x2_t sl2 = __builtin_amdgcn_permlane32_swap(lA[e2], lB[e2], false, false);
+          hi[e2] = sh.x; hi[2 + e2] = sh.y; lo[e2] = sl2.x; lo[2 + e2] = sl2.y;
+        }
+        if (n < p.T && 16 * blk < H) {
+          unsigned char* row = p.Ys + (((long long)blk * 4 + lh) * p.ysTp + (long long)n + p.ymargin) * 16;
+          *reinterpret_cast<u32x4*>(row) = hi;
+          *reinterpret_cast<u32x4*>(row + p.ysTp * 32) = lo;
+        }
+      }
+    }
+  } else if (p.Ys && !vt_tile) {
     if (p.zero_tail) {
 #pragma unroll
       for (int am = 0; am < AM; ++am)
@@ -912,6 +961,11 @@ void conv_x3s_run(const ConvLayer& L, hipStream_t s, const unsigned char* Xs, lo
   a.Co = L.Co; a.T = T; a.nunits = L.Ci / 16 * geom->ktaps + L.seg2_chunks;
   a.seg2_u = L.seg2_chunks ? L.Ci / 16 * geom->ktaps : 0x7fffffff; a.seg2_soff = (int)geom->seg2_off;
   a.ktaps = geom->ktaps; a.margin = geom->margin; a.ymargin = geom->margin; a.padw = geom->padw; a.ydeint = e.ys_out ? e.ys_deint_h : 0;
+  if (e.gate_h > 0) {
+    RVC_REQUIRE(G == 1 && L.mode == 1 && L.Co == 2 * e.gate_h && (e.gate_h & 15) == 0 && e.ys_out && Y == nullptr && !e.R && e.act == ACT_NONE && e.out_scale == 1.f && !e.vt_out && !e.ys_deint_h,
+                "conv_x3s_run: the gate epilogue wants a 2 H-row layer packed by wn_gate_row_order, an image output and nothing else");
+    a.gate_h = e.gate_h; a.gate_g = e.gate_g;
+  }
   a.vt_row0 = 0x7fffffff;
   if (e.vt_out) {
     RVC_REQUIRE(G == 1 && L.mode == 1 && e.vt_row0 > 0 && (e.vt_row0 & 127) == 0 && e.vt_row0 < L.Co && e.vt_tp >= kSplitMargin + (L.Co - e.vt_row0) && Y == nullptr && !e.R && !s2,

@@ -40,6 +40,7 @@ struct EncLayer {
 };
 struct FlowLayer {
   ConvLayer pre, post, in[3], res[2], skip[3];
+  ConvLayer in_gate[3];    // in_layers with their 2 H rows in wn_gate_row_order: the gate runs in the split-resident GEMM's epilogue (conv_x3s.hip), the 2 H-row tensor is never stored
   ConvLayer rs[2];         // res_skip_layers 0 / 1 whole (2 H rows: residual | skip) and
   ConvLayer post_neg;      // post with negated weights (x1 - m as a plain residual add): the split-resident path (conv_x3s.hip)
   DevVec cond_w, cond_b;   // weight-normed cond_layer [2*H*3][gin]
@@ -75,7 +76,7 @@ static void synth_free(Synth& S) {
   for (auto& e : S.enc) { fl(e.qk); e.bv.free_(); fl(e.relk); fl(e.relv); e.ek.free_(); e.ev.free_(); e.rel_img.free_(); fl(e.o); fl(e.ffn1); fl(e.ffn2); e.g1.free_(); e.b1.free_(); e.g2.free_(); e.b2.free_(); }
   S.enc.clear();
   fl(S.proj);
-  for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
+  for (auto& f : S.flow) { fl(f.pre); fl(f.post); for (auto& c : f.in) fl(c); for (auto& c : f.in_gate) fl(c); for (auto& c : f.res) fl(c); for (auto& c : f.skip) fl(c); for (auto& c : f.rs) fl(c); fl(f.post_neg); f.cond_w.free_(); f.cond_b.free_(); }
   fl(S.conv_pre); fl(S.conv_post); S.dec_cond_w.free_(); S.dec_cond_b.free_(); S.conv_post_w.free_();
   for (auto& st : S.stages) { fl(st.up); fl(st.noise); st.noise_w.free_(); st.noise_b.free_(); for (auto& rb : st.rb) for (int m = 0; m < 3; ++m) { fl(rb.c1[m]); fl(rb.c2[m]); } }
   S.stages.clear();
@@ -165,6 +166,21 @@ void synth_finalize(Synth* S) {
     F.post_neg = make_conv1d(ts, p + "post", 1, 0, 1, false, true, -1.f);
     for (int i = 0; i < 3; ++i) {
       F.in[i] = make_conv1d(ts, p + "enc.in_layers." + std::to_string(i), 1, 2, 1, true);
+      if ((C & 15) == 0) {
+        const std::string q = p + "enc.in_layers." + std::to_string(i);
+        const HostTensor& v = ts.get(q + ".weight_v");
+        const std::vector<float> w = weight_norm0(v, ts.get(q + ".weight_g"));
+        const std::vector<float>& b = ts.get(q + ".bias").data;
+        const int Ci = (int)v.shape[1], k = (int)v.shape[2];
+        RVC_REQUIRE((int)v.shape[0] == 2 * C, q + ": expected 2 H rows");
+        std::vector<float> wp(w.size()), bp(b.size());
+        for (int r = 0; r < 2 * C; ++r) {
+          const int src = wn_gate_row_order(r, C);
+          std::copy(w.begin() + (size_t)src * Ci * k, w.begin() + (size_t)(src + 1) * Ci * k, wp.begin() + (size_t)r * Ci * k);
+          bp[r] = b[src];
+        }
+        conv1d_layer_init(F.in_gate[i], wp.data(), bp.data(), 2 * C, Ci, k, 1, 2, 1, 1);
+      }
       const std::string rs = p + "enc.res_skip_layers." + std::to_string(i);
       if (i < 2) {
         F.res[i] = make_conv1d(ts, rs, 1, 0, 1, true, true, 1.f, 0, C);
@@ -397,8 +413,15 @@ static void synth_graph(Synth* S, hipStream_t s, Arena& A, const float* feat_cm,
           conv_x3s_run(F.pre, s, x0_s, tp, T, h, T, Eh);
           fill(s, wo, 0.f, (long long)C * T);
           for (int i = 0; i < 3; ++i) {
-            conv_x3s_run(F.in[i], s, hw_s, tp, T, xin, T, E0);                   // k = 5 over the first H channels of the [h | wo] image
-            wn_gate_split(s, xin, gcond[f] + (size_t)i * 2 * C, acts_s, tp, kSplitMargin, C, T);
+            static const bool gate1 = (exp_int("RVC_WN_GATE_FUSED", 1) != 0);
+            if (gate1 && F.in_gate[i].Wx_ && conv_x3s_eligible(F.in_gate[i])) {
+              // k = 5 over the first H channels of the [h | wo] image, the gate in the epilogue: acts leaves as its image, the 2 H-row tensor is never stored
+              ConvEpilogue Eg; Eg.ys_out = acts_s; Eg.ys_tp = tp; Eg.gate_h = C; Eg.gate_g = gcond[f] + (size_t)i * 2 * C;
+              conv_x3s_run(F.in_gate[i], s, hw_s, tp, T, nullptr, T, Eg);
+            } else {
+              conv_x3s_run(F.in[i], s, hw_s, tp, T, xin, T, E0);                 // k = 5 over the first H channels of the [h | wo] image
+              wn_gate_split(s, xin, gcond[f] + (size_t)i * 2 * C, acts_s, tp, kSplitMargin, C, T);
+            }
             if (i < 2) { ConvEpilogue Ea; Ea.R = hw; Ea.ldR = T; Ea.ys_out = hw_s; Ea.ys_tp = tp; conv_x3s_run(F.rs[i], s, acts_s, tp, T, hw, T, Ea); }
             else { ConvEpilogue Ea; Ea.R = wo; Ea.ldR = T; Ea.ys_out = wo_s; Ea.ys_tp = tp; conv_x3s_run(F.skip[2], s, acts_s, tp, T, wo, T, Ea); }
           }

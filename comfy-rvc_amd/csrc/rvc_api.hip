@@ -429,6 +429,37 @@ int rvc_op_gemm_split_swapped(void* stream, const float* x, const float* w, floa
   conv_layer_free(L);
   RVC_CATCH
 }
+int rvc_op_wn_in_gate_split(void* stream, const float* x, const float* w, const float* bias, const float* g_dev, float* y, int Ci, int H, int T, int k) {
+  RVC_TRY
+  RVC_REQUIRE(x && w && y && Ci > 0 && H > 0 && (H & 15) == 0 && T > 0 && k >= 1 && (k & 1) == 1, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  // the 2 H rows in the order the gate epilogue wants (wn_gate_row_order)
+  std::vector<float> wp((size_t)2 * H * Ci * k), bp((size_t)2 * H, 0.f);
+  for (int r = 0; r < 2 * H; ++r) {
+    const int src = wn_gate_row_order(r, H);
+    std::copy(w + (size_t)src * Ci * k, w + (size_t)(src + 1) * Ci * k, wp.begin() + (size_t)r * Ci * k);
+    if (bias) bp[r] = bias[src];
+  }
+  ConvLayer L;
+  { ConvBuildScope scope(2); conv1d_layer_init(L, wp.data(), bp.data(), 2 * H, Ci, k, 1, (k - 1) / 2, 1, 1); }
+  unsigned char* xs = nullptr; unsigned char* ys = nullptr;
+  try {
+    RVC_REQUIRE(conv_x3s_eligible(L), "layer not eligible for the split-resident kernel");
+    const long long tp = split_image_tp(T);
+    RVC_HIP_CHECK(hipMalloc(&xs, split_image_bytes(Ci, T)));
+    RVC_HIP_CHECK(hipMemsetAsync(xs, 0, split_image_bytes(Ci, T), s));
+    split_image_from_f32(s, x, T, Ci, T, xs, tp);
+    RVC_HIP_CHECK(hipMalloc(&ys, split_image_bytes(H, T)));
+    ConvEpilogue e; e.ys_out = ys; e.ys_tp = tp; e.gate_h = H; e.gate_g = g_dev;
+    conv_x3s_run(L, s, xs, tp, T, nullptr, T, e);
+    split_image_to_f32(s, ys, tp, H, T, y, T);
+    check_launch();
+    RVC_HIP_CHECK(hipStreamSynchronize(s));
+  } catch (...) { if (xs) (void)hipFree(xs); if (ys) (void)hipFree(ys); conv_layer_free(L); throw; }
+  (void)hipFree(xs); (void)hipFree(ys);
+  conv_layer_free(L);
+  RVC_CATCH
+}
 int rvc_op_gemm_split_qkv(void* stream, const float* x, const float* w, const float* bias, float* y_img_f32, float* yt, int Ci, int Co, int T, int vt_row0) {
   RVC_TRY
   RVC_REQUIRE(x && w && y_img_f32 && yt && Ci > 0 && Co > 0 && T > 0 && vt_row0 > 0 && vt_row0 < Co, "bad argument");

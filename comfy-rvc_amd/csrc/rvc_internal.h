@@ -116,6 +116,9 @@ struct ConvEpilogue {
   // conv_x3s_run only: rows [vt_row0, Co) of an image-only k = 1 projection are written TRANSPOSED as the V^T image of the attention (attention_vt_tp rows per plane) instead of
   // into ys_out - q | k | v in ONE launch (the rows below vt_row0 go to ys_out as usual); vt_row0 a multiple of 128
   unsigned char* vt_out = nullptr; long long vt_tp = 0; int vt_row0 = 0;
+  // conv_x3s_run only: the WaveNet gate in the epilogue - the layer's 2 H rows packed in wn_gate_row_order (physical row p of 32-row block b = p / 32: tanh row of channel
+  // 16 b + p % 32 for p % 32 < 16, sigmoid row of channel 16 b + p % 32 - 16 otherwise); ys_out receives tanh(a + g[c]) sigmoid(a' + g[H + c]) of the H channels
+  int gate_h = 0; const float* gate_g = nullptr;
   int ys_deint_h = 0;                     // conv_x3s_run only: the output image is written de-interleaved for a stride-2 consumer (split_s2_h of the output length)
   // fp16x2 arithmetic (conv_x3q.hip, H2) for BOTH halves of a ResBlock pair: the intermediate image is fp16 hi / lo and each layer multiplies with its
   // one-plane fp16 weight image; only valid when conv1d_pair_h2_eligible(c1, c2, T) said so (no other kernel reads that image format)
@@ -194,6 +197,7 @@ inline long long split_s2_tp(long long Tin) { return (kSplitMargin + 2LL * split
 inline size_t split_s2_bytes(int C, long long Tin) { return (size_t)(C / 16) * 2 * (size_t)split_s2_tp(Tin) * 32; }
 SplitGeom split_geom_s2(int k, long long Tin);
 bool conv_x3s_s2_eligible(const ConvLayer& L);
+inline int wn_gate_row_order(int p, int H) { const int b = p >> 5, q = p & 31; return q < 16 ? 16 * b + q : H + 16 * b + (q - 16); }      // physical row -> row of the reference's [tanh H | sigmoid H] layer
 void split_image_deint_from_f32(hipStream_t s, const float* X, long long ldX, int C, int T, unsigned char* img, long long tp, int H);      // (tests: in the models the producers' epilogues write the image)
 void split_image_deint_to_f32(hipStream_t s, const unsigned char* img, long long tp, int H, int C, int T, float* Y, long long ldY);
 bool conv_x3s_eligible(const ConvLayer& L);

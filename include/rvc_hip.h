@@ -337,6 +337,11 @@ int rvc_op_layernorm_c_split(void* stream, const float* x_dev, const float* gamm
  * the ReLU; rows < split_row go to y (+ res when given), the others to y2 (row - split_row): first convolution + 1 x 1 shortcut of a block in one launch. */
 int rvc_op_conv3_small(void* stream, const float* x_dev, const float* w_host, const float* b_host, const float* res_dev, float* y_dev, float* y2_dev, int Ci, int Co,
                        int H, int W, int split_row, int relu_rows);
+/* A WaveNet layer's in_layer with its gate in the GEMM's epilogue (reference lib/infer_pack/modules.py WN.forward: x_in = in_layers[i](x); acts =
+ * fused_add_tanh_sigmoid_multiply(x_in, g_l), commons.py): y[c][t] = tanh(a[c][t] + g[c]) * sigmoid(a[H + c][t] + g[H + c]) with a = conv1d(x, w [2 H][Ci][k]) + b,
+ * "same" padding; the 2 H-row tensor is never stored - the rows are packed so that a lane holds both halves of a channel - and y comes back from the image the
+ * res / skip layer would stage.  g_dev [2 H] on the device (or NULL).  Test / benchmark op. */
+int rvc_op_wn_in_gate_split(void* stream, const float* x_dev, const float* w_host, const float* bias_host, const float* g_dev, float* y_dev, int Ci, int H, int T, int k);
 /* A fused q | k | v projection on the split-resident GEMM (the attentions of HuBERT and of the synthesizer's text encoder: transformers modeling_hubert.py HubertAttention,
  * lib/infer_pack/attentions.py:57-69): y = W x + b in ONE launch, rows [0, vt_row0) written as their bf16 hi / lo image (read back into y_img_f32_dev [vt_row0][T]), rows
  * [vt_row0, Co) written TRANSPOSED as the attention's V^T image (read back into yt_dev [ceil64(T)][Co - vt_row0]; rows T .. ceil64(T) exact zeros).  vt_row0 a multiple of

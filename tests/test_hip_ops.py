@@ -434,6 +434,22 @@ def test_gemm_split_swapped_product(L, Ci, Co, T, row0, rows):
     assert torch.equal(y[T:], torch.zeros(T64 - T, rows, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("Ci,H,T,k", [(192, 192, 3198, 5), (192, 192, 200, 5), (64, 32, 1000, 3), (32, 48, 77, 1)])
+def test_wn_in_layer_with_gate_in_the_epilogue(L, Ci, H, T, k):
+    """The flow's WaveNet layer (reference lib/infer_pack/modules.py WN.forward, commons.fused_add_tanh_sigmoid_multiply): acts = tanh(a_t + g_t) * sigmoid(a_s + g_s) with
+    a = in_layer(x), computed in the epilogue of the split-resident GEMM from rows packed so that a lane holds both halves of a channel - against float64."""
+    g = torch.Generator().manual_seed(21 + T + H)
+    x = torch.randn(Ci, T, generator=g); w = torch.randn(2 * H, Ci, k, generator=g) / np.sqrt(Ci * k); b = torch.randn(2 * H, generator=g) * 0.1
+    gc = torch.randn(2 * H, generator=g) * 0.5
+    a = F.conv1d(x.double()[None], w.double(), b.double(), padding=(k - 1) // 2)[0] + gc.double()[:, None]
+    ref = torch.tanh(a[:H]) * torch.sigmoid(a[H:])
+    y = torch.full((H, T), 9.0, device="cuda")
+    xd, gd = dev(x), dev(gc)
+    L.check(L.lib.rvc_op_wn_in_gate_split(None, L.ptr(xd), w.contiguous().data_ptr(), b.contiguous().data_ptr(), L.ptr(gd), L.ptr(y), Ci, H, T, k))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().double(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("Ci,Co,T,vt_row0", [(768, 2304, 1599, 1536), (192, 576, 3198, 384), (768, 2304, 100, 1536), (192, 576, 61, 384), (64, 256, 333, 128), (256, 384, 1000, 256)])
 def test_gemm_split_fused_qkv_with_transposed_v(L, Ci, Co, T, vt_row0):
     """q | k | v as ONE launch of the split-resident GEMM (HuBERT: 768 -> 2304, text encoder: 192 -> 576): rows below vt_row0 as their image, the rows from vt_row0 on
