@@ -7,7 +7,7 @@ collective).  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CP
 Inside one GPU the same independence is used a second time (ClipLanes): a batch-1 clip cannot fill 256 CUs during its narrow
 stages (text encoder and flow at 100 fps, the transformer layers, the deep U-Net levels, the GRU scan), so several clips are kept in
 flight, each on its own host thread, HIP streams and model replica (weights 0.85 GB + as much again in weight images + arenas: ~7.5 GB per
-lane; 288 GB of HBM make the replica free).  Measured on MI355X, 30 s clips (round 6, profiles/r6zz_*): ~1580 xRT one at a time, ~2435 xRT with
+lane; 288 GB of HBM make the replica free).  Measured on MI355X, 30 s clips (round 6, profiles/r6zz_*): ~1580 xRT one at a time, ~2440 xRT with
 three lanes; a fourth adds nothing (the chip is at its power limit under the generator's persistent kernel).  RMVPE alone keeps eight in flight.
 """
 import glob
